@@ -1,0 +1,136 @@
+"""ctypes binding of libdmx.so — a 1:1 mirror of include/dmx.h (no logic here beyond marshalling).
+
+The library is loaded lazily from demuxlet_amd/libdmx.so (built in-tree by demuxlet_amd/build.py).  There is no Python
+or CPU fallback for the engine: if the library or the GPU is missing, calls raise DmxError."""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "libdmx.so"
+
+DMX_OK = 0
+DMX_MEM_HOST, DMX_MEM_DEVICE = 0, 1
+DMX_MODE_STRICT = 0
+
+# every symbol include/dmx.h declares (tests/test_abi.py checks the header against this list and the .so against both)
+SYMBOLS = [
+    "dmx_abi_version", "dmx_last_error", "dmx_phred_tables", "dmx_geno_from_gt", "dmx_geno_from_pl", "dmx_geno_from_gp",
+    "dmx_store_new", "dmx_store_free", "dmx_store_add_snp", "dmx_store_add_cell", "dmx_store_count_read",
+    "dmx_store_add_read", "dmx_store_n_cells", "dmx_store_n_snps", "dmx_store_barcode", "dmx_store_freeze",
+    "dmx_engine_create", "dmx_engine_destroy", "dmx_engine_set_stream", "dmx_engine_set_phred_tables",
+    "dmx_engine_set_genotypes", "dmx_engine_set_pileup", "dmx_engine_run_singlet", "dmx_engine_run_doublet",
+    "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
+    "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
+    "dmx_demuxlet_run",
+]
+
+
+class DmxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libdmx error {code}: {msg}")
+        self.code = code
+
+
+class Pileup(C.Structure):
+    _fields_ = [("n_cells", C.c_int32), ("n_snps", C.c_int32), ("n_pairs", C.c_int64), ("n_reads", C.c_int64),
+                ("cell_pair_off", C.c_void_p), ("cell_read_off", C.c_void_p), ("pair_snp", C.c_void_p),
+                ("pair_nrd", C.c_void_p), ("nrd_width", C.c_int32), ("memory", C.c_int32), ("reads", C.c_void_p),
+                ("rd_totl", C.c_void_p), ("rd_pass", C.c_void_p), ("rd_uniq", C.c_void_p)]
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("n_samples", C.c_int32), ("n_alpha", C.c_int32), ("alpha", C.c_void_p), ("doublet_prior", C.c_double),
+                ("device", C.c_int32), ("mode", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class CellSummary(C.Structure):
+    _fields_ = [("max_llk", C.c_double), ("sum_single", C.c_double), ("sum_double", C.c_double),
+                ("sing_llk1", C.c_double), ("sing_llk2", C.c_double),
+                ("llk12", C.c_double), ("llk1", C.c_double), ("llk2", C.c_double), ("llk10", C.c_double), ("llk20", C.c_double),
+                ("llk00_0", C.c_double), ("llk00_best", C.c_double),
+                ("i_sing1", C.c_int32), ("i_sing2", C.c_int32), ("j_best", C.c_int32), ("k_best", C.c_int32),
+                ("n_best", C.c_int32), ("n_pairs", C.c_int32)]
+
+
+SUMMARY_DTYPE = np.dtype([(n, np.float64) for n in ("max_llk", "sum_single", "sum_double", "sing_llk1", "sing_llk2", "llk12",
+                                                    "llk1", "llk2", "llk10", "llk20", "llk00_0", "llk00_best")] +
+                         [(n, np.int32) for n in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best", "n_pairs")])
+assert SUMMARY_DTYPE.itemsize == C.sizeof(CellSummary)
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("llks", C.c_void_p), ("llk0s", C.c_void_p), ("llksAB", C.c_void_p), ("llks00", C.c_void_p),
+                ("summary", C.c_void_p), ("gp0s", C.c_void_p)]
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("gp0_ms", C.c_float), ("singlet_ms", C.c_float), ("doublet_ms", C.c_float), ("reduce_ms", C.c_float)]
+
+
+class KernelBytes(C.Structure):
+    _fields_ = [("singlet_bytes", C.c_double), ("doublet_bytes", C.c_double), ("reduce_bytes", C.c_double)]
+
+
+class FinalInput(C.Structure):
+    _fields_ = [("n_cells", C.c_int32), ("n_samples", C.c_int32), ("n_alpha", C.c_int32), ("alpha", C.c_void_p),
+                ("doublet_prior", C.c_double), ("min_total", C.c_int32), ("min_uniq", C.c_int32), ("min_snp", C.c_int32),
+                ("write_pair", C.c_int32), ("barcodes", C.c_void_p), ("sample_ids", C.c_void_p),
+                ("rd_totl", C.c_void_p), ("rd_pass", C.c_void_p), ("rd_uniq", C.c_void_p), ("n_snp", C.c_void_p),
+                ("llks", C.c_void_p), ("llk0s", C.c_void_p), ("llksAB", C.c_void_p), ("llks00", C.c_void_p),
+                ("tie_pileup", C.c_void_p), ("tie_g", C.c_void_p), ("tie_tol", C.c_double)]
+
+
+class Job(C.Structure):
+    _fields_ = [("store", C.c_void_p), ("g", C.c_void_p), ("n_samples", C.c_int32), ("sample_ids", C.c_void_p),
+                ("n_alpha", C.c_int32), ("alpha", C.c_void_p), ("doublet_prior", C.c_double),
+                ("min_total", C.c_int32), ("min_uniq", C.c_int32), ("min_snp", C.c_int32), ("write_pair", C.c_int32),
+                ("out_prefix", C.c_char_p), ("device", C.c_int32), ("arbiter", C.c_int32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen libdmx.so; fails loudly when it has not been built (python -m demuxlet_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise DmxError(-100, f"{LIB_PATH} is missing — build it with `python -m demuxlet_amd.build` (hipcc, gfx950)")
+    L = C.CDLL(str(LIB_PATH))
+    vp, i32, dbl = C.c_void_p, C.c_int32, C.c_double
+    L.dmx_abi_version.restype = C.c_int
+    L.dmx_last_error.restype = C.c_char_p
+    sig = {
+        "dmx_phred_tables": [vp, vp], "dmx_geno_from_gt": [vp, i32, dbl, vp], "dmx_geno_from_pl": [vp, i32, vp],
+        "dmx_geno_from_gp": [vp, i32, dbl, vp], "dmx_store_free": [vp], "dmx_store_add_snp": [vp],
+        "dmx_store_add_cell": [vp, C.c_char_p], "dmx_store_count_read": [vp, i32],
+        "dmx_store_add_read": [vp, i32, i32, C.c_char_p, i32, i32], "dmx_store_n_cells": [vp], "dmx_store_n_snps": [vp],
+        "dmx_store_barcode": [vp, i32], "dmx_store_freeze": [vp, vp], "dmx_engine_create": [vp, vp],
+        "dmx_engine_destroy": [vp], "dmx_engine_set_stream": [vp, vp], "dmx_engine_set_phred_tables": [vp, vp, vp],
+        "dmx_engine_set_genotypes": [vp, vp, i32, i32], "dmx_engine_set_pileup": [vp, vp], "dmx_engine_run_singlet": [vp],
+        "dmx_engine_run_doublet": [vp], "dmx_engine_sync": [vp], "dmx_engine_get_singlet": [vp, vp, vp],
+        "dmx_engine_get_doublet": [vp, vp, vp, vp], "dmx_engine_device_view": [vp, vp],
+        "dmx_engine_last_kernel_times": [vp, vp], "dmx_engine_algorithmic_bytes": [vp, vp],
+        "dmx_write_single": [vp, C.c_char_p], "dmx_write_doublet": [vp, C.c_char_p], "dmx_demuxlet_run": [vp],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    L.dmx_store_new.restype = vp
+    L.dmx_store_new.argtypes = []
+    L.dmx_store_free.restype = None
+    L.dmx_store_barcode.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise DmxError(rc, load().dmx_last_error().decode(errors="replace"))
+    return rc

@@ -1,0 +1,846 @@
+// Device half of libdmx: the likelihood engine for one MI355X (gfx950).  Hand-written HIP, FP64 VALU + LDS; no MFMA
+// (contraction lengths are 3 and 9), no library kernels.  Built with -ffp-contract=off: in STRICT mode every
+// expression the reference evaluates is evaluated with the same operations in the same order (separate IEEE mul/add/
+// div); the only fused operations are inside dmx_log(), our own replacement for libm's log().
+//
+//   k_gp0        a4  gp0s[s][l] = (sum_j g[s][j][l]) / V                       cmd_cram_demuxlet.cpp:390-401
+//   k_singlet    a5  llks[c][k] += log(GL . g[s][k]),  llk0s[c] += log(GL . gp0s[s])        :412-461
+//   k_doublet_*  a8+a9  pG[A][3][3] per covered pair, llksAB[c][j][k][n] += log(sum_lm g_j[l] g_k[m] pG[n][l][m]),
+//                    llks00[c][n] likewise with gp0s                                        :576-710
+//   k_reduce     a10,a11,a13  per-cell max / posterior sums / top-2 singlets / best doublet :713-734,:746-758,:799-828
+//
+// Order guarantee (what makes STRICT strict): every accumulator is owned by exactly one lane, which adds that cell's
+// per-SNP terms in ascending SNP order — the order of the reference's std::map walks.  Terms themselves are computed
+// by whichever lane is free (k_singlet stages them through LDS), which does not change any rounding.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "dmx_internal.hpp"
+#include "dmx_log.hpp"
+
+using dmx::set_error;
+
+#define HIP_TRY(expr)                                                                                          \
+  do {                                                                                                         \
+    hipError_t _e = (expr);                                                                                    \
+    if (_e != hipSuccess) return set_error(DMX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                           __FILE__, __LINE__);                                                \
+  } while (0)
+
+namespace {
+
+struct PileupView {
+  int32_t B, S;
+  const int64_t* cell_pair_off;
+  const int64_t* cell_read_off;
+  const int32_t* pair_snp;     // nullptr = dense
+  const void* pair_nrd;
+  const uint8_t* reads;
+};
+
+constexpr int kThreads = 256;
+constexpr int kLut = 3 * 128;   // mat | err/3 | 0.5-err/3
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void k_gp0(const float* __restrict__ g, int32_t S, int32_t V, double* __restrict__ gp0) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)S * 3) return;
+  const int64_t s = i / 3;
+  const int l = (int)(i % 3);
+  const float* row = g + (size_t)s * V * 3 + l;
+  double acc = 0.0;                                   // calloc'ed, :391
+  for (int32_t j = 0; j < V; ++j) acc += (double)row[(size_t)j * 3];   // :393-397 sequential over samples
+  gp0[i] = acc / (double)V;                           // :398-400
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-read update of the three singlet genotype likelihoods with sum-renormalisation (:437-443)
+__device__ __forceinline__ void gl_read(double& G0, double& G1, double& G2, uint32_t byte, const double* s_lut) {
+  const uint32_t bq = byte & 127u;
+  const bool alt = (byte >> 7) != 0;
+  const double m = s_lut[bq], e3 = s_lut[128 + bq], h = s_lut[256 + bq];
+  G0 *= alt ? e3 : m;
+  G1 *= h;
+  G2 *= alt ? m : e3;
+  const double tmp = G0 + G1 + G2;
+  G0 /= tmp; G1 /= tmp; G2 /= tmp;
+}
+
+// K1.  A workgroup owns C cells for their whole SNP range.  Per tile of T = 256/C SNP-pairs per cell:
+//   compute phase  lane (cell ci, pair ti): GL of its pair, then the V+1 log terms of that pair, KC samples at a time,
+//                  into LDS;
+//   sum phase      lane (cell ci, sample k) adds the tile's T terms of its accumulator in pair order.
+template <typename NRD, int C, int NCH>
+__global__ __launch_bounds__(kThreads) void k_singlet(PileupView pv, const float* __restrict__ g,
+                                                      const double* __restrict__ gp0, const double* __restrict__ lut,
+                                                      const int32_t* __restrict__ sched, int32_t V,
+                                                      double* __restrict__ llks, double* __restrict__ llk0s) {
+  constexpr int T = kThreads / C;
+  constexpr int KC = 16;
+  constexpr int LD = KC + 1;
+  static_assert(T <= 64 && (64 % T) == 0, "a cell's tile segment must sit inside one wavefront");
+  __shared__ double s_lut[kLut];
+  __shared__ double s_term[kThreads * LD];
+  __shared__ int64_t s_np[C];
+
+  const int t = threadIdx.x;
+  for (int i = t; i < kLut; i += kThreads) s_lut[i] = lut[i];
+
+  const int ci = t / T, ti = t % T;
+  const int slot = blockIdx.x * C + ci;
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+  if (ti == 0) s_np[ci] = np;
+  __syncthreads();
+  int64_t max_np = 0;
+#pragma unroll
+  for (int c = 0; c < C; ++c) max_np = max(max_np, s_np[c]);
+
+  // sum-phase identity: lane a < C*KC owns (cell a/KC, sample-in-chunk a%KC) of every chunk
+  const int a_ci = t / KC, a_kk = t % KC;
+  const bool a_lane = t < C * KC;
+  const int a_slot = blockIdx.x * C + a_ci;
+  const bool a_ok = a_lane && a_slot < pv.B;
+  const int32_t a_cell = a_ok ? sched[a_slot] : 0;
+  const int64_t a_np = a_ok ? s_np[a_ci] : 0;
+  double acc[NCH];
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) acc[q] = 0.0;
+
+  const NRD* __restrict__ nrd = (const NRD*)pv.pair_nrd;
+
+  for (int64_t tile = 0; tile * T < max_np; ++tile) {
+    const int64_t pi = tile * T + ti;
+    const bool valid = pi < np;
+    const uint32_t n = valid ? (uint32_t)nrd[p_beg + pi] : 0u;
+    uint32_t incl = n;
+#pragma unroll
+    for (int d = 1; d < T; d <<= 1) {
+      const uint32_t y = __shfl_up(incl, d, T);
+      if (ti >= d) incl += y;
+    }
+    const uint32_t tot = __shfl(incl, T - 1, T);
+    const int64_t off = rd_base + (int64_t)(incl - n);
+    rd_base += tot;
+    const int32_t snp = valid ? (pv.pair_snp ? pv.pair_snp[p_beg + pi] : (int32_t)pi) : 0;
+
+    double G0 = 1.0, G1 = 1.0, G2 = 1.0;                                   // :427
+    for (uint32_t r = 0; r < n; ++r) gl_read(G0, G1, G2, pv.reads[off + r], s_lut);
+    G0 += 1e-6; G1 += 1e-6; G2 += 1e-6;                                    // :446-448
+    {
+      const double tmp = G0 + G1 + G2;
+      G0 /= tmp; G1 /= tmp; G2 /= tmp;                                     // :449-452
+    }
+    const float* __restrict__ grow = g + (size_t)snp * V * 3;
+    const double* __restrict__ g0row = gp0 + (size_t)snp * 3;
+
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      if (valid) {
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          const int k = q * KC + kk;
+          if (k < V) {
+            const double a0 = (double)grow[k * 3], a1 = (double)grow[k * 3 + 1], a2 = (double)grow[k * 3 + 2];
+            s_term[t * LD + kk] = dmx_log(G0 * a0 + G1 * a1 + G2 * a2);     // :456
+          } else if (k == V) {
+            s_term[t * LD + kk] = dmx_log(G0 * g0row[0] + G1 * g0row[1] + G2 * g0row[2]);   // :459
+          }
+        }
+      }
+      __syncthreads();
+      if (a_ok && q * KC + a_kk <= V) {
+        const int64_t left = a_np - tile * T;
+        const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
+        const double* col = &s_term[(a_ci * T) * LD + a_kk];
+        double s = acc[q];
+        for (int i = 0; i < cnt; ++i) s += col[i * LD];                    // ascending SNP order: the reference's order
+        acc[q] = s;
+      }
+      __syncthreads();
+    }
+  }
+  if (a_ok) {
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int k = q * KC + a_kk;
+      if (k < V) llks[(size_t)a_cell * V + k] = acc[q];
+      else if (k == V) llk0s[a_cell] = acc[q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K2, generic form (any V, any A).  One cell per workgroup.  Accumulator q of the cell (q < V*V*A: (j,k,n) row-major,
+// then A entries for llks00) lives in lane q % 256, register q / 256.
+//   phase 1  lane (pair ti, alpha n): the 9 mixture likelihoods pG[n][l][m] of that pair, reads in UMI order, with the
+//            one-max-across-all-alphas renormalisation after every read (:600-663); A is padded to a power of two so the
+//            A lanes of a pair sit together in a wavefront and share their max by butterfly shuffles;
+//   phase 2  every accumulator adds log(sum_lm ...) for the tile's pairs in ascending SNP order (:671-709).
+template <typename NRD, int NACC>
+__global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, const float* __restrict__ g,
+                                                              const double* __restrict__ gp0,
+                                                              const double* __restrict__ lut,
+                                                              const double* __restrict__ alpha,
+                                                              const int32_t* __restrict__ sched, int32_t V, int32_t A,
+                                                              int32_t A_pad, int32_t TP, double* __restrict__ grid,
+                                                              double* __restrict__ l00) {
+  __shared__ double s_lut[kLut];
+  __shared__ double s_pG[kThreads * 9];
+  __shared__ int32_t s_snp[32];
+  __shared__ uint32_t s_cnt[32];
+  __shared__ int64_t s_off[32];
+
+  const int t = threadIdx.x;
+  for (int i = t; i < kLut; i += kThreads) s_lut[i] = lut[i];
+  const int32_t cell = sched[blockIdx.x];
+  const int64_t p_beg = pv.cell_pair_off[cell];
+  const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
+  int64_t rd_base = pv.cell_read_off[cell];
+  const NRD* __restrict__ nrd = (const NRD*)pv.pair_nrd;
+
+  // phase-1 identity and the per-(l,m) mixing weights of this lane's alpha (:613)
+  const int ti1 = t / A_pad, n1 = t % A_pad;
+  const bool lane1 = (ti1 < TP) && (n1 < A);
+  double wA[9], wR[9];
+  {
+    const double al = lane1 ? alpha[n1] : 0.0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * al;
+        wA[l * 3 + m] = p;
+        wR[l * 3 + m] = 1.0 - p;
+      }
+  }
+
+  // phase-2 identity
+  const int32_t nAB = V * V * A;
+  const int32_t nacc = nAB + A;
+  int32_t code[NACC];          // (j << 20) | (k << 8) | n ; j = 0xFFF marks an llks00 entry
+  double acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int32_t q = t + i * kThreads;
+    acc[i] = 0.0;
+    if (q < nAB) {
+      const int32_t n = q % A, jk = q / A;
+      code[i] = ((jk / V) << 20) | ((jk % V) << 8) | n;
+    } else if (q < nacc) {
+      code[i] = (0xFFF << 20) | (q - nAB);
+    } else {
+      code[i] = -1;
+    }
+  }
+  __syncthreads();
+
+  for (int64_t base = 0; base < np; base += TP) {
+    const int tp = (int)min((int64_t)TP, np - base);
+    // pair headers of the tile
+    if (t < 32) {
+      const bool v = t < tp;
+      const uint32_t n = v ? (uint32_t)nrd[p_beg + base + t] : 0u;
+      uint32_t incl = n;
+#pragma unroll
+      for (int d = 1; d < 32; d <<= 1) {
+        const uint32_t y = __shfl_up(incl, d, 32);
+        if (t >= d) incl += y;
+      }
+      if (v) {
+        s_cnt[t] = n;
+        s_off[t] = rd_base + (int64_t)(incl - n);
+        s_snp[t] = pv.pair_snp ? pv.pair_snp[p_beg + base + t] : (int32_t)(base + t);
+      }
+    }
+    __syncthreads();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];     // first read byte of the next tile, for every lane
+
+    // ---- phase 1
+    {
+      const bool on = lane1 && ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      double pG[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                              // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt;
+        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_lut[128 + bq] : s_lut[bq];               // :606
+        const double pA = alt ? s_lut[bq] : s_lut[128 + bq];               // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            pG[i] *= (pR * wR[i] + pA * wA[i]);                            // :625
+            mx = (mx < pG[i]) ? pG[i] : mx;                                // :626-627
+          }
+        }
+        for (int d = 1; d < A_pad; d <<= 1) {                              // one max across ALL alphas of the pair
+          const double o = __shfl_xor(mx, d);
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) pG[i] /= mx;                         // :632-639
+        }
+      }
+      double mx = 0.0;
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          pG[i] += 1e-6;                                                    // :649
+          mx = (mx < pG[i]) ? pG[i] : mx;
+        }
+      }
+      for (int d = 1; d < A_pad; d <<= 1) {
+        const double o = __shfl_xor(mx, d);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s_pG[(ti1 * A + n1) * 9 + i] = pG[i] / mx;   // :656-663
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 2
+    for (int ti = 0; ti < tp; ++ti) {
+      const int32_t snp = s_snp[ti];
+      const float* __restrict__ grow = g + (size_t)snp * V * 3;
+      const double* __restrict__ g0 = gp0 + (size_t)snp * 3;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+        const int32_t cd = code[i];
+        if (cd < 0) continue;
+        const int32_t j = (cd >> 20) & 0xFFF, k = (cd >> 8) & 0xFFF, n = cd & 0xFF;
+        double a[3], b[3];
+        if (j == 0xFFF) {
+          a[0] = b[0] = g0[0]; a[1] = b[1] = g0[1]; a[2] = b[2] = g0[2];   // gp00 = gp0s[l]*gp0s[m]  (:555)
+        } else {
+          a[0] = (double)grow[j * 3]; a[1] = (double)grow[j * 3 + 1]; a[2] = (double)grow[j * 3 + 2];
+          b[0] = (double)grow[k * 3]; b[1] = (double)grow[k * 3 + 1]; b[2] = (double)grow[k * 3 + 2];
+        }
+        const double* P = &s_pG[(ti * A + n) * 9];
+        double sum = 0.0;                                                   // :674 std::fill(...,0)
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) sum += ((a[l] * b[m]) * P[l * 3 + m]);   // :553 then :677-679, l-major
+        acc[i] += dmx_log(sum);                                             // :683 / :709
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    const int32_t q = t + i * kThreads;
+    if (q < nAB) grid[(size_t)cell * nAB + q] = acc[i];
+    else if (q < nacc) l00[(size_t)cell * A + (q - nAB)] = acc[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K3.  One cell per workgroup over its finished grid.
+struct ArgMax { double v; int32_t i; };
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {      // larger value wins; equal values: lower scan index
+  return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
+}
+
+__global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ grid, const double* __restrict__ l00,
+                                                     const int64_t* __restrict__ cell_pair_off,
+                                                     const double* __restrict__ alpha, int32_t V, int32_t A,
+                                                     double prior, dmx_cell_summary* __restrict__ out) {
+  __shared__ double s_d[kThreads];
+  __shared__ double s_e[kThreads];
+  __shared__ int32_t s_i[kThreads];
+  const int t = threadIdx.x;
+  const int32_t cell = blockIdx.x;
+  const int32_t nAB = V * V * A;
+  const double* G = grid + (size_t)cell * nAB;
+  const int32_t npairs = (int32_t)(cell_pair_off[cell + 1] - cell_pair_off[cell]);
+
+  // (1) max over the whole grid (:713-721)
+  double mx = -1e300;
+  for (int32_t q = t; q < nAB; q += kThreads) mx = (mx < G[q]) ? G[q] : mx;
+  s_d[t] = mx;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) s_d[t] = (s_d[t] < s_d[t + s]) ? s_d[t + s] : s_d[t];
+    __syncthreads();
+  }
+  const double max_llk = s_d[0];
+  __syncthreads();
+
+  // (2) posterior sums (:724-734) — same per-term expression, tree order for the sum
+  double ss = 0.0, sd = 0.0;
+  for (int32_t q = t; q < nAB; q += kThreads) {
+    const int32_t n = q % A, jk = q / A, j = jk / V, k = jk % V;
+    const double e = exp(G[q] - max_llk);
+    if (k == 0 && n == 0) ss += (e * (1. - prior) / V);
+    if (j != k && n >= 1) sd += (e * prior / V / (V - 1) / (A - 1) / (alpha[n] == 0.5 ? 2.0 : 1.0));
+  }
+  s_d[t] = ss; s_e[t] = sd;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) { s_d[t] += s_d[t + s]; s_e[t] += s_e[t + s]; }
+    __syncthreads();
+  }
+  const double sum_single = s_d[0], sum_double = s_e[0];
+  __syncthreads();
+
+  // (3) best doublet: first maximum in (j,k,n) scan order over j != k, n >= 1 (:799-814)
+  ArgMax bd{-1e300, 0x7FFFFFFF};
+  for (int32_t q = t; q < nAB; q += kThreads) {
+    const int32_t n = q % A, jk = q / A, j = jk / V, k = jk % V;
+    if (j != k && n >= 1) bd = better(bd, ArgMax{G[q], q});
+  }
+  s_d[t] = bd.v; s_i[t] = bd.i;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) { ArgMax r = better(ArgMax{s_d[t], s_i[t]}, ArgMax{s_d[t + s], s_i[t + s]}); s_d[t] = r.v; s_i[t] = r.i; }
+    __syncthreads();
+  }
+  const int32_t qbest = s_i[0];
+  __syncthreads();
+
+  // (4) top-2 singlets from llksAB[j][0][0] (:746-758)
+  ArgMax b1{-1e300, 0x7FFFFFFF};
+  for (int32_t j = t; j < V; j += kThreads) b1 = better(b1, ArgMax{G[(size_t)j * V * A], j});
+  s_d[t] = b1.v; s_i[t] = b1.i;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) { ArgMax r = better(ArgMax{s_d[t], s_i[t]}, ArgMax{s_d[t + s], s_i[t + s]}); s_d[t] = r.v; s_i[t] = r.i; }
+    __syncthreads();
+  }
+  const int32_t i1 = s_i[0];
+  __syncthreads();
+  ArgMax b2{-1e300, 0x7FFFFFFF};
+  for (int32_t j = t; j < V; j += kThreads) if (j != i1) b2 = better(b2, ArgMax{G[(size_t)j * V * A], j});
+  s_d[t] = b2.v; s_i[t] = b2.i;
+  __syncthreads();
+  for (int s = kThreads / 2; s > 0; s >>= 1) {
+    if (t < s) { ArgMax r = better(ArgMax{s_d[t], s_i[t]}, ArgMax{s_d[t + s], s_i[t + s]}); s_d[t] = r.v; s_i[t] = r.i; }
+    __syncthreads();
+  }
+  const int32_t i2 = (s_i[0] == 0x7FFFFFFF) ? -1 : s_i[0];
+
+  if (t == 0) {
+    dmx_cell_summary r;
+    r.max_llk = max_llk; r.sum_single = sum_single; r.sum_double = sum_double;
+    r.i_sing1 = i1; r.i_sing2 = i2;
+    r.sing_llk1 = G[(size_t)i1 * V * A];
+    r.sing_llk2 = (i2 >= 0) ? G[(size_t)i2 * V * A] : -1e300;
+    const int32_t nb = qbest % A, jkb = qbest / A, jb = jkb / V, kb = jkb % V;
+    r.j_best = jb; r.k_best = kb; r.n_best = nb;
+    r.llk12 = G[qbest];
+    r.llk1 = G[(size_t)jb * V * A]; r.llk2 = G[(size_t)kb * V * A];
+    r.llk10 = G[(size_t)jb * V * A + nb]; r.llk20 = G[(size_t)kb * V * A + nb];    // :824-825
+    r.llk00_0 = l00[(size_t)cell * A]; r.llk00_best = l00[(size_t)cell * A + nb];
+    r.n_pairs = npairs;
+    out[cell] = r;
+  }
+}
+
+}  // namespace
+
+// =====================================================================================================================
+struct dmx_engine {
+  int32_t V = 0, A = 0, device = 0, mode = 0;
+  double prior = 0.5;
+  std::vector<double> alpha;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  double* d_lut = nullptr;
+  double* d_alpha = nullptr;
+  // genotypes
+  const float* d_g = nullptr; float* d_g_own = nullptr; int32_t S = 0; double* d_gp0 = nullptr;
+  // pileup
+  PileupView pv{}; int32_t nrd_width = 1; int64_t P = 0, R = 0; bool have_pileup = false;
+  void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int32_t* d_sched = nullptr;
+  // results
+  double *d_llks = nullptr, *d_llk0s = nullptr, *d_grid = nullptr, *d_l00 = nullptr;
+  dmx_cell_summary* d_sum = nullptr;
+  int32_t out_B = 0; bool have_grid = false, have_sing = false;
+  hipEvent_t ev[8] = {};
+  bool timed[4] = {false, false, false, false};
+};
+
+namespace {
+
+int free_pileup(dmx_engine* e) {
+  for (void*& p : e->own) { if (p) (void)hipFree(p); p = nullptr; }
+  if (e->d_sched) (void)hipFree(e->d_sched);
+  e->d_sched = nullptr;
+  e->have_pileup = false;
+  return DMX_OK;
+}
+int free_results(dmx_engine* e) {
+  if (e->d_llks) (void)hipFree(e->d_llks);
+  if (e->d_llk0s) (void)hipFree(e->d_llk0s);
+  if (e->d_grid) (void)hipFree(e->d_grid);
+  if (e->d_l00) (void)hipFree(e->d_l00);
+  if (e->d_sum) (void)hipFree(e->d_sum);
+  e->d_llks = e->d_llk0s = e->d_grid = e->d_l00 = nullptr; e->d_sum = nullptr;
+  e->out_B = 0; e->have_grid = e->have_sing = false;
+  return DMX_OK;
+}
+
+template <typename T>
+int upload(dmx_engine* e, const void* host, size_t count, void** slot, const T** view) {
+  void* d = nullptr;
+  const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+  HIP_TRY(hipMalloc(&d, bytes));
+  *slot = d;
+  if (count) HIP_TRY(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, e->stream));
+  *view = (const T*)d;
+  return DMX_OK;
+}
+
+}  // namespace
+
+extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out) {
+  if (!cfg || !out) return set_error(DMX_ERR_ARG, "dmx_engine_create: null argument");
+  if (cfg->n_samples < 1 || cfg->n_samples > 4095) return set_error(DMX_ERR_ARG, "dmx_engine_create: n_samples %d not in [1,4095]", cfg->n_samples);
+  if (cfg->n_alpha < 1 || cfg->n_alpha > 64 || !cfg->alpha) return set_error(DMX_ERR_ARG, "dmx_engine_create: n_alpha %d not in [1,64] or null grid", cfg->n_alpha);
+  if (cfg->mode != DMX_MODE_STRICT) return set_error(DMX_ERR_ARG, "dmx_engine_create: unknown mode %d", cfg->mode);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_error(DMX_ERR_NOGPU, "dmx_engine_create: no HIP device is visible (this library has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return set_error(DMX_ERR_ARG, "dmx_engine_create: device %d of %d", cfg->device, ndev);
+  HIP_TRY(hipSetDevice(cfg->device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_error(DMX_ERR_NOGPU, "dmx_engine_create: device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+  dmx_engine* e = new (std::nothrow) dmx_engine;
+  if (!e) return set_error(DMX_ERR_NOMEM, "dmx_engine_create: out of memory");
+  e->V = cfg->n_samples; e->A = cfg->n_alpha; e->device = cfg->device; e->mode = cfg->mode; e->prior = cfg->doublet_prior;
+  e->alpha.assign(cfg->alpha, cfg->alpha + cfg->n_alpha);
+  HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+  e->stream = e->own_stream;
+  for (hipEvent_t& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kLut));
+  HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
+  HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
+  double mat[256], err[256];
+  dmx_phred_tables(mat, err);
+  *out = e;
+  return dmx_engine_set_phred_tables(e, mat, err);
+}
+
+extern "C" int dmx_engine_destroy(dmx_engine* e) {
+  if (!e) return DMX_OK;
+  (void)hipSetDevice(e->device);
+  (void)hipStreamSynchronize(e->stream);
+  free_pileup(e); free_results(e);
+  if (e->d_g_own) (void)hipFree(e->d_g_own);
+  if (e->d_gp0) (void)hipFree(e->d_gp0);
+  if (e->d_lut) (void)hipFree(e->d_lut);
+  if (e->d_alpha) (void)hipFree(e->d_alpha);
+  for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_set_stream(dmx_engine* e, void* s) {
+  if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_set_stream: null engine");
+  e->stream = s ? (hipStream_t)s : e->own_stream;
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_set_phred_tables(dmx_engine* e, const double mat[256], const double err[256]) {
+  if (!e || !mat || !err) return set_error(DMX_ERR_ARG, "dmx_engine_set_phred_tables: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  dmx::ReadLut lut;
+  dmx::build_read_lut(mat, err, &lut);
+  HIP_TRY(hipMemcpy(e->d_lut, &lut, sizeof(double) * kLut, hipMemcpyHostToDevice));
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n_snps, int32_t memory) {
+  if (!e || !g || n_snps < 0) return set_error(DMX_ERR_ARG, "dmx_engine_set_genotypes: bad arguments");
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->d_g_own) { (void)hipFree(e->d_g_own); e->d_g_own = nullptr; }
+  if (e->d_gp0) { (void)hipFree(e->d_gp0); e->d_gp0 = nullptr; }
+  const size_t n = (size_t)n_snps * e->V * 3;
+  if (memory == DMX_MEM_DEVICE) {
+    e->d_g = g;
+  } else {
+    HIP_TRY(hipMalloc((void**)&e->d_g_own, std::max<size_t>(n * sizeof(float), 16)));
+    HIP_TRY(hipMemcpyAsync(e->d_g_own, g, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    e->d_g = e->d_g_own;
+  }
+  e->S = n_snps;
+  HIP_TRY(hipMalloc((void**)&e->d_gp0, std::max<size_t>((size_t)n_snps * 3 * sizeof(double), 16)));
+  if (n_snps > 0) {
+    const int64_t items = (int64_t)n_snps * 3;
+    HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+    hipLaunchKernelGGL(k_gp0, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, e->stream, e->d_g, n_snps, e->V, e->d_gp0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+    e->timed[0] = true;
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));   // the host buffer may go away after return
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
+  if (!e || !pl) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: null argument");
+  if (pl->n_cells < 0 || pl->n_pairs < 0 || pl->n_reads < 0) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: negative size");
+  if (pl->nrd_width != 1 && pl->nrd_width != 2 && pl->nrd_width != 4) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: nrd_width %d", pl->nrd_width);
+  if (!pl->cell_pair_off || !pl->cell_read_off || (pl->n_pairs && !pl->pair_nrd) || (pl->n_reads && !pl->reads))
+    return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: missing arrays");
+  if (e->S == 0 && pl->n_pairs > 0) return set_error(DMX_ERR_STATE, "dmx_engine_set_pileup: call dmx_engine_set_genotypes first");
+  if (pl->n_snps > e->S) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: pileup has %d SNPs, genotype matrix %d", pl->n_snps, e->S);
+  HIP_TRY(hipSetDevice(e->device));
+  free_pileup(e);
+  const int32_t B = pl->n_cells;
+  std::vector<int64_t> h_off((size_t)B + 1);
+  if (pl->memory == DMX_MEM_DEVICE) {
+    HIP_TRY(hipMemcpy(h_off.data(), pl->cell_pair_off, sizeof(int64_t) * ((size_t)B + 1), hipMemcpyDeviceToHost));
+    e->pv.cell_pair_off = pl->cell_pair_off; e->pv.cell_read_off = pl->cell_read_off; e->pv.pair_snp = pl->pair_snp;
+    e->pv.pair_nrd = pl->pair_nrd; e->pv.reads = pl->reads;
+  } else {
+    std::memcpy(h_off.data(), pl->cell_pair_off, sizeof(int64_t) * ((size_t)B + 1));
+    if (pl->pair_snp) {   // host-side validation of what the kernels will index with
+      for (int64_t p = 0; p < pl->n_pairs; ++p)
+        if (pl->pair_snp[p] < 0 || pl->pair_snp[p] >= e->S) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: pair_snp[%lld]=%d out of range", (long long)p, pl->pair_snp[p]);
+    }
+    if (int rc = upload<int64_t>(e, pl->cell_pair_off, (size_t)B + 1, &e->own[0], &e->pv.cell_pair_off)) return rc;
+    if (int rc = upload<int64_t>(e, pl->cell_read_off, (size_t)B + 1, &e->own[1], &e->pv.cell_read_off)) return rc;
+    if (pl->pair_snp) { if (int rc = upload<int32_t>(e, pl->pair_snp, (size_t)pl->n_pairs, &e->own[2], &e->pv.pair_snp)) return rc; }
+    else e->pv.pair_snp = nullptr;
+    const uint8_t* v = nullptr;
+    if (int rc = upload<uint8_t>(e, pl->pair_nrd, (size_t)pl->n_pairs * (size_t)pl->nrd_width, &e->own[3], &v)) return rc;
+    e->pv.pair_nrd = v;
+    if (int rc = upload<uint8_t>(e, pl->reads, (size_t)pl->n_reads, &e->own[4], &e->pv.reads)) return rc;
+  }
+  if (h_off[0] != 0 || h_off[(size_t)B] != pl->n_pairs) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off does not span n_pairs");
+  for (int32_t c = 0; c < B; ++c) {
+    if (h_off[c + 1] < h_off[c]) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off not monotone at %d", c);
+    if (!pl->pair_snp && h_off[c + 1] - h_off[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: dense layout needs n_snps pairs per cell (cell %d)", c);
+  }
+  e->pv.B = B; e->pv.S = e->S; e->nrd_width = pl->nrd_width; e->P = pl->n_pairs; e->R = pl->n_reads;
+  // launch order: longest cells first, so the tail of the grid is made of short cells and co-scheduled cells are alike
+  std::vector<int32_t> sched((size_t)B);
+  std::iota(sched.begin(), sched.end(), 0);
+  std::stable_sort(sched.begin(), sched.end(), [&](int32_t a, int32_t b) { return (h_off[a + 1] - h_off[a]) > (h_off[b + 1] - h_off[b]); });
+  HIP_TRY(hipMalloc((void**)&e->d_sched, std::max<size_t>(sizeof(int32_t) * (size_t)B, 16)));
+  if (B) HIP_TRY(hipMemcpyAsync(e->d_sched, sched.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (e->out_B != B) {
+    free_results(e);
+    HIP_TRY(hipMalloc((void**)&e->d_llks, std::max<size_t>(sizeof(double) * (size_t)B * e->V, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_llk0s, std::max<size_t>(sizeof(double) * (size_t)B, 16)));
+    e->out_B = B;
+  }
+  e->have_sing = e->have_grid = false;
+  e->have_pileup = true;
+  return DMX_OK;
+}
+
+namespace {
+
+template <typename NRD>
+int launch_singlet(dmx_engine* e) {
+  const int32_t B = e->pv.B, V = e->V;
+  const int nch = (V + 1 + 15) / 16;
+  // cells per workgroup: keep >= ~4 workgroups per CU when B allows it
+  const int C = (B >= 16 * 1024) ? 16 : (B >= 8 * 1024 ? 8 : 4);
+  const dim3 block(kThreads);
+#define DMX_K1(CC, NN)                                                                                              \
+  hipLaunchKernelGGL((k_singlet<NRD, CC, NN>), dim3((unsigned)((B + CC - 1) / CC)), block, 0, e->stream, e->pv, e->d_g, \
+                     e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
+#define DMX_K1_C(NN) do { if (C == 16) DMX_K1(16, NN); else if (C == 8) DMX_K1(8, NN); else DMX_K1(4, NN); } while (0)
+  if (nch <= 1) DMX_K1_C(1);
+  else if (nch <= 2) DMX_K1_C(2);
+  else if (nch <= 4) DMX_K1_C(4);
+  else if (nch <= 8) DMX_K1_C(8);
+  else if (nch <= 16) DMX_K1_C(16);
+  else return set_error(DMX_ERR_ARG, "run_singlet: n_samples %d > 255 is not supported by this build", V);
+#undef DMX_K1_C
+#undef DMX_K1
+  return DMX_OK;
+}
+
+template <typename NRD>
+int launch_doublet(dmx_engine* e) {
+  const int32_t B = e->pv.B, V = e->V, A = e->A;
+  int A_pad = 1;
+  while (A_pad < A) A_pad <<= 1;
+  const int TP = std::min(32, kThreads / A_pad);
+  const int64_t nacc = (int64_t)V * V * A + A;
+  const int per = (int)((nacc + kThreads - 1) / kThreads);
+  const dim3 grid((unsigned)B), block(kThreads);
+#define DMX_K2(NN)                                                                                                   \
+  hipLaunchKernelGGL((k_doublet_generic<NRD, NN>), grid, block, 0, e->stream, e->pv, e->d_g, e->d_gp0, e->d_lut,      \
+                     e->d_alpha, e->d_sched, V, A, A_pad, TP, e->d_grid, e->d_l00)
+  if (per <= 1) DMX_K2(1);
+  else if (per <= 2) DMX_K2(2);
+  else if (per <= 4) DMX_K2(4);
+  else if (per <= 8) DMX_K2(8);
+  else if (per <= 16) DMX_K2(16);
+  else if (per <= 33) DMX_K2(33);
+  else if (per <= 65) DMX_K2(65);
+  else return set_error(DMX_ERR_ARG, "run_doublet: V*V*A = %lld accumulators per cell exceed this build's limit", (long long)nacc);
+#undef DMX_K2
+  return DMX_OK;
+}
+
+}  // namespace
+
+extern "C" int dmx_engine_run_singlet(dmx_engine* e) {
+  if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_run_singlet: null engine");
+  if (!e->have_pileup || !e->d_g) return set_error(DMX_ERR_STATE, "dmx_engine_run_singlet: set genotypes and pileup first");
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->pv.B == 0) { e->have_sing = true; return DMX_OK; }
+  HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+  int rc = e->nrd_width == 1 ? launch_singlet<uint8_t>(e) : (e->nrd_width == 2 ? launch_singlet<uint16_t>(e) : launch_singlet<uint32_t>(e));
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e->ev[3], e->stream));
+  e->timed[1] = true; e->have_sing = true;
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
+  if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_run_doublet: null engine");
+  if (!e->have_pileup || !e->d_g) return set_error(DMX_ERR_STATE, "dmx_engine_run_doublet: set genotypes and pileup first");
+  if (e->V < 2 || e->A < 2) return set_error(DMX_ERR_ARG, "dmx_engine_run_doublet: needs >= 2 samples and >= 2 alphas (got %d, %d)", e->V, e->A);
+  HIP_TRY(hipSetDevice(e->device));
+  const int32_t B = e->pv.B;
+  const size_t nAB = (size_t)e->V * e->V * e->A;
+  if (!e->d_grid) {
+    HIP_TRY(hipMalloc((void**)&e->d_grid, std::max<size_t>(sizeof(double) * nAB * (size_t)B, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_l00, std::max<size_t>(sizeof(double) * (size_t)e->A * (size_t)B, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_sum, std::max<size_t>(sizeof(dmx_cell_summary) * (size_t)B, 16)));
+  }
+  if (B == 0) { e->have_grid = true; return DMX_OK; }
+  HIP_TRY(hipEventRecord(e->ev[4], e->stream));
+  int rc = e->nrd_width == 1 ? launch_doublet<uint8_t>(e) : (e->nrd_width == 2 ? launch_doublet<uint16_t>(e) : launch_doublet<uint32_t>(e));
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e->ev[5], e->stream));
+  hipLaunchKernelGGL(k_reduce, dim3((unsigned)B), dim3(kThreads), 0, e->stream, e->d_grid, e->d_l00, e->pv.cell_pair_off,
+                     e->d_alpha, e->V, e->A, e->prior, e->d_sum);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(e->ev[6], e->stream));
+  e->timed[2] = e->timed[3] = true; e->have_grid = true;
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_sync(dmx_engine* e) {
+  if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_sync: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_get_singlet(dmx_engine* e, double* llks, double* llk0s) {
+  if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_get_singlet: null engine");
+  if (!e->have_sing) return set_error(DMX_ERR_STATE, "dmx_engine_get_singlet: run_singlet has not been called");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t B = (size_t)e->pv.B;
+  if (llks && B) HIP_TRY(hipMemcpyAsync(llks, e->d_llks, sizeof(double) * B * e->V, hipMemcpyDeviceToHost, e->stream));
+  if (llk0s && B) HIP_TRY(hipMemcpyAsync(llk0s, e->d_llk0s, sizeof(double) * B, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_get_doublet(dmx_engine* e, double* llksAB, double* llks00, dmx_cell_summary* summary) {
+  if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_get_doublet: null engine");
+  if (!e->have_grid) return set_error(DMX_ERR_STATE, "dmx_engine_get_doublet: run_doublet has not been called");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t B = (size_t)e->pv.B, nAB = (size_t)e->V * e->V * e->A;
+  if (llksAB && B) HIP_TRY(hipMemcpyAsync(llksAB, e->d_grid, sizeof(double) * B * nAB, hipMemcpyDeviceToHost, e->stream));
+  if (llks00 && B) HIP_TRY(hipMemcpyAsync(llks00, e->d_l00, sizeof(double) * B * e->A, hipMemcpyDeviceToHost, e->stream));
+  if (summary && B) HIP_TRY(hipMemcpyAsync(summary, e->d_sum, sizeof(dmx_cell_summary) * B, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_device_view(dmx_engine* e, dmx_device_view* out) {
+  if (!e || !out) return set_error(DMX_ERR_ARG, "dmx_engine_device_view: null argument");
+  out->llks = e->d_llks; out->llk0s = e->d_llk0s; out->llksAB = e->d_grid; out->llks00 = e->d_l00; out->summary = e->d_sum;
+  out->gp0s = e->d_gp0;
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_last_kernel_times(dmx_engine* e, dmx_kernel_times* out) {
+  if (!e || !out) return set_error(DMX_ERR_ARG, "dmx_engine_last_kernel_times: null argument");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  out->gp0_ms = out->singlet_ms = out->doublet_ms = out->reduce_ms = 0.f;
+  if (e->timed[0]) HIP_TRY(hipEventElapsedTime(&out->gp0_ms, e->ev[0], e->ev[1]));
+  if (e->timed[1]) HIP_TRY(hipEventElapsedTime(&out->singlet_ms, e->ev[2], e->ev[3]));
+  if (e->timed[2]) HIP_TRY(hipEventElapsedTime(&out->doublet_ms, e->ev[4], e->ev[5]));
+  if (e->timed[3]) HIP_TRY(hipEventElapsedTime(&out->reduce_ms, e->ev[5], e->ev[6]));
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_algorithmic_bytes(dmx_engine* e, dmx_kernel_bytes* out) {
+  if (!e || !out) return set_error(DMX_ERR_ARG, "dmx_engine_algorithmic_bytes: null argument");
+  if (!e->have_pileup) return set_error(DMX_ERR_STATE, "dmx_engine_algorithmic_bytes: no pileup staged");
+  const double B = e->pv.B, V = e->V, A = e->A, S = e->S;
+  // every input array once: pair counts + read bytes (+ SNP ids when sparse) + per-cell offsets and
+  // launch order + the genotype matrix and gp0s once (they are L2/Infinity-Cache resident across cells)
+  const double in = (double)e->P * e->nrd_width + (double)e->R + (e->pv.pair_snp ? 4.0 * (double)e->P : 0.0) +
+                    (B + 1) * 16 + B * 4 + S * V * 12 + S * 24;
+  out->singlet_bytes = in + B * (V + 1) * 8;
+  out->doublet_bytes = in + B * (V * V * A + A) * 8;
+  out->reduce_bytes = B * (V * V * A + A) * 8 + B * (double)sizeof(dmx_cell_summary);
+  return DMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// cmd_cram_demuxlet.cpp:390-881 in one call: store + genotype matrix in, four text files out.
+extern "C" int dmx_demuxlet_run(const dmx_job* job) {
+  if (!job || !job->store || !job->g || !job->sample_ids || !job->alpha || !job->out_prefix)
+    return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: null argument");
+  dmx_pileup pl;
+  if (int rc = dmx_store_freeze(job->store, &pl)) return rc;
+  const int32_t B = pl.n_cells, V = job->n_samples, A = job->n_alpha;
+  dmx_engine_config cfg{};
+  cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior; cfg.device = job->device;
+  cfg.mode = DMX_MODE_STRICT;
+  dmx_engine* e = nullptr;
+  if (int rc = dmx_engine_create(&cfg, &e)) return rc;
+  struct Guard { dmx_engine* e; ~Guard() { dmx_engine_destroy(e); } } guard{e};
+  if (int rc = dmx_engine_set_genotypes(e, job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
+  if (int rc = dmx_engine_set_pileup(e, &pl)) return rc;
+  if (int rc = dmx_engine_run_singlet(e)) return rc;
+  std::vector<double> llks((size_t)B * V), llk0s((size_t)B);
+  if (int rc = dmx_engine_get_singlet(e, llks.data(), llk0s.data())) return rc;
+  std::vector<const char*> bcs((size_t)B);
+  std::vector<int32_t> nsnp((size_t)B);
+  for (int32_t c = 0; c < B; ++c) { bcs[c] = dmx_store_barcode(job->store, c); nsnp[c] = (int32_t)(pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]); }
+  dmx_final_input fin{};
+  fin.n_cells = B; fin.n_samples = V; fin.n_alpha = A; fin.alpha = job->alpha; fin.doublet_prior = job->doublet_prior;
+  fin.min_total = job->min_total; fin.min_uniq = job->min_uniq; fin.min_snp = job->min_snp; fin.write_pair = job->write_pair;
+  fin.barcodes = bcs.data(); fin.sample_ids = job->sample_ids;
+  fin.rd_totl = pl.rd_totl; fin.rd_pass = pl.rd_pass; fin.rd_uniq = pl.rd_uniq; fin.n_snp = nsnp.data();
+  fin.llks = llks.data(); fin.llk0s = llk0s.data();
+  const std::string pre(job->out_prefix);
+  if (int rc = dmx_write_single(&fin, (pre + ".single").c_str())) return rc;
+  if (int rc = dmx_engine_run_doublet(e)) return rc;
+  std::vector<double> grid((size_t)B * V * V * A), l00((size_t)B * A);
+  if (int rc = dmx_engine_get_doublet(e, grid.data(), l00.data(), nullptr)) return rc;
+  fin.llksAB = grid.data(); fin.llks00 = l00.data();
+  if (job->arbiter) { fin.tie_pileup = &pl; fin.tie_g = job->g; }
+  return dmx_write_doublet(&fin, job->out_prefix);
+}

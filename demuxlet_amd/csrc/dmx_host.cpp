@@ -1,0 +1,547 @@
+// Host half of libdmx: error plumbing, phred LUT (a2), genotype-field transforms (a3), the UMI-deduplicated pileup
+// store (a1), the finaliser/writers (a6, a10..a14) and the tie arbiter.  Plain C++17, no HIP in this file.
+//
+// Reference lines are cited per function (paths relative to statgen/demuxlet).  Nothing here includes, links or calls
+// anything under oracle/.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <unordered_map>
+
+#include "dmx_internal.hpp"
+
+namespace dmx {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+void build_read_lut(const double mat[256], const double err[256], ReadLut* out) {
+  for (int q = 0; q < 128; ++q) {
+    out->mat[q] = mat[q];
+    out->e3[q] = err[q] / 3.0;            // phredConv.phred2Err[bq]/3.0   (cmd_cram_demuxlet.cpp:437,:439,:606,:607)
+    out->het[q] = 0.5 - err[q] / 3.0;     // (0.5 - phredConv.phred2Err[bq]/3.0)   (:438)
+  }
+}
+
+}  // namespace dmx
+
+using dmx::set_error;
+
+extern "C" int dmx_abi_version(void) { return DMX_ABI_VERSION; }
+extern "C" const char* dmx_last_error(void) { return dmx::g_last_error.c_str(); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// a2  (PhredHelper.cpp:24-40)
+extern "C" int dmx_phred_tables(double mat[256], double err[256]) {
+  if (!mat || !err) return set_error(DMX_ERR_ARG, "dmx_phred_tables: null output");
+  for (int q = 0; q < 256; ++q) {
+    err[q] = (q > 1) ? std::pow(0.1, q * 0.1) : 0.75;
+    mat[q] = 1. - err[q];
+  }
+  return DMX_OK;
+}
+static double phred_to_prob(uint32_t phred) {     // phredConverter::toProb, PhredHelper.h:45 (phred2Prob has no 0.75 floor)
+  static double tab[256];
+  static bool ready = false;
+  if (!ready) { for (int q = 0; q < 256; ++q) tab[q] = std::pow(0.1, q * 0.1); ready = true; }
+  return phred > 255 ? tab[255] : tab[phred];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// a3  genotype-field transforms; biallelic diploid records (vfilt.maxAlleles = 2, cmd_cram_demuxlet.cpp:26,:106).
+// Everything lands in float32 exactly where the reference rounds to float (bcf_filtered_reader.h:78).
+static constexpr int kGenos = 3, kAlleles = 2;
+
+extern "C" int dmx_geno_from_gt(const int32_t* alleles, int32_t nv, double gt_error, float* out) {
+  if (!alleles || !out || nv < 0) return set_error(DMX_ERR_ARG, "dmx_geno_from_gt: bad arguments");
+  // allele counts over the selected samples: bcf_filtered_reader.cpp:230-240
+  double ac[kAlleles] = {0, 0};
+  int32_t an = 0;
+  for (int32_t i = 0; i < 2 * nv; ++i) {
+    const int32_t a = alleles[i];
+    if (a >= kAlleles) return set_error(DMX_ERR_ARG, "dmx_geno_from_gt: allele index %d on a biallelic record", a);
+    if (a >= 0) { ++an; ac[a] += 1; }
+  }
+  // HWE prior used for missing genotypes (:381-388); evaluated left to right as the reference's expression is
+  float hwe[kGenos];
+  {
+    int l = 0;
+    for (int j = 0; j < kAlleles; ++j)
+      for (int k = 0; k <= j; ++k, ++l)
+        hwe[l] = (float)((j == k ? 1.0 : 2.0) * (ac[j] + 1.0 / kAlleles) / (an + 1.0) * (ac[k] + 1.0 / kAlleles) / (an + 1.0));
+  }
+  const float hit = (float)(1.0 - gt_error), miss = (float)(gt_error / (kGenos - 1.0));   // :399
+  for (int32_t i = 0; i < nv; ++i) {
+    const int32_t a1 = alleles[2 * i], a2 = alleles[2 * i + 1];
+    float* o = out + 3 * (size_t)i;
+    if (a1 < 0 || a2 < 0) { o[0] = hwe[0]; o[1] = hwe[1]; o[2] = hwe[2]; continue; }     // .h:144-149 -> -1
+    const int32_t gt = a1 + a2;          // bcf_alleles2gt for alleles in {0,1}: (0,0)->0 (0,1)->1 (1,1)->2
+    for (int g = 0; g < kGenos; ++g) o[g] = (g == gt) ? hit : miss;
+  }
+  return DMX_OK;
+}
+
+extern "C" int dmx_geno_from_pl(const int32_t* pl, int32_t nv, float* out) {
+  if (!pl || !out || nv < 0) return set_error(DMX_ERR_ARG, "dmx_geno_from_pl: bad arguments");
+  // 10 EM rounds on the allele frequencies from a uniform start (bcf_filtered_reader.cpp:255-311); genotype order
+  // l = 0:(0,0) 1:(1,0) 2:(1,1) with HWE weights 1,2,1; the posterior of the LAST round is what is kept (:305-308).
+  double af[kAlleles] = {1.0 / kAlleles, 1.0 / kAlleles};
+  std::vector<double> like((size_t)nv * kGenos);
+  for (size_t i = 0; i < like.size(); ++i) like[i] = phred_to_prob((uint32_t)pl[i]);
+  for (int it = 0; it < 10; ++it) {
+    double next[kAlleles] = {0, 0};
+    int32_t an = 0;
+    const bool last = (it == 9);
+    for (int32_t i = 0; i < nv; ++i) {
+      const double* L = &like[(size_t)i * kGenos];
+      double gp[kGenos];
+      double sum = 0;
+      sum += (gp[0] = 1 * af[0] * af[0] * L[0]);       // (j==k ? 1 : 2) * acs[j] * acs[k] * toProb(pl)   (:279)
+      sum += (gp[1] = 2 * af[1] * af[0] * L[1]);
+      sum += (gp[2] = 1 * af[1] * af[1] * L[2]);
+      gp[0] /= sum; next[0] += gp[0]; next[0] += gp[0];   // newacs[j] += gp; newacs[k] += gp   (:284-286)
+      gp[1] /= sum; next[1] += gp[1]; next[0] += gp[1];
+      gp[2] /= sum; next[1] += gp[2]; next[1] += gp[2];
+      an += 2;
+      if (last) { float* o = out + 3 * (size_t)i; o[0] = (float)gp[0]; o[1] = (float)gp[1]; o[2] = (float)gp[2]; }
+    }
+    af[0] = next[0] / an; af[1] = next[1] / an;           // :310-311
+  }
+  return DMX_OK;
+}
+
+extern "C" int dmx_geno_from_gp(const float* gp, int32_t nv, double gt_error, float* out) {
+  if (!gp || !out || nv < 0) return set_error(DMX_ERR_ARG, "dmx_geno_from_gp: bad arguments");
+  // pseudo-sample: HWE at uniform allele frequency, ((i==j)?1:2)/nalleles^2 in float (bcf_filtered_reader.cpp:421-425)
+  float mean[kGenos] = {(float)(1.0 / (float)(kAlleles * kAlleles)), (float)(2.0 / (float)(kAlleles * kAlleles)),
+                        (float)(1.0 / (float)(kAlleles * kAlleles))};
+  for (int32_t i = 0; i < nv; ++i) {       // per-sample float normalisation, accumulated into the mean (:428-439)
+    const float* in = gp + 3 * (size_t)i;
+    float* o = out + 3 * (size_t)i;
+    float s = 0;
+    s += in[0]; s += in[1]; s += in[2];
+    for (int g = 0; g < kGenos; ++g) { o[g] = in[g] / s; mean[g] += o[g]; }
+  }
+  const int32_t denom = (int32_t)(nv + 1.0);            // gpSums[j] /= (int32_t)(sm_icols.size()+1.0)   (:442)
+  for (int g = 0; g < kGenos; ++g) mean[g] /= denom;
+  for (int32_t i = 0; i < nv; ++i) {                    // (1-e)*gp + e*mean in double, stored as float (:448)
+    float* o = out + 3 * (size_t)i;
+    for (int g = 0; g < kGenos; ++g) o[g] = (float)((1.0 - gt_error) * o[g] + gt_error * mean[g]);
+  }
+  return DMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// a1  pileup store.  The reference nests std::maps (snp -> cell -> umi -> packed word, plus a mirror cell -> snp);
+// what is observable downstream is (i) first observation of a (snp,cell,umi) key wins, later ones only count
+// (sc_drop_seq.cpp:44,53,57), (ii) the per-cell counters (:39,:75 and cmd_cram_demuxlet.cpp:295), (iii) iteration order.
+// Here: an append-only observation log with an open-addressing index for the "seen before?" test, and one sort at
+// freeze time that emits the GPU's CSR directly.
+struct dmx_store {
+  struct Obs { int32_t cell, snp; uint32_t umi_off, umi_len; uint8_t allele, bq; uint32_t count; };
+  std::vector<std::string> barcodes;
+  std::unordered_map<std::string, int32_t> barcode_id;
+  std::vector<int32_t> totl, pass, uniq;
+  int32_t n_snps = 0;
+  std::vector<Obs> obs;
+  std::string umi_pool;
+  std::vector<int64_t> index;          // open addressing over obs, -1 = empty
+  // frozen CSR
+  bool frozen = false;
+  std::vector<int64_t> cell_pair_off, cell_read_off;
+  std::vector<int32_t> pair_snp;
+  std::vector<uint8_t> pair_nrd_bytes;
+  int32_t nrd_width = 1;
+  std::vector<uint8_t> reads;
+
+  static uint64_t hash(int32_t cell, int32_t snp, const char* umi, size_t len) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL ^ ((uint64_t)(uint32_t)cell << 32 | (uint32_t)snp);
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL;
+    for (size_t i = 0; i < len; ++i) { h ^= (unsigned char)umi[i]; h *= 0x100000001B3ULL; }
+    h ^= h >> 32;
+    return h;
+  }
+  void rehash(size_t cap) {
+    index.assign(cap, -1);
+    for (size_t i = 0; i < obs.size(); ++i) {
+      const Obs& o = obs[i];
+      size_t p = hash(o.cell, o.snp, umi_pool.data() + o.umi_off, o.umi_len) & (cap - 1);
+      while (index[p] >= 0) p = (p + 1) & (cap - 1);
+      index[p] = (int64_t)i;
+    }
+  }
+};
+
+extern "C" dmx_store* dmx_store_new(void) {
+  dmx_store* s = new (std::nothrow) dmx_store;
+  if (!s) { set_error(DMX_ERR_NOMEM, "dmx_store_new: out of memory"); return nullptr; }
+  s->rehash(1 << 12);
+  return s;
+}
+extern "C" void dmx_store_free(dmx_store* s) { delete s; }
+extern "C" int32_t dmx_store_add_snp(dmx_store* s) {
+  if (!s) return set_error(DMX_ERR_ARG, "dmx_store_add_snp: null store");
+  s->frozen = false;
+  return s->n_snps++;
+}
+extern "C" int32_t dmx_store_add_cell(dmx_store* s, const char* barcode) {       // sc_drop_seq.cpp:20-32
+  if (!s || !barcode) return set_error(DMX_ERR_ARG, "dmx_store_add_cell: null argument");
+  auto it = s->barcode_id.find(barcode);
+  if (it != s->barcode_id.end()) return it->second;
+  const int32_t id = (int32_t)s->barcodes.size();
+  s->barcodes.emplace_back(barcode);
+  s->barcode_id.emplace(s->barcodes.back(), id);
+  s->totl.push_back(0); s->pass.push_back(0); s->uniq.push_back(0);
+  s->frozen = false;
+  return id;
+}
+extern "C" int dmx_store_count_read(dmx_store* s, int32_t cell) {                // cmd_cram_demuxlet.cpp:295
+  if (!s || cell < 0 || cell >= (int32_t)s->barcodes.size()) return set_error(DMX_ERR_ARG, "dmx_store_count_read: bad cell %d", cell);
+  ++s->totl[cell];
+  return DMX_OK;
+}
+extern "C" int dmx_store_add_read(dmx_store* s, int32_t snp, int32_t cell, const char* umi, int32_t allele, int32_t bq) {
+  if (!s || !umi) return set_error(DMX_ERR_ARG, "dmx_store_add_read: null argument");
+  if (snp < 0 || snp >= s->n_snps) return set_error(DMX_ERR_ARG, "dmx_store_add_read: snp %d out of range", snp);
+  if (cell < 0 || cell >= (int32_t)s->barcodes.size()) return set_error(DMX_ERR_ARG, "dmx_store_add_read: cell %d out of range", cell);
+  if (allele < 0 || allele > 2) return set_error(DMX_ERR_ARG, "dmx_store_add_read: allele %d not in {0,1,2}", allele);
+  if (bq < 0 || bq > 127) return set_error(DMX_ERR_ARG, "dmx_store_add_read: base quality %d not in [0,127]", bq);
+  ++s->pass[cell];                                                                 // sc_drop_seq.cpp:39
+  const size_t len = std::strlen(umi);
+  const size_t cap = s->index.size();
+  size_t p = dmx_store::hash(cell, snp, umi, len) & (cap - 1);
+  for (; s->index[p] >= 0; p = (p + 1) & (cap - 1)) {
+    dmx_store::Obs& o = s->obs[(size_t)s->index[p]];
+    if (o.cell == cell && o.snp == snp && o.umi_len == len && std::memcmp(s->umi_pool.data() + o.umi_off, umi, len) == 0) {
+      ++o.count;                                                                   // :57 duplicate: only the count moves
+      return 0;
+    }
+  }
+  dmx_store::Obs o{cell, snp, (uint32_t)s->umi_pool.size(), (uint32_t)len, (uint8_t)allele, (uint8_t)bq, 1u};
+  s->umi_pool.append(umi, len);
+  s->index[p] = (int64_t)s->obs.size();
+  s->obs.push_back(o);
+  if (s->obs.size() * 2 > cap) s->rehash(cap * 2);
+  ++s->uniq[cell];                                                                 // :75
+  s->frozen = false;
+  return 1;
+}
+extern "C" int32_t dmx_store_n_cells(const dmx_store* s) { return s ? (int32_t)s->barcodes.size() : 0; }
+extern "C" int32_t dmx_store_n_snps(const dmx_store* s) { return s ? s->n_snps : 0; }
+extern "C" const char* dmx_store_barcode(const dmx_store* s, int32_t cell) {
+  if (!s || cell < 0 || cell >= (int32_t)s->barcodes.size()) return nullptr;
+  return s->barcodes[cell].c_str();
+}
+
+extern "C" int dmx_store_freeze(dmx_store* s, dmx_pileup* out) {
+  if (!s || !out) return set_error(DMX_ERR_ARG, "dmx_store_freeze: null argument");
+  const int32_t B = (int32_t)s->barcodes.size();
+  if (!s->frozen) {
+    std::vector<uint32_t> ord(s->obs.size());
+    if (s->obs.size() > 0xFFFFFFFFull) return set_error(DMX_ERR_ARG, "dmx_store_freeze: more than 2^32 unique observations");
+    std::iota(ord.begin(), ord.end(), 0u);
+    const char* pool = s->umi_pool.data();
+    const std::vector<dmx_store::Obs>& obs = s->obs;
+    // cell id, then SNP id, then UMI as unsigned bytes with the shorter string first on a common prefix
+    // (== std::string::operator<, the order of the reference's std::map<std::string,uint32_t>)
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+      const dmx_store::Obs &x = obs[a], &y = obs[b];
+      if (x.cell != y.cell) return x.cell < y.cell;
+      if (x.snp != y.snp) return x.snp < y.snp;
+      const int c = std::memcmp(pool + x.umi_off, pool + y.umi_off, std::min(x.umi_len, y.umi_len));
+      if (c != 0) return c < 0;
+      return x.umi_len < y.umi_len;
+    });
+    s->cell_pair_off.assign((size_t)B + 1, 0);
+    s->cell_read_off.assign((size_t)B + 1, 0);
+    s->pair_snp.clear(); s->reads.clear();
+    std::vector<uint32_t> nrd;
+    uint32_t max_nrd = 0;
+    for (size_t i = 0; i < ord.size(); ++i) {
+      const dmx_store::Obs& o = obs[ord[i]];
+      const bool new_pair = (i == 0) || obs[ord[i - 1]].cell != o.cell || obs[ord[i - 1]].snp != o.snp;
+      if (new_pair) { s->pair_snp.push_back(o.snp); nrd.push_back(0); ++s->cell_pair_off[(size_t)o.cell + 1]; }
+      if (o.allele != 2) {            // allele 2 never enters a likelihood (cmd_cram_demuxlet.cpp:435,:604)
+        s->reads.push_back((uint8_t)((o.allele << 7) | o.bq));
+        max_nrd = std::max(max_nrd, ++nrd.back());
+        ++s->cell_read_off[(size_t)o.cell + 1];
+      }
+    }
+    for (int32_t c = 0; c < B; ++c) { s->cell_pair_off[c + 1] += s->cell_pair_off[c]; s->cell_read_off[c + 1] += s->cell_read_off[c]; }
+    s->nrd_width = max_nrd <= 0xFF ? 1 : (max_nrd <= 0xFFFF ? 2 : 4);
+    s->pair_nrd_bytes.assign(nrd.size() * (size_t)s->nrd_width + 4, 0);
+    for (size_t p = 0; p < nrd.size(); ++p) std::memcpy(&s->pair_nrd_bytes[p * (size_t)s->nrd_width], &nrd[p], (size_t)s->nrd_width); // little endian
+    s->frozen = true;
+  }
+  std::memset(out, 0, sizeof *out);
+  out->n_cells = B; out->n_snps = s->n_snps;
+  out->n_pairs = (int64_t)s->pair_snp.size(); out->n_reads = (int64_t)s->reads.size();
+  out->cell_pair_off = s->cell_pair_off.data(); out->cell_read_off = s->cell_read_off.data();
+  out->pair_snp = s->pair_snp.data(); out->pair_nrd = s->pair_nrd_bytes.data(); out->nrd_width = s->nrd_width;
+  out->memory = DMX_MEM_HOST; out->reads = s->reads.data();
+  out->rd_totl = s->totl.data(); out->rd_pass = s->pass.data(); out->rd_uniq = s->uniq.data();
+  return DMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tie arbiter: exact host re-evaluation of a few grid entries of one cell (cmd_cram_demuxlet.cpp:595-684)
+namespace dmx {
+
+static inline uint32_t nrd_at(const dmx_pileup& pl, int64_t p) {
+  const uint8_t* b = (const uint8_t*)pl.pair_nrd + (size_t)p * (size_t)pl.nrd_width;
+  uint32_t v = 0;
+  std::memcpy(&v, b, (size_t)pl.nrd_width);
+  return v;
+}
+
+void exact_grid_entries(const dmx_pileup& pl, const float* g, int32_t V, int32_t A, const double* alpha,
+                        const ReadLut& lut, int32_t cell, std::vector<GridReq>& reqs) {
+  for (GridReq& r : reqs) r.value = 0.0;
+  std::vector<double> pG((size_t)A * 9), mixR((size_t)A * 9), mixA((size_t)A * 9);
+  for (int32_t n = 0; n < A; ++n)
+    for (int l = 0; l < 3; ++l)
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * alpha[n];     // :613 expected ALT fraction
+        mixA[(size_t)n * 9 + l * 3 + m] = p;
+        mixR[(size_t)n * 9 + l * 3 + m] = 1.0 - p;
+      }
+  int64_t rd = pl.cell_read_off[cell];
+  const int64_t p0 = pl.cell_pair_off[cell], p1 = pl.cell_pair_off[cell + 1];
+  for (int64_t p = p0; p < p1; ++p) {
+    const int32_t snp = pl.pair_snp ? pl.pair_snp[p] : (int32_t)(p - p0);
+    const uint32_t nr = nrd_at(pl, p);
+    std::fill(pG.begin(), pG.end(), 1.0);
+    for (uint32_t r = 0; r < nr; ++r) {
+      const uint8_t b = pl.reads[rd + r];
+      const int al = b >> 7, bq = b & 127;
+      const double pR = (al == 0) ? lut.mat[bq] : lut.e3[bq];      // :606
+      const double pA = (al == 1) ? lut.mat[bq] : lut.e3[bq];      // :607
+      double mx = 0;
+      for (size_t q = 0; q < pG.size(); ++q) { pG[q] *= (pR * mixR[q] + pA * mixA[q]); if (mx < pG[q]) mx = pG[q]; }   // :625-627
+      for (size_t q = 0; q < pG.size(); ++q) pG[q] /= mx;                                                              // :632-639
+    }
+    rd += nr;
+    double mx = 0;
+    for (size_t q = 0; q < pG.size(); ++q) { pG[q] += 1e-6; if (mx < pG[q]) mx = pG[q]; }                              // :643-654
+    for (size_t q = 0; q < pG.size(); ++q) pG[q] /= mx;                                                                // :656-663
+    const float* gs = g + (size_t)snp * V * 3;
+    for (GridReq& r : reqs) {
+      const float* gj = gs + 3 * r.j;
+      const float* gk = gs + 3 * r.k;
+      const double* P = &pG[(size_t)r.n * 9];
+      double sum = 0;
+      for (int l = 0; l < 3; ++l)
+        for (int m = 0; m < 3; ++m) sum += ((double)gj[l] * (double)gk[m]) * P[l * 3 + m];                             // :553,:677-679
+      r.value += std::log(sum);                                                                                         // :683
+    }
+  }
+}
+
+}  // namespace dmx
+
+// ---------------------------------------------------------------------------------------------------------------------
+// a6, a10..a14  finaliser
+namespace {
+
+struct CellCall {
+  double max_llk, sum_single, sum_double;
+  int32_t i_sing1, i_sing2, j_best, k_best, n_best;
+};
+
+// One cell's grid -> the scalars every row of .sing2/.pair/.best is built from (cmd_cram_demuxlet.cpp:713-734,746-758,799-814)
+CellCall call_cell(const double* grid, int32_t V, int32_t A, const double* alpha, double prior) {
+  CellCall c;
+  const size_t n = (size_t)V * V * A;
+  c.max_llk = -1e300;
+  for (size_t q = 0; q < n; ++q) if (c.max_llk < grid[q]) c.max_llk = grid[q];
+  c.sum_single = 0; c.sum_double = 0;
+  for (int32_t j = 0; j < V; ++j) {
+    c.sum_single += (std::exp(grid[(size_t)j * V * A] - c.max_llk) * (1. - prior) / V);
+    for (int32_t k = 0; k < V; ++k) {
+      if (j == k) continue;
+      for (int32_t a = 1; a < A; ++a)
+        c.sum_double += (std::exp(grid[((size_t)j * V + k) * A + a] - c.max_llk) * prior / V / (V - 1) / (A - 1) / (alpha[a] == 0.5 ? 2.0 : 1.0));
+    }
+  }
+  c.i_sing1 = c.i_sing2 = -1;
+  double m1 = -1e300, m2 = -1e300;
+  for (int32_t j = 0; j < V; ++j) {
+    const double v = grid[(size_t)j * V * A];
+    if (m1 < v) { m2 = m1; c.i_sing2 = c.i_sing1; c.i_sing1 = j; m1 = v; }
+    else if (m2 < v) { c.i_sing2 = j; m2 = v; }
+  }
+  c.j_best = c.k_best = c.n_best = -1;
+  double mab = -1e300;
+  for (int32_t j = 0; j < V; ++j)
+    for (int32_t k = 0; k < V; ++k) {
+      if (j == k) continue;
+      for (int32_t a = 1; a < A; ++a) {
+        const double v = grid[((size_t)j * V + k) * A + a];
+        if (mab < v) { c.j_best = j; c.k_best = k; c.n_best = a; mab = v; }
+      }
+    }
+  return c;
+}
+
+std::vector<int32_t> barcode_order(const dmx_final_input* in) {
+  std::vector<int32_t> ord((size_t)in->n_cells);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::sort(ord.begin(), ord.end(), [&](int32_t a, int32_t b) { return std::strcmp(in->barcodes[a], in->barcodes[b]) < 0; });
+  return ord;
+}
+
+bool cell_filtered(const dmx_final_input* in, int32_t c) {      // :480,:581
+  return (in->rd_totl[c] < in->min_total) || (in->rd_uniq[c] < in->min_uniq) || (in->n_snp[c] < in->min_snp);
+}
+
+int check_common(const dmx_final_input* in, const char* who) {
+  if (!in) return set_error(DMX_ERR_ARG, "%s: null input", who);
+  if (in->n_cells < 0 || in->n_samples < 1) return set_error(DMX_ERR_ARG, "%s: bad sizes", who);
+  if (!in->barcodes || !in->sample_ids || !in->rd_totl || !in->rd_pass || !in->rd_uniq || !in->n_snp)
+    return set_error(DMX_ERR_ARG, "%s: missing per-cell arrays", who);
+  return DMX_OK;
+}
+
+struct File {
+  FILE* f = nullptr;
+  ~File() { if (f) fclose(f); }
+  bool open(const std::string& path) { f = fopen(path.c_str(), "w"); return f != nullptr; }
+};
+
+}  // namespace
+
+extern "C" int dmx_write_single(const dmx_final_input* in, const char* path) {
+  if (int rc = check_common(in, "dmx_write_single")) return rc;
+  if (!path || !in->llks || !in->llk0s) return set_error(DMX_ERR_ARG, "dmx_write_single: null llks/llk0s/path");
+  File w;
+  if (!w.open(path)) return set_error(DMX_ERR_IO, "Cannot create %s file", path);
+  const int32_t V = in->n_samples;
+  fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", w.f);                 // :470
+  for (int32_t c : barcode_order(in)) {
+    if (cell_filtered(in, c)) continue;
+    const double* row = in->llks + (size_t)c * V;
+    double lse = -1e300;                          // running log-sum-exp exactly as :484-489
+    for (int32_t j = 0; j < V; ++j) {
+      const double cur = row[j];
+      lse = (lse > cur) ? lse + std::log(1.0 + std::exp(cur - lse)) : cur + std::log(1.0 + std::exp(lse - cur));
+    }
+    for (int32_t j = 0; j < V; ++j)
+      fprintf(w.f, "%s\t%s\t%d\t%d\t%d\t%d\t%.5lf\t%.5lf\t%.3lg\n", in->barcodes[c], in->sample_ids[j], in->rd_totl[c],
+              in->rd_pass[c], in->rd_uniq[c], in->n_snp[c], row[j], in->llk0s[c], std::exp(row[j] - lse));   // :506-516
+  }
+  return DMX_OK;
+}
+
+extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_prefix) {
+  if (int rc = check_common(in, "dmx_write_doublet")) return rc;
+  if (!out_prefix || !in->llksAB || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "dmx_write_doublet: null grid/alpha/prefix");
+  const int32_t V = in->n_samples, A = in->n_alpha;
+  if (V < 2 || A < 2) return set_error(DMX_ERR_ARG, "dmx_write_doublet: needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
+  const std::string pre(out_prefix);
+  File sing2, pairf, best;
+  if (!sing2.open(pre + ".sing2") || !best.open(pre + ".best") || (in->write_pair && !pairf.open(pre + ".pair")))
+    return set_error(DMX_ERR_IO, "Cannot create %s.single, %s.pair files", out_prefix, out_prefix);     // :535-536
+  fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", sing2.f);             // :533
+  if (pairf.f) fputs("BARCODE\tSM1.ID\tSM2.ID\tLLK12\tPOSTPRB\n", pairf.f);                              // :570 (5 names for 6 fields: reference quirk)
+  fputs("BARCODE\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tBEST\tSNG.1ST\tSNG.LLK1\tSNG.2ND\tSNG.LLK2\tSNG.LLK0\tDBL.1ST\tDBL.2ND\tALPHA\tLLK12\tLLK1\tLLK2\tLLK10\tLLK20\tLLK00\tPRB.DBL\tPRB.SNG1\n", best.f);  // :571
+
+  const size_t ng = (size_t)V * V * A;
+  const double prior = in->doublet_prior;
+  const double tol = in->tie_tol > 0 ? in->tie_tol : 1e-7;
+  const bool arbiter = in->tie_pileup && in->tie_g;
+  dmx::ReadLut lut;
+  if (arbiter) {
+    if (in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "dmx_write_doublet: the tie arbiter needs a HOST pileup");
+    double mat[256], err[256];
+    dmx_phred_tables(mat, err);
+    dmx::build_read_lut(mat, err, &lut);
+  }
+  std::vector<double> scratch;
+  std::vector<dmx::GridReq> reqs;
+
+  for (int32_t c : barcode_order(in)) {
+    if (cell_filtered(in, c)) continue;
+    if (in->n_snp[c] == 0) continue;                                       // :592 no covered SNP: no rows
+    const double* grid = in->llksAB + (size_t)c * ng;
+    const double* l00 = in->llks00 + (size_t)c * A;
+    if (arbiter) {
+      // Which entries sit within tol of a decision?  top-2 singlets (:746-758) and the best doublet (:799-814).
+      reqs.clear();
+      double s1 = -1e300, s2 = -1e300;
+      for (int32_t j = 0; j < V; ++j) { const double v = grid[(size_t)j * V * A]; if (v > s1) { s2 = s1; s1 = v; } else if (v > s2) s2 = v; }
+      int near2 = 0;
+      for (int32_t j = 0; j < V; ++j) if (grid[(size_t)j * V * A] >= s2 - tol) ++near2;
+      if (near2 > 2 || s1 - s2 < tol)
+        for (int32_t j = 0; j < V; ++j) if (grid[(size_t)j * V * A] >= s2 - tol) reqs.push_back({j, 0, 0, 0.0});
+      double mab = -1e300;
+      for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) if (j != k) for (int32_t a = 1; a < A; ++a) mab = std::max(mab, grid[((size_t)j * V + k) * A + a]);
+      size_t nd0 = reqs.size();
+      for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) if (j != k) for (int32_t a = 1; a < A; ++a)
+        if (grid[((size_t)j * V + k) * A + a] >= mab - tol) reqs.push_back({j, k, a, 0.0});
+      if (reqs.size() - nd0 == 1) reqs.pop_back();
+      if (!reqs.empty()) {
+        dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, c, reqs);
+        scratch.assign(grid, grid + ng);
+        for (const dmx::GridReq& r : reqs) scratch[((size_t)r.j * V + r.k) * A + r.n] = r.value;
+        grid = scratch.data();
+      }
+    }
+    const CellCall cc = call_cell(grid, V, A, in->alpha, prior);
+    const char* bc = in->barcodes[c];
+    const int32_t t = in->rd_totl[c], p = in->rd_pass[c], u = in->rd_uniq[c], ns = in->n_snp[c];
+
+    for (int32_t j = 0; j < V; ++j) {                                      // :746-770 (.sing2)
+      const double v = grid[(size_t)j * V * A];
+      fprintf(sing2.f, "%s\t%s\t%d\t%d\t%d\t%d\t%.4lf\t%.4lf\t%.3lg\n", bc, in->sample_ids[j], t, p, u, ns, v, l00[0],
+              std::exp(v - cc.max_llk) * (1. - prior) / V / cc.sum_single);
+    }
+    if (pairf.f) {                                                         // :772-797 (.pair)
+      const double tot = cc.sum_single + cc.sum_double;
+      for (int32_t j = 0; j < V; ++j) {
+        const double vs = grid[(size_t)j * V * A];
+        fprintf(pairf.f, "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n", bc, in->sample_ids[j], in->sample_ids[j], in->alpha[0], vs,
+                std::exp(vs - cc.max_llk) * (1. - prior) / V / tot);
+        for (int32_t k = 0; k < V; ++k)
+          for (int32_t a = 1; a < A; ++a) {
+            if (j == k) continue;
+            if ((j > k) && (in->alpha[a] == 0.5)) continue;                // :785 symmetric half only
+            const double v = grid[((size_t)j * V + k) * A + a];
+            fprintf(pairf.f, "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n", bc, in->sample_ids[j], in->sample_ids[k], in->alpha[a], v,
+                    std::exp(v - cc.max_llk) * prior / V / (V - 1) / (A - 1) / tot);
+          }
+      }
+    }
+    // :816-874 (.best)
+    const double sing1 = grid[(size_t)cc.i_sing1 * V * A], sing2v = grid[(size_t)cc.i_sing2 * V * A], sing0 = l00[0];
+    const double l12 = grid[((size_t)cc.j_best * V + cc.k_best) * A + cc.n_best];
+    const double l1 = grid[(size_t)cc.j_best * V * A], l2 = grid[(size_t)cc.k_best * V * A];
+    const double l10 = grid[(size_t)cc.j_best * V * A + cc.n_best];        // :824 pairs with sample 0 (reference quirk)
+    const double l20 = grid[(size_t)cc.k_best * V * A + cc.n_best];        // :825
+    const double l00b = l00[cc.n_best];
+    const double post_dbl = cc.sum_double / (cc.sum_single + cc.sum_double);
+    const double post_sng = std::exp(sing1 - cc.max_llk) * (1. - prior) / V / cc.sum_single;
+    fprintf(best.f, "%s\t%d\t%d\t%d\t%d\t", bc, t, p, u, ns);
+    if ((l12 > l1) && (l12 > l2) && (l12 > sing1 + 2))                     // :837
+      fprintf(best.f, "DBL-%s-%s-%.3lf", in->sample_ids[cc.j_best], in->sample_ids[cc.k_best], in->alpha[cc.n_best]);
+    else if (sing1 > sing2v + 2)                                           // :844
+      fprintf(best.f, "SNG-%s", in->sample_ids[cc.i_sing1]);
+    else
+      fprintf(best.f, "AMB-%s-%s-%s/%s", in->sample_ids[cc.i_sing1], in->sample_ids[cc.i_sing2], in->sample_ids[cc.j_best], in->sample_ids[cc.k_best]);
+    fprintf(best.f, "\t%s\t%.4lf", in->sample_ids[cc.i_sing1], sing1);
+    fprintf(best.f, "\t%s\t%.4lf\t%.4lf", in->sample_ids[cc.i_sing2], sing2v, sing0);
+    fprintf(best.f, "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[cc.j_best],
+            in->sample_ids[cc.k_best], in->alpha[cc.n_best], l12, l1, l2, l10, l20, l00b, post_dbl, post_sng);
+  }
+  return DMX_OK;
+}

@@ -1,0 +1,26 @@
+// Internal helpers shared by the host (dmx_host.cpp) and device (dmx_engine.hip) halves of libdmx.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+#include "dmx.h"
+
+namespace dmx {
+
+int set_error(int code, const char* fmt, ...);   // records the message for dmx_last_error(), returns code
+
+// LUT in the form the kernels consume: for bq in [0,128): mat, err/3.0, 0.5-err/3.0 — the three per-read factors of
+// cmd_cram_demuxlet.cpp:437-439 / :606-607, formed on the host with the same IEEE operations the reference performs
+// per read (x/3.0 and 0.5-x are correctly rounded, so hoisting them is exact).
+struct ReadLut { double mat[128], e3[128], het[128]; };
+void build_read_lut(const double mat[256], const double err[256], ReadLut* out);
+
+// Host-side exact re-evaluation of selected doublet-grid entries of ONE cell, in the reference's operation order with
+// the host libm (tie arbiter; cmd_cram_demuxlet.cpp:595-684 restricted to the requested (j,k,n)).
+struct GridReq { int32_t j, k, n; double value; };
+void exact_grid_entries(const dmx_pileup& pl, const float* g, int32_t V, int32_t A, const double* alpha,
+                        const ReadLut& lut, int32_t cell, std::vector<GridReq>& reqs);
+
+}  // namespace dmx

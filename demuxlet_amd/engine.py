@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's interface for the likelihood path, over the C-ABI (demuxlet_amd/capi.py).
+
+Names follow the reference: `Store` is sc_dropseq_lib_t (add_snp/add_cell/add_read, sc_drop_seq.h:34-58); `Engine` runs what
+cmd_cram_demuxlet.cpp:390-734 computes; `write_single` / `write_doublet` are the writers of :465-527 and :713-875.
+Everything numerical happens in libdmx.so (HIP); this module only owns buffers and marshals pointers."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .capi import check
+
+
+def phred_tables():
+    mat, err = np.zeros(256), np.zeros(256)
+    check(capi.load().dmx_phred_tables(mat.ctypes.data, err.ctypes.data))
+    return mat, err
+
+
+def geno_from_gt(alleles, gt_error: float) -> np.ndarray:
+    a = np.ascontiguousarray(alleles, dtype=np.int32).reshape(-1, 2)
+    out = np.zeros((a.shape[0], 3), dtype=np.float32)
+    check(capi.load().dmx_geno_from_gt(a.ctypes.data, a.shape[0], gt_error, out.ctypes.data))
+    return out
+
+
+def geno_from_pl(pl) -> np.ndarray:
+    a = np.ascontiguousarray(pl, dtype=np.int32).reshape(-1, 3)
+    out = np.zeros((a.shape[0], 3), dtype=np.float32)
+    check(capi.load().dmx_geno_from_pl(a.ctypes.data, a.shape[0], out.ctypes.data))
+    return out
+
+
+def geno_from_gp(gp, gt_error: float) -> np.ndarray:
+    a = np.ascontiguousarray(gp, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros((a.shape[0], 3), dtype=np.float32)
+    check(capi.load().dmx_geno_from_gp(a.ctypes.data, a.shape[0], gt_error, out.ctypes.data))
+    return out
+
+
+@dataclass
+class HostPileup:
+    """numpy view of a dmx_pileup in host memory (arrays are kept alive by this object)."""
+    n_cells: int
+    n_snps: int
+    cell_pair_off: np.ndarray
+    cell_read_off: np.ndarray
+    pair_snp: Optional[np.ndarray]
+    pair_nrd: np.ndarray
+    reads: np.ndarray
+    rd_totl: np.ndarray
+    rd_pass: np.ndarray
+    rd_uniq: np.ndarray
+
+    def as_struct(self) -> capi.Pileup:
+        for name, dt in (("cell_pair_off", np.int64), ("cell_read_off", np.int64), ("reads", np.uint8),
+                         ("rd_totl", np.int32), ("rd_pass", np.int32), ("rd_uniq", np.int32)):
+            setattr(self, name, np.ascontiguousarray(getattr(self, name), dtype=dt))
+        if self.pair_snp is not None:
+            self.pair_snp = np.ascontiguousarray(self.pair_snp, dtype=np.int32)
+        if self.pair_nrd.dtype not in (np.uint8, np.uint16, np.uint32):
+            self.pair_nrd = self.pair_nrd.astype(np.uint32)
+        self.pair_nrd = np.ascontiguousarray(self.pair_nrd)
+        return capi.Pileup(self.n_cells, self.n_snps, len(self.pair_nrd), len(self.reads),
+                           self.cell_pair_off.ctypes.data, self.cell_read_off.ctypes.data,
+                           self.pair_snp.ctypes.data if self.pair_snp is not None else None,
+                           self.pair_nrd.ctypes.data, self.pair_nrd.dtype.itemsize, capi.DMX_MEM_HOST,
+                           self.reads.ctypes.data, self.rd_totl.ctypes.data, self.rd_pass.ctypes.data,
+                           self.rd_uniq.ctypes.data)
+
+    @property
+    def n_snp_per_cell(self) -> np.ndarray:
+        return np.diff(self.cell_pair_off).astype(np.int32)
+
+
+class Store:
+    """sc_dropseq_lib_t (sc_drop_seq.h:34-58): the UMI-deduplicated pileup, built read by read."""
+
+    def __init__(self):
+        self._L = capi.load()
+        self._h = self._L.dmx_store_new()
+        if not self._h:
+            check(-6)
+
+    def close(self):
+        if self._h:
+            self._L.dmx_store_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def add_snp(self) -> int: return check(self._L.dmx_store_add_snp(self._h))
+    def add_cell(self, barcode: str) -> int: return check(self._L.dmx_store_add_cell(self._h, barcode.encode()))
+    def count_read(self, cell: int) -> None: check(self._L.dmx_store_count_read(self._h, cell))
+
+    def add_read(self, snp: int, cell: int, umi: str, allele: int, bq: int) -> bool:
+        return bool(check(self._L.dmx_store_add_read(self._h, snp, cell, umi.encode(), allele, bq)))
+
+    @property
+    def n_cells(self) -> int: return self._L.dmx_store_n_cells(self._h)
+    @property
+    def n_snps(self) -> int: return self._L.dmx_store_n_snps(self._h)
+
+    def barcodes(self) -> List[str]:
+        return [self._L.dmx_store_barcode(self._h, i).decode() for i in range(self.n_cells)]
+
+    def freeze(self) -> HostPileup:
+        pl = capi.Pileup()
+        check(self._L.dmx_store_freeze(self._h, C.byref(pl)))
+
+        def arr(ptr, n, dt):
+            if n == 0 or not ptr:
+                return np.zeros(0, dtype=dt)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(n,)).copy()
+
+        nrd_dt = {1: np.uint8, 2: np.uint16, 4: np.uint32}[pl.nrd_width]
+        B = pl.n_cells
+        return HostPileup(B, pl.n_snps, arr(pl.cell_pair_off, B + 1, np.int64), arr(pl.cell_read_off, B + 1, np.int64),
+                          arr(pl.pair_snp, pl.n_pairs, np.int32), arr(pl.pair_nrd, pl.n_pairs, nrd_dt),
+                          arr(pl.reads, pl.n_reads, np.uint8), arr(pl.rd_totl, B, np.int32), arr(pl.rd_pass, B, np.int32),
+                          arr(pl.rd_uniq, B, np.int32))
+
+
+class Engine:
+    """The likelihood engine on one MI355X."""
+
+    def __init__(self, n_samples: int, alphas: Sequence[float] = (0.0, 0.5), doublet_prior: float = 0.5, device: int = 0):
+        self._L = capi.load()
+        self.V = int(n_samples)
+        self.alphas = np.ascontiguousarray(alphas, dtype=np.float64)
+        self.A = len(self.alphas)
+        self.prior = float(doublet_prior)
+        cfg = capi.EngineConfig(self.V, self.A, self.alphas.ctypes.data, self.prior, device, capi.DMX_MODE_STRICT)
+        h = C.c_void_p()
+        check(self._L.dmx_engine_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._keep = []
+        self.B = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.dmx_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_stream(self, hip_stream: int) -> None:
+        check(self._L.dmx_engine_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_genotypes(self, g: np.ndarray) -> None:
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        if g.ndim != 3 or g.shape[1] != self.V or g.shape[2] != 3:
+            raise ValueError(f"g must be [S][{self.V}][3]")
+        check(self._L.dmx_engine_set_genotypes(self._h, g.ctypes.data, g.shape[0], capi.DMX_MEM_HOST))
+
+    def set_genotypes_device(self, ptr: int, n_snps: int) -> None:
+        check(self._L.dmx_engine_set_genotypes(self._h, C.c_void_p(ptr), n_snps, capi.DMX_MEM_DEVICE))
+
+    def set_pileup(self, pl: HostPileup) -> None:
+        st = pl.as_struct()
+        self._keep = [pl]
+        check(self._L.dmx_engine_set_pileup(self._h, C.byref(st)))
+        self.B = pl.n_cells
+
+    def set_pileup_struct(self, st: capi.Pileup, keep=None) -> None:
+        self._keep = [keep]
+        check(self._L.dmx_engine_set_pileup(self._h, C.byref(st)))
+        self.B = st.n_cells
+
+    def run_singlet(self) -> None: check(self._L.dmx_engine_run_singlet(self._h))
+    def run_doublet(self) -> None: check(self._L.dmx_engine_run_doublet(self._h))
+    def sync(self) -> None: check(self._L.dmx_engine_sync(self._h))
+
+    def get_singlet(self):
+        llks = np.zeros((self.B, self.V))
+        llk0s = np.zeros(self.B)
+        check(self._L.dmx_engine_get_singlet(self._h, llks.ctypes.data, llk0s.ctypes.data))
+        return llks, llk0s
+
+    def get_doublet(self, want_grid: bool = True):
+        grid = np.zeros((self.B, self.V, self.V, self.A)) if want_grid else None
+        l00 = np.zeros((self.B, self.A))
+        summ = np.zeros(self.B, dtype=capi.SUMMARY_DTYPE)
+        check(self._L.dmx_engine_get_doublet(self._h, grid.ctypes.data if want_grid else None, l00.ctypes.data,
+                                             summ.ctypes.data))
+        return grid, l00, summ
+
+    def device_view(self) -> capi.DeviceView:
+        v = capi.DeviceView()
+        check(self._L.dmx_engine_device_view(self._h, C.byref(v)))
+        return v
+
+    def kernel_times(self) -> capi.KernelTimes:
+        t = capi.KernelTimes()
+        check(self._L.dmx_engine_last_kernel_times(self._h, C.byref(t)))
+        return t
+
+    def algorithmic_bytes(self) -> capi.KernelBytes:
+        b = capi.KernelBytes()
+        check(self._L.dmx_engine_algorithmic_bytes(self._h, C.byref(b)))
+        return b
+
+
+def _cstrs(strs: Sequence[str]):
+    keep = [s.encode() for s in strs]
+    arr = (C.c_char_p * max(1, len(keep)))(*keep) if keep else (C.c_char_p * 1)()
+    return arr, keep
+
+
+@dataclass
+class FinalArgs:
+    barcodes: Sequence[str]
+    sample_ids: Sequence[str]
+    alphas: Sequence[float]
+    doublet_prior: float
+    rd_totl: np.ndarray
+    rd_pass: np.ndarray
+    rd_uniq: np.ndarray
+    n_snp: np.ndarray
+    min_total: int = 0
+    min_uniq: int = 0
+    min_snp: int = 0
+    write_pair: bool = False
+
+
+def _final_struct(fa: FinalArgs, llks=None, llk0s=None, grid=None, l00=None, tie_pileup: Optional[HostPileup] = None,
+                  tie_g: Optional[np.ndarray] = None):
+    keep = []
+    alphas = np.ascontiguousarray(fa.alphas, dtype=np.float64)
+    bc, k1 = _cstrs(fa.barcodes)
+    sm, k2 = _cstrs(fa.sample_ids)
+    arrs = [np.ascontiguousarray(x, dtype=np.int32) for x in (fa.rd_totl, fa.rd_pass, fa.rd_uniq, fa.n_snp)]
+    keep += [alphas, bc, k1, sm, k2, arrs]
+
+    def p(x):
+        if x is None:
+            return None
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        keep.append(x)
+        return x.ctypes.data
+
+    tp = None
+    if tie_pileup is not None:
+        st = tie_pileup.as_struct()
+        keep += [st, tie_pileup]
+        tp = C.addressof(st)
+        tie_g = np.ascontiguousarray(tie_g, dtype=np.float32)
+        keep.append(tie_g)
+    fin = capi.FinalInput(len(fa.barcodes), len(fa.sample_ids), len(alphas), alphas.ctypes.data, fa.doublet_prior,
+                          fa.min_total, fa.min_uniq, fa.min_snp, int(fa.write_pair), C.cast(bc, C.c_void_p),
+                          C.cast(sm, C.c_void_p), arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
+                          arrs[3].ctypes.data, p(llks), p(llk0s), p(grid), p(l00), tp,
+                          tie_g.ctypes.data if tie_pileup is not None else None, 0.0)
+    return fin, keep
+
+
+def write_single(fa: FinalArgs, llks, llk0s, path: str) -> None:
+    fin, keep = _final_struct(fa, llks=llks, llk0s=llk0s)
+    check(capi.load().dmx_write_single(C.byref(fin), path.encode()))
+
+
+def write_doublet(fa: FinalArgs, grid, l00, out_prefix: str, tie_pileup: Optional[HostPileup] = None,
+                  tie_g: Optional[np.ndarray] = None) -> None:
+    fin, keep = _final_struct(fa, grid=grid, l00=l00, tie_pileup=tie_pileup, tie_g=tie_g)
+    check(capi.load().dmx_write_doublet(C.byref(fin), out_prefix.encode()))
+
+
+def demuxlet_run(store: Store, g: np.ndarray, sample_ids: Sequence[str], alphas: Sequence[float], out_prefix: str,
+                 doublet_prior: float = 0.5, min_total: int = 0, min_uniq: int = 0, min_snp: int = 0,
+                 write_pair: bool = False, device: int = 0, arbiter: bool = True) -> None:
+    """cmd_cram_demuxlet.cpp:390-881 in one call (dmx_demuxlet_run)."""
+    g = np.ascontiguousarray(g, dtype=np.float32)
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    sm, keep = _cstrs(sample_ids)
+    job = capi.Job(store.handle, g.ctypes.data, g.shape[1], C.cast(sm, C.c_void_p), len(al), al.ctypes.data, doublet_prior,
+                   min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter))
+    check(capi.load().dmx_demuxlet_run(C.byref(job)))

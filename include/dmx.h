@@ -1,0 +1,207 @@
+/* dmx.h — C-ABI of libdmx, the MI355X-native (gfx950, HIP) replacement for demuxlet's per-barcode
+ * genotype-likelihood engine.
+ *
+ * The reference (statgen/demuxlet) has no plugin/FFI interface: the engine is inline in main()
+ * (cmd_cram_demuxlet.cpp:390-881) between two in-memory cuts:
+ *     B1  after the BAM x VCF scan:  sc_dropseq_lib_t scl (sc_drop_seq.h:34-58) + per-SNP genotype probabilities
+ *     B2  before the text writers:   llks[B][V], llk0s[B], llksAB[V][V][A] per cell, llks00[A] per cell
+ * This header IS that boundary.  Every entry point names the reference lines it replaces.  A maintainer keeps
+ * cmd_cram_demuxlet.cpp:1-388 (options, htslib scan) and replaces :390-881 by the calls shown in INTEGRATION.md.
+ *
+ * Conventions: plain C, plain pointers and sizes, no C++/torch types.  Every function returns DMX_OK (0) or a negative
+ * dmx_status; dmx_last_error() gives the message of the last failure on the calling thread.  The library never exits
+ * or throws across the ABI (the reference's error() prints and throws, Error.cpp:27-41; the caller decides).
+ * Handles are not thread-safe; one engine drives one GPU on one HIP stream.  There is NO CPU fallback: engine entry
+ * points fail with DMX_ERR_NOGPU / DMX_ERR_HIP when no gfx950 device is usable.
+ */
+#ifndef DMX_H
+#define DMX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMX_ABI_VERSION 1
+
+typedef enum {
+  DMX_OK = 0,
+  DMX_ERR_ARG = -1,      /* bad argument / precondition (e.g. n_samples < 2 for the doublet stage, cmd_cram_demuxlet.cpp:731,:821) */
+  DMX_ERR_HIP = -2,      /* a HIP runtime call failed */
+  DMX_ERR_STATE = -3,    /* call order (e.g. run before set_pileup) */
+  DMX_ERR_IO = -4,       /* cannot create an output file (cmd_cram_demuxlet.cpp:409-410,:535-536) */
+  DMX_ERR_NOGPU = -5,    /* no usable gfx950 device */
+  DMX_ERR_NOMEM = -6
+} dmx_status;
+
+enum { DMX_MEM_HOST = 0, DMX_MEM_DEVICE = 1 };
+
+int         dmx_abi_version(void);
+const char* dmx_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a2  phred LUT — replaces the global phredConv (PhredHelper.cpp:24-40): err[q] = q>1 ? pow(0.1, q*0.1) : 0.75,
+ *     mat[q] = 1-err[q].  Computed with the HOST libm so that the device uses the very doubles the reference would. */
+int dmx_phred_tables(double mat[256], double err[256]);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a3  genotype FORMAT field -> float32 probability triplets (replaces BCFFilteredReader::parse_posteriors,
+ *     bcf_filtered_reader.cpp:360-454, parse_genotypes :186-242, parse_likelihoods :244-320) for one biallelic,
+ *     diploid record.  Inputs are the raw htslib arrays restricted to the selected samples:
+ *       alleles[2*i+h]  allele index (bcf_gt_allele) of haplotype h, or -1 when missing
+ *       pl[3*i+g]       PL integers (INT32_MIN = bcf_int32_missing)
+ *       gp[3*i+g]       GP floats
+ *     out[3*i+g] is what get_posterior_at(3*i+g) would return (bcf_filtered_reader.h:159-161). */
+int dmx_geno_from_gt(const int32_t* alleles, int32_t n_samples, double gt_error, float* out);
+int dmx_geno_from_pl(const int32_t* pl, int32_t n_samples, float* out);      /* --geno-error is not used on the PL path */
+int dmx_geno_from_gp(const float* gp, int32_t n_samples, double gt_error, float* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a1  UMI-deduplicated pileup store — replaces sc_dropseq_lib_t (sc_drop_seq.h:34-58, sc_drop_seq.cpp:3-77).
+ *     Same call sequence as the reference's scan loop: add_snp per VCF record (:184,:231), add_cell per read (:262),
+ *     count_read per read (:295 ++cell_totl_reads), add_read per (read, overlapping SNP) (:325).
+ *     add_read returns 1 when the (snp,cell,umi) key is new (first observation wins), 0 for a duplicate
+ *     (sc_drop_seq.cpp:44,53,57), <0 on error. */
+typedef struct dmx_store dmx_store;
+dmx_store* dmx_store_new(void);
+void       dmx_store_free(dmx_store*);
+int32_t    dmx_store_add_snp(dmx_store*);                              /* returns the new snp id */
+int32_t    dmx_store_add_cell(dmx_store*, const char* barcode);        /* returns the (new or existing) cell id */
+int        dmx_store_count_read(dmx_store*, int32_t cell);
+int        dmx_store_add_read(dmx_store*, int32_t snp, int32_t cell, const char* umi, int32_t allele, int32_t bq);
+int32_t    dmx_store_n_cells(const dmx_store*);
+int32_t    dmx_store_n_snps(const dmx_store*);
+const char* dmx_store_barcode(const dmx_store*, int32_t cell);
+
+/* The pileup in the layout the GPU consumes (SoA/CSR).  Cells are in id order; a cell's pairs are in ascending SNP id
+ * (iteration order of std::map<int32_t,...>, cmd_cram_demuxlet.cpp:595); a pair's reads are in ascending UMI byte
+ * order (std::map<std::string,...>, :428,:600) because the per-read renormalisation makes that order observable.
+ * Reads with allele 2 ("neither REF nor ALT") are not stored: both likelihood loops skip them (:435,:604); they still
+ * create their pair (N.SNP) and count in the read counters. */
+typedef struct {
+  int32_t  n_cells, n_snps;
+  int64_t  n_pairs, n_reads;
+  const int64_t* cell_pair_off;   /* [n_cells+1] first pair of each cell */
+  const int64_t* cell_read_off;   /* [n_cells+1] first read byte of each cell */
+  const int32_t* pair_snp;        /* [n_pairs] SNP id, or NULL = dense layout (every cell has n_snps pairs, pair t is SNP t) */
+  const void*    pair_nrd;        /* [n_pairs] stored reads of the pair, nrd_width bytes each */
+  int32_t        nrd_width;       /* 1, 2 or 4 */
+  int32_t        memory;          /* DMX_MEM_HOST or DMX_MEM_DEVICE — where ALL the arrays above and below live */
+  const uint8_t* reads;           /* [n_reads] (allele<<7)|bq, allele in {0,1}, bq <= 127 */
+  /* per-cell counters of the pileup stage; host memory always; only the finaliser reads them (may be NULL for dmx_engine_*) */
+  const int32_t *rd_totl, *rd_pass, *rd_uniq;   /* RD.TOTL (:295) RD.PASS (sc_drop_seq.cpp:39) RD.UNIQ (:75) */
+} dmx_pileup;
+
+/* Freeze the store into a dmx_pileup (host memory, owned by the store, valid until the next add_* or free). */
+int dmx_store_freeze(dmx_store*, dmx_pileup* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a4,a5,a7,a8,a9,a10  the likelihood engine on one MI355X — replaces cmd_cram_demuxlet.cpp:390-401 (gp0s), :412-461
+ *     (singlet accumulation), :542-560 (pair tables, never materialised) and :576-734 (doublet grid + per-cell sums). */
+typedef struct dmx_engine dmx_engine;
+
+typedef struct {
+  int32_t n_samples;           /* V  = vr.get_nsamples() */
+  int32_t n_alpha;             /* A  = gridAlpha.size(); alpha[0] is the singlet entry whatever its value (:726,:730) */
+  const double* alpha;         /* [A] */
+  double  doublet_prior;       /* --doublet-prior */
+  int32_t device;              /* HIP device ordinal */
+  int32_t mode;                /* DMX_MODE_STRICT (0): reference operation order, no FMA contraction, IEEE division */
+  int32_t reserved[4];
+} dmx_engine_config;
+enum { DMX_MODE_STRICT = 0 };
+
+/* per-cell result of the device-side reduction (K3) — what :713-734 and :746-770,:799-828 derive from one cell's grid */
+typedef struct {
+  double  max_llk;             /* :713-721 */
+  double  sum_single;          /* :726 */
+  double  sum_double;          /* :728-733 */
+  double  sing_llk1, sing_llk2;/* llksAB[iSing1][0][0], llksAB[iSing2][0][0]  (:816-817) */
+  double  llk12, llk1, llk2, llk10, llk20;   /* :820-825 */
+  double  llk00_0, llk00_best; /* llks00[0] (:819), llks00[alphaBest] (:826) */
+  int32_t i_sing1, i_sing2;    /* :746-758 (first maximum wins; second = first maximum of the rest) */
+  int32_t j_best, k_best, n_best;            /* :799-814 (strict <: lowest (j,k,n) scan index among equal maxima) */
+  int32_t n_pairs;             /* N.SNP of the cell; 0 => the cell has no .best row (:592) */
+} dmx_cell_summary;
+
+int dmx_engine_create(const dmx_engine_config*, dmx_engine** out);
+int dmx_engine_destroy(dmx_engine*);
+/* Run every later launch/copy on this hipStream_t (e.g. torch's current stream). NULL = the engine's own stream. */
+int dmx_engine_set_stream(dmx_engine*, void* hip_stream);
+/* The phred LUT (host doubles from dmx_phred_tables, or the caller's own). Optional: defaults to dmx_phred_tables. */
+int dmx_engine_set_phred_tables(dmx_engine*, const double mat[256], const double err[256]);
+/* g[n_snps][n_samples][3] float32 (HOST or DEVICE memory). Also computes gp0s[n_snps][3] on the device (:390-401). */
+int dmx_engine_set_genotypes(dmx_engine*, const float* g, int32_t n_snps, int32_t memory);
+/* Stage the pileup: HOST arrays are copied to HBM; DEVICE arrays are adopted (caller keeps them alive). */
+int dmx_engine_set_pileup(dmx_engine*, const dmx_pileup*);
+/* K1: llks[B][V], llk0s[B] (:412-461).  Asynchronous on the engine's stream. */
+int dmx_engine_run_singlet(dmx_engine*);
+/* K2 (+K3): llksAB[B][V][V][A], llks00[B][A] (:576-710) and the per-cell summaries (:713-734,:746-758,:799-828). */
+int dmx_engine_run_doublet(dmx_engine*);
+int dmx_engine_sync(dmx_engine*);
+/* Device->host copies of the results (any pointer may be NULL). Synchronises. */
+int dmx_engine_get_singlet(dmx_engine*, double* llks, double* llk0s);
+int dmx_engine_get_doublet(dmx_engine*, double* llksAB, double* llks00, dmx_cell_summary* summary);
+
+/* Device views for zero-copy hand-off (torch tensors over them, RCCL gather of the per-cell records). */
+typedef struct {
+  double* llks;  double* llk0s;  double* llksAB;  double* llks00;  dmx_cell_summary* summary;  double* gp0s;
+} dmx_device_view;
+int dmx_engine_device_view(dmx_engine*, dmx_device_view* out);
+
+/* HIP-event timing of the last launch of each kernel on the engine's stream, in milliseconds (0 when not run). */
+typedef struct { float gp0_ms, singlet_ms, doublet_ms, reduce_ms; } dmx_kernel_times;
+int dmx_engine_last_kernel_times(dmx_engine*, dmx_kernel_times* out);
+/* Algorithmic HBM bytes one launch of each kernel must move for the staged problem. */
+typedef struct { double singlet_bytes, doublet_bytes, reduce_bytes; } dmx_kernel_bytes;
+int dmx_engine_algorithmic_bytes(dmx_engine*, dmx_kernel_bytes* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * a6,a10..a14  finaliser and writers — replaces cmd_cram_demuxlet.cpp:465-527 (.single), :713-875 (.sing2/.pair/.best).
+ *     Rows come out in ascending byte-wise barcode order (std::map<std::string,int32_t>, :472,:576); cells failing
+ *     --min-total/--min-uniq/--min-snp are skipped (:480,:581); cells without any covered SNP get .single rows only
+ *     (:592).  All arrays are HOST memory. */
+typedef struct {
+  int32_t n_cells, n_samples, n_alpha;
+  const double* alpha;
+  double  doublet_prior;
+  int32_t min_total, min_uniq, min_snp;
+  int32_t write_pair;
+  const char* const* barcodes;     /* [n_cells] by cell id */
+  const char* const* sample_ids;   /* [n_samples] */
+  const int32_t *rd_totl, *rd_pass, *rd_uniq, *n_snp;   /* [n_cells] */
+  const double* llks;              /* [n_cells][V]       (for .single) */
+  const double* llk0s;             /* [n_cells] */
+  const double* llksAB;            /* [n_cells][V][V][A] (for .sing2/.pair/.best) */
+  const double* llks00;            /* [n_cells][A] */
+  /* Optional tie arbiter: with the host pileup and genotype matrix present, grid entries within
+   * tie_tol of a decision (top-2 singlets, best doublet) are re-evaluated on the host in the reference's exact
+   * operation order with the host libm before the strict-< scans run, so DBL-a-b vs DBL-b-a follows the reference. */
+  const dmx_pileup* tie_pileup;    /* NULL = no arbiter */
+  const float*  tie_g;             /* [n_snps][V][3] */
+  double  tie_tol;                 /* 0 = default 1e-7 */
+} dmx_final_input;
+
+int dmx_write_single(const dmx_final_input*, const char* path);                    /* <out>.single */
+int dmx_write_doublet(const dmx_final_input*, const char* out_prefix);            /* <out>.sing2, <out>.best, [<out>.pair] */
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * One call for the whole of cmd_cram_demuxlet.cpp:390-881: store + genotype matrix + options in, four files out. */
+typedef struct {
+  dmx_store*   store;
+  const float* g;                  /* [n_snps][V][3], HOST */
+  int32_t      n_samples;
+  const char* const* sample_ids;
+  int32_t      n_alpha;  const double* alpha;
+  double       doublet_prior;
+  int32_t      min_total, min_uniq, min_snp, write_pair;
+  const char*  out_prefix;
+  int32_t      device;
+  int32_t      arbiter;            /* 1 = run the tie arbiter (default in the CLI) */
+} dmx_job;
+int dmx_demuxlet_run(const dmx_job*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
