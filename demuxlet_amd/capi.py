@@ -25,7 +25,7 @@ SYMBOLS = [
     "dmx_engine_set_genotypes", "dmx_engine_set_pileup", "dmx_engine_run_singlet", "dmx_engine_run_doublet",
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
-    "dmx_demuxlet_run",
+    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div",
 ]
 
 
@@ -99,6 +99,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Load torch FIRST so that libdmx.so binds to
+        # that copy: two HIP runtimes in one process leave whichever comes second without a device.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not LIB_PATH.exists():
         raise DmxError(-100, f"{LIB_PATH} is missing — build it with `python -m demuxlet_amd.build` (hipcc, gfx950)")
     L = C.CDLL(str(LIB_PATH))
@@ -117,6 +123,8 @@ def load() -> C.CDLL:
         "dmx_engine_get_doublet": [vp, vp, vp, vp], "dmx_engine_device_view": [vp, vp],
         "dmx_engine_last_kernel_times": [vp, vp], "dmx_engine_algorithmic_bytes": [vp, vp],
         "dmx_write_single": [vp, C.c_char_p], "dmx_write_doublet": [vp, C.c_char_p], "dmx_demuxlet_run": [vp],
+        "dmx_debug_device_log": [vp, vp, C.c_int64, i32],
+        "dmx_debug_device_div": [vp, vp, vp, C.c_int64, i32],
     }
     for name, args in sig.items():
         f = getattr(L, name)

@@ -37,6 +37,7 @@ namespace {
 
 struct PileupView {
   int32_t B, S;
+  int64_t R;                   // total read bytes
   const int64_t* cell_pair_off;
   const int64_t* cell_read_off;
   const int32_t* pair_snp;     // nullptr = dense
@@ -46,6 +47,7 @@ struct PileupView {
 
 constexpr int kThreads = 256;
 constexpr int kLut = 3 * 128;   // mat | err/3 | 0.5-err/3
+constexpr int kTab = kLut + DMX_LOG_TABLE_DOUBLES;   // device table buffer: read LUT, then dmx_log's {invc,logc} table
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void k_gp0(const float* __restrict__ g, int32_t S, int32_t V, double* __restrict__ gp0) {
@@ -60,37 +62,90 @@ __global__ void k_gp0(const float* __restrict__ g, int32_t S, int32_t V, double*
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// per-read update of the three singlet genotype likelihoods with sum-renormalisation (:437-443)
-__device__ __forceinline__ void gl_read(double& G0, double& G1, double& G2, uint32_t byte, const double* s_lut) {
-  const uint32_t bq = byte & 127u;
-  const bool alt = (byte >> 7) != 0;
-  const double m = s_lut[bq], e3 = s_lut[128 + bq], h = s_lut[256 + bq];
-  G0 *= alt ? e3 : m;
-  G1 *= h;
-  G2 *= alt ? m : e3;
-  const double tmp = G0 + G1 + G2;
-  G0 /= tmp; G1 /= tmp; G2 /= tmp;
+// IEEE-754 binary64 division with the reciprocal refinement shared between several numerators of one denominator.
+// This is, operation for operation, the sequence the compiler emits for `a / b` (v_rcp_f64, two Newton steps, quotient,
+// residual, correction) minus v_div_scale / v_div_fmas-scaling / v_div_fixup, which only act when an exponent is
+// extreme; callers guarantee 2^-700 < a,b < 2^700 (otherwise they use the plain `/`).  Correctly rounded, so
+// bit-identical to the reference's x86 divsd (checked on the device by dmx_debug_device_div).
+__device__ __forceinline__ double rcp_refined(double b) {
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  return y;
+}
+__device__ __forceinline__ double div_by(double a, double b, double y) {
+  const double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  return __builtin_fma(r, y, q);
 }
 
-// K1.  A workgroup owns C cells for their whole SNP range.  Per tile of T = 256/C SNP-pairs per cell:
-//   compute phase  lane (cell ci, pair ti): GL of its pair, then the V+1 log terms of that pair, KC samples at a time,
-//                  into LDS;
-//   sum phase      lane (cell ci, sample k) adds the tile's T terms of its accumulator in pair order.
-template <typename NRD, int C, int NCH>
-__global__ __launch_bounds__(kThreads) void k_singlet(PileupView pv, const float* __restrict__ g,
-                                                      const double* __restrict__ gp0, const double* __restrict__ lut,
+constexpr uint32_t kSafeReads = 15;   // each read scales a likelihood by >= err(127)/3 > 2^-44: 15 reads stay above 2^-700
+
+// the three singlet genotype likelihoods of one covered pair (:427-452): per read multiply, then renormalise to sum 1
+__device__ __forceinline__ void pair_gl(const uint8_t* __restrict__ rd, uint32_t n, const double* s_lut, double& G0,
+                                        double& G1, double& G2) {
+  G0 = 1.0; G1 = 1.0; G2 = 1.0;                                            // :427
+  const bool safe = n <= kSafeReads;
+  for (uint32_t r = 0; r < n; ++r) {
+    const uint32_t byte = rd[r];
+    const uint32_t bq = byte & 127u;
+    const bool alt = (byte >> 7) != 0;
+    const double m = s_lut[bq], e3 = s_lut[128 + bq], h = s_lut[256 + bq];
+    G0 *= alt ? e3 : m;                                                    // :437
+    G1 *= h;                                                               // :438
+    G2 *= alt ? m : e3;                                                    // :439
+    const double tmp = G0 + G1 + G2;                                       // :440
+    if (safe) {
+      const double y = rcp_refined(tmp);
+      G0 = div_by(G0, tmp, y); G1 = div_by(G1, tmp, y); G2 = div_by(G2, tmp, y);   // :441-443
+    } else {
+      G0 /= tmp; G1 /= tmp; G2 /= tmp;
+    }
+  }
+  G0 += 1e-6; G1 += 1e-6; G2 += 1e-6;                                      // :446-448
+  const double tmp = G0 + G1 + G2;
+  const double y = rcp_refined(tmp);                                       // numerators >= 1e-6, tmp ~ 1
+  G0 = div_by(G0, tmp, y); G1 = div_by(G1, tmp, y); G2 = div_by(G2, tmp, y);       // :449-452
+}
+
+__device__ __forceinline__ uint32_t load_nrd(const void* __restrict__ base, int64_t p, int width) {
+  if (width == 1) return ((const uint8_t*)base)[p];
+  if (width == 2) return ((const uint16_t*)base)[p];
+  return ((const uint32_t*)base)[p];
+}
+
+// K1.  A workgroup owns C cells for their whole SNP range.  Per tile of T = 256/C SNP-pairs per cell and per chunk of
+// KC of the V+1 accumulators of a cell (V samples + the average-genotype model, row V of gd):
+//   compute  lane (cell ci, pair ti): GL of its pair (once per tile), then the chunk's KC log terms -> LDS (double-buffered)
+//   sum      lane (cell ci, accumulator kk): adds the tile's T terms of its accumulator in ascending pair order.
+// One barrier per (tile, chunk): a lane can only overwrite buffer b two steps later, i.e. after the barrier of the step
+// in between, which every lane passes only after finishing its sums on b.
+// The pair headers (read count, SNP id) and the first four read bytes of the NEXT tile are fetched while the current
+// one is computed, and all genotype rows of a chunk are loaded before the first log, so no global-memory latency sits
+// on the dependent path.
+struct TileHdr { uint32_t n; int32_t snp; };
+
+template <int C, int KC>
+__global__ __launch_bounds__(kThreads) void k_singlet(PileupView pv, int nrd_width, const double* __restrict__ gd,
+                                                      const double* __restrict__ tabs,
                                                       const int32_t* __restrict__ sched, int32_t V,
                                                       double* __restrict__ llks, double* __restrict__ llk0s) {
   constexpr int T = kThreads / C;
-  constexpr int KC = 16;
-  constexpr int LD = KC + 1;
+  constexpr int LD = KC | 1;                   // odd row stride (in doubles): conflict-free 8-byte stores across lanes
   static_assert(T <= 64 && (64 % T) == 0, "a cell's tile segment must sit inside one wavefront");
-  __shared__ double s_lut[kLut];
-  __shared__ double s_term[kThreads * LD];
+  static_assert(C * KC <= kThreads, "one lane per accumulator of a chunk");
+  extern __shared__ double s_dyn[];            // [nch][C*KC] running accumulators of all chunks
+  __shared__ double s_tab[kTab];
+  __shared__ double s_term[2][kThreads * LD];
   __shared__ int64_t s_np[C];
+  const double* s_log = s_tab + kLut;
 
   const int t = threadIdx.x;
-  for (int i = t; i < kLut; i += kThreads) s_lut[i] = lut[i];
+  const int nch = (V + 1 + KC - 1) / KC;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  for (int i = t; i < nch * C * KC; i += kThreads) s_dyn[i] = 0.0;
 
   const int ci = t / T, ti = t % T;
   const int slot = blockIdx.x * C + ci;
@@ -105,77 +160,147 @@ __global__ __launch_bounds__(kThreads) void k_singlet(PileupView pv, const float
 #pragma unroll
   for (int c = 0; c < C; ++c) max_np = max(max_np, s_np[c]);
 
-  // sum-phase identity: lane a < C*KC owns (cell a/KC, sample-in-chunk a%KC) of every chunk
+  // sum-phase identity: lane a < C*KC owns accumulator (cell a/KC, slot a%KC) of every chunk
   const int a_ci = t / KC, a_kk = t % KC;
-  const bool a_lane = t < C * KC;
-  const int a_slot = blockIdx.x * C + a_ci;
-  const bool a_ok = a_lane && a_slot < pv.B;
-  const int32_t a_cell = a_ok ? sched[a_slot] : 0;
+  const bool a_ok = (t < C * KC) && (blockIdx.x * C + a_ci < pv.B);
   const int64_t a_np = a_ok ? s_np[a_ci] : 0;
-  double acc[NCH];
-#pragma unroll
-  for (int q = 0; q < NCH; ++q) acc[q] = 0.0;
+  const size_t row_stride = (size_t)(V + 1) * 3;
 
-  const NRD* __restrict__ nrd = (const NRD*)pv.pair_nrd;
-
-  for (int64_t tile = 0; tile * T < max_np; ++tile) {
+  auto load_hdr = [&](int64_t tile) {
+    TileHdr h;
     const int64_t pi = tile * T + ti;
-    const bool valid = pi < np;
-    const uint32_t n = valid ? (uint32_t)nrd[p_beg + pi] : 0u;
+    const bool v = pi < np;
+    h.n = v ? load_nrd(pv.pair_nrd, p_beg + pi, nrd_width) : 0u;
+    h.snp = v ? (pv.pair_snp ? pv.pair_snp[p_beg + pi] : (int32_t)pi) : 0;
+    return h;
+  };
+  auto scan_offsets = [&](uint32_t n, int64_t& off) {     // exclusive prefix of the read counts inside the cell's segment
     uint32_t incl = n;
 #pragma unroll
     for (int d = 1; d < T; d <<= 1) {
       const uint32_t y = __shfl_up(incl, d, T);
       if (ti >= d) incl += y;
     }
-    const uint32_t tot = __shfl(incl, T - 1, T);
-    const int64_t off = rd_base + (int64_t)(incl - n);
-    rd_base += tot;
-    const int32_t snp = valid ? (pv.pair_snp ? pv.pair_snp[p_beg + pi] : (int32_t)pi) : 0;
-
-    double G0 = 1.0, G1 = 1.0, G2 = 1.0;                                   // :427
-    for (uint32_t r = 0; r < n; ++r) gl_read(G0, G1, G2, pv.reads[off + r], s_lut);
-    G0 += 1e-6; G1 += 1e-6; G2 += 1e-6;                                    // :446-448
-    {
-      const double tmp = G0 + G1 + G2;
-      G0 /= tmp; G1 /= tmp; G2 /= tmp;                                     // :449-452
+    off = rd_base + (int64_t)(incl - n);
+    rd_base += __shfl(incl, T - 1, T);
+  };
+  auto load_rd4 = [&](uint32_t n, int64_t off) {          // first four read bytes (little endian), 0 beyond n
+    uint32_t w = 0;
+    if (n > 0) {
+      if (off + 4 <= pv.R) {
+        __builtin_memcpy(&w, pv.reads + off, 4);      // bytes past the pair's own reads are never interpreted
+      } else {
+        for (int64_t i = off; i < pv.R; ++i) w |= (uint32_t)pv.reads[i] << (8 * (int)(i - off));
+      }
     }
-    const float* __restrict__ grow = g + (size_t)snp * V * 3;
-    const double* __restrict__ g0row = gp0 + (size_t)snp * 3;
+    return w;
+  };
 
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
+  TileHdr hdr = load_hdr(0);
+  int64_t off = 0;
+  scan_offsets(hdr.n, off);
+  uint32_t rd4 = load_rd4(hdr.n, off);
+
+  int step = 0;
+  for (int64_t tile = 0; tile * T < max_np; ++tile) {
+    const bool valid = tile * T + ti < np;
+    const uint32_t n = hdr.n;
+    const int32_t snp = hdr.snp;
+    const uint32_t cur4 = rd4;
+    const int64_t cur_off = off;
+    // ---- prefetch the next tile's header and leading read bytes
+    hdr = load_hdr(tile + 1);
+    scan_offsets(hdr.n, off);
+    rd4 = load_rd4(hdr.n, off);
+
+    // ---- genotype likelihoods of this lane's pair (:427-452)
+    double G0 = 1.0, G1 = 1.0, G2 = 1.0;
+    {
+      const bool safe = n <= kSafeReads;
+      for (uint32_t r = 0; r < n; ++r) {
+        const uint32_t byte = (r < 4) ? ((cur4 >> (8 * r)) & 0xFFu) : (uint32_t)pv.reads[cur_off + r];
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double m = s_tab[bq], e3 = s_tab[128 + bq], h = s_tab[256 + bq];
+        G0 *= alt ? e3 : m;                                                // :437
+        G1 *= h;                                                           // :438
+        G2 *= alt ? m : e3;                                                // :439
+        const double tmp = G0 + G1 + G2;                                   // :440
+        if (safe) {
+          const double y = rcp_refined(tmp);
+          G0 = div_by(G0, tmp, y); G1 = div_by(G1, tmp, y); G2 = div_by(G2, tmp, y);   // :441-443
+        } else {
+          G0 /= tmp; G1 /= tmp; G2 /= tmp;
+        }
+      }
+      G0 += 1e-6; G1 += 1e-6; G2 += 1e-6;                                  // :446-448
+      const double tmp = G0 + G1 + G2;
+      const double y = rcp_refined(tmp);
+      G0 = div_by(G0, tmp, y); G1 = div_by(G1, tmp, y); G2 = div_by(G2, tmp, y);       // :449-452
+    }
+    const double* __restrict__ grow = gd + (size_t)snp * row_stride;
+    const int64_t left = a_np - tile * T;
+    const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
+
+    for (int q = 0; q < nch; ++q, ++step) {
+      double* buf = s_term[step & 1];
       if (valid) {
+        const int k0 = q * KC;
+        double a[KC][3];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {        // all loads of the chunk first; slots past row V re-read row V (ignored)
+          const int k = min(k0 + kk, V);
+          a[kk][0] = grow[k * 3]; a[kk][1] = grow[k * 3 + 1]; a[kk][2] = grow[k * 3 + 2];
+        }
+        uint32_t special = 0;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-          const int k = q * KC + kk;
-          if (k < V) {
-            const double a0 = (double)grow[k * 3], a1 = (double)grow[k * 3 + 1], a2 = (double)grow[k * 3 + 2];
-            s_term[t * LD + kk] = dmx_log(G0 * a0 + G1 * a1 + G2 * a2);     // :456
-          } else if (k == V) {
-            s_term[t * LD + kk] = dmx_log(G0 * g0row[0] + G1 * g0row[1] + G2 * g0row[2]);   // :459
-          }
+          const double x = G0 * a[kk][0] + G1 * a[kk][1] + G2 * a[kk][2];   // :456 / :459
+          const bool sp = dmx_log_is_special(x);
+          special |= sp ? (1u << kk) : 0u;
+          buf[t * LD + kk] = sp ? x : dmx_log_fast(x, s_log);
+        }
+        if (__builtin_expect(special != 0, 0)) {   // never for real likelihoods; keeps log(0), log(nan) semantics
+          for (int kk = 0; kk < KC; ++kk)
+            if ((special >> kk) & 1u) buf[t * LD + kk] = log(buf[t * LD + kk]);
         }
       }
       __syncthreads();
       if (a_ok && q * KC + a_kk <= V) {
-        const int64_t left = a_np - tile * T;
-        const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
-        const double* col = &s_term[(a_ci * T) * LD + a_kk];
-        double s = acc[q];
-        for (int i = 0; i < cnt; ++i) s += col[i * LD];                    // ascending SNP order: the reference's order
-        acc[q] = s;
+        const double* col = &buf[(a_ci * T) * LD + a_kk];
+        double s = s_dyn[q * (C * KC) + t];
+        int i = 0;
+        for (; i + 16 <= cnt; i += 16) {          // loads first (LDS latency paid once), then the ordered adds
+          double v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = col[(i + j) * LD];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) s += v[j];
+        }
+        for (; i < cnt; ++i) s += col[i * LD];    // ascending SNP order: the reference's order
+        s_dyn[q * (C * KC) + t] = s;
       }
-      __syncthreads();
     }
   }
   if (a_ok) {
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
+    const int32_t a_cell = sched[blockIdx.x * C + a_ci];
+    for (int q = 0; q < nch; ++q) {
       const int k = q * KC + a_kk;
-      if (k < V) llks[(size_t)a_cell * V + k] = acc[q];
-      else if (k == V) llk0s[a_cell] = acc[q];
+      const double s = s_dyn[q * (C * KC) + t];
+      if (k < V) llks[(size_t)a_cell * V + k] = s;
+      else if (k == V) llk0s[a_cell] = s;
     }
+  }
+}
+
+// gd[s][k][l] = (double) g[s][k][l] for k < V, gp0s[s][l] for k == V: the genotype rows the singlet kernel streams
+__global__ void k_build_gd(const float* __restrict__ g, const double* __restrict__ gp0, int32_t S, int32_t V,
+                           double* __restrict__ gd) {
+  const int64_t n = (int64_t)S * (V + 1) * 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = i / ((V + 1) * 3);
+    const int r = (int)(i % ((V + 1) * 3));
+    gd[i] = (r < V * 3) ? (double)g[(size_t)s * V * 3 + r] : gp0[(size_t)s * 3 + (r - V * 3)];
   }
 }
 
@@ -194,14 +319,15 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
                                                               const int32_t* __restrict__ sched, int32_t V, int32_t A,
                                                               int32_t A_pad, int32_t TP, double* __restrict__ grid,
                                                               double* __restrict__ l00) {
-  __shared__ double s_lut[kLut];
+  __shared__ double s_lut[kTab];
   __shared__ double s_pG[kThreads * 9];
   __shared__ int32_t s_snp[32];
   __shared__ uint32_t s_cnt[32];
   __shared__ int64_t s_off[32];
 
   const int t = threadIdx.x;
-  for (int i = t; i < kLut; i += kThreads) s_lut[i] = lut[i];
+  for (int i = t; i < kTab; i += kThreads) s_lut[i] = lut[i];
+  const double* s_log = s_lut + kLut;
   const int32_t cell = sched[blockIdx.x];
   const int64_t p_beg = pv.cell_pair_off[cell];
   const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
@@ -227,7 +353,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
   // phase-2 identity
   const int32_t nAB = V * V * A;
   const int32_t nacc = nAB + A;
-  int32_t code[NACC];          // (j << 20) | (k << 8) | n ; j = 0xFFF marks an llks00 entry
+  uint32_t code[NACC];         // (j << 20) | (k << 8) | n ; j = 0xFFF marks an llks00 entry; ~0u = no accumulator
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
@@ -235,11 +361,11 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
     acc[i] = 0.0;
     if (q < nAB) {
       const int32_t n = q % A, jk = q / A;
-      code[i] = ((jk / V) << 20) | ((jk % V) << 8) | n;
+      code[i] = ((uint32_t)(jk / V) << 20) | ((uint32_t)(jk % V) << 8) | (uint32_t)n;
     } else if (q < nacc) {
-      code[i] = (0xFFF << 20) | (q - nAB);
+      code[i] = (0xFFFu << 20) | (uint32_t)(q - nAB);
     } else {
-      code[i] = -1;
+      code[i] = ~0u;
     }
   }
   __syncthreads();
@@ -293,8 +419,14 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
           mx = (mx < o) ? o : mx;
         }
         if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
 #pragma unroll
-          for (int i = 0; i < 9; ++i) pG[i] /= mx;                         // :632-639
+            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);      // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] /= mx;
+          }
         }
       }
       double mx = 0.0;
@@ -310,8 +442,9 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
         mx = (mx < o) ? o : mx;
       }
       if (on) {
+        const double y = rcp_refined(mx);                                   // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
 #pragma unroll
-        for (int i = 0; i < 9; ++i) s_pG[(ti1 * A + n1) * 9 + i] = pG[i] / mx;   // :656-663
+        for (int i = 0; i < 9; ++i) s_pG[(ti1 * A + n1) * 9 + i] = div_by(pG[i], mx, y);   // :656-663
       }
     }
     __syncthreads();
@@ -323,8 +456,8 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
       const double* __restrict__ g0 = gp0 + (size_t)snp * 3;
 #pragma unroll
       for (int i = 0; i < NACC; ++i) {
-        const int32_t cd = code[i];
-        if (cd < 0) continue;
+        const uint32_t cd = code[i];
+        if (cd == ~0u) continue;
         const int32_t j = (cd >> 20) & 0xFFF, k = (cd >> 8) & 0xFFF, n = cd & 0xFF;
         double a[3], b[3];
         if (j == 0xFFF) {
@@ -339,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
         for (int l = 0; l < 3; ++l)
 #pragma unroll
           for (int m = 0; m < 3; ++m) sum += ((a[l] * b[m]) * P[l * 3 + m]);   // :553 then :677-679, l-major
-        acc[i] += dmx_log(sum);                                             // :683 / :709
+        acc[i] += dmx_log(sum, s_log);                                             // :683 / :709
       }
     }
     __syncthreads();
@@ -466,7 +599,7 @@ struct dmx_engine {
   double* d_lut = nullptr;
   double* d_alpha = nullptr;
   // genotypes
-  const float* d_g = nullptr; float* d_g_own = nullptr; int32_t S = 0; double* d_gp0 = nullptr;
+  const float* d_g = nullptr; float* d_g_own = nullptr; int32_t S = 0; double* d_gp0 = nullptr; double* d_gd = nullptr;
   // pileup
   PileupView pv{}; int32_t nrd_width = 1; int64_t P = 0, R = 0; bool have_pileup = false;
   void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -514,7 +647,7 @@ int upload(dmx_engine* e, const void* host, size_t count, void** slot, const T**
 
 extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out) {
   if (!cfg || !out) return set_error(DMX_ERR_ARG, "dmx_engine_create: null argument");
-  if (cfg->n_samples < 1 || cfg->n_samples > 4095) return set_error(DMX_ERR_ARG, "dmx_engine_create: n_samples %d not in [1,4095]", cfg->n_samples);
+  if (cfg->n_samples < 1 || cfg->n_samples > 4094) return set_error(DMX_ERR_ARG, "dmx_engine_create: n_samples %d not in [1,4094]", cfg->n_samples);
   if (cfg->n_alpha < 1 || cfg->n_alpha > 64 || !cfg->alpha) return set_error(DMX_ERR_ARG, "dmx_engine_create: n_alpha %d not in [1,64] or null grid", cfg->n_alpha);
   if (cfg->mode != DMX_MODE_STRICT) return set_error(DMX_ERR_ARG, "dmx_engine_create: unknown mode %d", cfg->mode);
   int ndev = 0;
@@ -533,7 +666,8 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
   for (hipEvent_t& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
-  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kLut));
+  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTab));
+  HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
   HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
   double mat[256], err[256];
@@ -549,6 +683,7 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   free_pileup(e); free_results(e);
   if (e->d_g_own) (void)hipFree(e->d_g_own);
   if (e->d_gp0) (void)hipFree(e->d_gp0);
+  if (e->d_gd) (void)hipFree(e->d_gd);
   if (e->d_lut) (void)hipFree(e->d_lut);
   if (e->d_alpha) (void)hipFree(e->d_alpha);
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -577,6 +712,7 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
   HIP_TRY(hipSetDevice(e->device));
   if (e->d_g_own) { (void)hipFree(e->d_g_own); e->d_g_own = nullptr; }
   if (e->d_gp0) { (void)hipFree(e->d_gp0); e->d_gp0 = nullptr; }
+  if (e->d_gd) { (void)hipFree(e->d_gd); e->d_gd = nullptr; }
   const size_t n = (size_t)n_snps * e->V * 3;
   if (memory == DMX_MEM_DEVICE) {
     e->d_g = g;
@@ -594,6 +730,11 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(e->ev[1], e->stream));
     e->timed[0] = true;
+  }
+  HIP_TRY(hipMalloc((void**)&e->d_gd, std::max<size_t>((size_t)n_snps * (e->V + 1) * 3 * sizeof(double), 16)));
+  if (n_snps > 0) {
+    hipLaunchKernelGGL(k_build_gd, dim3(2048), dim3(256), 0, e->stream, e->d_g, e->d_gp0, n_snps, e->V, e->d_gd);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(e->stream));   // the host buffer may go away after return
   return DMX_OK;
@@ -635,7 +776,7 @@ extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
     if (h_off[c + 1] < h_off[c]) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off not monotone at %d", c);
     if (!pl->pair_snp && h_off[c + 1] - h_off[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: dense layout needs n_snps pairs per cell (cell %d)", c);
   }
-  e->pv.B = B; e->pv.S = e->S; e->nrd_width = pl->nrd_width; e->P = pl->n_pairs; e->R = pl->n_reads;
+  e->pv.B = B; e->pv.S = e->S; e->pv.R = pl->n_reads; e->nrd_width = pl->nrd_width; e->P = pl->n_pairs; e->R = pl->n_reads;
   // launch order: longest cells first, so the tail of the grid is made of short cells and co-scheduled cells are alike
   std::vector<int32_t> sched((size_t)B);
   std::iota(sched.begin(), sched.end(), 0);
@@ -656,24 +797,20 @@ extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
 
 namespace {
 
-template <typename NRD>
 int launch_singlet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V;
-  const int nch = (V + 1 + 15) / 16;
-  // cells per workgroup: keep >= ~4 workgroups per CU when B allows it
-  const int C = (B >= 16 * 1024) ? 16 : (B >= 8 * 1024 ? 8 : 4);
+  // cells per workgroup: aim for >= ~8 workgroups per CU while keeping tiles long
+  const int C = (B >= 32 * 1024) ? 16 : (B >= 16 * 1024 ? 8 : 4);
+  const int KC = (V + 1 <= 5) ? 5 : 9;
+  const int nch = (V + 1 + KC - 1) / KC;
+  const size_t dyn = sizeof(double) * (size_t)nch * C * KC;
+  if (dyn > 48 * 1024) return set_error(DMX_ERR_ARG, "run_singlet: n_samples %d too large for this build", V);
   const dim3 block(kThreads);
-#define DMX_K1(CC, NN)                                                                                              \
-  hipLaunchKernelGGL((k_singlet<NRD, CC, NN>), dim3((unsigned)((B + CC - 1) / CC)), block, 0, e->stream, e->pv, e->d_g, \
-                     e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
-#define DMX_K1_C(NN) do { if (C == 16) DMX_K1(16, NN); else if (C == 8) DMX_K1(8, NN); else DMX_K1(4, NN); } while (0)
-  if (nch <= 1) DMX_K1_C(1);
-  else if (nch <= 2) DMX_K1_C(2);
-  else if (nch <= 4) DMX_K1_C(4);
-  else if (nch <= 8) DMX_K1_C(8);
-  else if (nch <= 16) DMX_K1_C(16);
-  else return set_error(DMX_ERR_ARG, "run_singlet: n_samples %d > 255 is not supported by this build", V);
-#undef DMX_K1_C
+#define DMX_K1(CC, KK)                                                                                                \
+  hipLaunchKernelGGL((k_singlet<CC, KK>), dim3((unsigned)((B + CC - 1) / CC)), block, dyn, e->stream, e->pv, e->nrd_width, \
+                     e->d_gd, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
+  if (KC == 5) { if (C == 16) DMX_K1(16, 5); else if (C == 8) DMX_K1(8, 5); else DMX_K1(4, 5); }
+  else         { if (C == 16) DMX_K1(16, 9); else if (C == 8) DMX_K1(8, 9); else DMX_K1(4, 9); }
 #undef DMX_K1
   return DMX_OK;
 }
@@ -710,8 +847,7 @@ extern "C" int dmx_engine_run_singlet(dmx_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   if (e->pv.B == 0) { e->have_sing = true; return DMX_OK; }
   HIP_TRY(hipEventRecord(e->ev[2], e->stream));
-  int rc = e->nrd_width == 1 ? launch_singlet<uint8_t>(e) : (e->nrd_width == 2 ? launch_singlet<uint16_t>(e) : launch_singlet<uint32_t>(e));
-  if (rc) return rc;
+  if (int rc = launch_singlet(e)) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e->ev[3], e->stream));
   e->timed[1] = true; e->have_sing = true;
@@ -804,6 +940,58 @@ extern "C" int dmx_engine_algorithmic_bytes(dmx_engine* e, dmx_kernel_bytes* out
   out->singlet_bytes = in + B * (V + 1) * 8;
   out->doublet_bytes = in + B * (V * V * A + A) * 8;
   out->reduce_bytes = B * (V * V * A + A) * 8 + B * (double)sizeof(dmx_cell_summary);
+  return DMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_debug_log(const double* __restrict__ x, double* __restrict__ y, int64_t n, const double* __restrict__ tab) {
+  __shared__ double s_log[DMX_LOG_TABLE_DOUBLES];
+  dmx_log_stage(s_log, tab, threadIdx.x, blockDim.x);
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = dmx_log(x[i], s_log);
+}
+}  // namespace
+
+namespace {
+__global__ void k_debug_div(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ q, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    q[i] = div_by(a[i], b[i], rcp_refined(b[i]));
+}
+}  // namespace
+
+extern "C" int dmx_debug_device_div(const double* a, const double* b, double* q, int64_t n, int32_t device) {
+  if (!a || !b || !q || n < 0) return set_error(DMX_ERR_ARG, "dmx_debug_device_div: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return set_error(DMX_ERR_NOGPU, "dmx_debug_device_div: no such HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *da = nullptr, *db = nullptr, *dq = nullptr;
+  const size_t bytes = std::max<size_t>(sizeof(double) * (size_t)n, 16);
+  HIP_TRY(hipMalloc((void**)&da, bytes)); HIP_TRY(hipMalloc((void**)&db, bytes)); HIP_TRY(hipMalloc((void**)&dq, bytes));
+  HIP_TRY(hipMemcpy(da, a, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_div, dim3(1024), dim3(256), 0, 0, da, db, dq, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(q, dq, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dq);
+  return DMX_OK;
+}
+
+extern "C" int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device) {
+  if (!x || !y || n < 0) return set_error(DMX_ERR_ARG, "dmx_debug_device_log: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return set_error(DMX_ERR_NOGPU, "dmx_debug_device_log: no such HIP device");
+  HIP_TRY(hipSetDevice(device));
+  double *dx = nullptr, *dy = nullptr, *dt = nullptr;
+  HIP_TRY(hipMalloc((void**)&dx, std::max<size_t>(sizeof(double) * (size_t)n, 16)));
+  HIP_TRY(hipMalloc((void**)&dy, std::max<size_t>(sizeof(double) * (size_t)n, 16)));
+  HIP_TRY(hipMalloc((void**)&dt, sizeof(double) * DMX_LOG_TABLE_DOUBLES));
+  HIP_TRY(hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dt, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_debug_log, dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(y, dy, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dt);
   return DMX_OK;
 }
 

@@ -185,6 +185,13 @@ typedef struct {
 int dmx_write_single(const dmx_final_input*, const char* path);                    /* <out>.single */
 int dmx_write_doublet(const dmx_final_input*, const char* out_prefix);            /* <out>.sing2, <out>.best, [<out>.pair] */
 
+/* Diagnostics: evaluate the device's log() replacement (dmx_log, csrc/dmx_log.hpp) on n host doubles. Used by the tests
+ * to show the device function performs exactly the IEEE operation sequence whose accuracy is measured on the host. */
+int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device);
+/* Diagnostics: q[i] = a[i] / b[i] through the kernels' shared-reciprocal division (must equal IEEE division bit for bit
+ * for 2^-700 < a,b < 2^700). */
+int dmx_debug_device_div(const double* a, const double* b, double* q, int64_t n, int32_t device);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * One call for the whole of cmd_cram_demuxlet.cpp:390-881: store + genotype matrix + options in, four files out. */
 typedef struct {

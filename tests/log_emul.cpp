@@ -1,0 +1,4 @@
+// Test helper (CPU): the arithmetic of dmx_log() (demuxlet_amd/csrc/dmx_log.hpp) executed on the host, bit-for-bit the
+// operations the device performs (fma via libm's correctly-rounded fma()).
+#include "dmx_log.hpp"
+extern "C" void dmx_log_emul_n(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = dmx_log_host_emul(x[i]); }

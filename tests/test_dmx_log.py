@@ -1,0 +1,115 @@
+"""CPU: accuracy of dmx_log()'s arithmetic (host emulation of the exact device operation sequence) against mpmath.
+GPU (-m gpu): the device function agrees bit-for-bit with the host emulation (same IEEE operations)."""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def emul(tmp_path_factory):
+    so = tmp_path_factory.mktemp("logemul") / "liblogemul.so"
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", f"-I{ROOT / 'demuxlet_amd' / 'csrc'}",
+                           str(ROOT / "tests" / "log_emul.cpp"), "-o", str(so), "-lm"])
+    L = C.CDLL(str(so))
+    L.dmx_log_emul_n.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+
+    def f(x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        L.dmx_log_emul_n(x.ctypes.data, y.ctypes.data, len(x))
+        return y
+    return f
+
+
+def sample_points(rng, n):
+    xs = [np.exp(rng.uniform(np.log(1e-8), np.log(2.0), n)),          # the range the likelihood terms live in
+          rng.uniform(0.97, 1.03, n),                                  # around 1: the polynomial-only bin and its neighbours
+          1.0 + rng.uniform(-2 ** -8, 2 ** -7, n // 4),
+          np.exp(rng.uniform(np.log(1e-300), np.log(1e300), n // 4))]
+    # bin edges of the reduction (z = OFF + i*2^45 mantissa units) and their neighbours
+    off = 0x3FE5F00000000000
+    edges = np.array([off + (i << 45) + d for i in range(129) for d in (-1, 0, 1)], dtype=np.uint64).view(np.float64)
+    return np.concatenate(xs + [edges, np.array([1.0, 0.5, 2.0, np.nextafter(1.0, 0), np.nextafter(1.0, 2)])])
+
+
+def test_ulp_error_against_mpmath(emul):
+    import mpmath as mp
+    mp.mp.prec = 120
+    rng = np.random.default_rng(2024)
+    x = sample_points(rng, 40000)
+    y = emul(x)
+    worst, worst_abs, sq = 0.0, 0.0, 0.0
+    for xi, yi in zip(x, y):
+        t = mp.log(mp.mpf(float(xi)))
+        tf = float(t)
+        if tf == 0.0:
+            assert yi == 0.0
+            continue
+        ulp = np.spacing(abs(tf))
+        e = float(abs(mp.mpf(float(yi)) - t)) / ulp
+        worst = max(worst, e)
+        worst_abs = max(worst_abs, float(abs(mp.mpf(float(yi)) - t)) / max(abs(tf), 2.0 ** -7))
+        sq += e * e
+    rms = (sq / len(x)) ** 0.5
+    print(f"dmx_log vs mpmath over {len(x)} points: max {worst:.3f} ulp, rms {rms:.3f} ulp, max |err|/max(|y|,2^-7) = {worst_abs:.2e}")
+    assert worst < 1.0          # under 1 ulp everywhere sampled (glibc's own bound for log is ~0.52 ulp)
+    assert worst_abs < 1.2e-16  # the bound DESIGN.md uses for the accumulated-difference estimate
+
+
+def test_matches_libm_to_one_ulp(emul):
+    rng = np.random.default_rng(7)
+    x = sample_points(rng, 200000)
+    y = emul(x)
+    ref = np.log(x)
+    d = np.abs(y - ref) / np.spacing(np.abs(ref) + 1e-300)
+    print(f"vs glibc log: identical {np.mean(y == ref) * 100:.2f} %, max {d.max():.2f} ulp")
+    assert d.max() <= 1.0
+
+
+def test_special_values(emul):
+    with np.errstate(all="ignore"):
+        y = emul(np.array([0.0, -1.0, np.inf, np.nan, 5e-324, 2.2250738585072014e-308]))
+    assert y[0] == -np.inf and np.isnan(y[1]) and y[2] == np.inf and np.isnan(y[3])
+    assert y[4] == np.log(5e-324) and abs(y[5] - np.log(2.2250738585072014e-308)) <= np.spacing(708.0)
+
+
+@pytest.mark.gpu
+def test_device_log_is_the_emulated_arithmetic(emul):
+    """The device executes exactly the operation sequence measured above (IEEE fma/mul/add are deterministic), so the
+    host-side ulp measurement IS the device's accuracy."""
+    import ctypes as C
+    from demuxlet_amd import build, capi
+    build.build()
+    L = capi.load()
+    rng = np.random.default_rng(99)
+    x = sample_points(rng, 300000)
+    y = np.empty_like(x)
+    capi.check(L.dmx_debug_device_log(x.ctypes.data, y.ctypes.data, len(x), 0))
+    h = emul(x)
+    assert np.array_equal(y, h), f"{np.sum(y != h)} of {len(x)} differ"
+    with np.errstate(all="ignore"):
+        sp = np.array([0.0, -1.0, np.inf, np.nan, 5e-324])
+        ys = np.empty_like(sp)
+        capi.check(L.dmx_debug_device_log(sp.ctypes.data, ys.ctypes.data, len(sp), 0))
+    assert ys[0] == -np.inf and np.isnan(ys[1]) and ys[2] == np.inf and np.isnan(ys[3]) and abs(ys[4] - np.log(5e-324)) < 1e-12
+
+
+@pytest.mark.gpu
+def test_device_shared_reciprocal_division_is_ieee():
+    """The kernels divide three (nine) numerators by one denominator with a shared Newton-refined reciprocal; the result
+    must be the correctly rounded quotient, i.e. numpy's / bit for bit, over the operand ranges the kernels see."""
+    from demuxlet_amd import build, capi
+    build.build()
+    L = capi.load()
+    rng = np.random.default_rng(123)
+    n = 400000
+    a = np.concatenate([rng.random(n), np.exp(rng.uniform(np.log(1e-200), 0, n)), rng.random(n) * 1e-6 + 1e-6])
+    b = np.concatenate([rng.uniform(0.3, 3.0, n), np.exp(rng.uniform(np.log(1e-6), np.log(3.0), n)), 1.0 + rng.random(n) * 3e-6])
+    q = np.empty_like(a)
+    capi.check(L.dmx_debug_device_div(a.ctypes.data, b.ctypes.data, q.ctypes.data, len(a), 0))
+    assert np.array_equal(q, a / b), f"{np.sum(q != a / b)} of {len(a)} quotients differ from IEEE division"
