@@ -10,7 +10,9 @@ from typing import Optional
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent / "libdmx.so"
+import os
+
+LIB_PATH = Path(os.environ.get("DMX_LIB", Path(__file__).resolve().parent / "libdmx.so"))   # DMX_LIB: kernel experiments only
 
 DMX_OK = 0
 DMX_MEM_HOST, DMX_MEM_DEVICE = 0, 1

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -45,9 +46,23 @@ struct PileupView {
   const uint8_t* reads;
 };
 
+// Ordering of LDS stores and loads between the lanes of ONE wavefront: the LDS executes a wavefront's instructions in
+// program order, so only the compiler has to be kept from moving them across this point.
+#ifdef DMX_FENCE_VARIANT
+#define DMX_WAVE_LDS_ORDER() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define DMX_WAVE_LDS_ORDER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
+
+#ifndef DMX_ABLATE
+#define DMX_ABLATE 0
+#endif
+
 constexpr int kThreads = 256;
 constexpr int kLut = 3 * 128;   // mat | err/3 | 0.5-err/3
 constexpr int kTab = kLut + DMX_LOG_TABLE_DOUBLES;   // device table buffer: read LUT, then dmx_log's {invc,logc} table
+constexpr int kFirst = 256 * 3, kFinal = 257 * 3;     // then the singlet first-read tables (dmx::SingletTables)
+constexpr int kTabK1 = kTab + kFirst + kFinal;
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void k_gp0(const float* __restrict__ g, int32_t S, int32_t V, double* __restrict__ gp0) {
@@ -110,197 +125,255 @@ __device__ __forceinline__ void pair_gl(const uint8_t* __restrict__ rd, uint32_t
   G0 = div_by(G0, tmp, y); G1 = div_by(G1, tmp, y); G2 = div_by(G2, tmp, y);       // :449-452
 }
 
+// Inclusive prefix sum of v over segments of T consecutive lanes (T = 16, 32 or 64), on the VALU's DPP data path:
+// four row-shift adds give the scan inside each 16-lane row, row_bcast:15 / row_bcast:31 carry the row totals.
+template <int T>
+__device__ __forceinline__ uint32_t seg_scan_incl(uint32_t v) {
+  static_assert(T == 16 || T == 32 || T == 64, "segment width");
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1 (0 past the row start)
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  if (T >= 32) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+  if (T >= 64) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+  return v;
+}
+// value of the last lane of this lane's T-wide segment
+template <int T>
+__device__ __forceinline__ uint32_t seg_last(uint32_t v, int lane) {
+  if (T == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+  if (T == 32) {
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return lane < 32 ? a : b;
+  }
+  return (uint32_t)__shfl((int)v, T - 1, T);
+}
+
 __device__ __forceinline__ uint32_t load_nrd(const void* __restrict__ base, int64_t p, int width) {
   if (width == 1) return ((const uint8_t*)base)[p];
   if (width == 2) return ((const uint16_t*)base)[p];
   return ((const uint32_t*)base)[p];
 }
 
-// K1.  A workgroup owns C cells for their whole SNP range.  Per tile of T = 256/C SNP-pairs per cell and per chunk of
-// KC of the V+1 accumulators of a cell (V samples + the average-genotype model, row V of gd):
-//   compute  lane (cell ci, pair ti): GL of its pair (once per tile), then the chunk's KC log terms -> LDS (double-buffered)
-//   sum      lane (cell ci, accumulator kk): adds the tile's T terms of its accumulator in ascending pair order.
-// One barrier per (tile, chunk): a lane can only overwrite buffer b two steps later, i.e. after the barrier of the step
-// in between, which every lane passes only after finishing its sums on b.
-// The pair headers (read count, SNP id) and the first four read bytes of the NEXT tile are fetched while the current
-// one is computed, and all genotype rows of a chunk are loaded before the first log, so no global-memory latency sits
-// on the dependent path.
-struct TileHdr { uint32_t n; int32_t snp; };
-
-template <int C, int KC>
-__global__ __launch_bounds__(kThreads) void k_singlet(PileupView pv, int nrd_width, const double* __restrict__ gd,
-                                                      const double* __restrict__ tabs,
-                                                      const int32_t* __restrict__ sched, int32_t V,
-                                                      double* __restrict__ llks, double* __restrict__ llk0s) {
-  constexpr int T = kThreads / C;
-  constexpr int LD = KC | 1;                   // odd row stride (in doubles): conflict-free 8-byte stores across lanes
-  static_assert(T <= 64 && (64 % T) == 0, "a cell's tile segment must sit inside one wavefront");
-  static_assert(C * KC <= kThreads, "one lane per accumulator of a chunk");
-  extern __shared__ double s_dyn[];            // [nch][C*KC] running accumulators of all chunks
-  __shared__ double s_tab[kTab];
-  __shared__ double s_term[2][kThreads * LD];
-  __shared__ int64_t s_np[C];
+// K1.  Wavefronts are independent (no workgroup barrier in the loop).  A wavefront owns CW cells for their whole SNP
+// range and walks them tile by tile, T = 64/CW SNP-pairs per cell per tile:
+//   compute  lane (cell c = lane/T, pair ti = lane%T): GL of its pair once per tile, then per chunk of KC samples the KC
+//            log terms (plus, in chunk 0, the term of the average-genotype model llk0) -> LDS, chain-major
+//            ([cell][slot][ti]);
+//   sum      lane a < CW*(KC+1) owns accumulator (cell a/(KC+1), slot a%(KC+1)): adds the tile's T terms in ascending
+//            pair order (16-byte LDS reads, two terms each).
+// Genotype probabilities stay float32 in memory (they ARE float32 values, bcf_filtered_reader.h:78) and are widened in
+// registers.  Dense pileups (every cell covers every SNP, pair_snp == NULL) read them SNP-minor (gT[row element][snp],
+// g0T[l][snp]) so a cell's T lanes read contiguous addresses; sparse pileups read the row of the lane's own SNP from the
+// SNP-major originals (g[snp][k][l], gp0s[snp][l]).
+// A two-deep software pipeline keeps global-memory latency off the dependent path: the pair header (read count, SNP id)
+// of tile+2 is in flight while the read offsets of tile+1 are scanned and its leading read bytes requested, while tile
+// is computed.
+template <int CW, int KC, bool DENSE>
+__global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_width, const float* __restrict__ gq,
+                                                         const double* __restrict__ g0q, const double* __restrict__ tabs,
+                                                         const int32_t* __restrict__ sched, int32_t V,
+                                                         double* __restrict__ llks, double* __restrict__ llk0s) {
+  constexpr int ablate = DMX_ABLATE;             // profiling builds only (tools/build_variant.sh); 0 in the product
+  constexpr int T = 64 / CW;
+  constexpr int TS = T + 2;                      // row stride of a chain in LDS (doubles): keeps 16-byte alignment, and
+                                                 // 2*TS mod 64 == 4 dwords spreads the chains of a wavefront over the banks
+  constexpr int NC = KC + 1;                     // chains per cell and chunk: KC samples + llk0 (chunk 0 only)
+  constexpr int NW = kThreads / 64;
+  static_assert(CW * NC <= 64, "one lane per chain");
+  extern __shared__ double s_dyn[];              // [NW][nch][CW*NC] running accumulators
+  __shared__ double s_tab[kTabK1];
+  __shared__ __attribute__((aligned(16))) double s_term[NW][CW * NC * TS];
   const double* s_log = s_tab + kLut;
+  const double* s_first = s_tab + kTab;
+  const double* s_final = s_first + kFirst;
 
-  const int t = threadIdx.x;
-  const int nch = (V + 1 + KC - 1) / KC;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
-  for (int i = t; i < nch * C * KC; i += kThreads) s_dyn[i] = 0.0;
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const int nch = (V + KC - 1) / KC;
+  for (int i = t; i < kTabK1; i += kThreads) s_tab[i] = tabs[i];
+  for (int i = t; i < NW * nch * CW * NC; i += kThreads) s_dyn[i] = 0.0;
+  __syncthreads();                               // the only workgroup barrier
 
-  const int ci = t / T, ti = t % T;
-  const int slot = blockIdx.x * C + ci;
-  const bool cell_ok = slot < pv.B;
-  const int32_t cell = cell_ok ? sched[slot] : 0;
+  double* term = s_term[w];
+  double* accs = s_dyn + (size_t)w * nch * CW * NC;
+  const int slot0 = (blockIdx.x * NW + w) * CW;  // first of this wavefront's cells in launch order
+  if (slot0 >= pv.B) return;
+
+  // compute-phase identity
+  const int c = lane / T, ti = lane % T;
+  const bool cell_ok = slot0 + c < pv.B;
+  const int32_t cell = cell_ok ? sched[slot0 + c] : 0;
   const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
   const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
   int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
-  if (ti == 0) s_np[ci] = np;
-  __syncthreads();
-  int64_t max_np = 0;
+  int64_t max_np = np;
 #pragma unroll
-  for (int c = 0; c < C; ++c) max_np = max(max_np, s_np[c]);
+  for (int d = T; d < 64; d <<= 1) max_np = max(max_np, __shfl_xor(max_np, d));
+  // sum-phase identity
+  const int a_c = lane / NC, a_kk = lane % NC;
+  const bool a_ok = lane < CW * NC && slot0 + a_c < pv.B;
+  const int64_t a_np = __shfl(np, (a_ok ? a_c : 0) * T);
+  const int32_t a_cell = __shfl(cell, (a_ok ? a_c : 0) * T);
+  const size_t S = (size_t)pv.S;
 
-  // sum-phase identity: lane a < C*KC owns accumulator (cell a/KC, slot a%KC) of every chunk
-  const int a_ci = t / KC, a_kk = t % KC;
-  const bool a_ok = (t < C * KC) && (blockIdx.x * C + a_ci < pv.B);
-  const int64_t a_np = a_ok ? s_np[a_ci] : 0;
-  const size_t row_stride = (size_t)(V + 1) * 3;
-
-  auto load_hdr = [&](int64_t tile) {
-    TileHdr h;
+  struct Raw { uint32_t n; int32_t snp; };
+  struct Hdr { uint32_t n; int32_t snp; uint32_t rd4; int64_t off; };
+  auto issue = [&](int64_t tile) {               // loads only
+    Raw r;
     const int64_t pi = tile * T + ti;
     const bool v = pi < np;
-    h.n = v ? load_nrd(pv.pair_nrd, p_beg + pi, nrd_width) : 0u;
-    h.snp = v ? (pv.pair_snp ? pv.pair_snp[p_beg + pi] : (int32_t)pi) : 0;
+    r.n = v ? load_nrd(pv.pair_nrd, p_beg + pi, nrd_width) : 0u;
+    r.snp = v ? (DENSE ? (int32_t)pi : pv.pair_snp[p_beg + pi]) : 0;
+    return r;
+  };
+  auto prepare = [&](const Raw& r) {             // prefix-scan the read counts of the cell's T pairs, request the bytes
+    Hdr h;
+    h.n = r.n; h.snp = r.snp;
+    const uint32_t incl = seg_scan_incl<T>(r.n);
+    h.off = rd_base + (int64_t)(incl - r.n);
+    rd_base += seg_last<T>(incl, lane);
+    h.rd4 = 0;
+    if (r.n > 0) {
+      if (h.off + 4 <= pv.R) __builtin_memcpy(&h.rd4, pv.reads + h.off, 4);   // bytes past the pair's reads are never interpreted
+      else for (int64_t i = h.off; i < pv.R; ++i) h.rd4 |= (uint32_t)pv.reads[i] << (8 * (int)(i - h.off));
+    }
     return h;
   };
-  auto scan_offsets = [&](uint32_t n, int64_t& off) {     // exclusive prefix of the read counts inside the cell's segment
-    uint32_t incl = n;
-#pragma unroll
-    for (int d = 1; d < T; d <<= 1) {
-      const uint32_t y = __shfl_up(incl, d, T);
-      if (ti >= d) incl += y;
-    }
-    off = rd_base + (int64_t)(incl - n);
-    rd_base += __shfl(incl, T - 1, T);
-  };
-  auto load_rd4 = [&](uint32_t n, int64_t off) {          // first four read bytes (little endian), 0 beyond n
-    uint32_t w = 0;
-    if (n > 0) {
-      if (off + 4 <= pv.R) {
-        __builtin_memcpy(&w, pv.reads + off, 4);      // bytes past the pair's own reads are never interpreted
-      } else {
-        for (int64_t i = off; i < pv.R; ++i) w |= (uint32_t)pv.reads[i] << (8 * (int)(i - off));
-      }
-    }
-    return w;
-  };
 
-  TileHdr hdr = load_hdr(0);
-  int64_t off = 0;
-  scan_offsets(hdr.n, off);
-  uint32_t rd4 = load_rd4(hdr.n, off);
-
-  int step = 0;
+  Hdr nxt = prepare(issue(0));
+  Raw pre = issue(1);
   for (int64_t tile = 0; tile * T < max_np; ++tile) {
+    Hdr cur = nxt;
+    if (!(ablate & 16)) {
+      nxt = prepare(pre);                        // tile+1: its counts arrived a tile ago
+      pre = issue(tile + 2);                     // tile+2: loads in flight
+    } else { cur.n = 1; cur.rd4 = 0x9e; cur.snp = 0; }
     const bool valid = tile * T + ti < np;
-    const uint32_t n = hdr.n;
-    const int32_t snp = hdr.snp;
-    const uint32_t cur4 = rd4;
-    const int64_t cur_off = off;
-    // ---- prefetch the next tile's header and leading read bytes
-    hdr = load_hdr(tile + 1);
-    scan_offsets(hdr.n, off);
-    rd4 = load_rd4(hdr.n, off);
 
-    // ---- genotype likelihoods of this lane's pair (:427-452)
-    double G0 = 1.0, G1 = 1.0, G2 = 1.0;
+    // ---- genotype likelihoods of this lane's pair (:427-452).  Pairs with at most one read (the bulk of single-cell
+    // data) are a table lookup on the read byte; deeper pairs continue the reference's per-read loop from the table's
+    // state after the first read.
+    double G0, G1, G2;
     {
-      const bool safe = n <= kSafeReads;
-      for (uint32_t r = 0; r < n; ++r) {
-        const uint32_t byte = (r < 4) ? ((cur4 >> (8 * r)) & 0xFFu) : (uint32_t)pv.reads[cur_off + r];
-        const uint32_t bq = byte & 127u;
-        const bool alt = (byte >> 7) != 0;
-        const double m = s_tab[bq], e3 = s_tab[128 + bq], h = s_tab[256 + bq];
-        G0 *= alt ? e3 : m;                                                // :437
-        G1 *= h;                                                           // :438
-        G2 *= alt ? m : e3;                                                // :439
-        const double tmp = G0 + G1 + G2;                                   // :440
-        if (safe) {
-          const double y = rcp_refined(tmp);
-          G0 = div_by(G0, tmp, y); G1 = div_by(G1, tmp, y); G2 = div_by(G2, tmp, y);   // :441-443
-        } else {
-          G0 /= tmp; G1 /= tmp; G2 /= tmp;
+      const uint32_t n = cur.n;
+      const uint32_t b0 = cur.rd4 & 0xFFu;
+      const double* f = s_final + 3 * (n ? b0 : 256u);
+      G0 = f[0]; G1 = f[1]; G2 = f[2];
+      if (n >= 2 && !(ablate & 1)) {
+        const double* f1 = s_first + 3 * b0;
+        double g0 = f1[0], g1 = f1[1], g2 = f1[2];
+        const bool safe = n <= kSafeReads;
+        for (uint32_t r = 1; r < n; ++r) {
+          const uint32_t byte = (r < 4) ? ((cur.rd4 >> (8 * r)) & 0xFFu) : (uint32_t)pv.reads[cur.off + r];
+          const uint32_t bq = byte & 127u;
+          const bool alt = (byte >> 7) != 0;
+          const double m = s_tab[bq], e3 = s_tab[128 + bq], h = s_tab[256 + bq];
+          g0 *= alt ? e3 : m;                                                // :437
+          g1 *= h;                                                           // :438
+          g2 *= alt ? m : e3;                                                // :439
+          const double tmp = g0 + g1 + g2;                                   // :440
+          if (safe) {
+            const double y = rcp_refined(tmp);
+            g0 = div_by(g0, tmp, y); g1 = div_by(g1, tmp, y); g2 = div_by(g2, tmp, y);   // :441-443
+          } else {
+            g0 /= tmp; g1 /= tmp; g2 /= tmp;
+          }
         }
+        g0 += 1e-6; g1 += 1e-6; g2 += 1e-6;                                  // :446-448
+        const double tmp = g0 + g1 + g2;
+        const double y = rcp_refined(tmp);
+        G0 = div_by(g0, tmp, y); G1 = div_by(g1, tmp, y); G2 = div_by(g2, tmp, y);       // :449-452
       }
-      G0 += 1e-6; G1 += 1e-6; G2 += 1e-6;                                  // :446-448
-      const double tmp = G0 + G1 + G2;
-      const double y = rcp_refined(tmp);
-      G0 = div_by(G0, tmp, y); G1 = div_by(G1, tmp, y); G2 = div_by(G2, tmp, y);       // :449-452
     }
-    const double* __restrict__ grow = gd + (size_t)snp * row_stride;
-    const int64_t left = a_np - tile * T;
-    const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
+    // dense: uniform plane base per row element + this lane's SNP index (scalar base, 32-bit lane offset, no per-load
+    // address arithmetic); sparse: this lane's own row
+    const uint32_t s_idx = (uint32_t)min((int64_t)(tile * T + ti), (int64_t)S - 1);
+    const float* __restrict__ grow = gq + (size_t)cur.snp * V * 3;
+    const double* __restrict__ g0row = g0q + (size_t)cur.snp * 3;
 
-    for (int q = 0; q < nch; ++q, ++step) {
-      double* buf = s_term[step & 1];
-      if (valid) {
-        const int k0 = q * KC;
-        double a[KC][3];
+    for (int q = 0; q < nch; ++q) {
+      const int k0 = q * KC;
+      float a[KC][3];
+      double a0[3];
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {        // all loads of the chunk first; slots past row V re-read row V (ignored)
-          const int k = min(k0 + kk, V);
-          a[kk][0] = grow[k * 3]; a[kk][1] = grow[k * 3 + 1]; a[kk][2] = grow[k * 3 + 2];
-        }
-        uint32_t special = 0;
+      for (int kk = 0; kk < KC; ++kk) {          // all loads of the chunk first; slots past sample V-1 re-read it (ignored)
+        const int k = min(k0 + kk, V - 1);
+#pragma unroll
+        for (int l = 0; l < 3; ++l) a[kk][l] = (ablate & 8) ? 0.3f + 0.01f * kk : (DENSE ? (gq + (size_t)(k * 3 + l) * S)[s_idx] : grow[k * 3 + l]);
+      }
+      if (q == 0) {
+#pragma unroll
+        for (int l = 0; l < 3; ++l) a0[l] = (ablate & 8) ? 0.33 : (DENSE ? (g0q + (size_t)l * S)[s_idx] : g0row[l]);
+      }
+      if (valid) {
+        bool fast_ok = true;
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-          const double x = G0 * a[kk][0] + G1 * a[kk][1] + G2 * a[kk][2];   // :456 / :459
-          const bool sp = dmx_log_is_special(x);
-          special |= sp ? (1u << kk) : 0u;
-          buf[t * LD + kk] = sp ? x : dmx_log_fast(x, s_log);
+          const double x = G0 * (double)a[kk][0] + G1 * (double)a[kk][1] + G2 * (double)a[kk][2];   // :456
+          fast_ok &= __builtin_amdgcn_class(x, 0x100);                       // +normal: the fast path's domain
+          if (!(ablate & 32) || kk == 0) term[(c * NC + kk) * TS + ti] = (ablate & 2) ? x : dmx_log_fast(x, s_log); else G0 += x;
         }
-        if (__builtin_expect(special != 0, 0)) {   // never for real likelihoods; keeps log(0), log(nan) semantics
-          for (int kk = 0; kk < KC; ++kk)
-            if ((special >> kk) & 1u) buf[t * LD + kk] = log(buf[t * LD + kk]);
+        if (q == 0) {
+          const double x = G0 * a0[0] + G1 * a0[1] + G2 * a0[2];             // :459
+          fast_ok &= __builtin_amdgcn_class(x, 0x100);
+          term[(c * NC + KC) * TS + ti] = (ablate & 2) ? x : dmx_log_fast(x, s_log);
+        }
+        if (__builtin_expect(!fast_ok, 0)) {       // never for real likelihoods; keeps log(0) / log(nan) semantics
+          for (int kk = 0; kk <= KC; ++kk) {       // one rolled copy of ocml's log; operands re-read from memory
+            if (kk == KC && q != 0) break;
+            double b[3];
+            if (kk < KC) {
+              const int k = min(k0 + kk, V - 1);
+              for (int l = 0; l < 3; ++l) b[l] = (double)(DENSE ? (gq + (size_t)(k * 3 + l) * S)[s_idx] : grow[k * 3 + l]);
+            } else {
+              for (int l = 0; l < 3; ++l) b[l] = DENSE ? (g0q + (size_t)l * S)[s_idx] : g0row[l];
+            }
+            const double x = G0 * b[0] + G1 * b[1] + G2 * b[2];
+            if (!__builtin_amdgcn_class(x, 0x100)) term[(c * NC + kk) * TS + ti] = log(x);
+          }
         }
       }
-      __syncthreads();
-      if (a_ok && q * KC + a_kk <= V) {
-        const double* col = &buf[(a_ci * T) * LD + a_kk];
-        double s = s_dyn[q * (C * KC) + t];
+      // ---- ordered sums of this (tile, chunk).  Wavefront-local: the LDS serves one wavefront's accesses in program
+      // order; the compiler barrier only stops the compiler from moving the reads above the stores (and the next stores above the reads).
+      DMX_WAVE_LDS_ORDER();
+      if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
+        const int64_t left = a_np - tile * T;
+        const int cnt = (ablate & 4) ? 1 : (left >= T ? T : (left > 0 ? (int)left : 0));
+        const double* row = &term[lane * TS];
+        double s = accs[q * (CW * NC) + lane];
         int i = 0;
-        for (; i + 16 <= cnt; i += 16) {          // loads first (LDS latency paid once), then the ordered adds
-          double v[16];
+        for (; i + 16 <= cnt; i += 16) {           // loads first (latency paid once), then the ordered adds
+          double2 v[8];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = col[(i + j) * LD];
+          for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const double2*>(&row[i + 2 * j]);
 #pragma unroll
-          for (int j = 0; j < 16; ++j) s += v[j];
+          for (int j = 0; j < 8; ++j) { s += v[j].x; s += v[j].y; }
         }
-        for (; i < cnt; ++i) s += col[i * LD];    // ascending SNP order: the reference's order
-        s_dyn[q * (C * KC) + t] = s;
+        for (; i < cnt; ++i) s += row[i];           // ascending SNP order: the reference's order
+        accs[q * (CW * NC) + lane] = s;
       }
+      DMX_WAVE_LDS_ORDER();
     }
   }
   if (a_ok) {
-    const int32_t a_cell = sched[blockIdx.x * C + a_ci];
     for (int q = 0; q < nch; ++q) {
-      const int k = q * KC + a_kk;
-      const double s = s_dyn[q * (C * KC) + t];
-      if (k < V) llks[(size_t)a_cell * V + k] = s;
-      else if (k == V) llk0s[a_cell] = s;
+      const double s = accs[q * (CW * NC) + lane];
+      if (a_kk < KC) { const int k = q * KC + a_kk; if (k < V) llks[(size_t)a_cell * V + k] = s; }
+      else if (q == 0) llk0s[a_cell] = s;
     }
   }
 }
 
-// gd[s][k][l] = (double) g[s][k][l] for k < V, gp0s[s][l] for k == V: the genotype rows the singlet kernel streams
-__global__ void k_build_gd(const float* __restrict__ g, const double* __restrict__ gp0, int32_t S, int32_t V,
-                           double* __restrict__ gd) {
-  const int64_t n = (int64_t)S * (V + 1) * 3;
+// SNP-minor copies for dense pileups: gT[r][s] = g[s][r] (r = k*3+l, float32 as stored) and g0T[l][s] = gp0s[s][l].
+__global__ void k_transpose_geno(const float* __restrict__ g, const double* __restrict__ gp0, int32_t S, int32_t V,
+                                 float* __restrict__ gT, double* __restrict__ g0T) {
+  const int nrow = V * 3;
+  const int64_t n = (int64_t)S * nrow;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = i / ((V + 1) * 3);
-    const int r = (int)(i % ((V + 1) * 3));
-    gd[i] = (r < V * 3) ? (double)g[(size_t)s * V * 3 + r] : gp0[(size_t)s * 3 + (r - V * 3)];
+    const int64_t s = i % S;
+    const int r = (int)(i / S);
+    gT[i] = g[(size_t)s * nrow + r];
+    if (r < 3) g0T[i] = gp0[(size_t)s * 3 + r];
   }
 }
 
@@ -599,7 +672,7 @@ struct dmx_engine {
   double* d_lut = nullptr;
   double* d_alpha = nullptr;
   // genotypes
-  const float* d_g = nullptr; float* d_g_own = nullptr; int32_t S = 0; double* d_gp0 = nullptr; double* d_gd = nullptr;
+  const float* d_g = nullptr; float* d_g_own = nullptr; int32_t S = 0; double* d_gp0 = nullptr; float* d_gT = nullptr; double* d_g0T = nullptr;
   // pileup
   PileupView pv{}; int32_t nrd_width = 1; int64_t P = 0, R = 0; bool have_pileup = false;
   void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -666,7 +739,7 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
   for (hipEvent_t& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
-  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTab));
+  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTabK1));
   HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
   HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
@@ -683,7 +756,8 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   free_pileup(e); free_results(e);
   if (e->d_g_own) (void)hipFree(e->d_g_own);
   if (e->d_gp0) (void)hipFree(e->d_gp0);
-  if (e->d_gd) (void)hipFree(e->d_gd);
+  if (e->d_gT) (void)hipFree(e->d_gT);
+  if (e->d_g0T) (void)hipFree(e->d_g0T);
   if (e->d_lut) (void)hipFree(e->d_lut);
   if (e->d_alpha) (void)hipFree(e->d_alpha);
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -704,6 +778,10 @@ extern "C" int dmx_engine_set_phred_tables(dmx_engine* e, const double mat[256],
   dmx::ReadLut lut;
   dmx::build_read_lut(mat, err, &lut);
   HIP_TRY(hipMemcpy(e->d_lut, &lut, sizeof(double) * kLut, hipMemcpyHostToDevice));
+  static_assert(sizeof(dmx::SingletTables) == sizeof(double) * (kFirst + kFinal), "table layout");
+  dmx::SingletTables st;
+  dmx::build_singlet_tables(lut, &st);
+  HIP_TRY(hipMemcpy(e->d_lut + kTab, &st, sizeof st, hipMemcpyHostToDevice));
   return DMX_OK;
 }
 
@@ -712,7 +790,6 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
   HIP_TRY(hipSetDevice(e->device));
   if (e->d_g_own) { (void)hipFree(e->d_g_own); e->d_g_own = nullptr; }
   if (e->d_gp0) { (void)hipFree(e->d_gp0); e->d_gp0 = nullptr; }
-  if (e->d_gd) { (void)hipFree(e->d_gd); e->d_gd = nullptr; }
   const size_t n = (size_t)n_snps * e->V * 3;
   if (memory == DMX_MEM_DEVICE) {
     e->d_g = g;
@@ -731,11 +808,7 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     HIP_TRY(hipEventRecord(e->ev[1], e->stream));
     e->timed[0] = true;
   }
-  HIP_TRY(hipMalloc((void**)&e->d_gd, std::max<size_t>((size_t)n_snps * (e->V + 1) * 3 * sizeof(double), 16)));
-  if (n_snps > 0) {
-    hipLaunchKernelGGL(k_build_gd, dim3(2048), dim3(256), 0, e->stream, e->d_g, e->d_gp0, n_snps, e->V, e->d_gd);
-    HIP_TRY(hipGetLastError());
-  }
+
   HIP_TRY(hipStreamSynchronize(e->stream));   // the host buffer may go away after return
   return DMX_OK;
 }
@@ -776,6 +849,15 @@ extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
     if (h_off[c + 1] < h_off[c]) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off not monotone at %d", c);
     if (!pl->pair_snp && h_off[c + 1] - h_off[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: dense layout needs n_snps pairs per cell (cell %d)", c);
   }
+  // dense pileups: SNP-minor copies of the genotype probabilities for the singlet kernel
+  if (e->d_gT) { (void)hipFree(e->d_gT); e->d_gT = nullptr; }
+  if (e->d_g0T) { (void)hipFree(e->d_g0T); e->d_g0T = nullptr; }
+  if (!e->pv.pair_snp && e->S > 0) {
+    HIP_TRY(hipMalloc((void**)&e->d_gT, (size_t)e->S * e->V * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&e->d_g0T, (size_t)e->S * 3 * sizeof(double)));
+    hipLaunchKernelGGL(k_transpose_geno, dim3(2048), dim3(256), 0, e->stream, e->d_g, e->d_gp0, e->S, e->V, e->d_gT, e->d_g0T);
+    HIP_TRY(hipGetLastError());
+  }
   e->pv.B = B; e->pv.S = e->S; e->pv.R = pl->n_reads; e->nrd_width = pl->nrd_width; e->P = pl->n_pairs; e->R = pl->n_reads;
   // launch order: longest cells first, so the tail of the grid is made of short cells and co-scheduled cells are alike
   std::vector<int32_t> sched((size_t)B);
@@ -799,18 +881,25 @@ namespace {
 
 int launch_singlet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V;
-  // cells per workgroup: aim for >= ~8 workgroups per CU while keeping tiles long
-  const int C = (B >= 32 * 1024) ? 16 : (B >= 16 * 1024 ? 8 : 4);
-  const int KC = (V + 1 <= 5) ? 5 : 9;
-  const int nch = (V + 1 + KC - 1) / KC;
-  const size_t dyn = sizeof(double) * (size_t)nch * C * KC;
-  if (dyn > 48 * 1024) return set_error(DMX_ERR_ARG, "run_singlet: n_samples %d too large for this build", V);
-  const dim3 block(kThreads);
-#define DMX_K1(CC, KK)                                                                                                \
-  hipLaunchKernelGGL((k_singlet<CC, KK>), dim3((unsigned)((B + CC - 1) / CC)), block, dyn, e->stream, e->pv, e->nrd_width, \
-                     e->d_gd, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
-  if (KC == 5) { if (C == 16) DMX_K1(16, 5); else if (C == 8) DMX_K1(8, 5); else DMX_K1(4, 5); }
-  else         { if (C == 16) DMX_K1(16, 9); else if (C == 8) DMX_K1(8, 9); else DMX_K1(4, 9); }
+  // cells per wavefront: more cells amortise the ordered sums, fewer keep >= ~4 wavefronts per SIMD in flight (1024 SIMDs)
+  int CW = (B >= 32 * 1024) ? 4 : (B >= 8 * 1024 ? 2 : 1);
+  const int KC = (V <= 4) ? 4 : 8;
+  if (const char* cenv = getenv("DMX_K1_CW")) CW = atoi(cenv);     // kernel experiments only
+  const int nch = (V + KC - 1) / KC;
+  const int NW = kThreads / 64;
+  const size_t dyn = sizeof(double) * (size_t)NW * nch * CW * (KC + 1);
+  if (dyn > 16 * 1024) return set_error(DMX_ERR_ARG, "run_singlet: n_samples %d too large for this build", V);
+  const bool dense = e->pv.pair_snp == nullptr;
+  const float* gq = dense ? e->d_gT : e->d_g;
+  const double* g0q = dense ? e->d_g0T : e->d_gp0;
+  const dim3 block(kThreads), grid((unsigned)((B + NW * CW - 1) / (NW * CW)));
+#define DMX_K1(CC, KK, DD)                                                                                            \
+  hipLaunchKernelGGL((k_singlet<CC, KK, DD>), grid, block, dyn, e->stream, e->pv, e->nrd_width, gq, g0q, e->d_lut,     \
+                     e->d_sched, V, e->d_llks, e->d_llk0s)
+#define DMX_K1_D(CC, KK) do { if (dense) DMX_K1(CC, KK, true); else DMX_K1(CC, KK, false); } while (0)
+  if (KC == 4) { if (CW == 4) DMX_K1_D(4, 4); else if (CW == 2) DMX_K1_D(2, 4); else DMX_K1_D(1, 4); }
+  else         { if (CW == 4) DMX_K1_D(4, 8); else if (CW == 2) DMX_K1_D(2, 8); else DMX_K1_D(1, 8); }
+#undef DMX_K1_D
 #undef DMX_K1
   return DMX_OK;
 }

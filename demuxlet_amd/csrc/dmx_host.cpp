@@ -34,6 +34,27 @@ void build_read_lut(const double mat[256], const double err[256], ReadLut* out) 
   }
 }
 
+void build_singlet_tables(const ReadLut& lut, SingletTables* out) {
+  auto finish = [](const double in[3], double o[3]) {
+    double a = in[0] + 1e-6, b = in[1] + 1e-6, c = in[2] + 1e-6;   // :446-448
+    const double tmp = a + b + c;
+    o[0] = a / tmp; o[1] = b / tmp; o[2] = c / tmp;                // :449-452
+  };
+  for (int byte = 0; byte < 256; ++byte) {
+    const int bq = byte & 127;
+    const bool alt = (byte >> 7) != 0;
+    double G0 = 1.0, G1 = 1.0, G2 = 1.0;                           // :427
+    G0 *= alt ? lut.e3[bq] : lut.mat[bq];                          // :437
+    G1 *= lut.het[bq];                                             // :438
+    G2 *= alt ? lut.mat[bq] : lut.e3[bq];                          // :439
+    const double tmp = G0 + G1 + G2;                               // :440
+    out->first[byte][0] = G0 / tmp; out->first[byte][1] = G1 / tmp; out->first[byte][2] = G2 / tmp;   // :441-443
+    finish(out->first[byte], out->final1[byte]);
+  }
+  const double ones[3] = {1.0, 1.0, 1.0};
+  finish(ones, out->final1[256]);
+}
+
 }  // namespace dmx
 
 using dmx::set_error;

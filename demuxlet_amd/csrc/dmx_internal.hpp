@@ -17,6 +17,14 @@ int set_error(int code, const char* fmt, ...);   // records the message for dmx_
 struct ReadLut { double mat[128], e3[128], het[128]; };
 void build_read_lut(const double mat[256], const double err[256], ReadLut* out);
 
+// Singlet genotype likelihoods of a pair as a function of its FIRST read byte b = (allele<<7)|bq (cmd_cram_demuxlet.cpp
+// :427-452 evaluated on the host with the reference's IEEE operations):
+//   first[b]  = GL after that one read, renormalised to sum 1            (:437-443) — start of the loop for deeper pairs
+//   final1[b] = first[b] + 1e-6, renormalised                            (:446-452) — the whole answer for 1-read pairs
+//   final1[256] = the answer for a pair without usable reads: (1,1,1) + 1e-6, renormalised
+struct SingletTables { double first[256][3]; double final1[257][3]; };
+void build_singlet_tables(const ReadLut& lut, SingletTables* out);
+
 // Host-side exact re-evaluation of selected doublet-grid entries of ONE cell, in the reference's operation order with
 // the host libm (tie arbiter; cmd_cram_demuxlet.cpp:595-684 restricted to the requested (j,k,n)).
 struct GridReq { int32_t j, k, n; double value; };
