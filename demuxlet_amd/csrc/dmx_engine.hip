@@ -384,14 +384,18 @@ __global__ void k_transpose_geno(const float* __restrict__ g, const double* __re
 //            one-max-across-all-alphas renormalisation after every read (:600-663); A is padded to a power of two so the
 //            A lanes of a pair sit together in a wavefront and share their max by butterfly shuffles;
 //   phase 2  every accumulator adds log(sum_lm ...) for the tile's pairs in ascending SNP order (:671-709).
-template <typename NRD, int NACC>
+template <typename NRD, int NACC, bool FIXUP>
 __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, const float* __restrict__ g,
                                                               const double* __restrict__ gp0,
                                                               const double* __restrict__ lut,
                                                               const double* __restrict__ alpha,
                                                               const int32_t* __restrict__ sched, int32_t V, int32_t A,
                                                               int32_t A_pad, int32_t TP, double* __restrict__ grid,
-                                                              double* __restrict__ l00) {
+                                                              double* __restrict__ l00,
+                                                              const uint8_t* __restrict__ flagged) {
+  // FIXUP: second pass behind k_doublet_a2 — only cells in which that kernel met a log() argument outside the normal
+  // positive range (flagged[cell] != 0) are recomputed, with ocml's log() for exact log(0) / log(nan) semantics.
+  if (FIXUP && !flagged[sched[blockIdx.x]]) return;
   __shared__ double s_lut[kTab];
   __shared__ double s_pG[kThreads * 9];
   __shared__ int32_t s_snp[32];
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
         for (int l = 0; l < 3; ++l)
 #pragma unroll
           for (int m = 0; m < 3; ++m) sum += ((a[l] * b[m]) * P[l * 3 + m]);   // :553 then :677-679, l-major
-        acc[i] += dmx_log(sum, s_log);                                             // :683 / :709
+        acc[i] += FIXUP ? log(sum) : dmx_log(sum, s_log);                          // :683 / :709
       }
     }
     __syncthreads();
@@ -557,6 +561,233 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
     if (q < nAB) grid[(size_t)cell * nAB + q] = acc[i];
     else if (q < nacc) l00[(size_t)cell * A + (q - nAB)] = acc[i];
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K2 for the default alpha grid size A = 2 (alpha[0] = singlet entry, alpha[1] = the doublet mixture).
+// A cell is owned by TPC threads: TPC = 64 (V <= 16: one wavefront per cell, four independent cells per workgroup, no
+// workgroup barrier in the loop) or TPC = 256 (V <= 64: one cell per workgroup).  Thread (j, kb) of the cell owns the
+// 2*NK accumulators llksAB[j][kb*NK .. kb*NK+NK-1][0..1] in registers for the whole SNP range; it adds their log terms
+// pair after pair, i.e. in the reference's ascending-SNP order.  Per tile of 32 covered pairs:
+//   stage   the pairs' headers, then their genotype rows (float32, coalesced) into LDS;
+//   phase 1 lane (pair ti, alpha n) of the cell's first wavefront: pG[n][3][3] with the shared-max renormalisation after
+//           every read (:600-663) -> LDS; the same lane also forms the llks00 term of its (pair, alpha) (:699-709);
+//   phase 2 every thread, for each pair in order: gpAB[l][m] = g_j[l]*g_k[m] (exact: float32 x float32 in binary64,
+//           :553), the nine-term l-major sums for both alphas (:677-679), log, add (:683).
+// log() arguments outside the normal positive range cannot occur for genuine likelihoods; if one does, the cell is
+// flagged and recomputed by k_doublet_generic<FIXUP> with ocml's log().
+template <int TPC, int NK>
+__global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                         const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                         const double* __restrict__ alpha,
+                                                         const int32_t* __restrict__ sched, int32_t V, int32_t GS,
+                                                         double* __restrict__ grid, double* __restrict__ l00,
+                                                         uint8_t* __restrict__ flagged) {
+  constexpr int A = 2, TP = 32;
+  constexpr int CPW = kThreads / TPC;            // cells per workgroup
+  constexpr int T00 = TP + 2;
+#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  __syncthreads();
+
+  const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
+  // per-cell LDS regions
+  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * GS * 4 + 2 * T00 * 8 + TP * (4 + 4 + 8);
+  unsigned char* base = s_raw + (size_t)cw * cell_bytes;
+  double* s_pG = (double*)base;                                  // [TP][2][9]
+  float* s_g = (float*)(base + (size_t)TP * 18 * 8);             // [TP][GS]   genotype rows of the tile's SNPs
+  double* s_t00 = (double*)((unsigned char*)s_g + (size_t)TP * GS * 4);   // [2][T00]   llks00 terms
+  int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                  // [TP]
+  int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
+  uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
+
+  const int slot = blockIdx.x * CPW + cw;
+  if (TPC == 64 && slot >= pv.B) return;         // whole wavefront idle (no workgroup barriers below in this mode)
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+
+  // phase-2 identity
+  const int KB = (V + NK - 1) / NK;              // k-blocks per j
+  const int j = tid / KB, kb = tid % KB;
+  const bool owner = j < V;                      // V*KB <= TPC owners
+  double acc[NK][A];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
+  bool ok = true;
+  // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1; mixing weights of :613
+  const int ti1 = tid >> 1, n1 = tid & 1;
+  double wA[9], wR[9];
+  {
+    const double al = alpha[n1];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * al;
+        wA[l * 3 + m] = p;
+        wR[l * 3 + m] = 1.0 - p;
+      }
+  }
+  double acc00 = 0.0;                            // lane n1 == tid < 2 owns llks00[n]
+  const int row_len = V * 3;
+
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    // ---- headers of the tile's pairs (first 32 lanes of the cell)
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_K2_SYNC();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    // ---- genotype rows -> LDS (coalesced along the row)
+    {
+      int r = tid % row_len, ti = tid / row_len;
+      const int dr = TPC % row_len, dt = TPC / row_len;
+      while (ti < tp) {
+        s_g[ti * GS + r] = g[(size_t)s_snp[ti] * row_len + r];
+        r += dr; ti += dt;
+        if (r >= row_len) { r -= row_len; ++ti; }
+      }
+    }
+    // ---- phase 1
+    if (tid < 64) {
+      const bool on = ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      double pG[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt;
+        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+          }
+        }
+        {
+          const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);       // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] /= mx;
+          }
+        }
+      }
+      double mx = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        pG[i] += 1e-6;                                                       // :649
+        mx = (mx < pG[i]) ? pG[i] : mx;
+      }
+      {
+        const double o = __shfl_xor(mx, 1);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on) {
+        const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
+        const double* g0 = gp0 + (size_t)s_snp[ti1] * 3;
+        const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
+        const double qq[3] = {q0, q1, q2};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = div_by(pG[l * 3 + m], mx, y);                   // :656-663
+            s_pG[(ti1 * 2 + n1) * 9 + l * 3 + m] = v;
+            sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
+          }
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+      }
+    }
+    DMX_K2_SYNC();
+    // ---- llks00: lane n < 2 of the cell adds its alpha's terms in pair order
+    if (tid < 2) {
+      const double* row = &s_t00[tid * T00];
+      if (tp == TP) {                              // loads first (LDS latency paid once), then the ordered adds
+        double2 v[TP / 2];
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) v[i] = *reinterpret_cast<const double2*>(&row[2 * i]);
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+      } else {
+        for (int i = 0; i < tp; ++i) acc00 += row[i];
+      }
+    }
+    // ---- phase 2
+    if (owner) {
+      for (int ti = 0; ti < tp; ++ti) {
+        const double* P = &s_pG[ti * 18];
+        double P0[9], P1[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { P0[i] = P[i]; P1[i] = P[9 + i]; }
+        const float* gr = &s_g[ti * GS];
+        const double a0 = (double)gr[j * 3], a1 = (double)gr[j * 3 + 1], a2 = (double)gr[j * 3 + 2];
+        const double aj[3] = {a0, a1, a2};
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          const int k = min(kb * NK + kk, V - 1);
+          const double b0 = (double)gr[k * 3], b1 = (double)gr[k * 3 + 1], b2 = (double)gr[k * 3 + 2];
+          const double bk[3] = {b0, b1, b2};
+          double s0 = 0.0, s1 = 0.0;                                          // :674
+#pragma unroll
+          for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              const double gp = aj[l] * bk[m];                                // :553 (exact)
+              s0 += (gp * P0[l * 3 + m]);                                     // :677-679, l-major, alpha 0
+              s1 += (gp * P1[l * 3 + m]);                                     //                    alpha 1
+            }
+          ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
+          acc[kk][0] += dmx_log_fast(s0, s_log);                              // :683
+          acc[kk][1] += dmx_log_fast(s1, s_log);
+        }
+      }
+    }
+    DMX_K2_SYNC();
+  }
+  if (cell_ok) {
+    if (owner) {
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const int k = kb * NK + kk;
+        if (k < V) {
+          double* o = grid + (((size_t)cell * V + j) * V + k) * A;
+          o[0] = acc[kk][0]; o[1] = acc[kk][1];
+        }
+      }
+    }
+    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (!ok) flagged[cell] = 1;
+  }
+#undef DMX_K2_SYNC
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -680,6 +911,7 @@ struct dmx_engine {
   // results
   double *d_llks = nullptr, *d_llk0s = nullptr, *d_grid = nullptr, *d_l00 = nullptr;
   dmx_cell_summary* d_sum = nullptr;
+  uint8_t* d_flag = nullptr;
   int32_t out_B = 0; bool have_grid = false, have_sing = false;
   hipEvent_t ev[8] = {};
   bool timed[4] = {false, false, false, false};
@@ -700,6 +932,8 @@ int free_results(dmx_engine* e) {
   if (e->d_grid) (void)hipFree(e->d_grid);
   if (e->d_l00) (void)hipFree(e->d_l00);
   if (e->d_sum) (void)hipFree(e->d_sum);
+  if (e->d_flag) (void)hipFree(e->d_flag);
+  e->d_flag = nullptr;
   e->d_llks = e->d_llk0s = e->d_grid = e->d_l00 = nullptr; e->d_sum = nullptr;
   e->out_B = 0; e->have_grid = e->have_sing = false;
   return DMX_OK;
@@ -904,8 +1138,8 @@ int launch_singlet(dmx_engine* e) {
   return DMX_OK;
 }
 
-template <typename NRD>
-int launch_doublet(dmx_engine* e) {
+template <typename NRD, bool FIXUP>
+int launch_doublet_generic(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
   int A_pad = 1;
   while (A_pad < A) A_pad <<= 1;
@@ -914,8 +1148,8 @@ int launch_doublet(dmx_engine* e) {
   const int per = (int)((nacc + kThreads - 1) / kThreads);
   const dim3 grid((unsigned)B), block(kThreads);
 #define DMX_K2(NN)                                                                                                   \
-  hipLaunchKernelGGL((k_doublet_generic<NRD, NN>), grid, block, 0, e->stream, e->pv, e->d_g, e->d_gp0, e->d_lut,      \
-                     e->d_alpha, e->d_sched, V, A, A_pad, TP, e->d_grid, e->d_l00)
+  hipLaunchKernelGGL((k_doublet_generic<NRD, NN, FIXUP>), grid, block, 0, e->stream, e->pv, e->d_g, e->d_gp0, e->d_lut, \
+                     e->d_alpha, e->d_sched, V, A, A_pad, TP, e->d_grid, e->d_l00, e->d_flag)
   if (per <= 1) DMX_K2(1);
   else if (per <= 2) DMX_K2(2);
   else if (per <= 4) DMX_K2(4);
@@ -926,6 +1160,34 @@ int launch_doublet(dmx_engine* e) {
   else return set_error(DMX_ERR_ARG, "run_doublet: V*V*A = %lld accumulators per cell exceed this build's limit", (long long)nacc);
 #undef DMX_K2
   return DMX_OK;
+}
+
+template <bool FIXUP>
+int launch_doublet_generic_w(dmx_engine* e) {
+  return e->nrd_width == 1 ? launch_doublet_generic<uint8_t, FIXUP>(e)
+                           : (e->nrd_width == 2 ? launch_doublet_generic<uint16_t, FIXUP>(e) : launch_doublet_generic<uint32_t, FIXUP>(e));
+}
+
+// The A = 2 kernel with its fix-up pass; other alpha grids (or V > 64) take the generic kernel.
+int launch_doublet(dmx_engine* e) {
+  const int32_t B = e->pv.B, V = e->V, A = e->A;
+  const bool force_generic = getenv("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
+  if (A != 2 || V > 64 || force_generic) return launch_doublet_generic_w<false>(e);
+  const int GS = (V * 3 + 3) & ~3;               // LDS row stride of a genotype row (floats), 16-byte multiple
+  const size_t cell_bytes = (size_t)32 * 18 * 8 + (size_t)32 * GS * 4 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
+  HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+  const dim3 block(kThreads);
+#define DMX_K2A(TPC, NK)                                                                                             \
+  hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), block,  \
+                     cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
+                     e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag)
+  if (V <= 8) DMX_K2A(64, 1);
+  else if (V <= 16) DMX_K2A(64, 4);
+  else if (V <= 32) DMX_K2A(256, 4);
+  else DMX_K2A(256, 16);
+#undef DMX_K2A
+  HIP_TRY(hipGetLastError());
+  return launch_doublet_generic_w<true>(e);
 }
 
 }  // namespace
@@ -954,11 +1216,11 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
     HIP_TRY(hipMalloc((void**)&e->d_grid, std::max<size_t>(sizeof(double) * nAB * (size_t)B, 16)));
     HIP_TRY(hipMalloc((void**)&e->d_l00, std::max<size_t>(sizeof(double) * (size_t)e->A * (size_t)B, 16)));
     HIP_TRY(hipMalloc((void**)&e->d_sum, std::max<size_t>(sizeof(dmx_cell_summary) * (size_t)B, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_flag, std::max<size_t>((size_t)B, 16)));
   }
   if (B == 0) { e->have_grid = true; return DMX_OK; }
   HIP_TRY(hipEventRecord(e->ev[4], e->stream));
-  int rc = e->nrd_width == 1 ? launch_doublet<uint8_t>(e) : (e->nrd_width == 2 ? launch_doublet<uint16_t>(e) : launch_doublet<uint32_t>(e));
-  if (rc) return rc;
+  if (int rc = launch_doublet(e)) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e->ev[5], e->stream));
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)B), dim3(kThreads), 0, e->stream, e->d_grid, e->d_l00, e->pv.cell_pair_off,
