@@ -102,12 +102,15 @@ def main():
         sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # DMX_BENCH_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (1-GPU boxes: exercises the gather)
+    use_dist = world > 1 or bool(os.environ.get("DMX_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
     if rank == 0:
         build.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     cfg = dict(CONFIGS[args.config])
@@ -132,14 +135,16 @@ def main():
     eng.set_pileup_struct(dp.as_struct(), keep=dp)
     nbytes = eng.algorithmic_bytes()
 
-    # device views of the per-cell records, for the end-of-step gather
-    def record_tensors():
+    # device views of the per-cell records, for the end-of-step gather (same row layout as demuxlet_amd/dist.py)
+    def record_matrix():
         v = eng.device_view()
-        ts = [synth_torch.tensor_from_ptr(v.llks, (B, V), torch.float64, dev), synth_torch.tensor_from_ptr(v.llk0s, (B,), torch.float64, dev)]
+        cols = [synth_torch.tensor_from_ptr(v.llks, (B, V), torch.float64, dev),
+                synth_torch.tensor_from_ptr(v.llk0s, (B, 1), torch.float64, dev)]
         if cfg["doublet"]:
-            ts.append(synth_torch.tensor_from_ptr(v.summary, (B, engine.capi.SUMMARY_DTYPE.itemsize), torch.uint8, dev))
-            ts.append(synth_torch.tensor_from_ptr(v.llks00, (B, A), torch.float64, dev))
-        return ts
+            cols += [synth_torch.tensor_from_ptr(v.sing, (B, V), torch.float64, dev),
+                     synth_torch.tensor_from_ptr(v.llks00, (B, A), torch.float64, dev),
+                     synth_torch.tensor_from_ptr(v.summary, (B, engine.capi.SUMMARY_DTYPE.itemsize // 8), torch.float64, dev)]
+        return torch.cat(cols, dim=1)
 
     gathered = None
 
@@ -151,19 +156,17 @@ def main():
         if cfg["doublet"]:
             eng.run_doublet()
             if ev: ev[2].record()
-        if world > 1:
-            # the one collective of the job: per-cell records -> rank 0 (RCCL over xGMI)
-            outs = []
-            for tsr in record_tensors():
-                lst = [torch.empty_like(tsr) for _ in range(world)] if rank == 0 else None
-                dist.gather(tsr, lst, dst=0)
-                outs.append(lst)
+        if use_dist:
+            # THE collective of the job: one fixed-size record per barcode -> rank 0 (RCCL gather over xGMI)
+            rec = record_matrix()
+            outs = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
+            dist.gather(rec, outs, dst=0)
             gathered = outs
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
@@ -171,11 +174,11 @@ def main():
     for i in range(args.steps):
         step(evs[i])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -218,7 +221,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(dp, g, cfg)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
+        if rank == 0 and gathered is not None:
+            assert len(gathered) == world and tuple(gathered[0].shape) == tuple(record_matrix().shape)
         dist.barrier()
         dist.destroy_process_group()
 

@@ -27,7 +27,7 @@ SYMBOLS = [
     "dmx_engine_set_genotypes", "dmx_engine_set_pileup", "dmx_engine_run_singlet", "dmx_engine_run_doublet",
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
-    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div",
+    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_engine_get_sing", "dmx_write_doublet_summary",
 ]
 
 
@@ -66,7 +66,7 @@ assert SUMMARY_DTYPE.itemsize == C.sizeof(CellSummary)
 
 class DeviceView(C.Structure):
     _fields_ = [("llks", C.c_void_p), ("llk0s", C.c_void_p), ("llksAB", C.c_void_p), ("llks00", C.c_void_p),
-                ("summary", C.c_void_p), ("gp0s", C.c_void_p)]
+                ("summary", C.c_void_p), ("gp0s", C.c_void_p), ("sing", C.c_void_p)]
 
 
 class KernelTimes(C.Structure):
@@ -126,6 +126,7 @@ def load() -> C.CDLL:
         "dmx_engine_last_kernel_times": [vp, vp], "dmx_engine_algorithmic_bytes": [vp, vp],
         "dmx_write_single": [vp, C.c_char_p], "dmx_write_doublet": [vp, C.c_char_p], "dmx_demuxlet_run": [vp],
         "dmx_debug_device_log": [vp, vp, C.c_int64, i32],
+        "dmx_engine_get_sing": [vp, vp], "dmx_write_doublet_summary": [vp, vp, vp, C.c_char_p],
         "dmx_debug_device_div": [vp, vp, vp, C.c_int64, i32],
     }
     for name, args in sig.items():

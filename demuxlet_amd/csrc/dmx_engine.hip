@@ -800,7 +800,8 @@ __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {      // larger va
 __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ grid, const double* __restrict__ l00,
                                                      const int64_t* __restrict__ cell_pair_off,
                                                      const double* __restrict__ alpha, int32_t V, int32_t A,
-                                                     double prior, dmx_cell_summary* __restrict__ out) {
+                                                     double prior, dmx_cell_summary* __restrict__ out,
+                                                     double* __restrict__ sing) {
   __shared__ double s_d[kThreads];
   __shared__ double s_e[kThreads];
   __shared__ int32_t s_i[kThreads];
@@ -810,6 +811,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
   const double* G = grid + (size_t)cell * nAB;
   const int32_t npairs = (int32_t)(cell_pair_off[cell + 1] - cell_pair_off[cell]);
 
+  for (int32_t jj = t; jj < V; jj += kThreads) sing[(size_t)cell * V + jj] = G[(size_t)jj * V * A];   // llksAB[j][0][0]
   // (1) max over the whole grid (:713-721)
   double mx = -1e300;
   for (int32_t q = t; q < nAB; q += kThreads) mx = (mx < G[q]) ? G[q] : mx;
@@ -912,6 +914,7 @@ struct dmx_engine {
   double *d_llks = nullptr, *d_llk0s = nullptr, *d_grid = nullptr, *d_l00 = nullptr;
   dmx_cell_summary* d_sum = nullptr;
   uint8_t* d_flag = nullptr;
+  double* d_sing = nullptr;
   int32_t out_B = 0; bool have_grid = false, have_sing = false;
   hipEvent_t ev[8] = {};
   bool timed[4] = {false, false, false, false};
@@ -933,7 +936,8 @@ int free_results(dmx_engine* e) {
   if (e->d_l00) (void)hipFree(e->d_l00);
   if (e->d_sum) (void)hipFree(e->d_sum);
   if (e->d_flag) (void)hipFree(e->d_flag);
-  e->d_flag = nullptr;
+  if (e->d_sing) (void)hipFree(e->d_sing);
+  e->d_flag = nullptr; e->d_sing = nullptr;
   e->d_llks = e->d_llk0s = e->d_grid = e->d_l00 = nullptr; e->d_sum = nullptr;
   e->out_B = 0; e->have_grid = e->have_sing = false;
   return DMX_OK;
@@ -1217,6 +1221,7 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
     HIP_TRY(hipMalloc((void**)&e->d_l00, std::max<size_t>(sizeof(double) * (size_t)e->A * (size_t)B, 16)));
     HIP_TRY(hipMalloc((void**)&e->d_sum, std::max<size_t>(sizeof(dmx_cell_summary) * (size_t)B, 16)));
     HIP_TRY(hipMalloc((void**)&e->d_flag, std::max<size_t>((size_t)B, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_sing, std::max<size_t>(sizeof(double) * (size_t)B * e->V, 16)));
   }
   if (B == 0) { e->have_grid = true; return DMX_OK; }
   HIP_TRY(hipEventRecord(e->ev[4], e->stream));
@@ -1224,7 +1229,7 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e->ev[5], e->stream));
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)B), dim3(kThreads), 0, e->stream, e->d_grid, e->d_l00, e->pv.cell_pair_off,
-                     e->d_alpha, e->V, e->A, e->prior, e->d_sum);
+                     e->d_alpha, e->V, e->A, e->prior, e->d_sum, e->d_sing);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e->ev[6], e->stream));
   e->timed[2] = e->timed[3] = true; e->have_grid = true;
@@ -1261,10 +1266,20 @@ extern "C" int dmx_engine_get_doublet(dmx_engine* e, double* llksAB, double* llk
   return DMX_OK;
 }
 
+extern "C" int dmx_engine_get_sing(dmx_engine* e, double* sing) {
+  if (!e || !sing) return set_error(DMX_ERR_ARG, "dmx_engine_get_sing: null argument");
+  if (!e->have_grid) return set_error(DMX_ERR_STATE, "dmx_engine_get_sing: run_doublet has not been called");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t B = (size_t)e->pv.B;
+  if (B) HIP_TRY(hipMemcpyAsync(sing, e->d_sing, sizeof(double) * B * e->V, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DMX_OK;
+}
+
 extern "C" int dmx_engine_device_view(dmx_engine* e, dmx_device_view* out) {
   if (!e || !out) return set_error(DMX_ERR_ARG, "dmx_engine_device_view: null argument");
   out->llks = e->d_llks; out->llk0s = e->d_llk0s; out->llksAB = e->d_grid; out->llks00 = e->d_l00; out->summary = e->d_sum;
-  out->gp0s = e->d_gp0;
+  out->gp0s = e->d_gp0; out->sing = e->d_sing;
   return DMX_OK;
 }
 

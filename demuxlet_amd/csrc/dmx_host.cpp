@@ -566,3 +566,70 @@ extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_pref
   }
   return DMX_OK;
 }
+
+
+// .sing2 and .best from the per-cell records of the device reduction (K3) — the multi-GPU path gathers exactly these.
+extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double* sing, const dmx_cell_summary* summary,
+                                         const char* out_prefix) {
+  if (int rc = check_common(in, "dmx_write_doublet_summary")) return rc;
+  if (!out_prefix || !sing || !summary || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: null sing/summary/llks00/alpha/prefix");
+  if (in->write_pair) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: .pair rows need the full grid (use dmx_write_doublet)");
+  const int32_t V = in->n_samples, A = in->n_alpha;
+  if (V < 2 || A < 2) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
+  const std::string pre(out_prefix);
+  File sing2, best;
+  if (!sing2.open(pre + ".sing2") || !best.open(pre + ".best")) return set_error(DMX_ERR_IO, "Cannot create %s.single, %s.pair files", out_prefix, out_prefix);
+  fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", sing2.f);
+  fputs("BARCODE\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tBEST\tSNG.1ST\tSNG.LLK1\tSNG.2ND\tSNG.LLK2\tSNG.LLK0\tDBL.1ST\tDBL.2ND\tALPHA\tLLK12\tLLK1\tLLK2\tLLK10\tLLK20\tLLK00\tPRB.DBL\tPRB.SNG1\n", best.f);
+  const double prior = in->doublet_prior;
+  const bool arbiter = in->tie_pileup && in->tie_g;
+  dmx::ReadLut lut;
+  if (arbiter) {
+    if (in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: the tie arbiter needs a HOST pileup");
+    double mat[256], err[256];
+    dmx_phred_tables(mat, err);
+    dmx::build_read_lut(mat, err, &lut);
+  }
+  std::vector<dmx::GridReq> reqs;
+  for (int32_t c : barcode_order(in)) {
+    if (cell_filtered(in, c)) continue;
+    if (in->n_snp[c] == 0) continue;
+    const dmx_cell_summary& sm = summary[c];
+    const double* sg = sing + (size_t)c * V;
+    const double* l00 = in->llks00 + (size_t)c * A;
+    int32_t jb = sm.j_best, kb = sm.k_best;
+    double l12 = sm.llk12, l1 = sm.llk1, l2 = sm.llk2, l10 = sm.llk10, l20 = sm.llk20;
+    if (arbiter && in->alpha[sm.n_best] == 0.5) {
+      // (j,k) and (k,j) are one doublet at alpha = 0.5 and differ only by rounding: re-evaluate both in the
+      // reference's operation order and let its strict-< scan decide, which visits the smaller first index first.
+      const int32_t a = std::min(jb, kb), b = std::max(jb, kb);
+      reqs.assign({{a, b, sm.n_best, 0.0}, {b, a, sm.n_best, 0.0}});
+      dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, c, reqs);
+      const bool swap_to_ba = reqs[0].value < reqs[1].value;
+      const int32_t nj = swap_to_ba ? b : a, nk = swap_to_ba ? a : b;
+      if (nj != jb) { std::swap(l1, l2); std::swap(l10, l20); }
+      jb = nj; kb = nk;
+      l12 = swap_to_ba ? reqs[1].value : reqs[0].value;
+    }
+    const char* bc = in->barcodes[c];
+    const int32_t t = in->rd_totl[c], p = in->rd_pass[c], u = in->rd_uniq[c], ns = in->n_snp[c];
+    for (int32_t j = 0; j < V; ++j)
+      fprintf(sing2.f, "%s\t%s\t%d\t%d\t%d\t%d\t%.4lf\t%.4lf\t%.3lg\n", bc, in->sample_ids[j], t, p, u, ns, sg[j], l00[0],
+              std::exp(sg[j] - sm.max_llk) * (1. - prior) / V / sm.sum_single);
+    const double sing1 = sg[sm.i_sing1], sing2v = sg[sm.i_sing2];
+    const double post_dbl = sm.sum_double / (sm.sum_single + sm.sum_double);
+    const double post_sng = std::exp(sing1 - sm.max_llk) * (1. - prior) / V / sm.sum_single;
+    fprintf(best.f, "%s\t%d\t%d\t%d\t%d\t", bc, t, p, u, ns);
+    if ((l12 > l1) && (l12 > l2) && (l12 > sing1 + 2))
+      fprintf(best.f, "DBL-%s-%s-%.3lf", in->sample_ids[jb], in->sample_ids[kb], in->alpha[sm.n_best]);
+    else if (sing1 > sing2v + 2)
+      fprintf(best.f, "SNG-%s", in->sample_ids[sm.i_sing1]);
+    else
+      fprintf(best.f, "AMB-%s-%s-%s/%s", in->sample_ids[sm.i_sing1], in->sample_ids[sm.i_sing2], in->sample_ids[jb], in->sample_ids[kb]);
+    fprintf(best.f, "\t%s\t%.4lf", in->sample_ids[sm.i_sing1], sing1);
+    fprintf(best.f, "\t%s\t%.4lf\t%.4lf", in->sample_ids[sm.i_sing2], sing2v, l00[0]);
+    fprintf(best.f, "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[jb], in->sample_ids[kb],
+            in->alpha[sm.n_best], l12, l1, l2, l10, l20, l00[sm.n_best], post_dbl, post_sng);
+  }
+  return DMX_OK;
+}

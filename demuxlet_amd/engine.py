@@ -195,6 +195,11 @@ class Engine:
                                              summ.ctypes.data))
         return grid, l00, summ
 
+    def get_sing(self) -> np.ndarray:
+        sing = np.zeros((self.B, self.V))
+        check(self._L.dmx_engine_get_sing(self._h, sing.ctypes.data))
+        return sing
+
     def device_view(self) -> capi.DeviceView:
         v = capi.DeviceView()
         check(self._L.dmx_engine_device_view(self._h, C.byref(v)))
@@ -273,6 +278,15 @@ def write_doublet(fa: FinalArgs, grid, l00, out_prefix: str, tie_pileup: Optiona
                   tie_g: Optional[np.ndarray] = None) -> None:
     fin, keep = _final_struct(fa, grid=grid, l00=l00, tie_pileup=tie_pileup, tie_g=tie_g)
     check(capi.load().dmx_write_doublet(C.byref(fin), out_prefix.encode()))
+
+
+def write_doublet_summary(fa: FinalArgs, sing, l00, summary, out_prefix: str, tie_pileup: Optional[HostPileup] = None,
+                          tie_g: Optional[np.ndarray] = None) -> None:
+    """.sing2/.best from the per-cell records (K3 summaries) instead of the grid — what a multi-GPU run gathers."""
+    fin, keep = _final_struct(fa, l00=l00, tie_pileup=tie_pileup, tie_g=tie_g)
+    sing = np.ascontiguousarray(sing, dtype=np.float64)
+    summary = np.ascontiguousarray(summary, dtype=capi.SUMMARY_DTYPE)
+    check(capi.load().dmx_write_doublet_summary(C.byref(fin), sing.ctypes.data, summary.ctypes.data, out_prefix.encode()))
 
 
 def demuxlet_run(store: Store, g: np.ndarray, sample_ids: Sequence[str], alphas: Sequence[float], out_prefix: str,

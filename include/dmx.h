@@ -142,10 +142,14 @@ int dmx_engine_sync(dmx_engine*);
 /* Device->host copies of the results (any pointer may be NULL). Synchronises. */
 int dmx_engine_get_singlet(dmx_engine*, double* llks, double* llk0s);
 int dmx_engine_get_doublet(dmx_engine*, double* llksAB, double* llks00, dmx_cell_summary* summary);
+/* sing[B][V] = llksAB[c][j][0][0], the singlet column of the grid (what .sing2 prints, :746-770) — lets a caller skip
+ * the V*V*A grid entirely when --write-pair is off. */
+int dmx_engine_get_sing(dmx_engine*, double* sing);
 
 /* Device views for zero-copy hand-off (torch tensors over them, RCCL gather of the per-cell records). */
 typedef struct {
   double* llks;  double* llk0s;  double* llksAB;  double* llks00;  dmx_cell_summary* summary;  double* gp0s;
+  double* sing;                /* [B][V] */
 } dmx_device_view;
 int dmx_engine_device_view(dmx_engine*, dmx_device_view* out);
 
@@ -184,6 +188,11 @@ typedef struct {
 
 int dmx_write_single(const dmx_final_input*, const char* path);                    /* <out>.single */
 int dmx_write_doublet(const dmx_final_input*, const char* out_prefix);            /* <out>.sing2, <out>.best, [<out>.pair] */
+/* The same <out>.sing2 and <out>.best from the per-cell records of the device-side reduction (dmx_engine_get_sing,
+ * dmx_engine_get_doublet's summary and llks00) instead of the full grid: what a multi-GPU run gathers to rank 0.
+ * in->llksAB is ignored; in->write_pair must be 0 (the .pair rows need the grid).  With in->tie_pileup the order of
+ * the two samples of an alpha = 0.5 best doublet is arbitrated exactly. */
+int dmx_write_doublet_summary(const dmx_final_input*, const double* sing, const dmx_cell_summary* summary, const char* out_prefix);
 
 /* Diagnostics: evaluate the device's log() replacement (dmx_log, csrc/dmx_log.hpp) on n host doubles. Used by the tests
  * to show the device function performs exactly the IEEE operation sequence whose accuracy is measured on the host. */

@@ -27,3 +27,40 @@ class Golden:
                       z["ev_bq"], z["ev_newread"])
         return O.Problem(self.sample_ids, self.g, ev,
                          O.Params(self.alphas, self.doublet_prior, self.min_total, self.min_uniq, self.min_snp, self.write_pair))
+
+
+def summary_from_grid(grid, l00, alphas, prior, n_pairs, summary_dtype):
+    """The per-cell record K3 produces, computed with the reference's own scans (cmd_cram_demuxlet.cpp:713-734,
+    :746-758, :799-828) in numpy/python — test-side restatement for index-exact comparisons."""
+    import numpy as np
+    V, _, A = grid.shape
+    s = np.zeros((), dtype=summary_dtype)
+    mx = -1e300
+    for v in grid.ravel():
+        if mx < v: mx = v
+    ss = 0.0; sd = 0.0
+    for j in range(V):
+        ss += (np.exp(grid[j, 0, 0] - mx) * (1. - prior) / V)
+        for k in range(V):
+            if j == k: continue
+            for n in range(1, A):
+                sd += (np.exp(grid[j, k, n] - mx) * prior / V / (V - 1) / (A - 1) / (2.0 if alphas[n] == 0.5 else 1.0))
+    i1 = i2 = -1; m1 = m2 = -1e300
+    for j in range(V):
+        v = grid[j, 0, 0]
+        if m1 < v: m2, i2, i1, m1 = m1, i1, j, v
+        elif m2 < v: i2, m2 = j, v
+    jb = kb = nb = -1; mab = -1e300
+    for j in range(V):
+        for k in range(V):
+            if j == k: continue
+            for n in range(1, A):
+                if mab < grid[j, k, n]: jb, kb, nb, mab = j, k, n, grid[j, k, n]
+    s["max_llk"], s["sum_single"], s["sum_double"] = mx, ss, sd
+    s["i_sing1"], s["i_sing2"], s["j_best"], s["k_best"], s["n_best"] = i1, i2, jb, kb, nb
+    s["sing_llk1"], s["sing_llk2"] = grid[i1, 0, 0], grid[i2, 0, 0]
+    s["llk12"], s["llk1"], s["llk2"] = grid[jb, kb, nb], grid[jb, 0, 0], grid[kb, 0, 0]
+    s["llk10"], s["llk20"] = grid[jb, 0, nb], grid[kb, 0, nb]
+    s["llk00_0"], s["llk00_best"] = l00[0], l00[nb]
+    s["n_pairs"] = n_pairs
+    return s

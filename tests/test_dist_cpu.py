@@ -1,0 +1,118 @@
+"""CPU: the multi-GPU plumbing (demuxlet_amd/dist.py) — sharding of the sorted barcodes, the single gather of per-cell
+records (gloo, world_size 2), and the finaliser that works from those records — against the reference's outputs.
+The per-shard numbers come from the oracle here (the engine has no CPU path); on GPUs the same code runs the engine."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from golden_util import CASES, Golden, summary_from_grid
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_balanced_ranges_properties():
+    from demuxlet_amd import dist
+    rng = np.random.default_rng(0)
+    for n, w in ((0, 2), (1, 2), (5, 8), (1000, 8), (37, 3)):
+        cost = rng.integers(1, 1000, size=n).astype(float)
+        r = dist.balanced_ranges(cost, w)
+        assert len(r) == w and r[0][0] == 0 and r[-1][1] == n
+        assert all(r[i][1] == r[i + 1][0] for i in range(w - 1)) and all(a <= b for a, b in r)
+        if n >= 8 * w:
+            sums = [cost[a:b].sum() for a, b in r]
+            assert max(sums) <= cost.sum() / w + cost.max()
+    order = dist.sorted_barcode_order(["b", "a", "B", "ab", "a-1"])
+    assert [["b", "a", "B", "ab", "a-1"][i] for i in order] == ["B", "a", "a-1", "ab", "b"]
+
+
+def build_store(eng, pb):
+    st = eng.Store()
+    for _ in range(pb.n_snps):
+        st.add_snp()
+    ev = pb.events
+    for e in range(len(ev.barcode)):
+        c = st.add_cell(ev.barcode[e])
+        if ev.newread[e]:
+            st.count_read(c)
+        if ev.snp[e] >= 0:
+            st.add_read(int(ev.snp[e]), c, ev.umi[e], int(ev.allele[e]), int(ev.bq[e]))
+    return st
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if c not in ("gt_v64_a2",)])
+def test_summary_writer_reproduces_reference_files(oracle, name, tmp_path):
+    """.sing2/.best from per-cell records (what rank 0 holds after the gather) == the reference's files."""
+    from demuxlet_amd import build, capi, engine
+    build.build()
+    gd = Golden(name)
+    cnt = gd.z["ref_counters"]
+    B = len(gd.ref_barcodes)
+    grid, l00 = gd.z["ref_llksAB"], gd.z["ref_llks00"]
+    summ = np.zeros(B, dtype=capi.SUMMARY_DTYPE)
+    for c in range(B):
+        if gd.z["ref_processed"][c]:
+            summ[c] = summary_from_grid(grid[c], l00[c], gd.alphas, gd.doublet_prior, cnt[c, 3], capi.SUMMARY_DTYPE)
+    fa = engine.FinalArgs(gd.ref_barcodes, gd.sample_ids, gd.alphas, gd.doublet_prior, cnt[:, 0], cnt[:, 1], cnt[:, 2], cnt[:, 3],
+                          gd.min_total, gd.min_uniq, gd.min_snp, False)
+    engine.write_doublet_summary(fa, grid[:, :, 0, 0], l00, summ, str(tmp_path / "o"))
+    assert (tmp_path / "o.best").read_bytes() == gd.files["best"]
+    assert (tmp_path / "o.sing2").read_bytes() == gd.files["sing2"]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, name, outdir):
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+    from demuxlet_amd import capi, engine
+    from demuxlet_amd import dist as ddist
+    from golden_util import Golden, summary_from_grid
+    from oracle import oracle_py as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gd = Golden(name)
+    pb = gd.problem(O)
+    st = build_store(engine, pb)
+    pl = st.freeze()
+    barcodes = st.barcodes()
+    V, A = len(gd.sample_ids), len(gd.alphas)
+
+    def compute(shard):          # stands in for the GPU engine: same inputs (a dmx_pileup slice), same record layout
+        words = ((shard.reads >> 7).astype(np.uint32) << 24) | ((shard.reads & 0x7F).astype(np.uint32) << 16) | 1
+        csr = O.Csr([f"x{i}" for i in range(shard.n_cells)], shard.cell_pair_off, shard.pair_snp,
+                    np.concatenate([[0], np.cumsum(shard.pair_nrd.astype(np.int64))]), words, shard.rd_totl, shard.rd_pass, shard.rd_uniq)
+        r = O.run_csr(csr, gd.sample_ids, gd.g, O.Params(gd.alphas, gd.doublet_prior))
+        summ = np.zeros(shard.n_cells, dtype=capi.SUMMARY_DTYPE)
+        for c in range(shard.n_cells):
+            if shard.n_snp_per_cell[c] > 0:
+                summ[c] = summary_from_grid(r.llksAB[c], r.llks00[c], gd.alphas, gd.doublet_prior, shard.n_snp_per_cell[c], capi.SUMMARY_DTYPE)
+        return ddist.CellRecords(r.llks, r.llk0s, np.ascontiguousarray(r.llksAB[:, :, 0, 0]), r.llks00, summ)
+
+    res = ddist.run_sharded(pl, barcodes, V, A, compute, capi.SUMMARY_DTYPE)
+    if rank == 0:
+        order, rec = res
+        inv = np.empty_like(order); inv[order] = np.arange(len(order))      # records are in sorted-barcode order
+        fa = engine.FinalArgs(barcodes, gd.sample_ids, gd.alphas, gd.doublet_prior, pl.rd_totl, pl.rd_pass, pl.rd_uniq,
+                              pl.n_snp_per_cell, gd.min_total, gd.min_uniq, gd.min_snp, False)
+        engine.write_single(fa, rec.llks[inv], rec.llk0s[inv], os.path.join(outdir, "o.single"))
+        engine.write_doublet_summary(fa, rec.sing[inv], rec.llks00[inv], rec.summary[inv], os.path.join(outdir, "o"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["gt_v4_a2_pair", "gp_v8_a2_minsnp"])
+def test_sharded_run_world2_gloo(name, tmp_path):
+    import torch.multiprocessing as mp
+    from demuxlet_amd import build
+    from oracle import oracle_py
+    build.build(); oracle_py.build()
+    mp.spawn(_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    gd = Golden(name)
+    for suf in ("single", "sing2", "best"):
+        assert (tmp_path / f"o.{suf}").read_bytes() == gd.files[suf], suf

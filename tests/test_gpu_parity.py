@@ -266,3 +266,36 @@ def test_size_independent_properties(eng):
     g2 = np.concatenate([g, g], axis=1)
     out3 = run_engine(eng, host_pileup(eng, sp), g2, (0.0, 0.5), 0.5, doublet=False)
     assert np.array_equal(out3["llks"][:, :V], out["llks"]) and np.array_equal(out3["llks"][:, V:], out["llks"])
+
+
+@pytest.mark.parametrize("name", ["gt_v4_a2_pair", "gp_v8_a2_minsnp", "gt_v5_dense", "pl_v32_a3"])
+def test_records_path_end_to_end(eng, oracle, name, tmp_path):
+    """The multi-GPU record path on one GPU: engine -> (llks, llk0s, sing, llks00, K3 summary) -> summary writer with the
+    alpha=0.5 mirror arbiter == the reference's .single/.sing2/.best; the grid never leaves the device."""
+    gd = Golden(name)
+    st = build_store(eng, gd.problem(oracle))
+    pl = st.freeze()
+    e = eng.Engine(len(gd.sample_ids), gd.alphas, gd.doublet_prior)
+    e.set_genotypes(gd.g); e.set_pileup(pl)
+    e.run_singlet(); e.run_doublet()
+    llks, llk0s = e.get_singlet()
+    grid, l00, summ = e.get_doublet(want_grid=True)
+    sing = e.get_sing()
+    e.close()
+    assert np.array_equal(sing, grid[:, :, 0, 0])
+    fa = eng.FinalArgs(st.barcodes(), gd.sample_ids, gd.alphas, gd.doublet_prior, pl.rd_totl, pl.rd_pass, pl.rd_uniq,
+                       pl.n_snp_per_cell, gd.min_total, gd.min_uniq, gd.min_snp, False)
+    eng.write_single(fa, llks, llk0s, str(tmp_path / "o.single"))
+    eng.write_doublet_summary(fa, sing, l00, summ, str(tmp_path / "o"), tie_pileup=pl, tie_g=gd.g)
+    for suf in ("single", "sing2", "best"):
+        got = (tmp_path / f"o.{suf}").read_text().splitlines()
+        want = gd.files[suf].decode().splitlines()
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            fa_, fb_ = a.split("\t"), b.split("\t")
+            for x, y in zip(fa_, fb_):
+                try:
+                    fx, fy = float(x), float(y)
+                    assert abs(fx - fy) <= 1e-3 * max(1e-3, abs(fy)) + 1.01e-4
+                except ValueError:
+                    assert x == y, (suf, a, b)
