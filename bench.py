@@ -35,6 +35,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector peak (spec; half the 157.3 TF FP32 vector rate), FMA = 2 flop
+VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4   # FP64 wave64 instructions/s: 1024 SIMDs, 16 FP64 lanes/clk each (= 78.6 TF / 128)
 
 
 def genotype_matrix(engine, synth, rng, S, V, field):
@@ -195,10 +196,20 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         dom_ms, dom_bytes, dom_name = (k2_ms, nbytes.doublet_bytes, "k_doublet") if cfg["doublet"] else (k1_ms, nbytes.singlet_bytes, "k_singlet")
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic and VALU instruction counts of one launch of the dominant kernel are properties of the workload; they
+        # come from the committed rocprofv3 PMC passes of the same workload (profiles/, tools/profile_round.sh)
+        traffic, valu = None, None
         prof = ROOT / "profiles" / f"pmc_cfg{args.config}.json"
         if prof.exists():
-            traffic = json.loads(prof.read_text()).get("hbm_bytes_per_launch")
+            pj = json.loads(prof.read_text())
+            if pj.get("barcodes_per_gpu") == B:
+                traffic = pj.get("hbm_bytes_per_launch")
+                if pj.get("valu_wave_insts_per_launch"):
+                    rate = pj["valu_wave_insts_per_launch"] / (dom_ms * 1e-3)
+                    valu = {"bound": "fp64_valu", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave-instructions/s",
+                            "frac": rate / VALU_PEAK_WAVE_INSTS, "kernel": pj.get("kernel"),
+                            "note": "the binding roofline of this path: FP64 VALU issue (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 FP64 "
+                                    "instruction); instruction count per launch from profiles/ PMC (SQ_INSTS_VALU), time live"}
         logs = dp.n_pairs * ((V + 1) + (V * V * A + A if cfg["doublet"] else 0))
         out = {
             "metric": "cell-SNP-sample triples/sec (singlet+doublet llk); HBM GB/s vs roofline",
@@ -212,6 +223,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
                          "kernel_ms": dom_ms,
                          "note": "FP64-VALU/log-bound path (SURVEY §8d): HBM fraction is reported as the metric asks; see fp64_valu"},
+            "roofline_valu": valu,
             "fp64_valu": {"log_evals_per_s": logs / ((k1_ms + k2_ms) * 1e-3), "kernel_ms": {"k_singlet": k1_ms, "k_doublet+k_reduce": k2_ms},
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }

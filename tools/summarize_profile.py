@@ -42,7 +42,10 @@ json.dump(res, open(out / f"{tag}_cfg{cfg}_pmc_summary.json", "w"), indent=1)
 dom = [k for k in res if ("k_doublet_a2" in k or "k_doublet_generic" in k)] or [k for k in res if "k_singlet" in k]
 dom = max(dom, key=lambda k: res[k].get("SQ_WAVE_CYCLES", 0))
 d = res[dom]
-json.dump({"kernel": dom, "hbm_bytes_per_launch": d.get("hbm_read_bytes_x2", 0) + d.get("hbm_write_bytes", 0),
+bench = json.load(open(src / "bench.json"))
+json.dump({"kernel": dom, "barcodes_per_gpu": bench["config"]["barcodes_per_gpu"],
+           "valu_wave_insts_per_launch": d.get("SQ_INSTS_VALU"), "valu_busy_quadcycles_per_launch": d.get("SQ_ACTIVE_INST_VALU"),
+           "hbm_bytes_per_launch": d.get("hbm_read_bytes_x2", 0) + d.get("hbm_write_bytes", 0),
            "hbm_read_bytes_raw": d.get("hbm_read_bytes_raw"), "hbm_read_bytes_x2": d.get("hbm_read_bytes_x2"),
            "hbm_write_bytes": d.get("hbm_write_bytes"), "source": f"profiles/{tag}_cfg{cfg}_pmc_summary.json"},
           open(out / f"pmc_cfg{cfg}.json", "w"), indent=1)
