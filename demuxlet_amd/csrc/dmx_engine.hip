@@ -182,15 +182,24 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
   constexpr int NW = kThreads / 64;
   static_assert(CW * NC <= 64, "one lane per chain");
   extern __shared__ double s_dyn[];              // [NW][nch][CW*NC] running accumulators
+#ifdef DMX_K1_TABLES_GLOBAL
+  __shared__ double s_tab[kTab];
+  const double* s_first = tabs + kTab;             // L1/L2-resident, 12 KB
+#else
   __shared__ double s_tab[kTabK1];
+  const double* s_first = s_tab + kTab;
+#endif
   __shared__ __attribute__((aligned(16))) double s_term[NW][CW * NC * TS];
   const double* s_log = s_tab + kLut;
-  const double* s_first = s_tab + kTab;
   const double* s_final = s_first + kFirst;
 
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int nch = (V + KC - 1) / KC;
+#ifdef DMX_K1_TABLES_GLOBAL
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+#else
   for (int i = t; i < kTabK1; i += kThreads) s_tab[i] = tabs[i];
+#endif
   for (int i = t; i < NW * nch * CW * NC; i += kThreads) s_dyn[i] = 0.0;
   __syncthreads();                               // the only workgroup barrier
 
@@ -215,6 +224,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
   const int64_t a_np = __shfl(np, (a_ok ? a_c : 0) * T);
   const int32_t a_cell = __shfl(cell, (a_ok ? a_c : 0) * T);
   const size_t S = (size_t)pv.S;
+
+  // Dense genotype planes are read through buffer descriptors: address = descriptor base + scalar plane offset + lane
+  // offset, one instruction per element and no per-lane 64-bit address arithmetic (S*V*12 < 4 GiB is checked at launch).
+  const uint32_t plane4 = (uint32_t)S * 4u, plane8 = (uint32_t)S * 8u;
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)gq, 0, DENSE ? (int)min((size_t)0x7FFFFFFF, S * (size_t)V * 12) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g0 = __builtin_amdgcn_make_buffer_rsrc((void*)g0q, 0, DENSE ? (int)min((size_t)0x7FFFFFFF, S * (size_t)24) : 0, 0x00020000);
 
   struct Raw { uint32_t n; int32_t snp; };
   struct Hdr { uint32_t n; int32_t snp; uint32_t rd4; int64_t off; };
@@ -288,6 +303,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
     // dense: uniform plane base per row element + this lane's SNP index (scalar base, 32-bit lane offset, no per-load
     // address arithmetic); sparse: this lane's own row
     const uint32_t s_idx = (uint32_t)min((int64_t)(tile * T + ti), (int64_t)S - 1);
+    const uint32_t boff4 = s_idx * 4u, boff8 = s_idx * 8u;     // lane byte offsets for the buffer loads below
     const float* __restrict__ grow = gq + (size_t)cur.snp * V * 3;
     const double* __restrict__ g0row = g0q + (size_t)cur.snp * 3;
 
@@ -299,11 +315,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
       for (int kk = 0; kk < KC; ++kk) {          // all loads of the chunk first; slots past sample V-1 re-read it (ignored)
         const int k = min(k0 + kk, V - 1);
 #pragma unroll
-        for (int l = 0; l < 3; ++l) a[kk][l] = (ablate & 8) ? 0.3f + 0.01f * kk : (DENSE ? (gq + (size_t)(k * 3 + l) * S)[s_idx] : grow[k * 3 + l]);
+        for (int l = 0; l < 3; ++l)
+          a[kk][l] = (ablate & 8) ? 0.3f + 0.01f * kk
+                     : (DENSE ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, boff4, (uint32_t)(k * 3 + l) * plane4, 0))
+                              : grow[k * 3 + l]);
       }
       if (q == 0) {
 #pragma unroll
-        for (int l = 0; l < 3; ++l) a0[l] = (ablate & 8) ? 0.33 : (DENSE ? (g0q + (size_t)l * S)[s_idx] : g0row[l]);
+        for (int l = 0; l < 3; ++l)
+          a0[l] = (ablate & 8) ? 0.33
+                  : (DENSE ? __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_g0, boff8, (uint32_t)l * plane8, 0)) : g0row[l]);
       }
       if (valid) {
         bool fast_ok = true;
@@ -1120,7 +1141,7 @@ namespace {
 int launch_singlet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V;
   // cells per wavefront: more cells amortise the ordered sums, fewer keep >= ~4 wavefronts per SIMD in flight (1024 SIMDs)
-  int CW = (B >= 32 * 1024) ? 4 : (B >= 8 * 1024 ? 2 : 1);
+  int CW = (B >= 64 * 1024) ? 4 : (B >= 24 * 1024 ? 2 : 1);
   const int KC = (V <= 4) ? 4 : 8;
   if (const char* cenv = getenv("DMX_K1_CW")) CW = atoi(cenv);     // kernel experiments only
   const int nch = (V + KC - 1) / KC;
@@ -1128,6 +1149,7 @@ int launch_singlet(dmx_engine* e) {
   const size_t dyn = sizeof(double) * (size_t)NW * nch * CW * (KC + 1);
   if (dyn > 16 * 1024) return set_error(DMX_ERR_ARG, "run_singlet: n_samples %d too large for this build", V);
   const bool dense = e->pv.pair_snp == nullptr;
+  if (dense && (size_t)e->S * V * 12 > 0x7FFFFFFFull) return set_error(DMX_ERR_ARG, "run_singlet: dense genotype matrix over 2 GiB is not supported by this build");
   const float* gq = dense ? e->d_gT : e->d_g;
   const double* g0q = dense ? e->d_g0T : e->d_gp0;
   const dim3 block(kThreads), grid((unsigned)((B + NW * CW - 1) / (NW * CW)));
