@@ -30,6 +30,8 @@ CONFIGS = {
             name="cfg2: 10k barcodes x 50k SNPs x 8 samples, GT field, singlet-only, dense (delta=1, rbar=1.25)"),
     3: dict(B=10_000, S=50_000, V=32, field="GP", alphas=(0.0, 0.5), delta=1.0, rbar=1.25, doublet=True,
             name="cfg3: 10k barcodes x 50k SNPs x 32 samples, GP field, doublet grid alpha 0,0.5, dense"),
+    4: dict(B=12_500, S=100_000, V=64, field="GT", alphas=(0.0, 0.5), delta=1.0, rbar=1.25, doublet=True,
+            name="cfg4 (per-GPU shard): 12.5k of 100k barcodes x 100k SNPs x 64 samples, GT field, doublet grid, dense"),
     5: dict(B=20_000, S=200_000, V=16, field="PL", alphas=(0.0, 0.5), delta=0.05, rbar=2.0, doublet=True,
             name="cfg5: 20k barcodes x 200k SNPs x 16 samples, PL field, doublet grid, sparse (delta=0.05, rbar=2)"),
 }

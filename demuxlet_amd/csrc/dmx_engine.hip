@@ -182,24 +182,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
   constexpr int NW = kThreads / 64;
   static_assert(CW * NC <= 64, "one lane per chain");
   extern __shared__ double s_dyn[];              // [NW][nch][CW*NC] running accumulators
-#ifdef DMX_K1_TABLES_GLOBAL
-  __shared__ double s_tab[kTab];
-  const double* s_first = tabs + kTab;             // L1/L2-resident, 12 KB
-#else
   __shared__ double s_tab[kTabK1];
   const double* s_first = s_tab + kTab;
-#endif
   __shared__ __attribute__((aligned(16))) double s_term[NW][CW * NC * TS];
   const double* s_log = s_tab + kLut;
   const double* s_final = s_first + kFirst;
 
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int nch = (V + KC - 1) / KC;
-#ifdef DMX_K1_TABLES_GLOBAL
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
-#else
   for (int i = t; i < kTabK1; i += kThreads) s_tab[i] = tabs[i];
-#endif
   for (int i = t; i < NW * nch * CW * NC; i += kThreads) s_dyn[i] = 0.0;
   __syncthreads();                               // the only workgroup barrier
 
@@ -812,6 +803,276 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Genotype classes.  With --field GT every sample's probability row at a SNP is one of at most four float triplets
+// (the three one-hot rows and the HWE row shared by all missing genotypes, bcf_filtered_reader.cpp:381-400), so
+// log(sum_lm g_j[l] g_k[m] pG[l][m]) takes at most 16 distinct values per (pair, alpha) instead of V*V.  log and the
+// arithmetic in front of it are pure functions of their operands: evaluating each distinct (class_j, class_k) once
+// and adding the result into every accumulator that shares it is BIT-IDENTICAL to evaluating it V*V times, and keeps
+// the per-accumulator addition order.  Rows are compared bitwise.  More than kMaxCls classes at any SNP (GP / PL
+// inputs) => the class kernels are not used.
+constexpr int kMaxCls = 4;
+
+__global__ void k_build_classes(const float* __restrict__ g, int32_t S, int32_t V, float* __restrict__ rows /*[S][4][3]*/,
+                                uint8_t* __restrict__ ids /*[S][V]*/, int32_t* __restrict__ max_cls) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const uint32_t* gr = reinterpret_cast<const uint32_t*>(g + (size_t)s * V * 3);
+  uint32_t c[kMaxCls][3];
+  int n = 0;
+  bool over = false;
+  for (int32_t k = 0; k < V; ++k) {
+    const uint32_t a0 = gr[k * 3], a1 = gr[k * 3 + 1], a2 = gr[k * 3 + 2];
+    int id = -1;
+    for (int d = 0; d < n; ++d) if (c[d][0] == a0 && c[d][1] == a1 && c[d][2] == a2) { id = d; break; }
+    if (id < 0) {
+      if (n < kMaxCls) { id = n; c[n][0] = a0; c[n][1] = a1; c[n][2] = a2; ++n; }
+      else { over = true; id = 0; }
+    }
+    ids[(size_t)s * V + k] = (uint8_t)id;
+  }
+  uint32_t* ro = reinterpret_cast<uint32_t*>(rows + (size_t)s * kMaxCls * 3);
+  for (int d = 0; d < kMaxCls; ++d) {
+    const int e = d < n ? d : 0;                 // unused classes repeat class 0 (never referenced by an id)
+    ro[d * 3] = c[e][0]; ro[d * 3 + 1] = c[e][1]; ro[d * 3 + 2] = c[e][2];
+  }
+  atomicMax(max_cls, over ? kMaxCls + 1 : n);
+}
+
+// K2 over genotype classes (A = 2).  Same ownership and order as k_doublet_a2; per tile of 32 pairs:
+//   stage    headers, the pairs' class rows (4 x 3 float32) and per-sample class ids (V bytes) -> LDS
+//   phase 1  pG[n][3][3] per (pair, alpha) and the llks00 term, exactly as k_doublet_a2
+//   phase 1b the class table T[pair][cj][ck][n] = log(sum_lm row_cj[l] row_ck[m] pG[n][l][m]) — the very expression of
+//            :553,:677-683 on the very operands, once per distinct (cj, ck)
+//   phase 2  thread (j, k-block): acc[j][k][n] += T[pair][id_j][id_k][n], pairs in ascending SNP order
+template <int TPC, int NK>
+__global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
+                                                          const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
+                                                          const double* __restrict__ tabs, const double* __restrict__ alpha,
+                                                          const int32_t* __restrict__ sched, int32_t V, int32_t VS,
+                                                          double* __restrict__ grid, double* __restrict__ l00,
+                                                          uint8_t* __restrict__ flagged) {
+  constexpr int A = 2, TP = 32;
+  constexpr int CPW = kThreads / TPC;
+  constexpr int T00 = TP + 2;
+  constexpr int NT = kMaxCls * kMaxCls * A;      // class-table entries per pair
+#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  __syncthreads();
+
+  const int cw = t / TPC, tid = t % TPC;
+  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * NT * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)TP * 12 * 4 + (size_t)TP * VS;
+  unsigned char* base = s_raw + (size_t)cw * ((cell_bytes + 15) & ~(size_t)15);
+  double* s_pG = (double*)base;                                  // [TP][2][9]
+  double* s_T = s_pG + TP * 18;                                  // [TP][4][4][2]
+  double* s_t00 = s_T + TP * NT;                                 // [2][T00]
+  int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                  // [TP]
+  int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
+  uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
+  float* s_rows = (float*)(s_cnt + TP);                          // [TP][4][3]
+  uint8_t* s_ids = (uint8_t*)(s_rows + TP * 12);                 // [TP][VS]
+
+  const int slot = blockIdx.x * CPW + cw;
+  if (TPC == 64 && slot >= pv.B) return;
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+
+  const int KB = (V + NK - 1) / NK;
+  const int j = tid / KB, kb = tid % KB;
+  const bool owner = j < V;
+  double acc[NK][A];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
+  bool ok = true;
+  const int ti1 = tid >> 1, n1 = tid & 1;
+  double wA[9], wR[9];
+  {
+    const double al = alpha[n1];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * al;
+        wA[l * 3 + m] = p;
+        wR[l * 3 + m] = 1.0 - p;
+      }
+  }
+  double acc00 = 0.0;
+
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_K2_SYNC();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    // ---- class rows and ids -> LDS
+    for (int e = tid; e < tp * 12; e += TPC) s_rows[e] = rows[(size_t)s_snp[e / 12] * 12 + (e % 12)];
+    {
+      const int wpr = VS / 4;                    // id words per pair
+      for (int e = tid; e < tp * wpr; e += TPC) {
+        const int ti = e / wpr, wq = e % wpr;
+        const uint8_t* src = ids + (size_t)s_snp[ti] * V + wq * 4;
+        uint32_t wv = 0;
+        for (int b = 0; b < 4; ++b) if (wq * 4 + b < V) wv |= (uint32_t)src[b] << (8 * b);
+        reinterpret_cast<uint32_t*>(s_ids)[ti * wpr + wq] = wv;
+      }
+    }
+    // ---- phase 1 (identical to k_doublet_a2)
+    if (tid < 64) {
+      const bool on = ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      double pG[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pG[i] = 1.0;
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt;
+        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            pG[i] *= (pR * wR[i] + pA * wA[i]);
+            mx = (mx < pG[i]) ? pG[i] : mx;
+          }
+        }
+        {
+          const double o = __shfl_xor(mx, 1);
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] /= mx;
+          }
+        }
+      }
+      double mx = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        pG[i] += 1e-6;
+        mx = (mx < pG[i]) ? pG[i] : mx;
+      }
+      {
+        const double o = __shfl_xor(mx, 1);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on) {
+        const double y = rcp_refined(mx);
+        const double* g0 = gp0 + (size_t)s_snp[ti1] * 3;
+        const double qq[3] = {g0[0], g0[1], g0[2]};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = div_by(pG[l * 3 + m], mx, y);
+            s_pG[(ti1 * 2 + n1) * 9 + l * 3 + m] = v;
+            sum += ((qq[l] * qq[m]) * v);
+          }
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);
+      }
+    }
+    DMX_K2_SYNC();
+    if (tid < 2) {
+      const double* row = &s_t00[tid * T00];
+      if (tp == TP) {
+        double2 v[TP / 2];
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) v[i] = *reinterpret_cast<const double2*>(&row[2 * i]);
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+      } else {
+        for (int i = 0; i < tp; ++i) acc00 += row[i];
+      }
+    }
+    // ---- phase 1b: the class table
+    for (int e = tid; e < tp * NT; e += TPC) {
+      const int ti = e / NT, cc = e % NT;
+      const int cj = cc >> 3, ck = (cc >> 1) & 3, n = cc & 1;
+      const float* rj = &s_rows[ti * 12 + cj * 3];
+      const float* rk = &s_rows[ti * 12 + ck * 3];
+      const double* P = &s_pG[(ti * 2 + n) * 9];
+      const double aj[3] = {(double)rj[0], (double)rj[1], (double)rj[2]};
+      const double bk[3] = {(double)rk[0], (double)rk[1], (double)rk[2]};
+      double sum = 0.0;                                                          // :674
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) sum += ((aj[l] * bk[m]) * P[l * 3 + m]);     // :553, :677-679
+      ok &= __builtin_amdgcn_class(sum, 0x100);
+      s_T[ti * NT + cc] = dmx_log_fast(sum, s_log);                              // the :683 term
+    }
+    DMX_K2_SYNC();
+    // ---- phase 2: one lookup and two adds per (j, k)
+    if (owner) {
+      for (int ti = 0; ti < tp; ++ti) {
+        const uint8_t* idr = &s_ids[ti * VS];
+        const int cj = idr[j];
+        const double* Tj = &s_T[ti * NT + cj * 8];
+        if (NK >= 4) {                            // class ids of the k-block, four per 32-bit LDS read (VS is padded to 4)
+#pragma unroll
+          for (int kq = 0; kq < NK / 4; ++kq) {
+            const uint32_t w4 = reinterpret_cast<const uint32_t*>(idr)[(kb * NK) / 4 + kq];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const double2 tv = *reinterpret_cast<const double2*>(&Tj[((w4 >> (8 * b)) & 3u) * 2]);
+              acc[kq * 4 + b][0] += tv.x;                                        // :683, alpha 0
+              acc[kq * 4 + b][1] += tv.y;                                        //       alpha 1
+            }
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk) {
+            const int k = min(kb * NK + kk, V - 1);
+            const double2 tv = *reinterpret_cast<const double2*>(&Tj[idr[k] * 2]);
+            acc[kk][0] += tv.x;
+            acc[kk][1] += tv.y;
+          }
+        }
+      }
+    }
+    DMX_K2_SYNC();
+  }
+  if (cell_ok) {
+    if (owner) {
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const int k = kb * NK + kk;
+        if (k < V) {
+          double* o = grid + (((size_t)cell * V + j) * V + k) * A;
+          o[0] = acc[kk][0]; o[1] = acc[kk][1];
+        }
+      }
+    }
+    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (!ok) flagged[cell] = 1;
+  }
+#undef DMX_K2_SYNC
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K3.  One cell per workgroup over its finished grid.
 struct ArgMax { double v; int32_t i; };
 __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) {      // larger value wins; equal values: lower scan index
@@ -927,6 +1188,7 @@ struct dmx_engine {
   double* d_alpha = nullptr;
   // genotypes
   const float* d_g = nullptr; float* d_g_own = nullptr; int32_t S = 0; double* d_gp0 = nullptr; float* d_gT = nullptr; double* d_g0T = nullptr;
+  float* d_rows = nullptr; uint8_t* d_ids = nullptr; int32_t n_classes = 0;   // genotype classes (0 = not usable)
   // pileup
   PileupView pv{}; int32_t nrd_width = 1; int64_t P = 0, R = 0; bool have_pileup = false;
   void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1017,6 +1279,8 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_gp0) (void)hipFree(e->d_gp0);
   if (e->d_gT) (void)hipFree(e->d_gT);
   if (e->d_g0T) (void)hipFree(e->d_g0T);
+  if (e->d_rows) (void)hipFree(e->d_rows);
+  if (e->d_ids) (void)hipFree(e->d_ids);
   if (e->d_lut) (void)hipFree(e->d_lut);
   if (e->d_alpha) (void)hipFree(e->d_alpha);
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1068,6 +1332,26 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     e->timed[0] = true;
   }
 
+  // genotype classes (<= 4 distinct rows per SNP: --field GT): enables the class kernels
+  if (e->d_rows) { (void)hipFree(e->d_rows); e->d_rows = nullptr; }
+  if (e->d_ids) { (void)hipFree(e->d_ids); e->d_ids = nullptr; }
+  e->n_classes = 0;
+  if (n_snps > 0) {
+    int32_t* d_max = nullptr;
+    HIP_TRY(hipMalloc((void**)&e->d_rows, (size_t)n_snps * kMaxCls * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&e->d_ids, (size_t)n_snps * e->V + 16));
+    HIP_TRY(hipMalloc((void**)&d_max, sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), e->stream));
+    hipLaunchKernelGGL(k_build_classes, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_g, n_snps, e->V,
+                       e->d_rows, e->d_ids, d_max);
+    HIP_TRY(hipGetLastError());
+    int32_t h_max = 0;
+    HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    (void)hipFree(d_max);
+    e->n_classes = (h_max >= 1 && h_max <= kMaxCls) ? h_max : 0;
+    if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); e->d_rows = nullptr; e->d_ids = nullptr; }
+  }
   HIP_TRY(hipStreamSynchronize(e->stream));   // the host buffer may go away after return
   return DMX_OK;
 }
@@ -1199,6 +1483,25 @@ int launch_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
   const bool force_generic = getenv("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
   if (A != 2 || V > 64 || force_generic) return launch_doublet_generic_w<false>(e);
+  const bool no_classes = getenv("DMX_NO_CLASSES") != nullptr;          // kernel experiments / tests only
+  if (e->n_classes > 0 && !no_classes) {
+    const int VS = (V <= 32) ? ((V + 3) & ~3) : ((V + 15) & ~15);   // id row stride: a whole number of k-blocks
+    size_t cb = (size_t)32 * 18 * 8 + (size_t)32 * 32 * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8) + (size_t)32 * 12 * 4 + (size_t)32 * VS;
+    cb = (cb + 15) & ~(size_t)15;
+    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    const dim3 blk(kThreads);
+#define DMX_K2C(TPC, NK)                                                                                             \
+  hipLaunchKernelGGL((k_doublet_cls<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), blk,   \
+                     cb * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0, e->d_lut,   \
+                     e->d_alpha, e->d_sched, V, VS, e->d_grid, e->d_l00, e->d_flag)
+    if (V <= 8) DMX_K2C(64, 1);
+    else if (V <= 16) DMX_K2C(64, 4);
+    else if (V <= 32) DMX_K2C(256, 4);
+    else DMX_K2C(256, 16);
+#undef DMX_K2C
+    HIP_TRY(hipGetLastError());
+    return launch_doublet_generic_w<true>(e);
+  }
   const int GS = (V * 3 + 3) & ~3;               // LDS row stride of a genotype row (floats), 16-byte multiple
   const size_t cell_bytes = (size_t)32 * 18 * 8 + (size_t)32 * GS * 4 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
   HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));

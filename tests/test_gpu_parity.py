@@ -299,3 +299,27 @@ def test_records_path_end_to_end(eng, oracle, name, tmp_path):
                     assert abs(fx - fy) <= 1e-3 * max(1e-3, abs(fy)) + 1.01e-4
                 except ValueError:
                     assert x == y, (suf, a, b)
+
+
+@pytest.mark.parametrize("V,B,S,delta,missing", [(8, 40, 600, 0.3, 0.0), (16, 20, 500, 0.3, 0.1), (32, 12, 400, 0.5, 0.05), (64, 5, 300, 0.3, 0.0), (3, 30, 200, 1.0, 0.2)])
+def test_genotype_class_kernel_is_bit_identical_to_the_general_one(eng, oracle, V, B, S, delta, missing):
+    """--field GT gives <= 4 distinct probability rows per SNP; the class kernel evaluates log() once per distinct
+    (row_j, row_k) and must reproduce the general kernel BIT FOR BIT (same operands, same operations, same add order)."""
+    import os
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(4242 + V)
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=missing)
+    g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    sp = synth.make_pileup(rng, np.where(raw.alleles < 0, 0, raw.alleles), B, delta, 1.5, dense_layout=(delta >= 1.0))
+    pl = host_pileup(eng, sp)
+    os.environ.pop("DMX_NO_CLASSES", None)
+    a = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    os.environ["DMX_NO_CLASSES"] = "1"
+    try:
+        b = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    finally:
+        os.environ.pop("DMX_NO_CLASSES", None)
+    assert np.array_equal(a["grid"], b["grid"]) and np.array_equal(a["l00"], b["l00"])
+    assert np.array_equal(a["summ"], b["summ"])
+    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    assert np.abs(a["grid"] - ref.llksAB).max() < TOL
