@@ -376,6 +376,204 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
   }
 }
 
+// K1 over genotype classes (see "Genotype classes" below: <= 4 distinct probability rows per SNP, --field GT).
+// Same walk and ownership as k_singlet; per pair the lane evaluates log(GL . row_d) once per class d plus the llk0 term,
+// and stores those five terms and the SNP's packed class ids; chain lane (cell, k) then adds term[id[snp][k]] for the
+// tile's pairs in ascending order — the very doubles k_singlet would have formed for sample k, in the same order.
+template <int CW>
+__global__ __launch_bounds__(kThreads, 4) void k_singlet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
+                                                             const uint32_t* __restrict__ idw, const double* __restrict__ gp0,
+                                                             const double* __restrict__ tabs,
+                                                             const int32_t* __restrict__ sched, int32_t V,
+                                                             double* __restrict__ llks, double* __restrict__ llk0s) {
+  constexpr int T = 64 / CW;
+  constexpr int NW = kThreads / 64;
+  constexpr int TD = 6;                          // doubles per pair in LDS: 4 class terms, llk0 term, 1 pad
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dynraw[];   // per wavefront: id words [64][nwd]
+  __shared__ double s_tab[kTabK1];
+  __shared__ __attribute__((aligned(16))) double s_term[NW][64 * TD];
+  const double* s_log = s_tab + kLut;
+  const double* s_first = s_tab + kTab;
+  const double* s_final = s_first + kFirst;
+
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const int nwd = (V + 15) / 16;
+  for (int i = t; i < kTabK1; i += kThreads) s_tab[i] = tabs[i];
+  __syncthreads();                               // the only workgroup barrier
+
+  double* term = s_term[w];
+  uint32_t* s_idw = reinterpret_cast<uint32_t*>(s_dynraw) + (size_t)w * 64 * nwd;
+  const int slot0 = (blockIdx.x * NW + w) * CW;
+  if (slot0 >= pv.B) return;
+
+  const int c = lane / T, ti = lane % T;
+  const bool cell_ok = slot0 + c < pv.B;
+  const int32_t cell = cell_ok ? sched[slot0 + c] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+  int64_t max_np = np;
+#pragma unroll
+  for (int d = T; d < 64; d <<= 1) max_np = max(max_np, __shfl_xor(max_np, d));
+
+  // chains: a = lane + 64*i over CW*(V+1) accumulators, a -> (cell a/(V+1), sample a%(V+1)); sample V is llk0
+  constexpr int MAXCH = 4;
+  const int nchain = CW * (V + 1);
+  double acc[MAXCH];
+  int32_t ch_pair0[MAXCH], ch_k[MAXCH];
+  int64_t ch_np[MAXCH];
+  int32_t ch_cell[MAXCH];
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    const int a = lane + 64 * i;
+    const bool okc = a < nchain && slot0 + a / (V + 1) < pv.B;
+    const int ac = okc ? a / (V + 1) : 0;
+    acc[i] = 0.0;
+    ch_pair0[i] = ac * T;
+    ch_k[i] = okc ? a % (V + 1) : -1;
+    ch_np[i] = okc ? __shfl(np, ac * T) : 0;
+    ch_cell[i] = __shfl(cell, ac * T);
+    if (!okc) { ch_np[i] = 0; }
+  }
+
+  struct Raw { uint32_t n; int32_t snp; };
+  struct Hdr { uint32_t n; int32_t snp; uint32_t rd4; int64_t off; };
+  auto issue = [&](int64_t tile) {
+    Raw r;
+    const int64_t pi = tile * T + ti;
+    const bool v = pi < np;
+    r.n = v ? load_nrd(pv.pair_nrd, p_beg + pi, nrd_width) : 0u;
+    r.snp = v ? (pv.pair_snp ? pv.pair_snp[p_beg + pi] : (int32_t)pi) : 0;
+    return r;
+  };
+  auto prepare = [&](const Raw& r) {
+    Hdr h;
+    h.n = r.n; h.snp = r.snp;
+    const uint32_t incl = seg_scan_incl<T>(r.n);
+    h.off = rd_base + (int64_t)(incl - r.n);
+    rd_base += seg_last<T>(incl, lane);
+    h.rd4 = 0;
+    if (r.n > 0) {
+      if (h.off + 4 <= pv.R) __builtin_memcpy(&h.rd4, pv.reads + h.off, 4);
+      else for (int64_t i = h.off; i < pv.R; ++i) h.rd4 |= (uint32_t)pv.reads[i] << (8 * (int)(i - h.off));
+    }
+    return h;
+  };
+
+  Hdr nxt = prepare(issue(0));
+  Raw pre = issue(1);
+  for (int64_t tile = 0; tile * T < max_np; ++tile) {
+    const Hdr cur = nxt;
+    nxt = prepare(pre);
+    pre = issue(tile + 2);
+    const bool valid = tile * T + ti < np;
+
+    // class rows, llk0 row and id words of this lane's SNP (48 + 24 + 4*nwd bytes, SNP-major: contiguous across a dense tile)
+    const float4* rp = reinterpret_cast<const float4*>(rows + (size_t)cur.snp * 12);
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+    const double* g0 = gp0 + (size_t)cur.snp * 3;
+    const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
+    for (int wq = 0; wq < nwd; ++wq) s_idw[lane * nwd + wq] = idw[(size_t)cur.snp * nwd + wq];
+
+    double G0, G1, G2;                                                       // :427-452, as in k_singlet
+    {
+      const uint32_t n = cur.n;
+      const uint32_t b0 = cur.rd4 & 0xFFu;
+      const double* f = s_final + 3 * (n ? b0 : 256u);
+      G0 = f[0]; G1 = f[1]; G2 = f[2];
+      if (n >= 2) {
+        const double* f1 = s_first + 3 * b0;
+        double g0_ = f1[0], g1_ = f1[1], g2_ = f1[2];
+        const bool safe = n <= kSafeReads;
+        for (uint32_t r = 1; r < n; ++r) {
+          const uint32_t byte = (r < 4) ? ((cur.rd4 >> (8 * r)) & 0xFFu) : (uint32_t)pv.reads[cur.off + r];
+          const uint32_t bq = byte & 127u;
+          const bool alt = (byte >> 7) != 0;
+          const double m = s_tab[bq], e3 = s_tab[128 + bq], h = s_tab[256 + bq];
+          g0_ *= alt ? e3 : m;
+          g1_ *= h;
+          g2_ *= alt ? m : e3;
+          const double tmp = g0_ + g1_ + g2_;
+          if (safe) {
+            const double y = rcp_refined(tmp);
+            g0_ = div_by(g0_, tmp, y); g1_ = div_by(g1_, tmp, y); g2_ = div_by(g2_, tmp, y);
+          } else {
+            g0_ /= tmp; g1_ /= tmp; g2_ /= tmp;
+          }
+        }
+        g0_ += 1e-6; g1_ += 1e-6; g2_ += 1e-6;
+        const double tmp = g0_ + g1_ + g2_;
+        const double y = rcp_refined(tmp);
+        G0 = div_by(g0_, tmp, y); G1 = div_by(g1_, tmp, y); G2 = div_by(g2_, tmp, y);
+      }
+    }
+    if (valid) {
+      const double x0 = G0 * (double)r0.x + G1 * (double)r0.y + G2 * (double)r0.z;     // class 0   (:456)
+      const double x1 = G0 * (double)r0.w + G1 * (double)r1.x + G2 * (double)r1.y;     // class 1
+      const double x2 = G0 * (double)r1.z + G1 * (double)r1.w + G2 * (double)r2.x;     // class 2
+      const double x3 = G0 * (double)r2.y + G1 * (double)r2.z + G2 * (double)r2.w;     // class 3
+      const double x4 = G0 * q0 + G1 * q1 + G2 * q2;                                    // llk0      (:459)
+      const bool fast_ok = __builtin_amdgcn_class(x0, 0x100) && __builtin_amdgcn_class(x1, 0x100) && __builtin_amdgcn_class(x2, 0x100) &&
+                           __builtin_amdgcn_class(x3, 0x100) && __builtin_amdgcn_class(x4, 0x100);
+      double* tr = &term[lane * TD];
+      tr[0] = dmx_log_fast(x0, s_log); tr[1] = dmx_log_fast(x1, s_log); tr[2] = dmx_log_fast(x2, s_log);
+      tr[3] = dmx_log_fast(x3, s_log); tr[4] = dmx_log_fast(x4, s_log);
+      if (__builtin_expect(!fast_ok, 0)) {         // never for real likelihoods; keeps log(0) / log(nan) semantics
+        const double xs[5] = {x0, x1, x2, x3, x4};
+        for (int d = 0; d < 5; ++d) if (!__builtin_amdgcn_class(xs[d], 0x100)) tr[d] = log(xs[d]);
+      }
+    }
+    DMX_WAVE_LDS_ORDER();
+    // ---- ordered sums: chain (cell, k) adds term[pair][class of sample k at the pair's SNP] for the tile's pairs
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+      if (ch_k[i] < 0) continue;
+      const int64_t left = ch_np[i] - tile * T;
+      const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
+      const int k = ch_k[i];
+      const bool is0 = k == V;
+      const int wq = is0 ? 0 : (k >> 4), sh = is0 ? 0 : 2 * (k & 15);
+      const double* tb = &term[ch_pair0[i] * TD];
+      const uint32_t* ib = &s_idw[ch_pair0[i] * nwd + wq];
+      double s = acc[i];
+      int p = 0;
+      for (; p + 16 <= cnt; p += 16) {            // ids first, then the 16 term reads, then the 16 ordered adds
+        uint32_t wv[16];
+        if (nwd == 1) {
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const uint4 u = *reinterpret_cast<const uint4*>(&ib[p + 4 * q4]);
+            wv[4 * q4] = u.x; wv[4 * q4 + 1] = u.y; wv[4 * q4 + 2] = u.z; wv[4 * q4 + 3] = u.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) wv[q] = ib[(p + q) * nwd];
+        }
+        double tv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const uint32_t d = is0 ? 4u : ((wv[q] >> sh) & 3u);
+          tv[q] = tb[(p + q) * TD + d];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += tv[q];   // ascending SNP order: the reference's order
+      }
+      for (; p < cnt; ++p) {
+        const uint32_t d = is0 ? 4u : ((ib[p * nwd] >> sh) & 3u);
+        s += tb[p * TD + d];
+      }
+      acc[i] = s;
+    }
+    DMX_WAVE_LDS_ORDER();
+  }
+#pragma unroll
+  for (int i = 0; i < MAXCH; ++i) {
+    if (ch_k[i] < 0) continue;
+    if (ch_k[i] < V) llks[(size_t)ch_cell[i] * V + ch_k[i]] = acc[i];
+    else llk0s[ch_cell[i]] = acc[i];
+  }
+}
+
 // SNP-minor copies for dense pileups: gT[r][s] = g[s][r] (r = k*3+l, float32 as stored) and g0T[l][s] = gp0s[s][l].
 __global__ void k_transpose_geno(const float* __restrict__ g, const double* __restrict__ gp0, int32_t S, int32_t V,
                                  float* __restrict__ gT, double* __restrict__ g0T) {
@@ -813,7 +1011,8 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
 constexpr int kMaxCls = 4;
 
 __global__ void k_build_classes(const float* __restrict__ g, int32_t S, int32_t V, float* __restrict__ rows /*[S][4][3]*/,
-                                uint8_t* __restrict__ ids /*[S][V]*/, int32_t* __restrict__ max_cls) {
+                                uint8_t* __restrict__ ids /*[S][V]*/, uint32_t* __restrict__ idw /*[S][ceil(V/16)] 2 bits per sample*/,
+                                int32_t* __restrict__ max_cls) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   const uint32_t* gr = reinterpret_cast<const uint32_t*>(g + (size_t)s * V * 3);
@@ -829,6 +1028,12 @@ __global__ void k_build_classes(const float* __restrict__ g, int32_t S, int32_t 
       else { over = true; id = 0; }
     }
     ids[(size_t)s * V + k] = (uint8_t)id;
+  }
+  const int nwd = (V + 15) / 16;
+  for (int wq = 0; wq < nwd; ++wq) {
+    uint32_t wv = 0;
+    for (int b = 0; b < 16 && wq * 16 + b < V; ++b) wv |= (uint32_t)ids[(size_t)s * V + wq * 16 + b] << (2 * b);
+    idw[(size_t)s * nwd + wq] = wv;
   }
   uint32_t* ro = reinterpret_cast<uint32_t*>(rows + (size_t)s * kMaxCls * 3);
   for (int d = 0; d < kMaxCls; ++d) {
@@ -1188,7 +1393,7 @@ struct dmx_engine {
   double* d_alpha = nullptr;
   // genotypes
   const float* d_g = nullptr; float* d_g_own = nullptr; int32_t S = 0; double* d_gp0 = nullptr; float* d_gT = nullptr; double* d_g0T = nullptr;
-  float* d_rows = nullptr; uint8_t* d_ids = nullptr; int32_t n_classes = 0;   // genotype classes (0 = not usable)
+  float* d_rows = nullptr; uint8_t* d_ids = nullptr; uint32_t* d_idw = nullptr; int32_t n_classes = 0;   // genotype classes (0 = not usable)
   // pileup
   PileupView pv{}; int32_t nrd_width = 1; int64_t P = 0, R = 0; bool have_pileup = false;
   void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1281,6 +1486,7 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_g0T) (void)hipFree(e->d_g0T);
   if (e->d_rows) (void)hipFree(e->d_rows);
   if (e->d_ids) (void)hipFree(e->d_ids);
+  if (e->d_idw) (void)hipFree(e->d_idw);
   if (e->d_lut) (void)hipFree(e->d_lut);
   if (e->d_alpha) (void)hipFree(e->d_alpha);
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -1335,22 +1541,24 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
   // genotype classes (<= 4 distinct rows per SNP: --field GT): enables the class kernels
   if (e->d_rows) { (void)hipFree(e->d_rows); e->d_rows = nullptr; }
   if (e->d_ids) { (void)hipFree(e->d_ids); e->d_ids = nullptr; }
+  if (e->d_idw) { (void)hipFree(e->d_idw); e->d_idw = nullptr; }
   e->n_classes = 0;
   if (n_snps > 0) {
     int32_t* d_max = nullptr;
     HIP_TRY(hipMalloc((void**)&e->d_rows, (size_t)n_snps * kMaxCls * 3 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&e->d_ids, (size_t)n_snps * e->V + 16));
+    HIP_TRY(hipMalloc((void**)&e->d_idw, (size_t)n_snps * ((e->V + 15) / 16) * sizeof(uint32_t) + 16));
     HIP_TRY(hipMalloc((void**)&d_max, sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), e->stream));
     hipLaunchKernelGGL(k_build_classes, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_g, n_snps, e->V,
-                       e->d_rows, e->d_ids, d_max);
+                       e->d_rows, e->d_ids, e->d_idw, d_max);
     HIP_TRY(hipGetLastError());
     int32_t h_max = 0;
     HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     (void)hipFree(d_max);
     e->n_classes = (h_max >= 1 && h_max <= kMaxCls) ? h_max : 0;
-    if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); e->d_rows = nullptr; e->d_ids = nullptr; }
+    if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); (void)hipFree(e->d_idw); e->d_rows = nullptr; e->d_ids = nullptr; e->d_idw = nullptr; }
   }
   HIP_TRY(hipStreamSynchronize(e->stream));   // the host buffer may go away after return
   return DMX_OK;
@@ -1428,6 +1636,21 @@ int launch_singlet(dmx_engine* e) {
   int CW = (B >= 64 * 1024) ? 4 : (B >= 24 * 1024 ? 2 : 1);
   const int KC = (V <= 4) ? 4 : 8;
   if (const char* cenv = getenv("DMX_K1_CW")) CW = atoi(cenv);     // kernel experiments only
+  if (e->n_classes > 0 && V >= 12 && !getenv("DMX_NO_CLASSES")) {
+    // --field GT inputs: log() once per genotype class instead of once per sample (bit-identical, see k_singlet_cls).
+    // Measured on MI355X: pays from ~12 samples up (V=64: 2.6x); at V=8 the per-sample lookups cost what the logs save.
+    int cw = 1;
+    while (cw > 1 && cw * (V + 1) > 4 * 64) cw >>= 1;
+    if (cw * (V + 1) <= 4 * 64) {
+      const size_t dynb = (size_t)(kThreads / 64) * 64 * ((V + 15) / 16) * sizeof(uint32_t);
+      const dim3 blk(kThreads), grd((unsigned)((B + (kThreads / 64) * cw - 1) / ((kThreads / 64) * cw)));
+#define DMX_K1C(CC) hipLaunchKernelGGL((k_singlet_cls<CC>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, \
+                                       e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
+      if (cw == 4) DMX_K1C(4); else if (cw == 2) DMX_K1C(2); else DMX_K1C(1);
+#undef DMX_K1C
+      return DMX_OK;
+    }
+  }
   const int nch = (V + KC - 1) / KC;
   const int NW = kThreads / 64;
   const size_t dyn = sizeof(double) * (size_t)NW * nch * CW * (KC + 1);

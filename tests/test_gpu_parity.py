@@ -319,7 +319,8 @@ def test_genotype_class_kernel_is_bit_identical_to_the_general_one(eng, oracle, 
         b = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
     finally:
         os.environ.pop("DMX_NO_CLASSES", None)
-    assert np.array_equal(a["grid"], b["grid"]) and np.array_equal(a["l00"], b["l00"])
+    assert np.array_equal(a["llks"], b["llks"]) and np.array_equal(a["llk0s"], b["llk0s"])      # K1 over classes
+    assert np.array_equal(a["grid"], b["grid"]) and np.array_equal(a["l00"], b["l00"])            # K2 over classes
     assert np.array_equal(a["summ"], b["summ"])
     ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
-    assert np.abs(a["grid"] - ref.llksAB).max() < TOL
+    assert np.abs(a["grid"] - ref.llksAB).max() < TOL and np.abs(a["llks"] - ref.llks).max() < TOL
