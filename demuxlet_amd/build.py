@@ -35,13 +35,29 @@ def needs_build() -> bool:
     return any(p.stat().st_mtime > t for p in SOURCES + HEADERS + [Path(__file__)])
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc(), *FLAGS, "-x", "hip", *map(str, SOURCES), "-o", str(LIB)]
+CLI = PKG / "demuxlet"
+CLI_SRC = CSRC / "dmx_cli.cpp"
+
+
+def build_cli(force: bool = False, verbose: bool = False) -> Path:
+    """The `demuxlet` command-line front end (host C++ only; links libdmx.so and zlib)."""
+    if not force and CLI.exists() and CLI.stat().st_mtime >= max(CLI_SRC.stat().st_mtime, LIB.stat().st_mtime):
+        return CLI
+    cmd = [hipcc(), "-O2", "-std=c++17", "-Wall", "-x", "c++", f"-I{ROOT / 'include'}", str(CLI_SRC), "-o", str(CLI),
+           f"-L{PKG}", "-ldmx", "-lz", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    return CLI
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if force or needs_build():
+        cmd = [hipcc(), *FLAGS, "-x", "hip", *map(str, SOURCES), "-o", str(LIB)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    build_cli(force, verbose)
     return LIB
 
 

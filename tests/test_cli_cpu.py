@@ -1,0 +1,157 @@
+"""CPU: the `demuxlet` front end (rows f1-f4) up to the pileup — option parsing, SAM/BAM/VCF readers, variant filter,
+sample selection, CIGAR walk, base filters — via `--pileup-only`, against an independent Python restatement of the
+reference's scan (tests/sam_vcf_synth.py).  PARITY-UNPINNED by the reference (its scan needs htslib)."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import sam_vcf_synth as sv
+
+ROOT = Path(__file__).resolve().parents[1]
+CLI = ROOT / "demuxlet_amd" / "demuxlet"
+CONTIGS = [("1", 30000), ("2", 20000), ("X", 15000)]
+SAMPLES = ["smC", "smA", "smB", "smD"]
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from demuxlet_amd import build
+    build.build()
+    assert CLI.exists()
+    return str(CLI)
+
+
+def parse_dump(path):
+    d = dict(sm=[], snps=[], g=[], cells=[])
+    cur = None
+    for line in open(path):
+        t = line.rstrip("\n").split("\t")
+        if t[0] == "SM": d["sm"].append(t[1])
+        elif t[0] == "SNP":
+            d["snps"].append((int(t[2]), int(t[3]), t[4], t[5]))
+            d["g"].append([float.fromhex(x) for x in t[6:]])
+        elif t[0] == "CELL":
+            cur = dict(bc=t[2], cnt=tuple(map(int, t[3:6])), pairs=[])
+            d["cells"].append(cur)
+        elif t[0] == "PAIR":
+            cur["pairs"].append((int(t[1]), [tuple(map(int, x.split(":"))) for x in t[3:]]))
+    return d
+
+
+def expected_from_scan(oracle, snps, events, gts, recs, field, gt_error):
+    ev = oracle.Events([e[0] for e in events], np.array([e[1] for e in events], dtype=np.int32), [e[2] for e in events],
+                       np.array([e[3] for e in events], dtype=np.uint8), np.array([e[4] for e in events], dtype=np.uint8),
+                       np.array([e[5] for e in events], dtype=np.uint8))
+    return oracle.store_from_events(ev)
+
+
+def check_dump_against_scan(oracle, dump, snps, events, gts, recs, sm_cols, field="GT", gt_error=0.01):
+    csr = expected_from_scan(oracle, snps, events, gts, recs, field, gt_error)
+    assert [c["bc"] for c in dump["cells"]] == csr.barcodes
+    assert len(dump["snps"]) == len(snps)
+    for (rid, pos, ref, alt), i in zip(dump["snps"], snps):
+        assert pos == recs[i]["pos"] and ref == recs[i]["ref"][0] and alt == recs[i]["alt"].split(",")[0][0]
+    for c, cell in enumerate(dump["cells"]):
+        assert cell["cnt"] == (csr.rd_totl[c], csr.rd_pass[c], csr.rd_uniq[c])
+        p0, p1 = csr.cell_off[c], csr.cell_off[c + 1]
+        assert [p[0] for p in cell["pairs"]] == list(csr.pair_snp[p0:p1])
+        for (snp, rds), p in zip(cell["pairs"], range(p0, p1)):
+            w = csr.words[csr.pair_off[p]:csr.pair_off[p + 1]]
+            exp = [(int(x >> 24) & 0xFF, int(x >> 16) & 0xFF) for x in w if ((x >> 24) & 0xFF) != 2]
+            assert rds == exp
+    # genotype matrix through the oracle's a3 restatement
+    for row, i, a in zip(dump["g"], snps, gts):
+        if field == "GT":
+            exp = oracle.geno_from_gt(np.array(a), gt_error)
+        elif field == "PL":
+            pl = [[(np.iinfo(np.int32).min if x == "." else int(x)) for x in (recs[i]["fields"][c].split(":")[1].split(",") + [".", ".", "."])[:3]] for c in sm_cols]
+            exp = oracle.geno_from_pl(np.array(pl))
+        else:
+            gp = [[(np.nan if x == "." else float(x)) for x in (recs[i]["fields"][c].split(":")[2].split(",") + [".", ".", "."])[:3]] for c in sm_cols]
+            exp = oracle.geno_from_gp(np.array(gp, dtype=np.float32), gt_error)
+        got = np.array(row, dtype=np.float64).reshape(-1, 3)
+        assert np.array_equal(np.nan_to_num(got, nan=-1), np.nan_to_num(exp.astype(np.float64), nan=-1))
+
+
+@pytest.mark.parametrize("field,fmt", [("GT", "sam"), ("PL", "bam"), ("GP", "sam")])
+def test_scan_matches_restatement(cli, oracle, tmp_path, field, fmt):
+    rng = np.random.default_rng(31 + len(field))
+    recs = sv.make_vcf(rng, CONTIGS, 120, SAMPLES, tmp_path / "v.vcf.gz")
+    reads = sv.make_reads(rng, CONTIGS, recs, 4000, [f"BC{i:02d}-1" for i in range(25)], tmp_path / "r.sam", tmp_path / "r.bam")
+    out = tmp_path / "o"
+    subprocess.run([cli, "--sam", str(tmp_path / f"r.{fmt}"), "--vcf", str(tmp_path / "v.vcf.gz"), "--field", field, "--out", str(out),
+                    "--pileup-only"], check=True, stderr=subprocess.DEVNULL)
+    dump = parse_dump(str(out) + ".pileup.txt")
+    snps, events, gts, sm_cols = sv.scan(reads, recs, CONTIGS, SAMPLES)
+    assert dump["sm"] == SAMPLES
+    assert len(events) > 1000
+    check_dump_against_scan(oracle, dump, snps, events, gts, recs, sm_cols, field)
+
+
+def test_sam_and_bam_give_the_same_pileup(cli, tmp_path):
+    rng = np.random.default_rng(5)
+    recs = sv.make_vcf(rng, CONTIGS, 60, SAMPLES, tmp_path / "v.vcf")
+    sv.make_reads(rng, CONTIGS, recs, 1500, ["A-1", "C-1", "G-1"], tmp_path / "r.sam", tmp_path / "r.bam")
+    outs = []
+    for fmt in ("sam", "bam"):
+        subprocess.run([cli, "--sam", str(tmp_path / f"r.{fmt}"), "--vcf", str(tmp_path / "v.vcf"), "--field", "GT", "--out", str(tmp_path / fmt),
+                        "--pileup-only"], check=True, stderr=subprocess.DEVNULL)
+        outs.append((tmp_path / f"{fmt}.pileup.txt").read_bytes())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
+def test_options_filters_and_sample_selection(cli, oracle, tmp_path):
+    """--sm goes through a std::set (sorted id order, bcf_filtered_reader.cpp:107-124); --min-BQ/--cap-BQ/--min-MQ/--min-TD/
+    --excl-flag/--group-list change what reaches the store (cmd_cram_demuxlet.cpp:314-323, sam_filtered_reader.cpp:284-296)."""
+    rng = np.random.default_rng(8)
+    recs = sv.make_vcf(rng, CONTIGS, 100, SAMPLES, tmp_path / "v.vcf")
+    bcs = [f"BC{i:02d}-1" for i in range(12)]
+    reads = sv.make_reads(rng, CONTIGS, recs, 3000, bcs, tmp_path / "r.sam")
+    (tmp_path / "grp.txt").write_text("\n".join(bcs[:5]) + "\n")
+    out = tmp_path / "o"
+    subprocess.run([cli, "--sam", str(tmp_path / "r.sam"), "--vcf", str(tmp_path / "v.vcf"), "--field", "GT", "--out", str(out), "--pileup-only",
+                    "--sm", "smD", "--sm", "smA", "--sm", "smC", "--min-BQ", "20", "--cap-BQ", "30", "--min-MQ", "30", "--min-TD", "5",
+                    "--excl-flag", "3860", "--group-list", str(tmp_path / "grp.txt"), "--geno-error", "0.05"], check=True, stderr=subprocess.DEVNULL)
+    dump = parse_dump(str(out) + ".pileup.txt")
+    assert dump["sm"] == ["smA", "smC", "smD"]
+    snps, events, gts, sm_cols = sv.scan(reads, recs, CONTIGS, SAMPLES, sm_ids=["smD", "smA", "smC"], min_mq=30, excl_flag=3860, min_bq=20,
+                                         cap_bq=30, min_td=5, group=set(bcs[:5]))
+    check_dump_against_scan(oracle, dump, snps, events, gts, recs, sm_cols, "GT", 0.05)
+
+
+def test_option_errors(cli, tmp_path):
+    for args in (["--no-such-option"], ["--min-BQ", "abc"], ["--sam", "a", "--sam", "b"], ["stray"], ["--out", "x"]):
+        r = subprocess.run([cli] + args, capture_output=True, text=True)
+        assert r.returncode != 0 and "FATAL ERROR" in r.stderr, args
+    r = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--write-pair" in r.stderr and "--doublet-prior" in r.stderr      # params.cpp:457-463: help exits 1
+
+
+def test_tutorial_vcf_plumbing(cli, oracle, tmp_path):
+    """BASELINE config 1 plumbing: the reference tutorial's VCF (first 4000 records, a data fixture) + a synthetic SAM laid over
+    it -> the scan keeps exactly the biallelic records with call rate >= 0.5 and MAC >= 1 among jurkat/293T_RTG."""
+    import gzip
+    vcf = ROOT / "tests" / "golden" / "tutorial_jurkat_293T_first4000.vcf.gz"
+    recs, contigs = [], []
+    for line in gzip.open(vcf, "rt"):
+        if line.startswith("##contig=<ID="):
+            name = line[13:].split(",")[0].rstrip(">\n")
+            ln = int(line.split("length=")[1].split(">")[0].split(",")[0]) if "length=" in line else 250000000
+            contigs.append((name, ln))
+        elif not line.startswith("#"):
+            t = line.rstrip("\n").split("\t")
+            recs.append(dict(chrom=t[0], pos=int(t[1]) - 1, ref=t[3], alt=t[4], fields=t[9:]))
+    rng = np.random.default_rng(2)
+    used = [c for c in contigs if c[0] in {r["chrom"] for r in recs}]
+    reads = sv.make_reads(rng, used, recs, 3000, [f"CELL{i:03d}-1" for i in range(40)], tmp_path / "r.sam")
+    # make_reads' tids index `used`; write the header with the same list
+    subprocess.run([cli, "--sam", str(tmp_path / "r.sam"), "--vcf", str(vcf), "--field", "GT", "--out", str(tmp_path / "o"), "--pileup-only"],
+                   check=True, stderr=subprocess.DEVNULL)
+    dump = parse_dump(str(tmp_path / "o.pileup.txt"))
+    assert dump["sm"] == ["jurkat", "293T_RTG"]
+    snps, events, gts, sm_cols = sv.scan(reads, recs, used, ["jurkat", "293T_RTG"])
+    assert len(dump["snps"]) == len(snps) and len(snps) > 500
+    assert sum(len(c["pairs"]) for c in dump["cells"]) > 500
+    check_dump_against_scan(oracle, dump, snps, events, gts, recs, sm_cols, "GT")

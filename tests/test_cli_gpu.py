@@ -1,0 +1,71 @@
+"""GPU (-m gpu): the `demuxlet` binary end to end — SAM/BAM + VCF in, the four files out — against the oracle run on the
+events of the independent scan restatement (tests/sam_vcf_synth.py)."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import sam_vcf_synth as sv
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+CLI = ROOT / "demuxlet_amd" / "demuxlet"
+CONTIGS = [("1", 30000), ("2", 20000), ("X", 15000)]
+SAMPLES = ["smC", "smA", "smB", "smD"]
+
+
+def compare_files(got_path, want_path, best=False):
+    got = Path(got_path).read_text().splitlines()
+    want = Path(want_path).read_text().splitlines()
+    assert len(got) == len(want) and got[0] == want[0]
+    for a, b in zip(got[1:], want[1:]):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert len(fa) == len(fb)
+        for x, y in zip(fa, fb):
+            try:
+                fx, fy = float(x), float(y)
+                assert abs(fx - fy) <= 1e-3 * max(1e-3, abs(fy)) + 1.01e-4, (a, b)
+            except ValueError:
+                assert x == y, (a, b)
+
+
+@pytest.mark.parametrize("field,fmt,extra", [("GT", "bam", ["--write-pair"]), ("GP", "sam", ["--alpha", "0", "--alpha", "0.25", "--alpha", "0.5"]),
+                                              ("PL", "sam", ["--min-snp", "5", "--doublet-prior", "0.3"])])
+def test_cli_end_to_end(oracle, tmp_path, field, fmt, extra):
+    from demuxlet_amd import build
+    build.build()
+    rng = np.random.default_rng(77 + len(field) + len(extra))
+    recs = sv.make_vcf(rng, CONTIGS, 150, SAMPLES, tmp_path / "v.vcf.gz")
+    reads = sv.make_reads(rng, CONTIGS, recs, 6000, [f"BC{i:02d}-1" for i in range(20)], tmp_path / "r.sam", tmp_path / "r.bam")
+    out = tmp_path / "o"
+    subprocess.run([str(CLI), "--sam", str(tmp_path / f"r.{fmt}"), "--vcf", str(tmp_path / "v.vcf.gz"), "--field", field, "--out", str(out)] + extra,
+                   check=True, stderr=subprocess.DEVNULL)
+    # expectation: scan restatement -> oracle
+    snps, events, gts, sm_cols = sv.scan(reads, recs, CONTIGS, SAMPLES)
+    if field == "GT":
+        g = np.stack([oracle.geno_from_gt(np.array(a), 0.01) for a in gts])
+    elif field == "PL":
+        g = np.stack([oracle.geno_from_pl(np.array([[(np.iinfo(np.int32).min if x == "." else int(x)) for x in (recs[i]["fields"][c].split(":")[1].split(",") + ["."] * 3)[:3]]
+                                                    for c in sm_cols])) for i in snps])
+    else:
+        g = np.stack([oracle.geno_from_gp(np.array([[(np.nan if x == "." else float(x)) for x in (recs[i]["fields"][c].split(":")[2].split(",") + ["."] * 3)[:3]]
+                                                    for c in sm_cols], dtype=np.float32), 0.01) for i in snps])
+    ev = oracle.Events([e[0] for e in events], np.array([e[1] for e in events], dtype=np.int32), [e[2] for e in events],
+                       np.array([e[3] for e in events], dtype=np.uint8), np.array([e[4] for e in events], dtype=np.uint8),
+                       np.array([e[5] for e in events], dtype=np.uint8))
+    alphas = (0.0, 0.5)
+    params = oracle.Params()
+    if "--alpha" in extra:
+        params = oracle.Params(alphas=(0.0, 0.25, 0.5))
+    if "--min-snp" in extra:
+        params = oracle.Params(min_snp=5, doublet_prior=0.3)
+    if "--write-pair" in extra:
+        params = oracle.Params(write_pair=True)
+    pb = oracle.Problem(SAMPLES, np.nan_to_num(g.astype(np.float32)), ev, params)
+    oracle.run_problem(pb, str(tmp_path / "orc"))
+    for suf in ["single", "sing2", "best"] + (["pair"] if "--write-pair" in extra else []):
+        compare_files(f"{out}.{suf}", tmp_path / f"orc.{suf}")
+    got_best = [l.split("\t")[5] for l in Path(f"{out}.best").read_text().splitlines()]
+    want_best = [l.split("\t")[5] for l in (tmp_path / "orc.best").read_text().splitlines()]
+    assert got_best == want_best
