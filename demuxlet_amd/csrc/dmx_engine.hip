@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
                                                               const int32_t* __restrict__ sched, int32_t V, int32_t A,
                                                               int32_t A_pad, int32_t TP, double* __restrict__ grid,
                                                               double* __restrict__ l00,
-                                                              const uint8_t* __restrict__ flagged) {
+                                                              uint8_t* __restrict__ flagged) {
   // FIXUP: second pass behind k_doublet_a2 — only cells in which that kernel met a log() argument outside the normal
   // positive range (flagged[cell] != 0) are recomputed, with ocml's log() for exact log(0) / log(nan) semantics.
   if (FIXUP && !flagged[sched[blockIdx.x]]) return;
@@ -640,6 +640,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
   // phase-2 identity
   const int32_t nAB = V * V * A;
   const int32_t nacc = nAB + A;
+  bool ok = true;              // every log() argument so far was a normal positive double (the fast path's domain)
   uint32_t code[NACC];         // (j << 20) | (k << 8) | n ; j = 0xFFF marks an llks00 entry; ~0u = no accumulator
   double acc[NACC];
 #pragma unroll
@@ -759,7 +760,8 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
         for (int l = 0; l < 3; ++l)
 #pragma unroll
           for (int m = 0; m < 3; ++m) sum += ((a[l] * b[m]) * P[l * 3 + m]);   // :553 then :677-679, l-major
-        acc[i] += FIXUP ? log(sum) : dmx_log(sum, s_log);                          // :683 / :709
+        if (!FIXUP) ok &= __builtin_amdgcn_class(sum, 0x100);
+        acc[i] += FIXUP ? log(sum) : dmx_log_fast(sum, s_log);                     // :683 / :709
       }
     }
     __syncthreads();
@@ -771,6 +773,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
     if (q < nAB) grid[(size_t)cell * nAB + q] = acc[i];
     else if (q < nacc) l00[(size_t)cell * A + (q - nAB)] = acc[i];
   }
+  if (!FIXUP && !ok) flagged[cell] = 1;   // recomputed with ocml's log() by the FIXUP pass
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1365,16 +1368,21 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
   const int32_t i2 = (s_i[0] == 0x7FFFFFFF) ? -1 : s_i[0];
 
   if (t == 0) {
+    // NaN likelihoods (e.g. a GP record with a missing sample poisons the whole SNP, bcf_filtered_reader.cpp:431-448) make
+    // every `<` of the reference's scans false: it then indexes with -1 (:816-825, undefined behaviour).  Here the
+    // indices stay -1 and the dependent values are NaN; nothing is read out of bounds.
+    const double kNaN = __builtin_nan("");
     dmx_cell_summary r;
     r.max_llk = max_llk; r.sum_single = sum_single; r.sum_double = sum_double;
-    r.i_sing1 = i1; r.i_sing2 = i2;
-    r.sing_llk1 = G[(size_t)i1 * V * A];
+    const bool has1 = i1 != 0x7FFFFFFF, hasb = qbest != 0x7FFFFFFF;
+    r.i_sing1 = has1 ? i1 : -1; r.i_sing2 = i2;
+    r.sing_llk1 = has1 ? G[(size_t)i1 * V * A] : kNaN;
     r.sing_llk2 = (i2 >= 0) ? G[(size_t)i2 * V * A] : -1e300;
-    const int32_t nb = qbest % A, jkb = qbest / A, jb = jkb / V, kb = jkb % V;
-    r.j_best = jb; r.k_best = kb; r.n_best = nb;
-    r.llk12 = G[qbest];
-    r.llk1 = G[(size_t)jb * V * A]; r.llk2 = G[(size_t)kb * V * A];
-    r.llk10 = G[(size_t)jb * V * A + nb]; r.llk20 = G[(size_t)kb * V * A + nb];    // :824-825
+    const int32_t nb = hasb ? qbest % A : 0, jkb = hasb ? qbest / A : 0, jb = jkb / V, kb = jkb % V;
+    r.j_best = hasb ? jb : -1; r.k_best = hasb ? kb : -1; r.n_best = hasb ? nb : -1;
+    r.llk12 = hasb ? G[qbest] : kNaN;
+    r.llk1 = hasb ? G[(size_t)jb * V * A] : kNaN; r.llk2 = hasb ? G[(size_t)kb * V * A] : kNaN;
+    r.llk10 = hasb ? G[(size_t)jb * V * A + nb] : kNaN; r.llk20 = hasb ? G[(size_t)kb * V * A + nb] : kNaN;    // :824-825
     r.llk00_0 = l00[(size_t)cell * A]; r.llk00_best = l00[(size_t)cell * A + nb];
     r.n_pairs = npairs;
     out[cell] = r;
@@ -1705,7 +1713,12 @@ int launch_doublet_generic_w(dmx_engine* e) {
 int launch_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
   const bool force_generic = getenv("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
-  if (A != 2 || V > 64 || force_generic) return launch_doublet_generic_w<false>(e);
+  if (A != 2 || V > 64 || force_generic) {
+    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    if (int rc = launch_doublet_generic_w<false>(e)) return rc;
+    HIP_TRY(hipGetLastError());
+    return launch_doublet_generic_w<true>(e);
+  }
   const bool no_classes = getenv("DMX_NO_CLASSES") != nullptr;          // kernel experiments / tests only
   if (e->n_classes > 0 && !no_classes) {
     const int VS = (V <= 32) ? ((V + 3) & ~3) : ((V + 15) & ~15);   // id row stride: a whole number of k-blocks

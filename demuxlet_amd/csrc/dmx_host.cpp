@@ -518,7 +518,12 @@ extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_pref
         grid = scratch.data();
       }
     }
-    const CellCall cc = call_cell(grid, V, A, in->alpha, prior);
+    CellCall cc = call_cell(grid, V, A, in->alpha, prior);
+    // NaN likelihoods leave the reference's scans without a winner and it indexes with -1 (undefined behaviour, :816-825);
+    // we fall back to index 0 so that the row is still printable (its numbers are NaN).
+    if (cc.i_sing1 < 0) cc.i_sing1 = 0;
+    if (cc.i_sing2 < 0) cc.i_sing2 = 0;
+    if (cc.j_best < 0) { cc.j_best = 0; cc.k_best = 0; cc.n_best = 0; }
     const char* bc = in->barcodes[c];
     const int32_t t = in->rd_totl[c], p = in->rd_pass[c], u = in->rd_uniq[c], ns = in->n_snp[c];
 
@@ -594,7 +599,10 @@ extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double
   for (int32_t c : barcode_order(in)) {
     if (cell_filtered(in, c)) continue;
     if (in->n_snp[c] == 0) continue;
-    const dmx_cell_summary& sm = summary[c];
+    dmx_cell_summary sm = summary[c];
+    if (sm.i_sing1 < 0) sm.i_sing1 = 0;         // NaN likelihoods: see dmx_write_doublet
+    if (sm.i_sing2 < 0) sm.i_sing2 = 0;
+    if (sm.j_best < 0) { sm.j_best = 0; sm.k_best = 0; sm.n_best = 0; }
     const double* sg = sing + (size_t)c * V;
     const double* l00 = in->llks00 + (size_t)c * A;
     int32_t jb = sm.j_best, kb = sm.k_best;

@@ -36,7 +36,7 @@ def test_cli_end_to_end(oracle, tmp_path, field, fmt, extra):
     from demuxlet_amd import build
     build.build()
     rng = np.random.default_rng(77 + len(field) + len(extra))
-    recs = sv.make_vcf(rng, CONTIGS, 150, SAMPLES, tmp_path / "v.vcf.gz")
+    recs = sv.make_vcf(rng, CONTIGS, 150, SAMPLES, tmp_path / "v.vcf.gz", with_noise=(field != "GP"))
     reads = sv.make_reads(rng, CONTIGS, recs, 6000, [f"BC{i:02d}-1" for i in range(20)], tmp_path / "r.sam", tmp_path / "r.bam")
     out = tmp_path / "o"
     subprocess.run([str(CLI), "--sam", str(tmp_path / f"r.{fmt}"), "--vcf", str(tmp_path / "v.vcf.gz"), "--field", field, "--out", str(out)] + extra,
@@ -69,3 +69,18 @@ def test_cli_end_to_end(oracle, tmp_path, field, fmt, extra):
     got_best = [l.split("\t")[5] for l in Path(f"{out}.best").read_text().splitlines()]
     want_best = [l.split("\t")[5] for l in (tmp_path / "orc.best").read_text().splitlines()]
     assert got_best == want_best
+
+
+def test_nan_likelihoods_do_not_crash(tmp_path):
+    """A GP record with a missing sample turns the whole SNP into NaN (bcf_filtered_reader.cpp:431-448) and the reference then
+    indexes its grid with -1; the product must neither fault on the GPU nor on the host, and must still write all files."""
+    from demuxlet_amd import build
+    build.build()
+    rng = np.random.default_rng(3)
+    recs = sv.make_vcf(rng, CONTIGS, 100, SAMPLES, tmp_path / "v.vcf.gz", with_noise=True)
+    sv.make_reads(rng, CONTIGS, recs, 3000, [f"BC{i:02d}-1" for i in range(10)], tmp_path / "r.sam")
+    r = subprocess.run([str(CLI), "--sam", str(tmp_path / "r.sam"), "--vcf", str(tmp_path / "v.vcf.gz"), "--field", "GP", "--out", str(tmp_path / "o"),
+                        "--write-pair"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    for suf in ("single", "sing2", "best", "pair"):
+        assert (tmp_path / f"o.{suf}").stat().st_size > 100
