@@ -90,7 +90,7 @@ class Job(C.Structure):
     _fields_ = [("store", C.c_void_p), ("g", C.c_void_p), ("n_samples", C.c_int32), ("sample_ids", C.c_void_p),
                 ("n_alpha", C.c_int32), ("alpha", C.c_void_p), ("doublet_prior", C.c_double),
                 ("min_total", C.c_int32), ("min_uniq", C.c_int32), ("min_snp", C.c_int32), ("write_pair", C.c_int32),
-                ("out_prefix", C.c_char_p), ("device", C.c_int32), ("arbiter", C.c_int32)]
+                ("out_prefix", C.c_char_p), ("device", C.c_int32), ("arbiter", C.c_int32), ("n_gpus", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -67,7 +67,7 @@ struct Options {
   std::string group_list;
   int min_total = 0, min_uniq = 0, min_snp = 0;
   // additions of this implementation (do not collide with any reference option)
-  int gpu = 0;
+  int gpu = 0, gpus = 1;
   bool pileup_only = false;      // stop after the scan and write <out>.pileup.txt (no GPU needed)
   bool no_arbiter = false;
 };
@@ -124,6 +124,7 @@ void parse_options(int argc, char** argv, Options& o) {
       {"min-uniq", O_INT, &o.min_uniq, "Minimum number of unique reads (determined by UMI/SNP pair) for a droplet/cell to be considered", "Cell/droplet filtering options"},
       {"min-snp", O_INT, &o.min_snp, "Minimum number of SNPs with coverage for a droplet/cell to be considered", "Cell/droplet filtering options"},
       {"gpu", O_INT, &o.gpu, "[MI355X build] HIP device ordinal", "MI355X build"},
+      {"gpus", O_INT, &o.gpus, "[MI355X build] number of GPUs to shard the barcodes over (starting at --gpu)", "MI355X build"},
       {"pileup-only", O_BOOL, &o.pileup_only, "[MI355X build] stop after the BAM x VCF scan and write <out>.pileup.txt", "MI355X build"},
       {"no-arbiter", O_BOOL, &o.no_arbiter, "[MI355X build] skip the host tie arbiter (DESIGN.md, Ties)", "MI355X build"},
   };
@@ -709,7 +710,7 @@ int main(int argc, char** argv) {
   job.store = scl; job.g = G.data(); job.n_samples = nv; job.sample_ids = sm.data();
   job.n_alpha = (int32_t)o.alpha.size(); job.alpha = o.alpha.data(); job.doublet_prior = o.doublet_prior;
   job.min_total = o.min_total; job.min_uniq = o.min_uniq; job.min_snp = o.min_snp; job.write_pair = o.write_pair;
-  job.out_prefix = o.out.c_str(); job.device = o.gpu; job.arbiter = o.no_arbiter ? 0 : 1;
+  job.out_prefix = o.out.c_str(); job.device = o.gpu; job.arbiter = o.no_arbiter ? 0 : 1; job.n_gpus = o.gpus;
   if (dmx_demuxlet_run(&job) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
   notice("Finished writing output files");                                                                 // :876
   dmx_store_free(scl);

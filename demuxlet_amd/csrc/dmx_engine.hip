@@ -1930,20 +1930,113 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   dmx_pileup pl;
   if (int rc = dmx_store_freeze(job->store, &pl)) return rc;
   const int32_t B = pl.n_cells, V = job->n_samples, A = job->n_alpha;
-  dmx_engine_config cfg{};
-  cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior; cfg.device = job->device;
-  cfg.mode = DMX_MODE_STRICT;
-  dmx_engine* e = nullptr;
-  if (int rc = dmx_engine_create(&cfg, &e)) return rc;
-  struct Guard { dmx_engine* e; ~Guard() { dmx_engine_destroy(e); } } guard{e};
-  if (int rc = dmx_engine_set_genotypes(e, job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
-  if (int rc = dmx_engine_set_pileup(e, &pl)) return rc;
-  if (int rc = dmx_engine_run_singlet(e)) return rc;
-  std::vector<double> llks((size_t)B * V), llk0s((size_t)B);
-  if (int rc = dmx_engine_get_singlet(e, llks.data(), llk0s.data())) return rc;
+  const size_t nAB = (size_t)V * V * A;
   std::vector<const char*> bcs((size_t)B);
   std::vector<int32_t> nsnp((size_t)B);
   for (int32_t c = 0; c < B; ++c) { bcs[c] = dmx_store_barcode(job->store, c); nsnp[c] = (int32_t)(pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]); }
+
+  // ---- shards: contiguous ranges of the byte-wise sorted barcodes with equal work (log evaluations)
+  const int nshard = std::max(1, std::min(job->n_gpus > 0 ? job->n_gpus : 1, std::max(B, 1)));
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_error(DMX_ERR_NOGPU, "dmx_demuxlet_run: no HIP device is visible (this library has no CPU fallback)");
+  std::vector<int32_t> order((size_t)B);
+  std::iota(order.begin(), order.end(), 0);
+  if (nshard > 1) std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return std::strcmp(bcs[a], bcs[b]) < 0; });
+  std::vector<int32_t> cut((size_t)nshard + 1, 0);
+  {
+    const double per_pair = (double)(V + 1) + (double)nAB + A;
+    double total = 0;
+    for (int32_t c = 0; c < B; ++c) total += nsnp[c] * per_pair + 1.0;
+    double run = 0;
+    int r = 1;
+    for (int32_t i = 0; i < B && r < nshard; ++i) {
+      run += nsnp[order[i]] * per_pair + 1.0;
+      while (r < nshard && run >= total * r / nshard) cut[(size_t)r++] = i + 1;
+    }
+    for (; r <= nshard; ++r) cut[(size_t)r] = B;
+    cut[(size_t)nshard] = B;
+  }
+
+  struct Shard {
+    dmx_engine* e = nullptr;
+    std::vector<int64_t> pair_off, read_off;
+    std::vector<int32_t> snp;
+    std::vector<uint8_t> nrd, reads;
+    dmx_pileup pl{};
+    int32_t lo = 0, hi = 0;
+  };
+  std::vector<Shard> sh((size_t)nshard);
+  struct Guard { std::vector<Shard>* s; ~Guard() { for (Shard& x : *s) if (x.e) dmx_engine_destroy(x.e); } } guard{&sh};
+
+  for (int i = 0; i < nshard; ++i) {
+    Shard& x = sh[(size_t)i];
+    x.lo = cut[(size_t)i]; x.hi = cut[(size_t)i + 1];
+    const int32_t nb = x.hi - x.lo;
+    const dmx_pileup* use = &pl;
+    if (nshard > 1) {                            // slice the CSR: cells order[lo..hi) become cells 0..nb-1 of the shard
+      x.pair_off.assign((size_t)nb + 1, 0); x.read_off.assign((size_t)nb + 1, 0);
+      for (int32_t k = 0; k < nb; ++k) {
+        const int32_t c = order[(size_t)x.lo + k];
+        x.pair_off[(size_t)k + 1] = x.pair_off[(size_t)k] + (pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]);
+        x.read_off[(size_t)k + 1] = x.read_off[(size_t)k] + (pl.cell_read_off[c + 1] - pl.cell_read_off[c]);
+      }
+      x.snp.resize((size_t)x.pair_off[(size_t)nb]);
+      x.nrd.resize((size_t)x.pair_off[(size_t)nb] * (size_t)pl.nrd_width + 4);
+      x.reads.resize((size_t)x.read_off[(size_t)nb] + 4);
+      for (int32_t k = 0; k < nb; ++k) {
+        const int32_t c = order[(size_t)x.lo + k];
+        const int64_t np = pl.cell_pair_off[c + 1] - pl.cell_pair_off[c], nr = pl.cell_read_off[c + 1] - pl.cell_read_off[c];
+        if (np) {
+          std::memcpy(&x.snp[(size_t)x.pair_off[(size_t)k]], pl.pair_snp + pl.cell_pair_off[c], sizeof(int32_t) * (size_t)np);
+          std::memcpy(&x.nrd[(size_t)x.pair_off[(size_t)k] * (size_t)pl.nrd_width],
+                      (const uint8_t*)pl.pair_nrd + (size_t)pl.cell_pair_off[c] * (size_t)pl.nrd_width, (size_t)np * (size_t)pl.nrd_width);
+        }
+        if (nr) std::memcpy(&x.reads[(size_t)x.read_off[(size_t)k]], pl.reads + pl.cell_read_off[c], (size_t)nr);
+      }
+      x.pl = pl;
+      x.pl.n_cells = nb; x.pl.n_pairs = x.pair_off[(size_t)nb]; x.pl.n_reads = x.read_off[(size_t)nb];
+      x.pl.cell_pair_off = x.pair_off.data(); x.pl.cell_read_off = x.read_off.data(); x.pl.pair_snp = x.snp.data();
+      x.pl.pair_nrd = x.nrd.data(); x.pl.reads = x.reads.data();
+      x.pl.rd_totl = x.pl.rd_pass = x.pl.rd_uniq = nullptr;
+      use = &x.pl;
+    }
+    dmx_engine_config cfg{};
+    cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior;
+    cfg.device = (job->device + i) % ndev; cfg.mode = DMX_MODE_STRICT;
+    if (int rc = dmx_engine_create(&cfg, &x.e)) return rc;
+    if (int rc = dmx_engine_set_genotypes(x.e, job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
+    if (int rc = dmx_engine_set_pileup(x.e, use)) return rc;
+  }
+  // ---- all shards compute concurrently (every engine has its own stream; launches are asynchronous)
+  for (Shard& x : sh) if (int rc = dmx_engine_run_singlet(x.e)) return rc;
+  const bool doublet_ok = V >= 2 && A >= 2;
+  if (doublet_ok) for (Shard& x : sh) if (int rc = dmx_engine_run_doublet(x.e)) return rc;
+
+  // ---- collect per-cell results on the host, back in cell-id order
+  std::vector<double> llks((size_t)B * V), llk0s((size_t)B);
+  std::vector<double> grid, l00;
+  if (doublet_ok) { grid.resize((size_t)B * nAB); l00.resize((size_t)B * A); }
+  for (Shard& x : sh) {
+    const int32_t nb = x.hi - x.lo;
+    if (nshard == 1) {
+      if (int rc = dmx_engine_get_singlet(x.e, llks.data(), llk0s.data())) return rc;
+      if (doublet_ok) if (int rc = dmx_engine_get_doublet(x.e, grid.data(), l00.data(), nullptr)) return rc;
+    } else {
+      std::vector<double> a((size_t)nb * V), b((size_t)nb), g2, z;
+      if (int rc = dmx_engine_get_singlet(x.e, a.data(), b.data())) return rc;
+      if (doublet_ok) { g2.resize((size_t)nb * nAB); z.resize((size_t)nb * A); if (int rc = dmx_engine_get_doublet(x.e, g2.data(), z.data(), nullptr)) return rc; }
+      for (int32_t k = 0; k < nb; ++k) {
+        const int32_t c = order[(size_t)x.lo + k];
+        std::memcpy(&llks[(size_t)c * V], &a[(size_t)k * V], sizeof(double) * (size_t)V);
+        llk0s[(size_t)c] = b[(size_t)k];
+        if (doublet_ok) {
+          std::memcpy(&grid[(size_t)c * nAB], &g2[(size_t)k * nAB], sizeof(double) * nAB);
+          std::memcpy(&l00[(size_t)c * A], &z[(size_t)k * A], sizeof(double) * (size_t)A);
+        }
+      }
+    }
+  }
   dmx_final_input fin{};
   fin.n_cells = B; fin.n_samples = V; fin.n_alpha = A; fin.alpha = job->alpha; fin.doublet_prior = job->doublet_prior;
   fin.min_total = job->min_total; fin.min_uniq = job->min_uniq; fin.min_snp = job->min_snp; fin.write_pair = job->write_pair;
@@ -1952,9 +2045,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   fin.llks = llks.data(); fin.llk0s = llk0s.data();
   const std::string pre(job->out_prefix);
   if (int rc = dmx_write_single(&fin, (pre + ".single").c_str())) return rc;
-  if (int rc = dmx_engine_run_doublet(e)) return rc;
-  std::vector<double> grid((size_t)B * V * V * A), l00((size_t)B * A);
-  if (int rc = dmx_engine_get_doublet(e, grid.data(), l00.data(), nullptr)) return rc;
+  if (!doublet_ok) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: the doublet stage needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
   fin.llksAB = grid.data(); fin.llks00 = l00.data();
   if (job->arbiter) { fin.tie_pileup = &pl; fin.tie_g = job->g; }
   return dmx_write_doublet(&fin, job->out_prefix);

@@ -291,11 +291,11 @@ def write_doublet_summary(fa: FinalArgs, sing, l00, summary, out_prefix: str, ti
 
 def demuxlet_run(store: Store, g: np.ndarray, sample_ids: Sequence[str], alphas: Sequence[float], out_prefix: str,
                  doublet_prior: float = 0.5, min_total: int = 0, min_uniq: int = 0, min_snp: int = 0,
-                 write_pair: bool = False, device: int = 0, arbiter: bool = True) -> None:
+                 write_pair: bool = False, device: int = 0, arbiter: bool = True, n_gpus: int = 1) -> None:
     """cmd_cram_demuxlet.cpp:390-881 in one call (dmx_demuxlet_run)."""
     g = np.ascontiguousarray(g, dtype=np.float32)
     al = np.ascontiguousarray(alphas, dtype=np.float64)
     sm, keep = _cstrs(sample_ids)
     job = capi.Job(store.handle, g.ctypes.data, g.shape[1], C.cast(sm, C.c_void_p), len(al), al.ctypes.data, doublet_prior,
-                   min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter))
+                   min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter), n_gpus)
     check(capi.load().dmx_demuxlet_run(C.byref(job)))

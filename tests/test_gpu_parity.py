@@ -68,14 +68,16 @@ def test_golden_raw_arrays(eng, oracle, name):
     assert max(d1, d0, dg, d00) < TOL
 
 
+@pytest.mark.parametrize("n_gpus", [1, 3])
 @pytest.mark.parametrize("name", CASES)
-def test_golden_files_end_to_end(eng, oracle, name, tmp_path):
-    """Store -> engine -> finaliser with the tie arbiter == the reference's four files."""
+def test_golden_files_end_to_end(eng, oracle, name, n_gpus, tmp_path):
+    """Store -> engine -> finaliser with the tie arbiter == the reference's four files.  n_gpus = 3 shards the sorted
+    barcodes over three engines (all on device 0 on a 1-GPU box: same code path as three devices) and must not change a byte."""
     gd = Golden(name)
     pb = gd.problem(oracle)
     st = build_store(eng, pb)
     eng.demuxlet_run(st, gd.g, gd.sample_ids, gd.alphas, str(tmp_path / "o"), gd.doublet_prior, gd.min_total, gd.min_uniq,
-                     gd.min_snp, gd.write_pair, arbiter=True)
+                     gd.min_snp, gd.write_pair, arbiter=True, n_gpus=n_gpus)
     for suf, ref in gd.files.items():
         got = (tmp_path / f"o.{suf}").read_text().splitlines()
         want = ref.decode().splitlines()
