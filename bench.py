@@ -231,7 +231,7 @@ def main():
         }
         if cfg["doublet"]:
             out["pair_evals_per_s"] = total_pairs * V * V * A * args.steps / elapsed
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 leg only
             out["cpu_baseline"] = cpu_baseline(dp, g, cfg)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -326,3 +326,36 @@ def test_genotype_class_kernel_is_bit_identical_to_the_general_one(eng, oracle, 
     assert np.array_equal(a["summ"], b["summ"])
     ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
     assert np.abs(a["grid"] - ref.llksAB).max() < TOL and np.abs(a["llks"] - ref.llks).max() < TOL
+
+
+def test_all_base_qualities_and_depths(eng, oracle):
+    """Base qualities over the whole ABI range 0..127 (the first-read tables cover < 64, the rest takes the generic loop,
+    q <= 1 has the 0.75 error floor of PhredHelper.cpp:30) and pair depths 0..6, dense and sparse layouts."""
+    rng = np.random.default_rng(99)
+    for dense in (False, True):
+        S, V, B = 200, 5, 30
+        g = rng.dirichlet([1, 1, 1], size=(S, V)).astype(np.float32)
+        if dense:
+            npair = np.full(B, S)
+            pair_snp = None
+        else:
+            cov = rng.random((B, S)) < 0.3
+            npair = cov.sum(axis=1)
+            pair_snp = np.concatenate([np.nonzero(cov[c])[0] for c in range(B)]).astype(np.int32)
+        P = int(npair.sum())
+        nrd = rng.integers(0, 7, size=P).astype(np.uint8)
+        reads = (rng.integers(0, 128, size=int(nrd.sum())).astype(np.uint8) | (rng.integers(0, 2, size=int(nrd.sum())).astype(np.uint8) << 7))
+        cpo = np.concatenate([[0], np.cumsum(npair)]).astype(np.int64)
+        pair_cell = np.repeat(np.arange(B), npair)
+        cro = np.concatenate([[0], np.cumsum(np.bincount(pair_cell, weights=nrd, minlength=B))]).astype(np.int64)
+        z = np.zeros(B, dtype=np.int32)
+        pl = eng.HostPileup(B, S, cpo, cro, pair_snp, nrd, reads, z, z, z)
+        out = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+
+        class SP: pass
+        sp = SP(); sp.reads = reads; sp.pair_snp = pair_snp; sp.n_snps = S; sp.n_cells = B; sp.pair_nrd = nrd
+        sp.cell_pair_off = cpo; sp.rd_totl = sp.rd_pass = sp.rd_uniq = z
+        ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+        d = max(np.abs(out["llks"] - ref.llks).max(), np.abs(out["llk0s"] - ref.llk0s).max(), np.abs(out["grid"] - ref.llksAB).max())
+        print(f"dense={dense}: max|d| = {d:.2e}")
+        assert d < TOL
