@@ -74,11 +74,12 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
                   singlet_only=not cfg["doublet"], want_grid=False)
         return time.perf_counter() - t0, int(h["cell_pair_off"][-1])
 
-    n0 = 2
-    t, pairs = run(n0)
-    n = int(max(n0, min(dp.n_cells, round(n0 * target_s / max(t, 1e-3)))))
-    if n > n0:
-        t, pairs = run(n)
+    # size the sample from the reference's measured cost (~35 ns per log evaluation) so ONE run lands near target_s
+    A = len(cfg["alphas"])
+    logs_per_pair = (V + 1) + ((V * V * A + A) if cfg["doublet"] else 0)
+    pairs_per_cell = max(1.0, dp.n_pairs / max(dp.n_cells, 1))
+    n = int(max(1, min(dp.n_cells, round(target_s / (35e-9 * logs_per_pair * pairs_per_cell)))))
+    t, pairs = run(n)
     return dict(value=pairs * V / t, unit="cell-SNP-sample triples/s", cores=1, kind="port",
                 sample=f"first {n} barcodes of the same workload ({pairs} covered pairs), oracle/dmx_oracle.c "
                        f"(gcc -O2 -ffp-contract=off), {t:.1f} s wall", seconds=t)
