@@ -359,3 +359,22 @@ def test_all_base_qualities_and_depths(eng, oracle):
         d = max(np.abs(out["llks"] - ref.llks).max(), np.abs(out["llk0s"] - ref.llk0s).max(), np.abs(out["grid"] - ref.llksAB).max())
         print(f"dense={dense}: max|d| = {d:.2e}")
         assert d < TOL
+
+
+@pytest.mark.parametrize("name", ["gt_v4_a2_pair", "gp_v8_a2_minsnp", "pl_v32_a3", "gt_v64_a2"])
+def test_without_the_arbiter_only_the_order_inside_a_doublet_can_differ(eng, oracle, name, tmp_path):
+    """arbiter=False: every number comes from the GPU.  The SNG/DBL/AMB call, the best singlets and the UNORDERED best
+    doublet pair still equal the reference's; only which of the two samples of an alpha=0.5 doublet is printed first may
+    differ (the reference decides that by its own 1e-14 rounding noise)."""
+    gd = Golden(name)
+    st = build_store(eng, gd.problem(oracle))
+    eng.demuxlet_run(st, gd.g, gd.sample_ids, gd.alphas, str(tmp_path / "o"), gd.doublet_prior, gd.min_total, gd.min_uniq,
+                     gd.min_snp, gd.write_pair, arbiter=False)
+    got = [r.split("\t") for r in (tmp_path / "o.best").read_text().splitlines()[1:]]
+    want = [r.split("\t") for r in gd.files["best"].decode().splitlines()[1:]]
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert a[0] == b[0] and a[5].split("-")[0] == b[5].split("-")[0]          # barcode, SNG / DBL / AMB
+        assert (a[6], a[8]) == (b[6], b[8])                                          # SNG.1ST, SNG.2ND
+        assert {a[11], a[12]} == {b[11], b[12]} and a[13] == b[13]                   # unordered DBL pair, ALPHA
+        assert abs(float(a[14]) - float(b[14])) < 1.01e-4                            # LLK12
