@@ -377,11 +377,191 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
 }
 
 // K1 over genotype classes (see "Genotype classes" below: <= 4 distinct probability rows per SNP, --field GT).
+// Same walk, ownership and ordered sums as k_singlet.  Per pair the lane evaluates log(GL . row_d) ONCE per class d (plus
+// the llk0 term), parks those doubles in a per-lane LDS scratch, and for every sample k of the chunk copies
+// scratch[class id of (snp, k)] into the chain buffer — the very double k_singlet would have computed for sample k
+// (same operands, same operations), so the sums that follow are bit-identical.  4+1 logs per pair instead of V+1.
+template <int CW, int KC>
+__global__ __launch_bounds__(kThreads, 4) void k_singlet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
+                                                             const uint32_t* __restrict__ idw, const double* __restrict__ gp0,
+                                                             const double* __restrict__ tabs,
+                                                             const int32_t* __restrict__ sched, int32_t V,
+                                                             double* __restrict__ llks, double* __restrict__ llk0s) {
+  static_assert(KC == 8 || KC == 4, "a chunk's 2-bit class ids must sit inside one 32-bit id word");
+  constexpr int T = 64 / CW;
+  constexpr int TS = T + 2;
+  constexpr int NC = KC + 1;
+  constexpr int NW = kThreads / 64;
+  constexpr int SD = 5;                          // scratch doubles per lane: 4 class terms + llk0 term
+  static_assert(CW * NC <= 64, "one lane per chain");
+  extern __shared__ double s_dyn[];              // [NW][nch][CW*NC] running accumulators
+  __shared__ double s_tab[kTab];                 // read LUT + log table; the first-read tables stay in global memory (L1-hot)
+  __shared__ __attribute__((aligned(16))) double s_term[NW][CW * NC * TS];
+  __shared__ double s_scr[NW][64 * SD];
+  const double* s_log = s_tab + kLut;
+  const double* g_first = tabs + kTab;
+  const double* g_final = g_first + kFirst;
+
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const int nch = (V + KC - 1) / KC;
+  const int nwd = (V + 15) / 16;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  for (int i = t; i < NW * nch * CW * NC; i += kThreads) s_dyn[i] = 0.0;
+  __syncthreads();                               // the only workgroup barrier
+
+  double* term = s_term[w];
+  double* scr = &s_scr[w][lane * SD];
+  double* accs = s_dyn + (size_t)w * nch * CW * NC;
+  const int slot0 = (blockIdx.x * NW + w) * CW;
+  if (slot0 >= pv.B) return;
+
+  const int c = lane / T, ti = lane % T;
+  const bool cell_ok = slot0 + c < pv.B;
+  const int32_t cell = cell_ok ? sched[slot0 + c] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+  int64_t max_np = np;
+#pragma unroll
+  for (int d = T; d < 64; d <<= 1) max_np = max(max_np, __shfl_xor(max_np, d));
+  const int a_c = lane / NC, a_kk = lane % NC;
+  const bool a_ok = lane < CW * NC && slot0 + a_c < pv.B;
+  const int64_t a_np = __shfl(np, (a_ok ? a_c : 0) * T);
+  const int32_t a_cell = __shfl(cell, (a_ok ? a_c : 0) * T);
+
+  struct Raw { uint32_t n; int32_t snp; };
+  struct Hdr { uint32_t n; int32_t snp; uint32_t rd4; int64_t off; };
+  auto issue = [&](int64_t tile) {
+    Raw r;
+    const int64_t pi = tile * T + ti;
+    const bool v = pi < np;
+    r.n = v ? load_nrd(pv.pair_nrd, p_beg + pi, nrd_width) : 0u;
+    r.snp = v ? (pv.pair_snp ? pv.pair_snp[p_beg + pi] : (int32_t)pi) : 0;
+    return r;
+  };
+  auto prepare = [&](const Raw& r) {
+    Hdr h;
+    h.n = r.n; h.snp = r.snp;
+    const uint32_t incl = seg_scan_incl<T>(r.n);
+    h.off = rd_base + (int64_t)(incl - r.n);
+    rd_base += seg_last<T>(incl, lane);
+    h.rd4 = 0;
+    if (r.n > 0) {
+      if (h.off + 4 <= pv.R) __builtin_memcpy(&h.rd4, pv.reads + h.off, 4);
+      else for (int64_t i = h.off; i < pv.R; ++i) h.rd4 |= (uint32_t)pv.reads[i] << (8 * (int)(i - h.off));
+    }
+    return h;
+  };
+
+  Hdr nxt = prepare(issue(0));
+  Raw pre = issue(1);
+  for (int64_t tile = 0; tile * T < max_np; ++tile) {
+    const Hdr cur = nxt;
+    nxt = prepare(pre);
+    pre = issue(tile + 2);
+    const bool valid = tile * T + ti < np;
+
+    // class rows, llk0 row and the first id word of this lane's SNP (SNP-major: contiguous across a dense tile)
+    const float4* rp = reinterpret_cast<const float4*>(rows + (size_t)cur.snp * 12);
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+    const double* g0 = gp0 + (size_t)cur.snp * 3;
+    const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
+    const uint32_t* idrow = idw + (size_t)cur.snp * nwd;
+    uint32_t wcur = idrow[0];
+
+    double G0, G1, G2;                                                       // :427-452, as in k_singlet
+    {
+      const uint32_t n = cur.n;
+      const uint32_t b0 = cur.rd4 & 0xFFu;
+      const double* f = g_final + 3 * (n ? b0 : 256u);
+      G0 = f[0]; G1 = f[1]; G2 = f[2];
+      if (n >= 2) {
+        const double* f1 = g_first + 3 * b0;
+        double g0_ = f1[0], g1_ = f1[1], g2_ = f1[2];
+        const bool safe = n <= kSafeReads;
+        for (uint32_t r = 1; r < n; ++r) {
+          const uint32_t byte = (r < 4) ? ((cur.rd4 >> (8 * r)) & 0xFFu) : (uint32_t)pv.reads[cur.off + r];
+          const uint32_t bq = byte & 127u;
+          const bool alt = (byte >> 7) != 0;
+          const double m = s_tab[bq], e3 = s_tab[128 + bq], h = s_tab[256 + bq];
+          g0_ *= alt ? e3 : m;
+          g1_ *= h;
+          g2_ *= alt ? m : e3;
+          const double tmp = g0_ + g1_ + g2_;
+          if (safe) {
+            const double y = rcp_refined(tmp);
+            g0_ = div_by(g0_, tmp, y); g1_ = div_by(g1_, tmp, y); g2_ = div_by(g2_, tmp, y);
+          } else {
+            g0_ /= tmp; g1_ /= tmp; g2_ /= tmp;
+          }
+        }
+        g0_ += 1e-6; g1_ += 1e-6; g2_ += 1e-6;
+        const double tmp = g0_ + g1_ + g2_;
+        const double y = rcp_refined(tmp);
+        G0 = div_by(g0_, tmp, y); G1 = div_by(g1_, tmp, y); G2 = div_by(g2_, tmp, y);
+      }
+    }
+    if (valid) {
+      const double x0 = G0 * (double)r0.x + G1 * (double)r0.y + G2 * (double)r0.z;     // class 0   (:456)
+      const double x1 = G0 * (double)r0.w + G1 * (double)r1.x + G2 * (double)r1.y;     // class 1
+      const double x2 = G0 * (double)r1.z + G1 * (double)r1.w + G2 * (double)r2.x;     // class 2
+      const double x3 = G0 * (double)r2.y + G1 * (double)r2.z + G2 * (double)r2.w;     // class 3
+      const double x4 = G0 * q0 + G1 * q1 + G2 * q2;                                    // llk0      (:459)
+      const bool fast_ok = __builtin_amdgcn_class(x0, 0x100) && __builtin_amdgcn_class(x1, 0x100) && __builtin_amdgcn_class(x2, 0x100) &&
+                           __builtin_amdgcn_class(x3, 0x100) && __builtin_amdgcn_class(x4, 0x100);
+      if (__builtin_expect(fast_ok, 1)) {
+        scr[0] = dmx_log_fast(x0, s_log); scr[1] = dmx_log_fast(x1, s_log); scr[2] = dmx_log_fast(x2, s_log);
+        scr[3] = dmx_log_fast(x3, s_log); scr[4] = dmx_log_fast(x4, s_log);
+      } else {                                     // never for real likelihoods; keeps log(0) / log(nan) semantics
+        scr[0] = x0; scr[1] = x1; scr[2] = x2; scr[3] = x3; scr[4] = x4;
+        for (int d = 0; d < SD; ++d) scr[d] = log(scr[d]);
+      }
+    }
+    for (int q = 0; q < nch; ++q) {
+      const int k0 = q * KC;
+      if (q > 0 && (k0 & 15) == 0) wcur = idrow[k0 >> 4];
+      if (valid) {
+        const uint32_t bits = wcur >> (2 * (k0 & 15));      // the chunk's KC class ids, 2 bits each
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk)
+          term[(c * NC + kk) * TS + ti] = scr[(bits >> (2 * kk)) & 3u];     // sample k0+kk's term (slots past V-1 are never summed)
+        if (q == 0) term[(c * NC + KC) * TS + ti] = scr[4];
+      }
+      DMX_WAVE_LDS_ORDER();
+      if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
+        const int64_t left = a_np - tile * T;
+        const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
+        const double* row = &term[lane * TS];
+        double s = accs[q * (CW * NC) + lane];
+        int i = 0;
+        for (; i + 16 <= cnt; i += 16) {
+          double2 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const double2*>(&row[i + 2 * j]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s += v[j].x; s += v[j].y; }
+        }
+        for (; i < cnt; ++i) s += row[i];           // ascending SNP order: the reference's order
+        accs[q * (CW * NC) + lane] = s;
+      }
+      DMX_WAVE_LDS_ORDER();
+    }
+  }
+  if (a_ok) {
+    for (int q = 0; q < nch; ++q) {
+      const double s = accs[q * (CW * NC) + lane];
+      if (a_kk < KC) { const int k = q * KC + a_kk; if (k < V) llks[(size_t)a_cell * V + k] = s; }
+      else if (q == 0) llk0s[a_cell] = s;
+    }
+  }
+}
+
+// K1 over genotype classes, wide-panel form (V >= 20, measured crossover): all V+1 accumulators of a cell are summed in one pass per tile.
 // Same walk and ownership as k_singlet; per pair the lane evaluates log(GL . row_d) once per class d plus the llk0 term,
 // and stores those five terms and the SNP's packed class ids; chain lane (cell, k) then adds term[id[snp][k]] for the
 // tile's pairs in ascending order — the very doubles k_singlet would have formed for sample k, in the same order.
 template <int CW>
-__global__ __launch_bounds__(kThreads, 4) void k_singlet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
+__global__ __launch_bounds__(kThreads, 4) void k_singlet_clsw(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                              const uint32_t* __restrict__ idw, const double* __restrict__ gp0,
                                                              const double* __restrict__ tabs,
                                                              const int32_t* __restrict__ sched, int32_t V,
@@ -1644,17 +1824,24 @@ int launch_singlet(dmx_engine* e) {
   int CW = (B >= 64 * 1024) ? 4 : (B >= 24 * 1024 ? 2 : 1);
   const int KC = (V <= 4) ? 4 : 8;
   if (const char* cenv = getenv("DMX_K1_CW")) CW = atoi(cenv);     // kernel experiments only
-  if (e->n_classes > 0 && V >= 12 && !getenv("DMX_NO_CLASSES")) {
-    // --field GT inputs: log() once per genotype class instead of once per sample (bit-identical, see k_singlet_cls).
-    // Measured on MI355X: pays from ~12 samples up (V=64: 2.6x); at V=8 the per-sample lookups cost what the logs save.
-    int cw = 1;
-    while (cw > 1 && cw * (V + 1) > 4 * 64) cw >>= 1;
-    if (cw * (V + 1) <= 4 * 64) {
-      const size_t dynb = (size_t)(kThreads / 64) * 64 * ((V + 15) / 16) * sizeof(uint32_t);
-      const dim3 blk(kThreads), grd((unsigned)((B + (kThreads / 64) * cw - 1) / ((kThreads / 64) * cw)));
-#define DMX_K1C(CC) hipLaunchKernelGGL((k_singlet_cls<CC>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, \
-                                       e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
-      if (cw == 4) DMX_K1C(4); else if (cw == 2) DMX_K1C(2); else DMX_K1C(1);
+  if (e->n_classes > 0 && !getenv("DMX_NO_CLASSES") && !getenv("DMX_NO_K1_CLASSES")) {
+    // --field GT inputs: log() once per genotype class instead of once per sample (bit-identical, see k_singlet_cls)
+    const int wide_v = getenv("DMX_K1_WIDE_V") ? atoi(getenv("DMX_K1_WIDE_V")) : 20;      // kernel experiments only
+    if (V >= wide_v && V + 1 <= 4 * 64) {        // wide panels: chains look the class terms up themselves, one pass per tile
+      const size_t dynw = (size_t)(kThreads / 64) * 64 * ((V + 15) / 16) * sizeof(uint32_t);
+      const dim3 blkw(kThreads), grdw((unsigned)((B + (kThreads / 64) - 1) / (kThreads / 64)));
+      hipLaunchKernelGGL((k_singlet_clsw<1>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,
+                         e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s);
+      return DMX_OK;
+    }
+    const int nchc = (V + KC - 1) / KC;
+    const size_t dynb = sizeof(double) * (size_t)(kThreads / 64) * nchc * CW * (KC + 1);
+    if (dynb <= 16 * 1024) {
+      const dim3 blk(kThreads), grd((unsigned)((B + (kThreads / 64) * CW - 1) / ((kThreads / 64) * CW)));
+#define DMX_K1C(CC, KK) hipLaunchKernelGGL((k_singlet_cls<CC, KK>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, \
+                                           e->d_idw, e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
+      if (KC == 4) { if (CW == 4) DMX_K1C(4, 4); else if (CW == 2) DMX_K1C(2, 4); else DMX_K1C(1, 4); }
+      else         { if (CW == 4) DMX_K1C(4, 8); else if (CW == 2) DMX_K1C(2, 8); else DMX_K1C(1, 8); }
 #undef DMX_K1C
       return DMX_OK;
     }
