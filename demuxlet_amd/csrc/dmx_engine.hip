@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
 // scratch[class id of (snp, k)] into the chain buffer — the very double k_singlet would have computed for sample k
 // (same operands, same operations), so the sums that follow are bit-identical.  4+1 logs per pair instead of V+1.
 template <int CW, int KC>
-__global__ __launch_bounds__(kThreads, 4) void k_singlet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
+__global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                              const uint32_t* __restrict__ idw, const double* __restrict__ gp0,
                                                              const double* __restrict__ tabs,
                                                              const int32_t* __restrict__ sched, int32_t V,
@@ -392,20 +392,24 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet_cls(PileupView pv, int 
   constexpr int TS = T + 2;
   constexpr int NC = KC + 1;
   constexpr int NW = kThreads / 64;
-  constexpr int SD = 5;                          // scratch doubles per lane: 4 class terms + llk0 term
+  constexpr int SD = 4;                          // scratch doubles per lane: the 4 class terms (the llk0 term goes straight to its chain)
   static_assert(CW * NC <= 64, "one lane per chain");
   extern __shared__ double s_dyn[];              // [NW][nch][CW*NC] running accumulators
-  __shared__ double s_tab[kTab];                 // read LUT + log table; the first-read tables stay in global memory (L1-hot)
+  // LDS budget: 5 workgroups per CU (<= 32 KB each) so that 10 k wavefronts make two full rounds of 5 120 instead of
+  // three of 4 096.  Only dmx_log's table is staged; the read LUT and the first-read tables are read from global memory
+  // (L1-hot, 3 + 12 KB) — they are touched once per pair at most.
+  __shared__ double s_log_tab[DMX_LOG_TABLE_DOUBLES];
   __shared__ __attribute__((aligned(16))) double s_term[NW][CW * NC * TS];
   __shared__ double s_scr[NW][64 * SD];
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_log_tab;
+  const double* s_tab = tabs;                    // read LUT in global memory
   const double* g_first = tabs + kTab;
   const double* g_final = g_first + kFirst;
 
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int nch = (V + KC - 1) / KC;
   const int nwd = (V + 15) / 16;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  for (int i = t; i < DMX_LOG_TABLE_DOUBLES; i += kThreads) s_log_tab[i] = tabs[kLut + i];
   for (int i = t; i < NW * nch * CW * NC; i += kThreads) s_dyn[i] = 0.0;
   __syncthreads();                               // the only workgroup barrier
 
@@ -509,12 +513,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet_cls(PileupView pv, int 
       const double x4 = G0 * q0 + G1 * q1 + G2 * q2;                                    // llk0      (:459)
       const bool fast_ok = __builtin_amdgcn_class(x0, 0x100) && __builtin_amdgcn_class(x1, 0x100) && __builtin_amdgcn_class(x2, 0x100) &&
                            __builtin_amdgcn_class(x3, 0x100) && __builtin_amdgcn_class(x4, 0x100);
+      double* t0 = &term[(c * NC + KC) * TS + ti];   // the llk0 chain's slot of this pair
       if (__builtin_expect(fast_ok, 1)) {
         scr[0] = dmx_log_fast(x0, s_log); scr[1] = dmx_log_fast(x1, s_log); scr[2] = dmx_log_fast(x2, s_log);
-        scr[3] = dmx_log_fast(x3, s_log); scr[4] = dmx_log_fast(x4, s_log);
+        scr[3] = dmx_log_fast(x3, s_log); *t0 = dmx_log_fast(x4, s_log);
       } else {                                     // never for real likelihoods; keeps log(0) / log(nan) semantics
-        scr[0] = x0; scr[1] = x1; scr[2] = x2; scr[3] = x3; scr[4] = x4;
+        scr[0] = x0; scr[1] = x1; scr[2] = x2; scr[3] = x3; *t0 = x4;
         for (int d = 0; d < SD; ++d) scr[d] = log(scr[d]);
+        *t0 = log(*t0);
       }
     }
     for (int q = 0; q < nch; ++q) {
@@ -525,7 +531,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet_cls(PileupView pv, int 
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk)
           term[(c * NC + kk) * TS + ti] = scr[(bits >> (2 * kk)) & 3u];     // sample k0+kk's term (slots past V-1 are never summed)
-        if (q == 0) term[(c * NC + KC) * TS + ti] = scr[4];
       }
       DMX_WAVE_LDS_ORDER();
       if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
