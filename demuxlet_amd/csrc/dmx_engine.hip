@@ -1839,6 +1839,9 @@ int launch_singlet(dmx_engine* e) {
                          e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s);
       return DMX_OK;
     }
+    // measured on cfg2-shaped inputs (profiles/): CW 2 wins from 10 k barcodes (6.90 vs 7.14 ms; 5 k: 5.07 vs 3.94), CW 4 still
+    // loses at 40 k (27.7 vs 24.6 ms)
+    if (!getenv("DMX_K1_CW")) CW = (B >= 128 * 1024) ? 4 : (B >= 10000 ? 2 : 1);
     const int nchc = (V + KC - 1) / KC;
     const size_t dynb = sizeof(double) * (size_t)(kThreads / 64) * nchc * CW * (KC + 1);
     if (dynb <= 16 * 1024) {

@@ -1,0 +1,194 @@
+"""GPU (-m gpu): BASELINE.json's configurations at their FULL sizes (the workloads bench.py times), checked two ways:
+
+* a sample of barcodes (first / spread / last of the launch) is copied back and pushed through the oracle at the full SNP depth
+  -> every log-likelihood within 1e-9 absolute, the per-cell K3 indices equal to the reference's scans on the device grid;
+* size-independent properties on ALL barcodes: the genotype-class kernels equal the general kernels bit-for-bit, a re-run is
+  bit-identical (no atomics, no order dependence on scheduling), and the sampled barcodes computed ALONE (another launch
+  geometry: other wavefronts, other cells-per-wavefront) give the same bits as inside the full launch.
+
+Nothing here reads /root/reference; the oracle is the checker only."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from demuxlet_amd import build, capi, engine, synth, synth_torch
+    build.build()
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    capi.load()
+    import bench
+    from oracle import oracle_py as O
+    O.build()
+    return dict(torch=torch, engine=engine, synth=synth, st=synth_torch, bench=bench, O=O)
+
+
+def sample_cells(B, n, seed):
+    rng = np.random.default_rng(seed)
+    k = max(1, n // 3)
+    mid = rng.choice(np.arange(k, B - k), size=n - 2 * k, replace=False)
+    return np.unique(np.concatenate([np.arange(k), mid, np.arange(B - k, B)])).astype(np.int64)
+
+
+def slice_device_pileup(m, dp, cells):
+    """The chosen cells of a DevicePileup as (a) host arrays for the oracle, (b) a new DevicePileup with only those cells."""
+    torch = m["torch"]
+    po = dp.cell_pair_off.cpu().numpy()
+    ro = dp.cell_read_off.cpu().numpy()
+    pidx = torch.cat([torch.arange(po[c], po[c + 1], device=dp.pair_nrd.device) for c in cells])
+    ridx = torch.cat([torch.arange(ro[c], ro[c + 1], device=dp.reads.device) for c in cells])
+    npair = po[cells + 1] - po[cells]
+    nread = ro[cells + 1] - ro[cells]
+    z = np.zeros(1, dtype=np.int64)
+    sub = m["st"].DevicePileup(len(cells), dp.n_snps,
+                               torch.from_numpy(np.concatenate([z, np.cumsum(npair)])).to(dp.reads.device),
+                               torch.from_numpy(np.concatenate([z, np.cumsum(nread)])).to(dp.reads.device),
+                               None if dp.pair_snp is None else dp.pair_snp[pidx].contiguous(),
+                               dp.pair_nrd[pidx].contiguous(), dp.reads[ridx].contiguous(), dp.truth[torch.from_numpy(cells).to(dp.truth.device)])
+    return sub
+
+
+def oracle_on(m, sub, g, cfg):
+    O = m["O"]
+    n = sub.n_cells
+    reads = sub.reads.cpu().numpy()
+    words = ((reads >> 7).astype(np.uint32) << 24) | ((reads & 0x7F).astype(np.uint32) << 16) | 1
+    pair_snp = (sub.pair_snp.cpu().numpy() if sub.pair_snp is not None
+                else np.tile(np.arange(sub.n_snps, dtype=np.int32), n))
+    nrd = sub.pair_nrd.cpu().numpy().astype(np.int64)
+    csr = O.Csr([f"c{i:07d}" for i in range(n)], sub.cell_pair_off.cpu().numpy(), pair_snp,
+                np.concatenate([[0], np.cumsum(nrd)]), words, np.zeros(n, np.int32), np.zeros(n, np.int32),
+                np.zeros(n, np.int32))
+    return O.run_csr(csr, [f"s{j}" for j in range(g.shape[1])], g, O.Params(tuple(cfg["alphas"]), 0.5), None,
+                     singlet_only=not cfg["doublet"], want_grid=cfg["doublet"])
+
+
+def device_results(m, eng, B, V, A, doublet, rows=None):
+    torch, st = m["torch"], m["st"]
+    dev = torch.device("cuda", 0)
+    v = eng.device_view()
+    pick = (lambda t: t) if rows is None else (lambda t: t[torch.from_numpy(rows).to(dev)])
+    out = dict(llks=pick(st.tensor_from_ptr(v.llks, (B, V), torch.float64, dev)).cpu().numpy(),
+               llk0s=pick(st.tensor_from_ptr(v.llk0s, (B,), torch.float64, dev)).cpu().numpy())
+    if doublet:
+        out["grid"] = pick(st.tensor_from_ptr(v.llksAB, (B, V, V, A), torch.float64, dev)).cpu().numpy()
+        out["l00"] = pick(st.tensor_from_ptr(v.llks00, (B, A), torch.float64, dev)).cpu().numpy()
+        words = m["engine"].capi.SUMMARY_DTYPE.itemsize // 8
+        sm = pick(st.tensor_from_ptr(v.summary, (B, words), torch.float64, dev)).cpu().numpy()
+        out["summ"] = np.ascontiguousarray(sm).view(m["engine"].capi.SUMMARY_DTYPE).reshape(-1)
+    return out
+
+
+def run_full(m, cfg_id, n_sample, check_general, barcodes=0):
+    torch, engine, bench = m["torch"], m["engine"], m["bench"]
+    cfg = dict(bench.CONFIGS[cfg_id])
+    if barcodes:
+        cfg["B"] = barcodes
+    B, S, V, A = cfg["B"], cfg["S"], cfg["V"], len(cfg["alphas"])
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0xD3A00000 + cfg_id)          # bench.py's panel and pileup for this config
+    raw, g = bench.genotype_matrix(engine, m["synth"], rng, S, V, cfg["field"])
+    dosage = torch.from_numpy(np.clip(raw.alleles, 0, 1).sum(axis=2).astype(np.float32)).to(dev)
+    dp = m["st"].make_device_pileup(dosage, B, cfg["delta"], cfg["rbar"], seed=0xD3A0 + 1000 * cfg_id, device=dev)
+    torch.cuda.synchronize()
+
+    def run(pileup, env=None):
+        old = {}
+        for k, val in (env or {}).items():
+            old[k] = os.environ.get(k)
+            os.environ[k] = val
+        try:
+            e = engine.Engine(V, cfg["alphas"], 0.5, device=0)
+            e.set_genotypes(g)
+            e.set_pileup_struct(pileup.as_struct(), keep=pileup)
+            e.run_singlet()
+            if cfg["doublet"]:
+                e.run_doublet()
+            e.sync()
+            return e
+        finally:
+            for k, val in old.items():
+                if val is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = val
+
+    cells = sample_cells(B, n_sample, 1234 + cfg_id)
+    e = run(dp)
+    full = device_results(m, e, B, V, A, cfg["doublet"])
+    # (1) the sampled barcodes against the oracle at full depth
+    sub = slice_device_pileup(m, dp, cells)
+    want = oracle_on(m, sub, g, cfg)
+    d1 = np.abs(full["llks"][cells] - want.llks).max()
+    d0 = np.abs(full["llk0s"][cells] - want.llk0s).max()
+    assert d1 <= TOL and d0 <= TOL, (d1, d0)
+    worst = max(d1, d0)
+    if cfg["doublet"]:
+        dg = np.abs(full["grid"][cells] - want.llksAB).max()
+        dl = np.abs(full["l00"][cells] - want.llks00).max()
+        assert dg <= TOL and dl <= TOL, (dg, dl)
+        worst = max(worst, dg, dl)
+        # K3's indices are the reference's scans (strict <, first maximum) of the device grid
+        from golden_util import summary_from_grid
+        for c in cells:
+            sm = full["summ"][c]
+            ref = summary_from_grid(full["grid"][c], full["l00"][c], cfg["alphas"], 0.5, int(sm["n_pairs"]),
+                                    m["engine"].capi.SUMMARY_DTYPE)
+            assert sm["max_llk"] == ref["max_llk"]
+            for f in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best"):
+                assert sm[f] == ref[f], (c, f)
+    # (2) a second run is bit-identical
+    e2 = run(dp)
+    again = device_results(m, e2, B, V, A, cfg["doublet"])
+    for k in ("llks", "llk0s") + (("grid", "l00") if cfg["doublet"] else ()):
+        assert np.array_equal(full[k], again[k]), k
+    e2.close()
+    # (3) the sampled barcodes alone: another launch geometry, same bits
+    e3 = run(sub)
+    alone = device_results(m, e3, len(cells), V, A, cfg["doublet"])
+    for k in ("llks", "llk0s") + (("grid", "l00") if cfg["doublet"] else ()):
+        assert np.array_equal(alone[k], full[k][cells]), k
+    e3.close()
+    # (4) genotype-class kernels == general kernels on every barcode (GT inputs only)
+    if check_general:
+        e4 = run(dp, env={"DMX_NO_CLASSES": "1"})
+        gen = device_results(m, e4, B, V, A, cfg["doublet"])
+        for k in ("llks", "llk0s") + (("grid", "l00") if cfg["doublet"] else ()):
+            assert np.array_equal(full[k], gen[k]), k
+        e4.close()
+    e.close()
+    assert np.abs(want.llks).min() > 0 and np.isfinite(full["llks"]).all()
+    print(f"cfg{cfg_id}: {len(cells)} of {B} barcodes at S={S} through the oracle, max |delta| = {worst:.3e} "
+          f"(|llk| up to {np.abs(want.llks).max():.4e})")
+    return worst
+
+
+def test_cfg2_full_size(mods):
+    """10k barcodes x 50k SNPs x 8 samples, GT, singlet-only: 48 barcodes through the oracle + properties on all 10k."""
+    run_full(mods, 2, 48, check_general=True)
+
+
+def test_cfg3_full_size(mods):
+    """10k x 50k x 32, GP, alpha {0, 0.5}: 4 barcodes x 1.0e8 pair-evaluations through the oracle + properties on all."""
+    run_full(mods, 3, 4, check_general=False)
+
+
+def test_cfg5_full_size(mods):
+    """20k x 200k x 16, PL, sparse: 12 barcodes through the oracle + properties on all."""
+    run_full(mods, 5, 12, check_general=False)
+
+
+def test_cfg4_full_depth_and_panel(mods):
+    """cfg4's SNP depth and panel (100k SNPs x 64 samples, GT) on 1 000 of its barcodes (its 12.5k-barcode shard repeats this
+    work 12.5x; the oracle needs 15 s per barcode here): 2 barcodes x 8.2e8 pair-evaluations through the oracle, class kernels
+    == general kernels on all 1 000."""
+    run_full(mods, 4, 2, check_general=True, barcodes=1000)
