@@ -33,15 +33,15 @@ class DevicePileup:
                            self.cell_read_off.data_ptr(), self.pair_snp.data_ptr() if self.pair_snp is not None else None,
                            self.pair_nrd.data_ptr(), 1, capi.DMX_MEM_DEVICE, self.reads.data_ptr(), None, None, None)
 
-    def host_slice(self, n_cells: int):
-        """First n_cells cells as numpy arrays (for the bounded CPU baseline)."""
-        p1 = int(self.cell_pair_off[n_cells].item())
-        r1 = int(self.cell_read_off[n_cells].item())
-        return dict(n_cells=n_cells, n_snps=self.n_snps,
-                    cell_pair_off=self.cell_pair_off[:n_cells + 1].cpu().numpy(),
-                    cell_read_off=self.cell_read_off[:n_cells + 1].cpu().numpy(),
-                    pair_snp=None if self.pair_snp is None else self.pair_snp[:p1].cpu().numpy(),
-                    pair_nrd=self.pair_nrd[:p1].cpu().numpy(), reads=self.reads[:r1].cpu().numpy())
+    def host_slice(self, first: int, n_cells: int):
+        """Cells [first, first + n_cells) as numpy arrays, offsets rebased to 0 (for the bounded CPU baseline)."""
+        po = self.cell_pair_off[first:first + n_cells + 1]
+        ro = self.cell_read_off[first:first + n_cells + 1]
+        p0, p1, r0, r1 = int(po[0].item()), int(po[-1].item()), int(ro[0].item()), int(ro[-1].item())
+        return dict(n_cells=n_cells, n_snps=self.n_snps, cell_pair_off=(po - p0).cpu().numpy(),
+                    cell_read_off=(ro - r0).cpu().numpy(),
+                    pair_snp=None if self.pair_snp is None else self.pair_snp[p0:p1].cpu().numpy(),
+                    pair_nrd=self.pair_nrd[p0:p1].cpu().numpy(), reads=self.reads[r0:r1].cpu().numpy())
 
 
 def make_device_pileup(dosage: torch.Tensor, B: int, delta: float, rbar: float, seed: int, device: torch.device,

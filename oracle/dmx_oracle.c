@@ -261,7 +261,7 @@ const int32_t*  orc_store_totl(const orc_store* s) { return s->totl; }
 const int32_t*  orc_store_pass(const orc_store* s) { return s->pass; }
 const int32_t*  orc_store_uniq(const orc_store* s) { return s->uniq; }
 const char*     orc_store_barcode(const orc_store* s, int32_t c) { return s->bc[c]; }
-static char** g_sort_bc;
+static __thread char** g_sort_bc;            /* thread-local: orc_* calls may run concurrently (bench.py's all-cores leg) */
 static int order_cmp(const void* a, const void* b) { return strcmp(g_sort_bc[*(const int32_t*)a], g_sort_bc[*(const int32_t*)b]); }
 void orc_store_sorted_order(const orc_store* s, int32_t* order) {
   for (int32_t i = 0; i < s->nbc; ++i) order[i] = i;
@@ -270,7 +270,7 @@ void orc_store_sorted_order(const orc_store* s, int32_t* order) {
 
 /* ------------------------------------------------------------------------------------------------------------ */
 /* a4..a14  the engine */
-static const char* const* g_sort_names;
+static __thread const char* const* g_sort_names;
 static int name_cmp(const void* a, const void* b) { return strcmp(g_sort_names[*(const int32_t*)a], g_sort_names[*(const int32_t*)b]); }
 
 double orc_wall_seconds(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }

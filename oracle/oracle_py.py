@@ -190,42 +190,58 @@ def _cstr_array(strs: Sequence[str]):
     return arr, keep
 
 
+class CsrPlan:
+    """Everything orc_run needs, marshalled once; execute() is then the bare C call (ctypes drops the GIL around it, so
+    several plans can run on several host threads at the same time)."""
+
+    def __init__(self, csr: Csr, sample_ids: Sequence[str], g: np.ndarray, params: Params, out_prefix: Optional[str] = None,
+                 singlet_only: bool = False, want_grid: bool = True):
+        self.L = lib()
+        g = np.ascontiguousarray(g, dtype=np.float32)
+        S, V, _ = g.shape
+        B = csr.n_cells
+        alphas = np.ascontiguousarray(params.alphas, dtype=np.float64)
+        A = len(alphas)
+        sm, _k1 = _cstr_array(sample_ids)
+        bc, _k2 = _cstr_array(csr.barcodes)
+        cell_off = np.ascontiguousarray(csr.cell_off, dtype=np.int64)
+        pair_snp = np.ascontiguousarray(csr.pair_snp, dtype=np.int32)
+        pair_off = np.ascontiguousarray(csr.pair_off, dtype=np.int64)
+        words = np.ascontiguousarray(csr.words, dtype=np.uint32)
+        totl = np.ascontiguousarray(csr.rd_totl, dtype=np.int32)
+        pas = np.ascontiguousarray(csr.rd_pass, dtype=np.int32)
+        uniq = np.ascontiguousarray(csr.rd_uniq, dtype=np.int32)
+        if len(pair_snp) and (pair_snp.min() < 0 or pair_snp.max() >= S):
+            raise ValueError("pair_snp out of range")
+        self.P = _Problem(B, S, V, A, alphas.ctypes.data, params.doublet_prior, params.min_total, params.min_uniq,
+                          params.min_snp, int(params.write_pair), cell_off.ctypes.data,
+                          pair_snp.ctypes.data if len(pair_snp) else None, pair_off.ctypes.data,
+                          words.ctypes.data if len(words) else None, totl.ctypes.data if B else None,
+                          pas.ctypes.data if B else None, uniq.ctypes.data if B else None, g.ctypes.data,
+                          C.cast(sm, C.c_void_p), C.cast(bc, C.c_void_p), int(singlet_only))
+        llks = np.zeros((B, V), dtype=np.float64)
+        llk0s = np.zeros(B, dtype=np.float64)
+        grid = np.zeros((B, V, V, A), dtype=np.float64) if (want_grid and not singlet_only) else None
+        l00 = np.zeros((B, A), dtype=np.float64) if not singlet_only else None
+        proc = np.zeros(B, dtype=np.uint8) if not singlet_only else None
+        self.R = _Raw(llks.ctypes.data, llk0s.ctypes.data, grid.ctypes.data if grid is not None else None,
+                      l00.ctypes.data if l00 is not None else None, proc.ctypes.data if proc is not None else None)
+        self.out = RawOut(llks, llk0s, grid, l00, proc)
+        self.prefix = out_prefix.encode() if out_prefix else None
+        self.n_pairs = int(cell_off[-1]) if B else 0
+        self._keep = (g, alphas, sm, _k1, bc, _k2, cell_off, pair_snp, pair_off, words, totl, pas, uniq)
+
+    def execute(self) -> RawOut:
+        rc = self.L.orc_run(C.byref(self.P), C.byref(self.R), self.prefix)
+        if rc != 0:
+            raise RuntimeError(f"orc_run failed rc={rc}")
+        return self.out
+
+
 def run_csr(csr: Csr, sample_ids: Sequence[str], g: np.ndarray, params: Params, out_prefix: Optional[str] = None,
             singlet_only: bool = False, want_grid: bool = True) -> RawOut:
     """Rows a4..a14 through the oracle."""
-    L = lib()
-    g = np.ascontiguousarray(g, dtype=np.float32)
-    S, V, _ = g.shape
-    B = csr.n_cells
-    alphas = np.ascontiguousarray(params.alphas, dtype=np.float64)
-    A = len(alphas)
-    sm, _k1 = _cstr_array(sample_ids)
-    bc, _k2 = _cstr_array(csr.barcodes)
-    cell_off = np.ascontiguousarray(csr.cell_off, dtype=np.int64)
-    pair_snp = np.ascontiguousarray(csr.pair_snp, dtype=np.int32)
-    pair_off = np.ascontiguousarray(csr.pair_off, dtype=np.int64)
-    words = np.ascontiguousarray(csr.words, dtype=np.uint32)
-    totl = np.ascontiguousarray(csr.rd_totl, dtype=np.int32)
-    pas = np.ascontiguousarray(csr.rd_pass, dtype=np.int32)
-    uniq = np.ascontiguousarray(csr.rd_uniq, dtype=np.int32)
-    if len(pair_snp) and (pair_snp.min() < 0 or pair_snp.max() >= S):
-        raise ValueError("pair_snp out of range")
-    P = _Problem(B, S, V, A, alphas.ctypes.data, params.doublet_prior, params.min_total, params.min_uniq, params.min_snp,
-                 int(params.write_pair), cell_off.ctypes.data, pair_snp.ctypes.data if len(pair_snp) else None,
-                 pair_off.ctypes.data, words.ctypes.data if len(words) else None,
-                 totl.ctypes.data if B else None, pas.ctypes.data if B else None, uniq.ctypes.data if B else None,
-                 g.ctypes.data, C.cast(sm, C.c_void_p), C.cast(bc, C.c_void_p), int(singlet_only))
-    llks = np.zeros((B, V), dtype=np.float64)
-    llk0s = np.zeros(B, dtype=np.float64)
-    grid = np.zeros((B, V, V, A), dtype=np.float64) if (want_grid and not singlet_only) else None
-    l00 = np.zeros((B, A), dtype=np.float64) if not singlet_only else None
-    proc = np.zeros(B, dtype=np.uint8) if not singlet_only else None
-    R = _Raw(llks.ctypes.data, llk0s.ctypes.data, grid.ctypes.data if grid is not None else None,
-             l00.ctypes.data if l00 is not None else None, proc.ctypes.data if proc is not None else None)
-    rc = L.orc_run(C.byref(P), C.byref(R), out_prefix.encode() if out_prefix else None)
-    if rc != 0:
-        raise RuntimeError(f"orc_run failed rc={rc}")
-    return RawOut(llks, llk0s, grid, l00, proc)
+    return CsrPlan(csr, sample_ids, g, params, out_prefix, singlet_only, want_grid).execute()
 
 
 def run_problem(pb: Problem, out_prefix: Optional[str] = None, singlet_only: bool = False):

@@ -66,3 +66,22 @@ def test_phred_and_store_units(oracle):
     assert np.array_equal(arr(L.orc_store_pass(st), B, C.c_int32), cnt[:, 0])
     assert np.array_equal(arr(L.orc_store_uniq(st), B, C.c_int32), cnt[:, 1])
     L.orc_store_free(st)
+
+
+def test_oracle_runs_concurrently(oracle):
+    """bench.py's all-cores CPU leg calls orc_run from several threads at once: results must equal the serial ones."""
+    import threading
+    gd = Golden("gt_v64_a2")
+    pb = gd.problem(oracle)
+    csr = oracle.store_from_events(pb.events)
+    want = oracle.run_csr(csr, pb.sample_ids, pb.g, pb.params)
+    res = [None] * 6
+
+    def work(i):
+        res[i] = oracle.run_csr(csr, pb.sample_ids, pb.g, pb.params)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(res))]
+    for t in th: t.start()
+    for t in th: t.join()
+    for r in res:
+        assert np.array_equal(r.llks, want.llks) and np.array_equal(r.llksAB, want.llksAB) and np.array_equal(r.llks00, want.llks00)
