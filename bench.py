@@ -34,6 +34,9 @@ CONFIGS = {
             name="cfg4 (per-GPU shard): 12.5k of 100k barcodes x 100k SNPs x 64 samples, GT field, doublet grid, dense"),
     5: dict(B=20_000, S=200_000, V=16, field="PL", alphas=(0.0, 0.5), delta=0.05, rbar=2.0, doublet=True,
             name="cfg5: 20k barcodes x 200k SNPs x 16 samples, PL field, doublet grid, sparse (delta=0.05, rbar=2)"),
+    6: dict(B=20_000, S=100_000, V=16, field="GT", alphas=(0.0, 0.5), delta=0.02, rbar=1.25, doublet=True,
+            name="cfg6 (not in BASELINE.json; SURVEY 8d's realistic 10x shape): 20k barcodes x 100k SNPs x 16 samples, GT, doublet "
+                 "grid, sparse (delta=0.02 -> ~2000 covered SNPs per barcode, rbar=1.25)"),
 }
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector peak (spec; half the 157.3 TF FP32 vector rate), FMA = 2 flop
@@ -279,6 +282,18 @@ def main():
             "fp64_valu": {"logical_log_terms_per_s": logs / ((k1_ms + k2_ms) * 1e-3), "kernel_ms": {"k_singlet": k1_ms, "k_doublet+k_reduce": k2_ms},
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }
+        if world == 1:
+            # the device's log() ceiling from a register-resident microkernel, same run: what fraction of it the
+            # path's LOGICAL log terms amount to (the genotype-class kernels execute fewer logs than the reference's count,
+            # so this fraction can exceed 1 for GT inputs; it cannot for GP/PL inputs)
+            import ctypes
+            rates = []
+            for which in (0, 1):
+                r = ctypes.c_double(0.0)
+                engine.check(engine.capi.load().dmx_debug_log_rate(which, 4096, local, ctypes.byref(r)))
+                rates.append(r.value)
+            out["log_microkernel"] = {"dmx_log_per_s": rates[0], "ocml_log_per_s": rates[1],
+                                      "path_logical_logs_over_dmx_log_ceiling": out["fp64_valu"]["logical_log_terms_per_s"] / rates[0]}
         if cfg["doublet"]:
             out["pair_evals_per_s"] = total_pairs * V * V * A * args.steps / elapsed
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 leg only

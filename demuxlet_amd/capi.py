@@ -27,7 +27,7 @@ SYMBOLS = [
     "dmx_engine_set_genotypes", "dmx_engine_set_pileup", "dmx_engine_run_singlet", "dmx_engine_run_doublet",
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
-    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_engine_get_sing", "dmx_write_doublet_summary",
+    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_write_doublet_summary",
 ]
 
 
@@ -128,6 +128,7 @@ def load() -> C.CDLL:
         "dmx_debug_device_log": [vp, vp, C.c_int64, i32],
         "dmx_engine_get_sing": [vp, vp], "dmx_write_doublet_summary": [vp, vp, vp, C.c_char_p],
         "dmx_debug_device_div": [vp, vp, vp, C.c_int64, i32],
+        "dmx_debug_log_rate": [i32, i32, i32, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)

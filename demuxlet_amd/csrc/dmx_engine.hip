@@ -2082,6 +2082,60 @@ __global__ void k_debug_div(const double* __restrict__ a, const double* __restri
 }
 }  // namespace
 
+namespace {
+// log() ceiling of the device: every lane evaluates `iters` logs of register-resident arguments spread over (0.01, 1] (the
+// range likelihood terms live in), four independent streams per lane so the issue rate, not the latency, is measured.
+// WHICH = 0: dmx_log (what the kernels use), 1: ocml log().
+template <int WHICH>
+__global__ __launch_bounds__(256) void k_log_rate(int iters, const double* __restrict__ tab, double* __restrict__ sink) {
+  __shared__ double s_log[DMX_LOG_TABLE_DOUBLES];
+  dmx_log_stage(s_log, tab, threadIdx.x, blockDim.x);
+  __syncthreads();
+  const double x0 = 0.01 + 0.9 * ((threadIdx.x * 37 + blockIdx.x * 11) % 1024) / 1024.0;
+  double x[4] = {x0, x0 * 0.75, x0 * 0.5, x0 * 0.31}, acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const double dx = 1.0 / (1024.0 * 1024.0);
+  for (int i = 0; i < iters; i += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc[u] += WHICH == 0 ? dmx_log(x[u], s_log) : log(x[u]);
+      x[u] += dx;
+    }
+  }
+  sink[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+}  // namespace
+
+extern "C" int dmx_debug_log_rate(int32_t which, int32_t iters, int32_t device, double* logs_per_second) {
+  if ((which != 0 && which != 1) || iters < 4 || !logs_per_second) return set_error(DMX_ERR_ARG, "dmx_debug_log_rate: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return set_error(DMX_ERR_NOGPU, "dmx_debug_log_rate: no such HIP device");
+  HIP_TRY(hipSetDevice(device));
+  const int blocks = 256 * 8, threads = 256;                  // 8 workgroups (32 wavefronts) per CU
+  double *dt = nullptr, *ds = nullptr;
+  HIP_TRY(hipMalloc((void**)&dt, sizeof(double) * DMX_LOG_TABLE_DOUBLES));
+  HIP_TRY(hipMalloc((void**)&ds, sizeof(double) * (size_t)blocks * threads));
+  HIP_TRY(hipMemcpy(dt, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  iters &= ~3;
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; ++rep) {                          // first pass warms up; keep the fastest
+    HIP_TRY(hipEventRecord(e0, 0));
+    if (which == 0) hipLaunchKernelGGL((k_log_rate<0>), dim3(blocks), dim3(threads), 0, 0, iters, dt, ds);
+    else            hipLaunchKernelGGL((k_log_rate<1>), dim3(blocks), dim3(threads), 0, 0, iters, dt, ds);
+    HIP_TRY(hipEventRecord(e1, 0));
+    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipGetLastError());
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (rep > 0 && ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(dt); (void)hipFree(ds);
+  *logs_per_second = (double)blocks * threads * iters / (best * 1e-3);
+  return DMX_OK;
+}
+
 extern "C" int dmx_debug_device_div(const double* a, const double* b, double* q, int64_t n, int32_t device) {
   if (!a || !b || !q || n < 0) return set_error(DMX_ERR_ARG, "dmx_debug_device_div: bad arguments");
   int ndev = 0;
