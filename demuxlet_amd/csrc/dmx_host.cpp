@@ -5,9 +5,15 @@
 // anything under oracle/.
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <memory>
+#include <mutex>
 #include <numeric>
+#include <thread>
 #include <unordered_map>
 
 #include "dmx_internal.hpp"
@@ -440,6 +446,155 @@ struct File {
   bool open(const std::string& path) { f = fopen(path.c_str(), "w"); return f != nullptr; }
 };
 
+// ---- rows are formatted by several host threads and written in barcode order ----------------------------------------
+// The reference prints every row with hprintf (= vsnprintf of glibc, hts_utils.cpp:1013-1034); the same conversions are
+// used here (so the bytes are the same), into per-chunk buffers.  `--write-pair` at cfg4 is 2.1e8 rows / 10 GB of text
+// (SURVEY 8a-a12): at ~3 us per row one thread would need ten minutes for what the GPUs compute in seconds.
+void appendf(std::string& out, const char* fmt, ...) {
+  char buf[768];
+  va_list ap;
+  va_start(ap, fmt);
+  const int n = vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (n < 0) return;
+  if ((size_t)n < sizeof buf) { out.append(buf, (size_t)n); return; }
+  std::vector<char> big((size_t)n + 1);
+  va_start(ap, fmt);
+  vsnprintf(big.data(), big.size(), fmt, ap);
+  va_end(ap);
+  out.append(big.data(), (size_t)n);
+}
+
+// printf("%.<prec>lf") without printf: the decimal expansion of a binary64 is finite, so rounding m*2^e*10^prec to an
+// integer in exact 128-bit arithmetic (ties to even, the default rounding mode glibc's printf honours) gives the same
+// digits.  Anything outside the comfortable range goes to vsnprintf.  tests/test_host_units.py compares the two on
+// millions of values.
+void put_fixed(std::string& out, double v, int prec) {
+  static const uint64_t kPow10[7] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull};
+  uint64_t bits;
+  std::memcpy(&bits, &v, sizeof bits);
+  const uint64_t frac = bits & 0xFFFFFFFFFFFFFull;
+  const int ex = (int)((bits >> 52) & 0x7FF);
+  if (prec < 0 || prec > 6 || ex == 0x7FF || ex >= 1023 + 43) { appendf(out, "%.*lf", prec, v); return; }   // nan, inf, |v| >= 2^43
+  const uint64_t m = ex ? (frac | (1ull << 52)) : frac;
+  const int e = (ex ? ex : 1) - 1075;                                      // |v| = m * 2^e
+  unsigned __int128 N = (unsigned __int128)m * kPow10[prec];               // < 2^73
+  uint64_t q;
+  if (e >= 0) q = (uint64_t)(N << e);                                      // unreachable for |v| < 2^43 with m >= 2^52, kept for clarity
+  else {
+    const int sh = -e;
+    if (sh >= 127) q = 0;                                                  // N < 2^73 is far below half of 2^127
+    else {
+      const unsigned __int128 one = 1;
+      const unsigned __int128 rem = N & ((one << sh) - 1), half = one << (sh - 1);
+      q = (uint64_t)(N >> sh);
+      if (rem > half || (rem == half && (q & 1))) ++q;
+    }
+  }
+  char buf[40];
+  int n = 0;
+  const uint64_t ip = q / kPow10[prec];
+  uint64_t fp = q % kPow10[prec];
+  for (int i = 0; i < prec; ++i) { buf[n++] = (char)('0' + fp % 10); fp /= 10; }
+  if (prec > 0) buf[n++] = '.';
+  uint64_t t = ip;
+  do { buf[n++] = (char)('0' + t % 10); t /= 10; } while (t);
+  if (bits >> 63) buf[n++] = '-';
+  std::reverse(buf, buf + n);
+  out.append(buf, (size_t)n);
+}
+
+void put_int(std::string& out, int32_t v) {
+  char buf[16];
+  int n = 0;
+  uint32_t u = v < 0 ? 0u - (uint32_t)v : (uint32_t)v;
+  do { buf[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+  if (v < 0) buf[n++] = '-';
+  std::reverse(buf, buf + n);
+  out.append(buf, (size_t)n);
+}
+
+// printf("%.<prec>lg"): zero (every underflowed posterior) is "0"; the rest is left to vsnprintf.
+void put_general(std::string& out, double v, int prec) {
+  if (v == 0.0 && !std::signbit(v)) { out.push_back('0'); return; }
+  appendf(out, "%.*lg", prec, v);
+}
+
+// Host threads for the formatters: DMX_THREADS, else the smaller of the visible CPUs and the container's CPU quota.
+int host_threads() {
+  if (const char* e = getenv("DMX_THREADS")) { const int n = atoi(e); if (n >= 1) return std::min(n, 256); }
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  std::ifstream q("/sys/fs/cgroup/cpu.max");
+  std::string quota; long long period = 0;
+  if (q >> quota >> period && quota != "max" && period > 0) n = std::max(1, std::min(n, (int)(atoll(quota.c_str()) / period)));
+  return std::min(n, 64);
+}
+
+constexpr int kOutFiles = 3;
+struct Chunk { std::string out[kOutFiles]; };
+
+// fn(first, last, chunk) formats items [first, last) into chunk.out[i]; chunks reach files[i] in item order.
+template <class Fn>
+int format_in_order(size_t n_items, size_t per_chunk, FILE* const files[kOutFiles], Fn&& fn) {
+  per_chunk = std::max<size_t>(per_chunk, 1);
+  const size_t n_chunks = (n_items + per_chunk - 1) / per_chunk;
+  const int n_threads = (int)std::min<size_t>((size_t)host_threads(), n_chunks);
+  bool io_ok = true;
+  auto flush = [&](Chunk& ck) {
+    for (int i = 0; i < kOutFiles; ++i) {
+      if (files[i] && !ck.out[i].empty() && fwrite(ck.out[i].data(), 1, ck.out[i].size(), files[i]) != ck.out[i].size()) io_ok = false;
+      ck.out[i].clear();
+    }
+  };
+  if (n_threads <= 1) {
+    Chunk ck;
+    for (size_t k = 0; k < n_chunks; ++k) { fn(k * per_chunk, std::min(n_items, (k + 1) * per_chunk), ck); flush(ck); }
+    return io_ok ? DMX_OK : set_error(DMX_ERR_IO, "write failed");
+  }
+  const size_t W = (size_t)n_threads * 2;                 // chunks in flight (bounds the buffered text)
+  std::vector<Chunk> slots(W);
+  std::vector<char> ready(W, 0);
+  std::mutex mu;
+  std::condition_variable cv_ready, cv_free;
+  size_t next = 0, written = 0;
+  auto worker = [&]() {
+    for (;;) {
+      size_t k;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        k = next++;
+        if (k >= n_chunks) return;
+        cv_free.wait(lk, [&] { return k < written + W; });      // slot k % W was chunk k - W's: wait until that is on disk
+      }
+      fn(k * per_chunk, std::min(n_items, (k + 1) * per_chunk), slots[k % W]);
+      { std::lock_guard<std::mutex> lk(mu); ready[k % W] = 1; }
+      cv_ready.notify_all();
+    }
+  };
+  std::vector<std::thread> pool;
+  for (int t = 0; t < n_threads; ++t) pool.emplace_back(worker);
+  for (size_t k = 0; k < n_chunks; ++k) {
+    { std::unique_lock<std::mutex> lk(mu); cv_ready.wait(lk, [&] { return ready[k % W] != 0; }); }
+    flush(slots[k % W]);
+    { std::lock_guard<std::mutex> lk(mu); ready[k % W] = 0; ++written; }
+    cv_free.notify_all();
+  }
+  for (std::thread& t : pool) t.join();
+  return io_ok ? DMX_OK : set_error(DMX_ERR_IO, "write failed");
+}
+
+// cells that produce rows, in output order
+std::vector<int32_t> output_cells(const dmx_final_input* in, bool need_snps) {
+  std::vector<int32_t> out;
+  for (int32_t c : barcode_order(in)) {
+    if (cell_filtered(in, c)) continue;
+    if (need_snps && in->n_snp[c] == 0) continue;                          // :592 no covered SNP: no rows
+    out.push_back(c);
+  }
+  return out;
+}
+
 }  // namespace
 
 extern "C" int dmx_write_single(const dmx_final_input* in, const char* path) {
@@ -449,19 +604,30 @@ extern "C" int dmx_write_single(const dmx_final_input* in, const char* path) {
   if (!w.open(path)) return set_error(DMX_ERR_IO, "Cannot create %s file", path);
   const int32_t V = in->n_samples;
   fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", w.f);                 // :470
-  for (int32_t c : barcode_order(in)) {
-    if (cell_filtered(in, c)) continue;
-    const double* row = in->llks + (size_t)c * V;
-    double lse = -1e300;                          // running log-sum-exp exactly as :484-489
-    for (int32_t j = 0; j < V; ++j) {
-      const double cur = row[j];
-      lse = (lse > cur) ? lse + std::log(1.0 + std::exp(cur - lse)) : cur + std::log(1.0 + std::exp(lse - cur));
+  const std::vector<int32_t> cells = output_cells(in, false);
+  FILE* const files[kOutFiles] = {w.f, nullptr, nullptr};
+  return format_in_order(cells.size(), std::max<size_t>(1, 8192 / (size_t)V), files, [&](size_t first, size_t last, Chunk& ck) {
+    for (size_t q = first; q < last; ++q) {
+      const int32_t c = cells[q];
+      const double* row = in->llks + (size_t)c * V;
+      double lse = -1e300;                          // running log-sum-exp exactly as :484-489
+      for (int32_t j = 0; j < V; ++j) {
+        const double cur = row[j];
+        lse = (lse > cur) ? lse + std::log(1.0 + std::exp(cur - lse)) : cur + std::log(1.0 + std::exp(lse - cur));
+      }
+      std::string head, mid;                        // "%s\t%s\t%d\t%d\t%d\t%d\t%.5lf\t%.5lf\t%.3lg\n" (:506-516), constant parts once
+      head.append(in->barcodes[c]).push_back('\t');
+      mid.push_back('\t'); put_int(mid, in->rd_totl[c]); mid.push_back('\t'); put_int(mid, in->rd_pass[c]); mid.push_back('\t');
+      put_int(mid, in->rd_uniq[c]); mid.push_back('\t'); put_int(mid, in->n_snp[c]); mid.push_back('\t');
+      std::string l0; put_fixed(l0, in->llk0s[c], 5);
+      std::string& o = ck.out[0];
+      for (int32_t j = 0; j < V; ++j) {
+        o.append(head).append(in->sample_ids[j]).append(mid);
+        put_fixed(o, row[j], 5); o.push_back('\t'); o.append(l0); o.push_back('\t');
+        put_general(o, std::exp(row[j] - lse), 3); o.push_back('\n');
+      }
     }
-    for (int32_t j = 0; j < V; ++j)
-      fprintf(w.f, "%s\t%s\t%d\t%d\t%d\t%d\t%.5lf\t%.5lf\t%.3lg\n", in->barcodes[c], in->sample_ids[j], in->rd_totl[c],
-              in->rd_pass[c], in->rd_uniq[c], in->n_snp[c], row[j], in->llk0s[c], std::exp(row[j] - lse));   // :506-516
-  }
-  return DMX_OK;
+  });
 }
 
 extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_prefix) {
@@ -488,12 +654,16 @@ extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_pref
     dmx_phred_tables(mat, err);
     dmx::build_read_lut(mat, err, &lut);
   }
+  const std::vector<int32_t> cells = output_cells(in, true);
+  FILE* const files[kOutFiles] = {sing2.f, pairf.f, best.f};
+  std::vector<std::string> alpha_txt((size_t)A);                           // "\t%.3lf\t" of every alpha
+  for (int32_t a = 0; a < A; ++a) { alpha_txt[(size_t)a].push_back('\t'); put_fixed(alpha_txt[(size_t)a], in->alpha[a], 3); alpha_txt[(size_t)a].push_back('\t'); }
+  const size_t rows_per_cell = (size_t)V + (pairf.f ? (size_t)V * V * (A - 1) : 0);
+  return format_in_order(cells.size(), std::max<size_t>(1, 16384 / rows_per_cell), files, [&](size_t first, size_t last, Chunk& ck) {
   std::vector<double> scratch;
   std::vector<dmx::GridReq> reqs;
-
-  for (int32_t c : barcode_order(in)) {
-    if (cell_filtered(in, c)) continue;
-    if (in->n_snp[c] == 0) continue;                                       // :592 no covered SNP: no rows
+  for (size_t q = first; q < last; ++q) {
+    const int32_t c = cells[q];
     const double* grid = in->llksAB + (size_t)c * ng;
     const double* l00 = in->llks00 + (size_t)c * A;
     if (arbiter) {
@@ -527,24 +697,36 @@ extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_pref
     const char* bc = in->barcodes[c];
     const int32_t t = in->rd_totl[c], p = in->rd_pass[c], u = in->rd_uniq[c], ns = in->n_snp[c];
 
-    for (int32_t j = 0; j < V; ++j) {                                      // :746-770 (.sing2)
+    std::string head, mid, l0s;                                            // constant parts of this cell's rows, once
+    head.append(bc).push_back('\t');
+    mid.push_back('\t'); put_int(mid, t); mid.push_back('\t'); put_int(mid, p); mid.push_back('\t'); put_int(mid, u);
+    mid.push_back('\t'); put_int(mid, ns); mid.push_back('\t');
+    put_fixed(l0s, l00[0], 4);
+    for (int32_t j = 0; j < V; ++j) {                                      // :746-770 (.sing2) "%s\t%s\t%d\t%d\t%d\t%d\t%.4lf\t%.4lf\t%.3lg\n"
       const double v = grid[(size_t)j * V * A];
-      fprintf(sing2.f, "%s\t%s\t%d\t%d\t%d\t%d\t%.4lf\t%.4lf\t%.3lg\n", bc, in->sample_ids[j], t, p, u, ns, v, l00[0],
-              std::exp(v - cc.max_llk) * (1. - prior) / V / cc.sum_single);
+      std::string& o = ck.out[0];
+      o.append(head).append(in->sample_ids[j]).append(mid);
+      put_fixed(o, v, 4); o.push_back('\t'); o.append(l0s); o.push_back('\t');
+      put_general(o, std::exp(v - cc.max_llk) * (1. - prior) / V / cc.sum_single, 3); o.push_back('\n');
     }
-    if (pairf.f) {                                                         // :772-797 (.pair)
+    if (pairf.f) {                                                         // :772-797 (.pair) "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n"
       const double tot = cc.sum_single + cc.sum_double;
+      std::string& o = ck.out[1];
       for (int32_t j = 0; j < V; ++j) {
         const double vs = grid[(size_t)j * V * A];
-        fprintf(pairf.f, "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n", bc, in->sample_ids[j], in->sample_ids[j], in->alpha[0], vs,
-                std::exp(vs - cc.max_llk) * (1. - prior) / V / tot);
+        std::string hj;
+        hj.append(head).append(in->sample_ids[j]).push_back('\t');
+        o.append(hj).append(in->sample_ids[j]).append(alpha_txt[0]);
+        put_fixed(o, vs, 5); o.push_back('\t');
+        put_general(o, std::exp(vs - cc.max_llk) * (1. - prior) / V / tot, 5); o.push_back('\n');
         for (int32_t k = 0; k < V; ++k)
           for (int32_t a = 1; a < A; ++a) {
             if (j == k) continue;
             if ((j > k) && (in->alpha[a] == 0.5)) continue;                // :785 symmetric half only
             const double v = grid[((size_t)j * V + k) * A + a];
-            fprintf(pairf.f, "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n", bc, in->sample_ids[j], in->sample_ids[k], in->alpha[a], v,
-                    std::exp(v - cc.max_llk) * prior / V / (V - 1) / (A - 1) / tot);
+            o.append(hj).append(in->sample_ids[k]).append(alpha_txt[(size_t)a]);
+            put_fixed(o, v, 5); o.push_back('\t');
+            put_general(o, std::exp(v - cc.max_llk) * prior / V / (V - 1) / (A - 1) / tot, 5); o.push_back('\n');
           }
       }
     }
@@ -557,19 +739,19 @@ extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_pref
     const double l00b = l00[cc.n_best];
     const double post_dbl = cc.sum_double / (cc.sum_single + cc.sum_double);
     const double post_sng = std::exp(sing1 - cc.max_llk) * (1. - prior) / V / cc.sum_single;
-    fprintf(best.f, "%s\t%d\t%d\t%d\t%d\t", bc, t, p, u, ns);
+    appendf(ck.out[2], "%s\t%d\t%d\t%d\t%d\t", bc, t, p, u, ns);
     if ((l12 > l1) && (l12 > l2) && (l12 > sing1 + 2))                     // :837
-      fprintf(best.f, "DBL-%s-%s-%.3lf", in->sample_ids[cc.j_best], in->sample_ids[cc.k_best], in->alpha[cc.n_best]);
+      appendf(ck.out[2], "DBL-%s-%s-%.3lf", in->sample_ids[cc.j_best], in->sample_ids[cc.k_best], in->alpha[cc.n_best]);
     else if (sing1 > sing2v + 2)                                           // :844
-      fprintf(best.f, "SNG-%s", in->sample_ids[cc.i_sing1]);
+      appendf(ck.out[2], "SNG-%s", in->sample_ids[cc.i_sing1]);
     else
-      fprintf(best.f, "AMB-%s-%s-%s/%s", in->sample_ids[cc.i_sing1], in->sample_ids[cc.i_sing2], in->sample_ids[cc.j_best], in->sample_ids[cc.k_best]);
-    fprintf(best.f, "\t%s\t%.4lf", in->sample_ids[cc.i_sing1], sing1);
-    fprintf(best.f, "\t%s\t%.4lf\t%.4lf", in->sample_ids[cc.i_sing2], sing2v, sing0);
-    fprintf(best.f, "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[cc.j_best],
+      appendf(ck.out[2], "AMB-%s-%s-%s/%s", in->sample_ids[cc.i_sing1], in->sample_ids[cc.i_sing2], in->sample_ids[cc.j_best], in->sample_ids[cc.k_best]);
+    appendf(ck.out[2], "\t%s\t%.4lf", in->sample_ids[cc.i_sing1], sing1);
+    appendf(ck.out[2], "\t%s\t%.4lf\t%.4lf", in->sample_ids[cc.i_sing2], sing2v, sing0);
+    appendf(ck.out[2], "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[cc.j_best],
             in->sample_ids[cc.k_best], in->alpha[cc.n_best], l12, l1, l2, l10, l20, l00b, post_dbl, post_sng);
   }
-  return DMX_OK;
+  });
 }
 
 
@@ -595,10 +777,12 @@ extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double
     dmx_phred_tables(mat, err);
     dmx::build_read_lut(mat, err, &lut);
   }
+  const std::vector<int32_t> cells = output_cells(in, true);
+  FILE* const files[kOutFiles] = {sing2.f, nullptr, best.f};
+  return format_in_order(cells.size(), std::max<size_t>(1, 8192 / (size_t)V), files, [&](size_t first, size_t last, Chunk& ck) {
   std::vector<dmx::GridReq> reqs;
-  for (int32_t c : barcode_order(in)) {
-    if (cell_filtered(in, c)) continue;
-    if (in->n_snp[c] == 0) continue;
+  for (size_t q = first; q < last; ++q) {
+    const int32_t c = cells[q];
     dmx_cell_summary sm = summary[c];
     if (sm.i_sing1 < 0) sm.i_sing1 = 0;         // NaN likelihoods: see dmx_write_doublet
     if (sm.i_sing2 < 0) sm.i_sing2 = 0;
@@ -621,23 +805,31 @@ extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double
     }
     const char* bc = in->barcodes[c];
     const int32_t t = in->rd_totl[c], p = in->rd_pass[c], u = in->rd_uniq[c], ns = in->n_snp[c];
-    for (int32_t j = 0; j < V; ++j)
-      fprintf(sing2.f, "%s\t%s\t%d\t%d\t%d\t%d\t%.4lf\t%.4lf\t%.3lg\n", bc, in->sample_ids[j], t, p, u, ns, sg[j], l00[0],
-              std::exp(sg[j] - sm.max_llk) * (1. - prior) / V / sm.sum_single);
+    std::string head, mid, l0s;
+    head.append(bc).push_back('\t');
+    mid.push_back('\t'); put_int(mid, t); mid.push_back('\t'); put_int(mid, p); mid.push_back('\t'); put_int(mid, u);
+    mid.push_back('\t'); put_int(mid, ns); mid.push_back('\t');
+    put_fixed(l0s, l00[0], 4);
+    for (int32_t j = 0; j < V; ++j) {                                      // "%s\t%s\t%d\t%d\t%d\t%d\t%.4lf\t%.4lf\t%.3lg\n"
+      std::string& o = ck.out[0];
+      o.append(head).append(in->sample_ids[j]).append(mid);
+      put_fixed(o, sg[j], 4); o.push_back('\t'); o.append(l0s); o.push_back('\t');
+      put_general(o, std::exp(sg[j] - sm.max_llk) * (1. - prior) / V / sm.sum_single, 3); o.push_back('\n');
+    }
     const double sing1 = sg[sm.i_sing1], sing2v = sg[sm.i_sing2];
     const double post_dbl = sm.sum_double / (sm.sum_single + sm.sum_double);
     const double post_sng = std::exp(sing1 - sm.max_llk) * (1. - prior) / V / sm.sum_single;
-    fprintf(best.f, "%s\t%d\t%d\t%d\t%d\t", bc, t, p, u, ns);
+    appendf(ck.out[2], "%s\t%d\t%d\t%d\t%d\t", bc, t, p, u, ns);
     if ((l12 > l1) && (l12 > l2) && (l12 > sing1 + 2))
-      fprintf(best.f, "DBL-%s-%s-%.3lf", in->sample_ids[jb], in->sample_ids[kb], in->alpha[sm.n_best]);
+      appendf(ck.out[2], "DBL-%s-%s-%.3lf", in->sample_ids[jb], in->sample_ids[kb], in->alpha[sm.n_best]);
     else if (sing1 > sing2v + 2)
-      fprintf(best.f, "SNG-%s", in->sample_ids[sm.i_sing1]);
+      appendf(ck.out[2], "SNG-%s", in->sample_ids[sm.i_sing1]);
     else
-      fprintf(best.f, "AMB-%s-%s-%s/%s", in->sample_ids[sm.i_sing1], in->sample_ids[sm.i_sing2], in->sample_ids[jb], in->sample_ids[kb]);
-    fprintf(best.f, "\t%s\t%.4lf", in->sample_ids[sm.i_sing1], sing1);
-    fprintf(best.f, "\t%s\t%.4lf\t%.4lf", in->sample_ids[sm.i_sing2], sing2v, l00[0]);
-    fprintf(best.f, "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[jb], in->sample_ids[kb],
+      appendf(ck.out[2], "AMB-%s-%s-%s/%s", in->sample_ids[sm.i_sing1], in->sample_ids[sm.i_sing2], in->sample_ids[jb], in->sample_ids[kb]);
+    appendf(ck.out[2], "\t%s\t%.4lf", in->sample_ids[sm.i_sing1], sing1);
+    appendf(ck.out[2], "\t%s\t%.4lf\t%.4lf", in->sample_ids[sm.i_sing2], sing2v, l00[0]);
+    appendf(ck.out[2], "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[jb], in->sample_ids[kb],
             in->alpha[sm.n_best], l12, l1, l2, l10, l20, l00[sm.n_best], post_dbl, post_sng);
   }
-  return DMX_OK;
+  });
 }

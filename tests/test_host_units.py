@@ -162,3 +162,31 @@ def test_store_rejects_bad_arguments(eng):
             st.add_read(*args)
     pl = st.freeze()
     assert pl.n_cells == 1 and len(pl.pair_nrd) == 0
+
+
+def test_row_formatter_equals_printf(eng, tmp_path, monkeypatch):
+    """The writers format `%.5lf`/`%.4lf`/`%d` columns without printf (exact 128-bit decimal rounding, csrc/dmx_host.cpp
+    put_fixed) and on several host threads; the bytes must be what printf produces.  Python's % operator is correctly
+    rounded (round-half-even on the exact binary value) like glibc's printf, so it is the checker.  Covered: exact ties at
+    the 5th decimal (k/2^n), values that round up across a power of ten, negative zero, subnormals, |v| >= 2^43 (printf
+    fallback), and a few hundred thousand random magnitudes."""
+    rng = np.random.default_rng(7)
+    ties = np.array([k / 2.0 ** n for n in range(1, 20) for k in (1, 3, 5, 7, 2 ** n - 1, 2 ** n + 1)])
+    edge = np.array([0.0, -0.0, 5e-324, -5e-324, 1e-6, 4.999995e-6, 5.000005e-6, 0.999995, 0.9999949999, 9.999995, 99999.999995,
+                     -123456.789015, 2.0 ** 43, -(2.0 ** 43), 2.0 ** 42 + 0.5, 1e15, -1e22, 1e300, 0.1, 0.15, 0.25, 0.35, 1e-300])
+    rnd = np.concatenate([-rng.uniform(0, 1e5, 100000), rng.normal(0, 1, 100000), rng.uniform(-1, 1, 50000) * 10.0 ** rng.integers(-12, 13, 50000),
+                          np.round(rng.uniform(-1e3, 1e3, 50000), 5), np.round(rng.uniform(-10, 10, 50000), 5) + 5e-6])
+    vals = np.concatenate([ties, -ties, ties * 1000 + 7, edge, rnd])
+    B = len(vals)
+    z = rng.integers(0, 2 ** 31 - 1, B).astype(np.int32)
+    fa = eng.FinalArgs([f"BC{i:07d}" for i in range(B)], ["S0"], (0.0, 0.5), 0.5, z, z, z, z)
+    want = ["BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n"]
+    for i in range(B):
+        want.append("BC%07d\tS0\t%d\t%d\t%d\t%d\t%.5f\t%.5f\t1\n" % (i, z[i], z[i], z[i], z[i], vals[i], -vals[i]))
+    want = "".join(want)
+    for threads in ("1", "5"):
+        monkeypatch.setenv("DMX_THREADS", threads)
+        path = str(tmp_path / f"fmt{threads}.single")
+        eng.write_single(fa, vals.reshape(B, 1), -vals, path)
+        got = open(path).read()
+        assert got == want, next((a, b) for a, b in zip(got.split("\n"), want.split("\n")) if a != b)
