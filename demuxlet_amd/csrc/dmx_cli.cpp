@@ -17,8 +17,15 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <ctime>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <map>
 #include <set>
 #include <string>
@@ -159,22 +166,192 @@ void parse_options(int argc, char** argv, Options& o) {
   if (!errors.empty()) fatal("Problems encountered parsing command line:\n\n%s", errors.c_str());                   // params.cpp:562-567
 }
 
-// ---- line / byte input over zlib (plain files pass through) ----------------------------------------------------------
+// ---- line / byte input: plain files, gzip, and BGZF (bgzip'd VCF, BAM) ------------------------------------------------
+// BGZF is a series of independent <= 64 KiB gzip members whose compressed size sits in a 'BC' extra field (SAM spec 4.1), so
+// the members of a batch are inflated on several host threads while the parser consumes the previous batch; inflate is what
+// bounds a single-threaded BAM scan (0.8 M reads/s here against 3 M reads/s for the same records as text).  Anything that
+// is not BGZF goes through zlib's gzFile (which also passes plain text through).
+int cli_threads() {
+  if (const char* e = getenv("DMX_THREADS")) { const int n = atoi(e); if (n >= 1) return std::min(n, 64); }
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  if (FILE* q = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32]; long long period = 0;
+    if (fscanf(q, "%31s %lld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) n = std::max(1, std::min(n, (int)(atoll(quota) / period)));
+    fclose(q);
+  }
+  return std::min(n, 32);
+}
+
+struct BgzfPipe {
+  FILE* fp = nullptr;
+  std::thread producer;
+  std::mutex mu;
+  std::condition_variable cv_put, cv_get;
+  std::deque<std::vector<uint8_t>> queue;       // inflated batches, in file order
+  bool done = false, stop = false;
+  std::string error;
+  static constexpr size_t kBatchBlocks = 256, kQueueDepth = 3;
+
+  struct Block { std::vector<uint8_t> raw; size_t data_off = 0, data_len = 0; uint32_t crc = 0, isize = 0; std::vector<uint8_t> out; std::string err; };
+
+  // one BGZF member into b.raw; false at a clean EOF
+  bool read_block(Block& b) {
+    uint8_t h[12];
+    const size_t got = fread(h, 1, 12, fp);
+    if (got == 0) return false;
+    if (got != 12 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { error = "corrupt BGZF block header"; return false; }
+    const size_t xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+    std::vector<uint8_t> extra(xlen);
+    if (fread(extra.data(), 1, xlen, fp) != xlen) { error = "truncated BGZF block"; return false; }
+    size_t bsize = 0;
+    for (size_t o = 0; o + 4 <= xlen;) {
+      const size_t sl = (size_t)extra[o + 2] | ((size_t)extra[o + 3] << 8);
+      if (extra[o] == 'B' && extra[o + 1] == 'C' && sl == 2 && o + 6 <= xlen) bsize = ((size_t)extra[o + 4] | ((size_t)extra[o + 5] << 8)) + 1;
+      o += 4 + sl;
+    }
+    if (bsize < 12 + xlen + 8) { error = "BGZF block without a BC field"; return false; }
+    const size_t rest = bsize - 12 - xlen;          // deflate data + CRC32 + ISIZE
+    b.raw.resize(rest);
+    if (fread(b.raw.data(), 1, rest, fp) != rest) { error = "truncated BGZF block"; return false; }
+    b.data_off = 0; b.data_len = rest - 8;
+    memcpy(&b.crc, &b.raw[rest - 8], 4); memcpy(&b.isize, &b.raw[rest - 4], 4);
+    return true;
+  }
+  static void inflate_block(Block& b) {
+    b.out.resize(b.isize);
+    if (b.isize == 0) return;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { b.err = "inflateInit2 failed"; return; }
+    zs.next_in = b.raw.data() + b.data_off; zs.avail_in = (uInt)b.data_len;
+    zs.next_out = b.out.data(); zs.avail_out = (uInt)b.out.size();
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    if (rc != Z_STREAM_END || zs.avail_out != 0) { b.err = "BGZF block does not inflate to its ISIZE"; return; }
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), b.out.data(), (uInt)b.out.size()) != b.crc) b.err = "BGZF block CRC mismatch";
+  }
+  void run(int nthreads) {
+    std::vector<Block> blocks(kBatchBlocks);
+    for (;;) {
+      size_t n = 0;
+      while (n < kBatchBlocks && read_block(blocks[n])) ++n;
+      std::string err = error;
+      if (n) {
+        const int nt = (int)std::min<size_t>((size_t)nthreads, n);
+        std::atomic<size_t> next{0};
+        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) inflate_block(blocks[i]); };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+        size_t total = 0;
+        for (size_t i = 0; i < n; ++i) { total += blocks[i].out.size(); if (err.empty() && !blocks[i].err.empty()) err = blocks[i].err; }
+        std::vector<uint8_t> batch(total);
+        size_t o = 0;
+        for (size_t i = 0; i < n; ++i) { if (!blocks[i].out.empty()) memcpy(&batch[o], blocks[i].out.data(), blocks[i].out.size()); o += blocks[i].out.size(); }
+        std::unique_lock<std::mutex> lk(mu);
+        cv_put.wait(lk, [&] { return queue.size() < kQueueDepth || stop; });
+        if (stop) return;
+        queue.push_back(std::move(batch));
+        cv_get.notify_one();
+      }
+      if (n < kBatchBlocks || !err.empty()) {
+        std::lock_guard<std::mutex> lk(mu);
+        error = err; done = true;
+        cv_get.notify_one();
+        return;
+      }
+    }
+  }
+  void start(FILE* f, int nthreads) { fp = f; producer = std::thread([this, nthreads] { run(nthreads); }); }
+  // next inflated batch; false at EOF (or error: see `error`)
+  bool next(std::vector<uint8_t>& out) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_get.wait(lk, [&] { return !queue.empty() || done; });
+    if (queue.empty()) return false;
+    out = std::move(queue.front());
+    queue.pop_front();
+    cv_put.notify_one();
+    return true;
+  }
+  ~BgzfPipe() {
+    { std::lock_guard<std::mutex> lk(mu); stop = true; }
+    cv_put.notify_all();
+    if (producer.joinable()) producer.join();
+    if (fp) fclose(fp);
+  }
+};
+
 struct GzIn {
-  gzFile f = nullptr;
+  gzFile f = nullptr;                            // plain text / ordinary gzip
+  std::unique_ptr<BgzfPipe> bgzf;                // BGZF
   std::string path;
-  bool open(const std::string& p) { path = p; f = gzopen(p.c_str(), "rb"); if (f) gzbuffer(f, 1 << 20); return f != nullptr; }
+  std::vector<uint8_t> cur;                      // current decompressed chunk
+  size_t pos = 0;
+  bool open(const std::string& p) {
+    path = p;
+    FILE* fp = fopen(p.c_str(), "rb");
+    if (!fp) return false;
+    uint8_t h[18];
+    const size_t got = fread(h, 1, sizeof h, fp);
+    const bool is_bgzf = got == 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C';
+    if (is_bgzf) {
+      rewind(fp);
+      bgzf.reset(new BgzfPipe);
+      bgzf->start(fp, cli_threads());
+      return true;
+    }
+    fclose(fp);
+    f = gzopen(p.c_str(), "rb");
+    if (f) gzbuffer(f, 1 << 20);
+    return f != nullptr;
+  }
   ~GzIn() { if (f) gzclose(f); }
+  bool fill() {                                  // next chunk into cur; false at EOF
+    pos = 0;
+    if (bgzf) {
+      if (bgzf->next(cur)) return true;
+      if (!bgzf->error.empty()) fatal("[E:%s] %s: %s", __func__, path.c_str(), bgzf->error.c_str());
+      cur.clear();
+      return false;
+    }
+    cur.resize(1 << 20);
+    const int n = gzread(f, cur.data(), (unsigned)cur.size());
+    if (n < 0) fatal("[E:%s] %s: read error", __func__, path.c_str());
+    cur.resize((size_t)n);
+    return n > 0;
+  }
   bool getline(std::string& line) {
     line.clear();
-    char buf[65536];
-    while (gzgets(f, buf, sizeof buf)) {
-      line += buf;
-      if (!line.empty() && line.back() == '\n') { line.pop_back(); if (!line.empty() && line.back() == '\r') line.pop_back(); return true; }
+    bool any = false;
+    for (;;) {
+      if (pos >= cur.size() && !fill()) break;
+      any = true;
+      const uint8_t* b = cur.data() + pos;
+      const uint8_t* nl = (const uint8_t*)memchr(b, '\n', cur.size() - pos);
+      if (nl) {
+        line.append((const char*)b, (size_t)(nl - b));
+        pos += (size_t)(nl - b) + 1;
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        return true;
+      }
+      line.append((const char*)b, cur.size() - pos);
+      pos = cur.size();
     }
-    return !line.empty();
+    return any && !line.empty();
   }
-  bool read(void* dst, size_t n) { return gzread(f, dst, (unsigned)n) == (int)n; }
+  bool read(void* dst, size_t n) {
+    uint8_t* d = (uint8_t*)dst;
+    while (n) {
+      if (pos >= cur.size() && !fill()) return false;
+      const size_t k = std::min(n, cur.size() - pos);
+      memcpy(d, cur.data() + pos, k);
+      d += k; pos += k; n -= k;
+    }
+    return true;
+  }
+  void unread_all_to(size_t p) { pos = p; }      // rewind inside the first chunk (SAM text sniffing)
 };
 
 std::vector<std::string> split(const std::string& s, char sep) {
@@ -320,12 +497,29 @@ struct VcfReader {
 
 // ---- f2: SAM / BAM reader -------------------------------------------------------------------------------------------------
 struct Read {
-  std::string qname, seq, qual, cb, ub;
+  // One alignment.  The record's bytes stay where the reader put them (a reused buffer): sequence and qualities are
+  // decoded per queried base (a read overlaps 0-2 SNPs), names and tags are views into the record.
+  std::string cb, ub;           // group / UMI tag values (copied: the store and the warnings want C strings)
   bool has_cb = false, has_ub = false;
   int flag = 0, tid = -1, mapq = 0;
   int64_t pos = 0;              // 0-based
   std::vector<std::pair<char, uint32_t>> cigar;
   int l_qseq = 0;
+  const char* qname_p = ""; size_t qname_n = 0;
+  const uint8_t* seq4 = nullptr;   // BAM: 4-bit packed bases
+  const char* seq_txt = nullptr;   // SAM: text bases
+  const uint8_t* qual_raw = nullptr;  // BAM: phred values; SAM: phred + 33; nullptr = "*" (0xff)
+  bool qual_is_text = false;
+  std::string qname() const { return std::string(qname_p, qname_n); }
+  char base(size_t i) const {      // htslib stores 4-bit codes and prints "=ACMGRSVTWYHKDBN"
+    if (seq4) return "=ACMGRSVTWYHKDBN"[(seq4[i >> 1] >> ((i & 1) ? 0 : 4)) & 0xf];
+    const char ch = (char)toupper((unsigned char)seq_txt[i]);
+    return strchr("=ACMGRSVTWYHKDBN", ch) && ch ? ch : 'N';
+  }
+  char qual33(size_t i) const {    // quality character as the reference sees it (phred + 33)
+    if (!qual_raw) return (char)(0xff + 33);
+    return qual_is_text ? (char)qual_raw[i] : (char)(qual_raw[i] + 33);
+  }
 };
 
 struct SamReader {
@@ -335,6 +529,9 @@ struct SamReader {
   std::map<std::string, int> target_id;
   std::string pending;          // first alignment line of a SAM text file
   bool have_pending = false;
+  std::string last_rname; int last_tid = -1;
+  std::string line_buf;         // current SAM line (the Read's views point into it)
+  std::vector<uint8_t> rec_buf; // current BAM record
   char gtag[3] = {0, 0, 0}, utag[3] = {0, 0, 0};
   int min_mq = 20, excl_flag = 0x0f04, verbose = 1000000;
   int64_t n_read = 0, n_skip = 0;
@@ -342,7 +539,7 @@ struct SamReader {
   void open(const std::string& path) {
     if (!in.open(path)) fatal("[E:%s] Cannot open SAM/BAM file %s", __func__, path.c_str());
     char magic[4] = {0, 0, 0, 0};
-    const int got = gzread(in.f, magic, 4);
+    const int got = in.read(magic, 4) ? 4 : 0;
     if (got == 4 && memcmp(magic, "BAM\1", 4) == 0) {
       is_bam = true;
       int32_t l_text = 0, n_ref = 0;
@@ -360,7 +557,7 @@ struct SamReader {
       }
     } else {
       if (got == 4 && memcmp(magic, "CRAM", 4) == 0) fatal("[E:%s] CRAM input needs htslib, which this build does not use", __func__);
-      gzrewind(in.f);
+      in.unread_all_to(0);                       // the 4 sniffed bytes are inside the first chunk
       std::string line;
       while (in.getline(line)) {
         if (!line.empty() && line[0] == '@') {
@@ -380,31 +577,50 @@ struct SamReader {
   }
 
   bool parse_sam_line(const std::string& line, Read& r) {
-    auto f = split(line, '\t');
-    if (f.size() < 11) fatal("[E:%s] SAM record with %u fields", __func__, (unsigned)f.size());
-    r.qname = f[0]; r.flag = atoi(f[1].c_str());
-    auto it = target_id.find(f[2]);
-    r.tid = (f[2] == "*" || it == target_id.end()) ? -1 : it->second;
-    r.pos = atoll(f[3].c_str()) - 1; r.mapq = atoi(f[4].c_str());
-    r.cigar.clear();
-    if (f[5] != "*") {
-      uint32_t n = 0;
-      for (char ch : f[5]) { if (ch >= '0' && ch <= '9') n = n * 10 + (uint32_t)(ch - '0'); else { r.cigar.emplace_back(ch, n); n = 0; } }
+    // fields in place: [b[i], b[i+1]-1) without copying
+    const char* p = line.data();
+    const char* const end = p + line.size();
+    const char* fb[12]; size_t fn[12];
+    int nf = 0;
+    const char* q = p;
+    while (nf < 11) {
+      const char* t = (const char*)memchr(q, '\t', (size_t)(end - q));
+      fb[nf] = q; fn[nf] = (size_t)((t ? t : end) - q); ++nf;
+      if (!t) { q = end; break; }
+      q = t + 1;
     }
-    if (f[9] == "*") { r.seq.clear(); } else { r.seq = f[9]; }
-    r.l_qseq = (int)r.seq.size();
-    for (char& ch : r.seq) {                    // htslib stores 4-bit codes and prints "=ACMGRSVTWYHKDBN"
-      ch = (char)toupper((unsigned char)ch);
-      if (!strchr("=ACMGRSVTWYHKDBN", ch)) ch = 'N';
-    }
-    if (f[10] == "*") r.qual.assign((size_t)r.l_qseq, (char)(0xff + 33)); else r.qual = f[10];
-    r.has_cb = r.has_ub = false;
-    for (size_t i = 11; i < f.size(); ++i) {
-      const std::string& t = f[i];
-      if (t.size() >= 5 && t[2] == ':' && t[4] == ':') {
-        if (gtag[0] && t[0] == gtag[0] && t[1] == gtag[1] && t[3] == 'Z') { r.cb = t.substr(5); r.has_cb = true; }
-        if (utag[0] && t[0] == utag[0] && t[1] == utag[1] && t[3] == 'Z') { r.ub = t.substr(5); r.has_ub = true; }
+    if (nf < 11) fatal("[E:%s] SAM record with %u fields", __func__, (unsigned)nf);
+    auto eq = [&](int i, const char* lit) { return fn[i] == strlen(lit) && memcmp(fb[i], lit, fn[i]) == 0; };
+    r.qname_p = fb[0]; r.qname_n = fn[0];
+    r.flag = atoi(fb[1]);
+    if (eq(2, "*")) r.tid = -1;
+    else {
+      if (fn[2] != last_rname.size() || memcmp(fb[2], last_rname.data(), fn[2]) != 0) {     // reads come sorted: one lookup per contig
+        last_rname.assign(fb[2], fn[2]);
+        auto it = target_id.find(last_rname);
+        last_tid = it == target_id.end() ? -1 : it->second;
       }
+      r.tid = last_tid;
+    }
+    r.pos = atoll(fb[3]) - 1; r.mapq = atoi(fb[4]);
+    r.cigar.clear();
+    if (!eq(5, "*")) {
+      uint32_t n = 0;
+      for (size_t i = 0; i < fn[5]; ++i) { const char ch = fb[5][i]; if (ch >= '0' && ch <= '9') n = n * 10 + (uint32_t)(ch - '0'); else { r.cigar.emplace_back(ch, n); n = 0; } }
+    }
+    r.seq4 = nullptr;
+    if (eq(9, "*")) { r.seq_txt = ""; r.l_qseq = 0; } else { r.seq_txt = fb[9]; r.l_qseq = (int)fn[9]; }
+    if (eq(10, "*")) r.qual_raw = nullptr; else { r.qual_raw = (const uint8_t*)fb[10]; r.qual_is_text = true; }
+    r.has_cb = r.has_ub = false;
+    while (q < end) {                             // optional fields TAG:TYPE:VALUE
+      const char* t = (const char*)memchr(q, '\t', (size_t)(end - q));
+      const char* fe = t ? t : end;
+      if (fe - q >= 5 && q[2] == ':' && q[4] == ':' && q[3] == 'Z') {
+        if (gtag[0] && q[0] == gtag[0] && q[1] == gtag[1]) { r.cb.assign(q + 5, (size_t)(fe - q - 5)); r.has_cb = true; }
+        if (utag[0] && q[0] == utag[0] && q[1] == utag[1]) { r.ub.assign(q + 5, (size_t)(fe - q - 5)); r.has_ub = true; }
+      }
+      if (!t) break;
+      q = t + 1;
     }
     return true;
   }
@@ -412,7 +628,9 @@ struct SamReader {
   bool parse_bam_record(Read& r) {
     int32_t block = 0;
     if (!in.read(&block, 4)) return false;
-    std::vector<uint8_t> b((size_t)block);
+    if (block < 32) fatal("[E:%s] corrupt BAM record (block size %d)", __func__, block);
+    std::vector<uint8_t>& b = rec_buf;
+    b.resize((size_t)block);
     if (!in.read(b.data(), (size_t)block)) fatal("[E:%s] truncated BAM record", __func__);
     auto i32 = [&](size_t o) { int32_t v; memcpy(&v, &b[o], 4); return v; };
     auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, &b[o], 2); return v; };
@@ -421,14 +639,13 @@ struct SamReader {
     const int n_cigar = u16(12); r.flag = u16(14);
     r.l_qseq = i32(16);
     size_t o = 32;
-    r.qname.assign((const char*)&b[o], (size_t)std::max(0, l_read_name - 1)); o += (size_t)l_read_name;
+    if (o + (size_t)l_read_name + 4 * (size_t)n_cigar + (size_t)(r.l_qseq + 1) / 2 + (size_t)r.l_qseq > b.size()) fatal("[E:%s] corrupt BAM record", __func__);
+    r.qname_p = (const char*)&b[o]; r.qname_n = (size_t)std::max(0, l_read_name - 1); o += (size_t)l_read_name;
     r.cigar.clear();
     for (int i = 0; i < n_cigar; ++i) { uint32_t c; memcpy(&c, &b[o], 4); o += 4; r.cigar.emplace_back("MIDNSHP=XB"[std::min<uint32_t>(c & 0xf, 9)], c >> 4); }
-    r.seq.resize((size_t)r.l_qseq);
-    for (int i = 0; i < r.l_qseq; ++i) r.seq[i] = "=ACMGRSVTWYHKDBN"[(b[o + (size_t)i / 2] >> ((i & 1) ? 0 : 4)) & 0xf];
+    r.seq4 = &b[o]; r.seq_txt = nullptr;
     o += (size_t)(r.l_qseq + 1) / 2;
-    r.qual.resize((size_t)r.l_qseq);
-    for (int i = 0; i < r.l_qseq; ++i) r.qual[i] = (char)(b[o + (size_t)i] + 33);
+    r.qual_raw = &b[o]; r.qual_is_text = false;
     o += (size_t)r.l_qseq;
     r.has_cb = r.has_ub = false;
     while (o + 3 <= b.size()) {                 // aux fields
@@ -459,11 +676,10 @@ struct SamReader {
     for (;;) {
       if (is_bam) { if (!parse_bam_record(r)) return false; }
       else {
-        std::string line;
-        if (have_pending) { line.swap(pending); have_pending = false; }
-        else if (!in.getline(line)) return false;
-        if (line.empty()) continue;
-        parse_sam_line(line, r);
+        if (have_pending) { line_buf.swap(pending); have_pending = false; }
+        else if (!in.getline(line_buf)) return false;
+        if (line_buf.empty()) continue;
+        parse_sam_line(line_buf, r);
       }
       ++n_read;
       if (verbose > 0 && n_read % verbose == 0) notice("Reading %lld reads at %s:%lld and skipping %lld", (long long)n_read, r.tid >= 0 ? targets[r.tid].c_str() : "*", (long long)r.pos + 1, (long long)n_skip);
@@ -495,7 +711,7 @@ void base_at(const Read& r, int64_t pos, char& base, char& qual, int& rpos) {
       }
     }
     if (rp >= 0 && rp <= rlen) {
-      if (rp < rlen) { base = r.seq[(size_t)rp]; qual = r.qual[(size_t)rp]; } else { base = 0; qual = 0; }
+      if (rp < rlen) { base = r.base((size_t)rp); qual = r.qual33((size_t)rp); } else { base = 0; qual = 0; }
     } else {
       rp = kNA;
     }
@@ -504,6 +720,16 @@ void base_at(const Read& r, int64_t pos, char& base, char& qual, int& rpos) {
   rpos = (int)rp;
 }
 
+}  // namespace
+
+namespace {
+struct Stopwatch {             // DMX_CLI_TIMING=1: where the scan's wall-clock goes (reported as NOTICE lines)
+  bool on = getenv("DMX_CLI_TIMING") != nullptr;
+  double acc[4] = {0, 0, 0, 0};
+  std::chrono::steady_clock::time_point t0;
+  void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+  void stop(int i) { if (on) acc[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -580,10 +806,21 @@ int main(int argc, char** argv) {
   long nReadsMultiSNPs = 0, nReadsSkipBCD = 0, nReadsPass = 0, nReadsRedundant = 0, nReadsN = 0, nReadsLQ = 0, nReadsTMP = 0, nNonBiallelic = 0;
   int n_warn_g = 0, n_warn_u = 0;
 
+  std::vector<int> tid_rid(sr.targets.size());                 // SAM target id -> VCF contig id; VCFs without ##contig lines
+  size_t tid_rid_for = (size_t)-1;                             // learn their contigs while being read, so refresh on growth
   Read rd;
-  while (sr.read(rd)) {                                                                                    // :195
+  Stopwatch sw;
+  for (;;) {                                                                                               // :195
+    sw.start();
+    const bool more = sr.read(rd);
+    sw.stop(0);
+    if (!more) break;
+    if (tid_rid_for != vr.contig_rid.size()) {
+      for (size_t t = 0; t < sr.targets.size(); ++t) tid_rid[t] = vr.name2id(sr.targets[t]);
+      tid_rid_for = vr.contig_rid.size();
+    }
     const int64_t endpos = SamReader::endpos(rd);
-    const int tid2rid = rd.tid >= 0 ? vr.name2id(sr.targets[(size_t)rd.tid]) : -1;
+    const int tid2rid = (rd.tid >= 0 && (size_t)rd.tid < tid_rid.size()) ? tid_rid[(size_t)rd.tid] : -1;
     if (tid2rid < 0) continue;                                                                             // :198-200
     {   // clear_buffer_before(chrom, read start) — bcf_filtered_reader.cpp:649-669
       int64_t n_rm = 0;
@@ -597,7 +834,10 @@ int main(int argc, char** argv) {
     }
     while (!veof && (snps.back().rid < tid2rid || (snps.back().rid == tid2rid && snps.back().pos < endpos))) {    // :209
       Variant v;
-      if (vr.read(v)) {
+      sw.start();
+      const bool got = vr.read(v);
+      sw.stop(1);
+      if (got) {
         if (v.rlen > 1 || v.n_allele != 2 || v.ref.size() > 1) {                                           // :215-225 (warn only)
           if (nNonBiallelic < 10) warning("VCF record must be biallelic SNPs. Ignoring non-SNPs and/or multi-allelic variants at %d:%lld", v.rid, (long long)v.pos + 1);
           ++nNonBiallelic;
@@ -616,7 +856,7 @@ int main(int argc, char** argv) {
       const char* sbcd = ".";
       if (rd.has_cb) sbcd = rd.cb.c_str();
       else {
-        if (n_warn_g < 10) notice("WARNING: Cannot find Droplet/Cell tag %s from %lld-th read %s at %s:%lld-%lld. Treating all of them as a single group", o.tag_group.c_str(), (long long)sr.n_read, rd.qname.c_str(), sr.targets[(size_t)rd.tid].c_str(), (long long)rd.pos, (long long)endpos);
+        if (n_warn_g < 10) notice("WARNING: Cannot find Droplet/Cell tag %s from %lld-th read %s at %s:%lld-%lld. Treating all of them as a single group", o.tag_group.c_str(), (long long)sr.n_read, rd.qname().c_str(), sr.targets[(size_t)rd.tid].c_str(), (long long)rd.pos, (long long)endpos);
         else if (n_warn_g == 10) notice("WARNING: Suppressing 10+ missing Droplet/Cell tag warnings...");
         ++n_warn_g;
       }
@@ -632,12 +872,13 @@ int main(int argc, char** argv) {
     if (o.tag_umi.empty()) { char b[32]; snprintf(b, sizeof b, "%x", rand()); sumi += b; }
     else if (rd.has_ub) sumi = rd.ub;
     else {
-      if (n_warn_u < 10) notice("WARNING: Cannot find UMI tag %s from %lld-th read %s at %s:%lld-%lld. Treating all of them as a single UMI", o.tag_umi.c_str(), (long long)sr.n_read, rd.qname.c_str(), sr.targets[(size_t)rd.tid].c_str(), (long long)rd.pos, (long long)endpos);
+      if (n_warn_u < 10) notice("WARNING: Cannot find UMI tag %s from %lld-th read %s at %s:%lld-%lld. Treating all of them as a single UMI", o.tag_umi.c_str(), (long long)sr.n_read, rd.qname().c_str(), sr.targets[(size_t)rd.tid].c_str(), (long long)rd.pos, (long long)endpos);
       else if (n_warn_u == 10) notice("WARNING: Suppressing 10+ UMI warnings...");
       ++n_warn_u;
     }
     dmx_store_count_read(scl, ibcd);                                                                       // :295
     int nv_pass = 0, nv_red = 0, nv_valid = 0;
+    sw.start();
     for (int64_t i = ibeg; i < ibeg + nbuf; ++i) {                                                         // :306
       char base, qual; int rpos;
       base_at(rd, snps[(size_t)i].pos, base, qual, rpos);
@@ -653,11 +894,13 @@ int main(int argc, char** argv) {
       if (ret < 0) fatal("%s", dmx_last_error());
       if (ret) ++nv_pass; else ++nv_red;
     }
+    sw.stop(2);
     if (nv_pass > 1) ++nReadsMultiSNPs;
     if (nv_pass > 0) ++nReadsPass; else if (nv_red > 0) ++nReadsRedundant; else if (nv_valid > 0) ++nReadsLQ; else ++nReadsN;
   }
   if (n_warn_u > 10) notice("WARNING: Suppressed a total of %d UMI warnings...", n_warn_u);
   if (n_warn_g > 10) notice("WARNING: Suppressed a total of %d droplet/cell barcode warnings...", n_warn_g);
+  if (sw.on) notice("scan timing: alignment reader %.3f s, VCF reader %.3f s, overlap + store %.3f s", sw.acc[0], sw.acc[1], sw.acc[2]);
   notice("Finished reading %d markers from the VCF file", (int)snps.size());
   notice("Total number input reads : %lld", (long long)sr.n_read);
   notice("Total number valid droplets observed : %d", dmx_store_n_cells(scl));

@@ -112,8 +112,23 @@ def make_reads(rng, contigs, recs, n_reads, barcodes, path_sam, path_bam=None):
     return reads
 
 
-def write_bam(contigs, reads, path):
-    """Minimal BAM writer (one gzip member; BGZF readers other than ours would want 64 KiB blocks — ours uses zlib)."""
+def bgzf_compress(data: bytes, block: int = 0xff00) -> bytes:
+    """BGZF framing (SAM spec 4.1): independent gzip members of <= 64 KiB with the member size in a 'BC' extra field,
+    closed by the 28-byte empty EOF block — what samtools/bgzip write."""
+    import zlib
+    out = bytearray()
+    for o in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if o is None else data[o:o + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out += struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b"BC" + struct.pack("<HH", 2, bsize)
+        out += body + struct.pack("<II", zlib.crc32(chunk) & 0xffffffff, len(chunk))
+    return bytes(out)
+
+
+def write_bam(contigs, reads, path, bgzf=True):
+    """Minimal BAM writer: BGZF blocks as samtools writes them, or (bgzf=False) one ordinary gzip member."""
     out = bytearray(b"BAM\x01")
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in contigs)
     out += struct.pack("<i", len(text)) + text.encode() + struct.pack("<i", len(contigs))
@@ -135,7 +150,7 @@ def write_bam(contigs, reads, path):
         body = struct.pack("<iiBBHHHIiii", r["tid"], r["pos"], len(name), r["mapq"], 4680, len(r["cigar"]), r["flag"], l, -1, -1, 0) + name + cig + bytes(sq) + ql + aux
         out += struct.pack("<i", len(body)) + body
     with open(path, "wb") as f:
-        f.write(gzip.compress(bytes(out)))
+        f.write(bgzf_compress(bytes(out)) if bgzf else gzip.compress(bytes(out)))
 
 
 # ---- independent restatement of the scan --------------------------------------------------------------------------------

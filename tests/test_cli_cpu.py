@@ -1,6 +1,7 @@
 """CPU: the `demuxlet` front end (rows f1-f4) up to the pileup — option parsing, SAM/BAM/VCF readers, variant filter,
 sample selection, CIGAR walk, base filters — via `--pileup-only`, against an independent Python restatement of the
 reference's scan (tests/sam_vcf_synth.py).  PARITY-UNPINNED by the reference (its scan needs htslib)."""
+import os
 import subprocess
 from pathlib import Path
 
@@ -91,15 +92,46 @@ def test_scan_matches_restatement(cli, oracle, tmp_path, field, fmt):
 
 
 def test_sam_and_bam_give_the_same_pileup(cli, tmp_path):
+    """Every container the readers accept gives the same pileup: SAM text, gzip'd SAM, BAM in BGZF blocks (what samtools
+    writes; inflated on several threads: block size forced down so that batches span many blocks), BAM as one ordinary
+    gzip member, bgzip'd SAM and bgzip'd VCF."""
+    import gzip
     rng = np.random.default_rng(5)
     recs = sv.make_vcf(rng, CONTIGS, 60, SAMPLES, tmp_path / "v.vcf")
-    sv.make_reads(rng, CONTIGS, recs, 1500, ["A-1", "C-1", "G-1"], tmp_path / "r.sam", tmp_path / "r.bam")
-    outs = []
-    for fmt in ("sam", "bam"):
-        subprocess.run([cli, "--sam", str(tmp_path / f"r.{fmt}"), "--vcf", str(tmp_path / "v.vcf"), "--field", "GT", "--out", str(tmp_path / fmt),
-                        "--pileup-only"], check=True, stderr=subprocess.DEVNULL)
-        outs.append((tmp_path / f"{fmt}.pileup.txt").read_bytes())
-    assert outs[0] == outs[1] and len(outs[0]) > 1000
+    reads = sv.make_reads(rng, CONTIGS, recs, 1500, ["A-1", "C-1", "G-1"], tmp_path / "r.sam", tmp_path / "r.bam")
+    sv.write_bam(CONTIGS, reads, tmp_path / "plain.bam", bgzf=False)
+    sam_text = (tmp_path / "r.sam").read_bytes()
+    (tmp_path / "r.sam.gz").write_bytes(gzip.compress(sam_text))
+    (tmp_path / "rb.sam.gz").write_bytes(sv.bgzf_compress(sam_text, block=3000))          # hundreds of tiny BGZF blocks
+    (tmp_path / "vb.vcf.gz").write_bytes(sv.bgzf_compress((tmp_path / "v.vcf").read_bytes(), block=777))
+    raw_bam = gzip.decompress((tmp_path / "plain.bam").read_bytes())
+    (tmp_path / "small.bam").write_bytes(sv.bgzf_compress(raw_bam, block=1021))          # records straddle block boundaries
+    outs = {}
+    runs = [("r.sam", "v.vcf", "1"), ("r.sam.gz", "v.vcf", "1"), ("rb.sam.gz", "v.vcf", "3"), ("r.bam", "v.vcf", "1"), ("r.bam", "vb.vcf.gz", "4"),
+            ("plain.bam", "v.vcf", "2"), ("small.bam", "vb.vcf.gz", "7")]
+    for i, (sam, vcf, threads) in enumerate(runs):
+        env = dict(os.environ, DMX_THREADS=threads)
+        subprocess.run([cli, "--sam", str(tmp_path / sam), "--vcf", str(tmp_path / vcf), "--field", "GT", "--out", str(tmp_path / f"o{i}"),
+                        "--pileup-only"], check=True, stderr=subprocess.DEVNULL, env=env)
+        outs[i] = (tmp_path / f"o{i}.pileup.txt").read_bytes()
+    assert len(outs[0]) > 1000
+    for i in outs:
+        assert outs[i] == outs[0], runs[i]
+
+
+def test_corrupt_bgzf_is_fatal(cli, tmp_path):
+    """A flipped byte inside a BGZF block (CRC mismatch) and a truncated file stop the run with a message, as htslib would."""
+    rng = np.random.default_rng(6)
+    recs = sv.make_vcf(rng, CONTIGS, 30, SAMPLES, tmp_path / "v.vcf")
+    sv.make_reads(rng, CONTIGS, recs, 800, ["A-1", "C-1"], tmp_path / "r.sam", tmp_path / "r.bam")
+    good = bytearray((tmp_path / "r.bam").read_bytes())
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x5a
+    (tmp_path / "flip.bam").write_bytes(bytes(bad))
+    (tmp_path / "trunc.bam").write_bytes(bytes(good[: len(good) // 2]))
+    for name in ("flip.bam", "trunc.bam"):
+        r = subprocess.run([cli, "--sam", str(tmp_path / name), "--vcf", str(tmp_path / "v.vcf"), "--field", "GT", "--out", str(tmp_path / "x"),
+                            "--pileup-only"], capture_output=True, text=True)
+        assert r.returncode != 0 and ("BGZF" in r.stderr or "truncated" in r.stderr or "corrupt" in r.stderr), (name, r.stderr[-300:])
 
 
 def test_options_filters_and_sample_selection(cli, oracle, tmp_path):
