@@ -774,7 +774,8 @@ __global__ void k_transpose_geno(const float* __restrict__ g, const double* __re
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K2, generic form (any V, any A).  One cell per workgroup.  Accumulator q of the cell (q < V*V*A: (j,k,n) row-major,
-// then A entries for llks00) lives in lane q % 256, register q / 256.
+// then A entries for llks00) lives in lane q % 256, register q / 256; grids with more than NACC*256 accumulators are cut into
+// slabs of that many, one workgroup (blockIdx.y) per slab, each repeating the cheap phase 1 for itself.
 //   phase 1  lane (pair ti, alpha n): the 9 mixture likelihoods pG[n][l][m] of that pair, reads in UMI order, with the
 //            one-max-across-all-alphas renormalisation after every read (:600-663); A is padded to a power of two so the
 //            A lanes of a pair sit together in a wavefront and share their max by butterfly shuffles;
@@ -825,12 +826,13 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
   // phase-2 identity
   const int32_t nAB = V * V * A;
   const int32_t nacc = nAB + A;
+  const int32_t q0 = (int32_t)blockIdx.y * NACC * kThreads;      // first accumulator of this workgroup's slab
   bool ok = true;              // every log() argument so far was a normal positive double (the fast path's domain)
   uint32_t code[NACC];         // (j << 20) | (k << 8) | n ; j = 0xFFF marks an llks00 entry; ~0u = no accumulator
   double acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
-    const int32_t q = t + i * kThreads;
+    const int32_t q = q0 + t + i * kThreads;
     acc[i] = 0.0;
     if (q < nAB) {
       const int32_t n = q % A, jk = q / A;
@@ -954,7 +956,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 
 #pragma unroll
   for (int i = 0; i < NACC; ++i) {
-    const int32_t q = t + i * kThreads;
+    const int32_t q = q0 + t + i * kThreads;
     if (q < nAB) grid[(size_t)cell * nAB + q] = acc[i];
     else if (q < nacc) l00[(size_t)cell * A + (q - nAB)] = acc[i];
   }
@@ -1011,10 +1013,13 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
   const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
   int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
 
-  // phase-2 identity
+  // phase-2 identity.  A workgroup covers JS = TPC / KB rows j of the cell's grid; panels with more rows than that are cut
+  // into j-slabs, one workgroup (blockIdx.y) per slab, each repeating the cheap phases 0-1 for itself.
   const int KB = (V + NK - 1) / NK;              // k-blocks per j
-  const int j = tid / KB, kb = tid % KB;
-  const bool owner = j < V;                      // V*KB <= TPC owners
+  const int JS = TPC / KB;
+  const int jl = tid / KB, kb = tid % KB;
+  const int j = (int)blockIdx.y * JS + jl;
+  const bool owner = jl < JS && j < V;
   double acc[NK][A];
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
@@ -1182,7 +1187,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
         }
       }
     }
-    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (tid < 2 && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
     if (!ok) flagged[cell] = 1;
   }
 #undef DMX_K2_SYNC
@@ -1277,8 +1282,10 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
   int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
 
   const int KB = (V + NK - 1) / NK;
-  const int j = tid / KB, kb = tid % KB;
-  const bool owner = j < V;
+  const int JS = TPC / KB;                       // rows per workgroup; more rows => j-slabs over blockIdx.y (see k_doublet_a2)
+  const int jl = tid / KB, kb = tid % KB;
+  const int j = (int)blockIdx.y * JS + jl;
+  const bool owner = jl < JS && j < V;
   double acc[NK][A];
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
@@ -1459,7 +1466,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
         }
       }
     }
-    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (tid < 2 && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
     if (!ok) flagged[cell] = 1;
   }
 #undef DMX_K2_SYNC
@@ -1882,7 +1889,10 @@ int launch_doublet_generic(dmx_engine* e) {
   const int TP = std::min(32, kThreads / A_pad);
   const int64_t nacc = (int64_t)V * V * A + A;
   const int per = (int)((nacc + kThreads - 1) / kThreads);
-  const dim3 grid((unsigned)B), block(kThreads);
+  if (nacc > 0x7FFFFFFFll || V > 0xFFE) return set_error(DMX_ERR_ARG, "run_doublet: V*V*A = %lld accumulators per cell exceed this build's limit", (long long)nacc);
+  const int slab_acc = 33;                        // accumulators per thread when the grid is cut into slabs
+  const unsigned slabs = per <= 65 ? 1u : (unsigned)((nacc + (int64_t)slab_acc * kThreads - 1) / ((int64_t)slab_acc * kThreads));
+  const dim3 grid((unsigned)B, slabs), block(kThreads);
 #define DMX_K2(NN)                                                                                                   \
   hipLaunchKernelGGL((k_doublet_generic<NRD, NN, FIXUP>), grid, block, 0, e->stream, e->pv, e->d_g, e->d_gp0, e->d_lut, \
                      e->d_alpha, e->d_sched, V, A, A_pad, TP, e->d_grid, e->d_l00, e->d_flag)
@@ -1893,7 +1903,7 @@ int launch_doublet_generic(dmx_engine* e) {
   else if (per <= 16) DMX_K2(16);
   else if (per <= 33) DMX_K2(33);
   else if (per <= 65) DMX_K2(65);
-  else return set_error(DMX_ERR_ARG, "run_doublet: V*V*A = %lld accumulators per cell exceed this build's limit", (long long)nacc);
+  else DMX_K2(33);                                // slabs of 33 * 256 accumulators
 #undef DMX_K2
   return DMX_OK;
 }
@@ -1908,21 +1918,23 @@ int launch_doublet_generic_w(dmx_engine* e) {
 int launch_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
   const bool force_generic = getenv("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
-  if (A != 2 || V > 64 || force_generic) {
+  const bool use_cls = e->n_classes > 0 && !getenv("DMX_NO_CLASSES");
+  // wide panels: the class kernel's LDS grows by 32 bytes per sample, the general A = 2 kernel's by 384 (64 KB at V = 128)
+  if (A != 2 || force_generic || V > (use_cls ? 1024 : 128)) {
     HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
     if (int rc = launch_doublet_generic_w<false>(e)) return rc;
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
   }
-  const bool no_classes = getenv("DMX_NO_CLASSES") != nullptr;          // kernel experiments / tests only
-  if (e->n_classes > 0 && !no_classes) {
+  auto slabs_of = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
+  if (use_cls) {
     const int VS = (V <= 32) ? ((V + 3) & ~3) : ((V + 15) & ~15);   // id row stride: a whole number of k-blocks
     size_t cb = (size_t)32 * 18 * 8 + (size_t)32 * 32 * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8) + (size_t)32 * 12 * 4 + (size_t)32 * VS;
     cb = (cb + 15) & ~(size_t)15;
     HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
     const dim3 blk(kThreads);
 #define DMX_K2C(TPC, NK)                                                                                             \
-  hipLaunchKernelGGL((k_doublet_cls<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), blk,   \
+  hipLaunchKernelGGL((k_doublet_cls<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), blk,   \
                      cb * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0, e->d_lut,   \
                      e->d_alpha, e->d_sched, V, VS, e->d_grid, e->d_l00, e->d_flag)
     if (V <= 8) DMX_K2C(64, 1);
@@ -1938,7 +1950,7 @@ int launch_doublet(dmx_engine* e) {
   HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
   const dim3 block(kThreads);
 #define DMX_K2A(TPC, NK)                                                                                             \
-  hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), block,  \
+  hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
                      e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag)
   if (V <= 8) DMX_K2A(64, 1);

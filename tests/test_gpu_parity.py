@@ -173,6 +173,9 @@ def host_pileup(eng, sp):
     (9, 400, 33, (0.0, 0.3, 0.5), 0.3, 1.25, False),    # V not a multiple of anything, A=3
     (5, 300, 65, (0.0, 0.5), 0.3, 1.25, False),         # V just above a chunk/register boundary
     (20, 500, 5, (0.0, 0.1, 0.2, 0.3, 0.5), 0.3, 4.0, False),   # A=5 (padded to 8 lanes per pair)
+    (4, 200, 100, (0.0, 0.5), 0.3, 1.25, False),        # wide panel: 20 002 accumulators per cell -> 3 slabs of the generic K2
+    (3, 150, 70, (0.0, 0.1, 0.25, 0.4, 0.5), 0.3, 1.5, False),   # V=70 x A=5: 24 505 accumulators, slabs + padded alphas
+    (2, 120, 200, (0.0, 0.5), 0.4, 1.25, True),         # V=200 (dense): general K1 with 25 chunks, 10 slabs in K2
 ])
 def test_seeded_problems_against_oracle(eng, oracle, B, S, V, alphas, delta, rbar, dense):
     rng, raw, sp = synth_problem(1000 + B + V, B, S, V, delta, rbar, dense)
@@ -303,7 +306,10 @@ def test_records_path_end_to_end(eng, oracle, name, tmp_path):
                     assert x == y, (suf, a, b)
 
 
-@pytest.mark.parametrize("V,B,S,delta,missing", [(8, 40, 600, 0.3, 0.0), (16, 20, 500, 0.3, 0.1), (32, 12, 400, 0.5, 0.05), (64, 5, 300, 0.3, 0.0), (3, 30, 200, 1.0, 0.2)])
+@pytest.mark.parametrize("V,B,S,delta,missing", [(8, 40, 600, 0.3, 0.0), (16, 20, 500, 0.3, 0.1), (32, 12, 400, 0.5, 0.05), (64, 5, 300, 0.3, 0.0), (3, 30, 200, 1.0, 0.2),
+                                                 (100, 4, 200, 0.3, 0.05),     # wide panels: j-slabs (class: 3 slabs; general A=2: 3 slabs)
+                                                 (128, 3, 150, 0.4, 0.0),      # 4 x 32 rows, the general kernel's LDS limit
+                                                 (200, 2, 120, 0.4, 0.1)])     # class K2 in 11 slabs vs the generic slab kernel
 def test_genotype_class_kernel_is_bit_identical_to_the_general_one(eng, oracle, V, B, S, delta, missing):
     """--field GT gives <= 4 distinct probability rows per SNP; the class kernel evaluates log() once per distinct
     (row_j, row_k) and must reproduce the general kernel BIT FOR BIT (same operands, same operations, same add order)."""
@@ -378,3 +384,26 @@ def test_without_the_arbiter_only_the_order_inside_a_doublet_can_differ(eng, ora
         assert (a[6], a[8]) == (b[6], b[8])                                          # SNG.1ST, SNG.2ND
         assert {a[11], a[12]} == {b[11], b[12]} and a[13] == b[13]                   # unordered DBL pair, ALPHA
         assert abs(float(a[14]) - float(b[14])) < 1.01e-4                            # LLK12
+
+
+@pytest.mark.parametrize("V,field", [(70, "GP"), (100, "GP"), (128, "PL"), (150, "GP")])
+def test_wide_panels_against_oracle(eng, oracle, V, field):
+    """Panels wider than one workgroup's 64 rows (pooled designs with 70-150 donors), soft genotype fields (no classes):
+    the A = 2 kernel in j-slabs up to V = 128, the generic kernel in accumulator slabs beyond."""
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(900 + V)
+    S, B = 150, 3
+    raw = synth.make_raw_genotypes(rng, S, V)
+    if field == "GP":
+        gp = synth.raw_gp_from_alleles(rng, raw.alleles)
+        g = np.stack([eng.geno_from_gp(gp[s], 0.01) for s in range(S)])
+    else:
+        plv = synth.raw_pl_from_alleles(rng, raw.alleles)
+        g = np.stack([eng.geno_from_pl(plv[s]) for s in range(S)])
+    sp = synth.make_pileup(rng, raw.alleles, B, 0.4, 1.5, dense_layout=False, doublet_rate=0.3)
+    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    out = run_engine(eng, host_pileup(eng, sp), g, (0.0, 0.5), 0.5)
+    d = [np.abs(out["llks"] - ref.llks).max(), np.abs(out["llk0s"] - ref.llk0s).max(), np.abs(out["grid"] - ref.llksAB).max(),
+         np.abs(out["l00"] - ref.llks00).max()]
+    print(f"V={V} {field}: max|d| = " + " ".join(f"{x:.2e}" for x in d))
+    assert max(d) < TOL
