@@ -172,7 +172,7 @@ __device__ __forceinline__ uint32_t load_nrd(const void* __restrict__ base, int6
 template <int CW, int KC, bool DENSE>
 __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_width, const float* __restrict__ gq,
                                                          const double* __restrict__ g0q, const double* __restrict__ tabs,
-                                                         const int32_t* __restrict__ sched, int32_t V,
+                                                         const int32_t* __restrict__ sched, int32_t V, int32_t QS,
                                                          double* __restrict__ llks, double* __restrict__ llk0s) {
   constexpr int ablate = DMX_ABLATE;             // profiling builds only (tools/build_variant.sh); 0 in the product
   constexpr int T = 64 / CW;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
   constexpr int NC = KC + 1;                     // chains per cell and chunk: KC samples + llk0 (chunk 0 only)
   constexpr int NW = kThreads / 64;
   static_assert(CW * NC <= 64, "one lane per chain");
-  extern __shared__ double s_dyn[];              // [NW][nch][CW*NC] running accumulators
+  extern __shared__ double s_dyn[];              // [NW][nq][CW*NC] running accumulators of this workgroup's sample chunks
   __shared__ double s_tab[kTabK1];
   const double* s_first = s_tab + kTab;
   __shared__ __attribute__((aligned(16))) double s_term[NW][CW * NC * TS];
@@ -190,12 +190,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
 
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int nch = (V + KC - 1) / KC;
+  // panels with more than QS chunks of KC samples are cut into sample slabs, one workgroup (blockIdx.y) per slab; each
+  // slab recomputes the (cheap) genotype likelihoods of its cells' pairs
+  const int q_lo = (int)blockIdx.y * QS, q_hi = min(nch, q_lo + QS), nq = q_hi - q_lo;
   for (int i = t; i < kTabK1; i += kThreads) s_tab[i] = tabs[i];
-  for (int i = t; i < NW * nch * CW * NC; i += kThreads) s_dyn[i] = 0.0;
+  for (int i = t; i < NW * nq * CW * NC; i += kThreads) s_dyn[i] = 0.0;
   __syncthreads();                               // the only workgroup barrier
 
   double* term = s_term[w];
-  double* accs = s_dyn + (size_t)w * nch * CW * NC;
+  double* accs = s_dyn + (size_t)w * nq * CW * NC;
   const int slot0 = (blockIdx.x * NW + w) * CW;  // first of this wavefront's cells in launch order
   if (slot0 >= pv.B) return;
 
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
     const float* __restrict__ grow = gq + (size_t)cur.snp * V * 3;
     const double* __restrict__ g0row = g0q + (size_t)cur.snp * 3;
 
-    for (int q = 0; q < nch; ++q) {
+    for (int q = q_lo; q < q_hi; ++q) {
       const int k0 = q * KC;
       float a[KC][3];
       double a0[3];
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
         const int64_t left = a_np - tile * T;
         const int cnt = (ablate & 4) ? 1 : (left >= T ? T : (left > 0 ? (int)left : 0));
         const double* row = &term[lane * TS];
-        double s = accs[q * (CW * NC) + lane];
+        double s = accs[(q - q_lo) * (CW * NC) + lane];
         int i = 0;
         for (; i + 16 <= cnt; i += 16) {           // loads first (latency paid once), then the ordered adds
           double2 v[8];
@@ -362,14 +365,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
           for (int j = 0; j < 8; ++j) { s += v[j].x; s += v[j].y; }
         }
         for (; i < cnt; ++i) s += row[i];           // ascending SNP order: the reference's order
-        accs[q * (CW * NC) + lane] = s;
+        accs[(q - q_lo) * (CW * NC) + lane] = s;
       }
       DMX_WAVE_LDS_ORDER();
     }
   }
   if (a_ok) {
-    for (int q = 0; q < nch; ++q) {
-      const double s = accs[q * (CW * NC) + lane];
+    for (int q = q_lo; q < q_hi; ++q) {
+      const double s = accs[(q - q_lo) * (CW * NC) + lane];
       if (a_kk < KC) { const int k = q * KC + a_kk; if (k < V) llks[(size_t)a_cell * V + k] = s; }
       else if (q == 0) llk0s[a_cell] = s;
     }
@@ -1863,16 +1866,17 @@ int launch_singlet(dmx_engine* e) {
   }
   const int nch = (V + KC - 1) / KC;
   const int NW = kThreads / 64;
-  const size_t dyn = sizeof(double) * (size_t)NW * nch * CW * (KC + 1);
-  if (dyn > 16 * 1024) return set_error(DMX_ERR_ARG, "run_singlet: n_samples %d too large for this build", V);
+  const int QS = std::min(nch, (int)(16 * 1024 / (sizeof(double) * (size_t)NW * CW * (KC + 1))));   // chunks per workgroup: 16 KB of sums
+  const unsigned q_slabs = (unsigned)((nch + QS - 1) / QS);
+  const size_t dyn = sizeof(double) * (size_t)NW * QS * CW * (KC + 1);
   const bool dense = e->pv.pair_snp == nullptr;
   if (dense && (size_t)e->S * V * 12 > 0x7FFFFFFFull) return set_error(DMX_ERR_ARG, "run_singlet: dense genotype matrix over 2 GiB is not supported by this build");
   const float* gq = dense ? e->d_gT : e->d_g;
   const double* g0q = dense ? e->d_g0T : e->d_gp0;
-  const dim3 block(kThreads), grid((unsigned)((B + NW * CW - 1) / (NW * CW)));
+  const dim3 block(kThreads), grid((unsigned)((B + NW * CW - 1) / (NW * CW)), q_slabs);
 #define DMX_K1(CC, KK, DD)                                                                                            \
   hipLaunchKernelGGL((k_singlet<CC, KK, DD>), grid, block, dyn, e->stream, e->pv, e->nrd_width, gq, g0q, e->d_lut,     \
-                     e->d_sched, V, e->d_llks, e->d_llk0s)
+                     e->d_sched, V, QS, e->d_llks, e->d_llk0s)
 #define DMX_K1_D(CC, KK) do { if (dense) DMX_K1(CC, KK, true); else DMX_K1(CC, KK, false); } while (0)
   if (KC == 4) { if (CW == 4) DMX_K1_D(4, 4); else if (CW == 2) DMX_K1_D(2, 4); else DMX_K1_D(1, 4); }
   else         { if (CW == 4) DMX_K1_D(4, 8); else if (CW == 2) DMX_K1_D(2, 8); else DMX_K1_D(1, 8); }

@@ -176,6 +176,7 @@ def host_pileup(eng, sp):
     (4, 200, 100, (0.0, 0.5), 0.3, 1.25, False),        # wide panel: 20 002 accumulators per cell -> 3 slabs of the generic K2
     (3, 150, 70, (0.0, 0.1, 0.25, 0.4, 0.5), 0.3, 1.5, False),   # V=70 x A=5: 24 505 accumulators, slabs + padded alphas
     (2, 120, 200, (0.0, 0.5), 0.4, 1.25, True),         # V=200 (dense): general K1 with 25 chunks, 10 slabs in K2
+    (2, 60, 600, (0.0, 0.5), 0.4, 1.25, False),         # V=600: K1 in two sample slabs (75 chunks > 56), class K2 in 100 j-slabs
 ])
 def test_seeded_problems_against_oracle(eng, oracle, B, S, V, alphas, delta, rbar, dense):
     rng, raw, sp = synth_problem(1000 + B + V, B, S, V, delta, rbar, dense)
@@ -386,7 +387,7 @@ def test_without_the_arbiter_only_the_order_inside_a_doublet_can_differ(eng, ora
         assert abs(float(a[14]) - float(b[14])) < 1.01e-4                            # LLK12
 
 
-@pytest.mark.parametrize("V,field", [(70, "GP"), (100, "GP"), (128, "PL"), (150, "GP")])
+@pytest.mark.parametrize("V,field", [(70, "GP"), (100, "GP"), (128, "PL"), (150, "GP"), (500, "GP")])
 def test_wide_panels_against_oracle(eng, oracle, V, field):
     """Panels wider than one workgroup's 64 rows (pooled designs with 70-150 donors), soft genotype fields (no classes):
     the A = 2 kernel in j-slabs up to V = 128, the generic kernel in accumulator slabs beyond."""
