@@ -2196,55 +2196,85 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   if (int rc = dmx_store_freeze(job->store, &pl)) return rc;
   const int32_t B = pl.n_cells, V = job->n_samples, A = job->n_alpha;
   const size_t nAB = (size_t)V * V * A;
+  const bool doublet_ok = V >= 2 && A >= 2;
   std::vector<const char*> bcs((size_t)B);
   std::vector<int32_t> nsnp((size_t)B);
   for (int32_t c = 0; c < B; ++c) { bcs[c] = dmx_store_barcode(job->store, c); nsnp[c] = (int32_t)(pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]); }
-
-  // ---- shards: contiguous ranges of the byte-wise sorted barcodes with equal work (log evaluations)
-  const int nshard = std::max(1, std::min(job->n_gpus > 0 ? job->n_gpus : 1, std::max(B, 1)));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return set_error(DMX_ERR_NOGPU, "dmx_demuxlet_run: no HIP device is visible (this library has no CPU fallback)");
+
+  // ---- ranges: contiguous runs of the byte-wise sorted barcodes (= output order, cmd_cram_demuxlet.cpp:472,:576) with equal
+  // work.  One engine per GPU; a range is what one engine holds at a time, sized so that its doublet grid stays inside a
+  // byte budget (the grid, nb * V*V*A doubles, is the only thing that grows with the panel).  Ranges go through the engines
+  // in waves; while the host formats and appends the rows of wave w, the GPUs already compute wave w + 1.
+  const int ngpu = std::max(1, std::min(job->n_gpus > 0 ? job->n_gpus : 1, std::max(B, 1)));
+  size_t budget = (size_t)4 << 30;                                   // bytes of grid per range (host holds two waves of them)
+  if (const char* env = getenv("DMX_RANGE_BYTES")) budget = (size_t)std::max(1ll, atoll(env));   // tests: force many ranges
+  {
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipSetDevice(job->device % ndev));
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < budget) budget = std::max<size_t>(free_b / 3, 1);
+  }
+  const double grid_total = doublet_ok ? (double)B * (double)nAB * 8.0 : 0.0;
+  const int by_mem = (int)std::min<double>((double)std::max(B, 1), std::ceil(grid_total / (double)budget));
+  int R = std::max(ngpu, by_mem);
+  R = ((R + ngpu - 1) / ngpu) * ngpu;                                 // whole waves
+  R = std::max(1, std::min(R, std::max(B, 1)));
   std::vector<int32_t> order((size_t)B);
   std::iota(order.begin(), order.end(), 0);
-  if (nshard > 1) std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return std::strcmp(bcs[a], bcs[b]) < 0; });
-  std::vector<int32_t> cut((size_t)nshard + 1, 0);
+  if (R > 1) std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return std::strcmp(bcs[a], bcs[b]) < 0; });
+  std::vector<int32_t> cut((size_t)R + 1, 0);
   {
     const double per_pair = (double)(V + 1) + (double)nAB + A;
     double total = 0;
     for (int32_t c = 0; c < B; ++c) total += nsnp[c] * per_pair + 1.0;
     double run = 0;
     int r = 1;
-    for (int32_t i = 0; i < B && r < nshard; ++i) {
+    for (int32_t i = 0; i < B && r < R; ++i) {
       run += nsnp[order[i]] * per_pair + 1.0;
-      while (r < nshard && run >= total * r / nshard) cut[(size_t)r++] = i + 1;
+      while (r < R && run >= total * r / R) cut[(size_t)r++] = i + 1;
     }
-    for (; r <= nshard; ++r) cut[(size_t)r] = B;
-    cut[(size_t)nshard] = B;
+    for (; r <= R; ++r) cut[(size_t)r] = B;
+    cut[(size_t)R] = B;
   }
 
-  struct Shard {
-    dmx_engine* e = nullptr;
+  struct Range {
     std::vector<int64_t> pair_off, read_off;
-    std::vector<int32_t> snp;
+    std::vector<int32_t> snp, totl, pass, uniq, ns;
     std::vector<uint8_t> nrd, reads;
+    std::vector<const char*> bc;
+    std::vector<double> llks, llk0s, grid, l00;
     dmx_pileup pl{};
     int32_t lo = 0, hi = 0;
+    void release() { *this = Range(); }
   };
-  std::vector<Shard> sh((size_t)nshard);
-  struct Guard { std::vector<Shard>* s; ~Guard() { for (Shard& x : *s) if (x.e) dmx_engine_destroy(x.e); } } guard{&sh};
+  std::vector<Range> rg((size_t)R);
+  std::vector<dmx_engine*> eng((size_t)std::min(ngpu, R), nullptr);
+  struct Guard { std::vector<dmx_engine*>* e; ~Guard() { for (dmx_engine* x : *e) if (x) dmx_engine_destroy(x); } } guard{&eng};
+  for (size_t i = 0; i < eng.size(); ++i) {
+    dmx_engine_config cfg{};
+    cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior;
+    cfg.device = (job->device + (int)i) % ndev; cfg.mode = DMX_MODE_STRICT;
+    if (int rc = dmx_engine_create(&cfg, &eng[i])) return rc;
+    if (int rc = dmx_engine_set_genotypes(eng[i], job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
+  }
 
-  for (int i = 0; i < nshard; ++i) {
-    Shard& x = sh[(size_t)i];
-    x.lo = cut[(size_t)i]; x.hi = cut[(size_t)i + 1];
+  auto launch = [&](int r) -> int {              // stage range r on its engine and start its kernels (asynchronous)
+    Range& x = rg[(size_t)r];
+    x.lo = cut[(size_t)r]; x.hi = cut[(size_t)r + 1];
     const int32_t nb = x.hi - x.lo;
     const dmx_pileup* use = &pl;
-    if (nshard > 1) {                            // slice the CSR: cells order[lo..hi) become cells 0..nb-1 of the shard
+    if (R > 1) {                                 // slice the CSR: cells order[lo..hi) become cells 0..nb-1 of the range
       x.pair_off.assign((size_t)nb + 1, 0); x.read_off.assign((size_t)nb + 1, 0);
+      const size_t nb1 = (size_t)std::max(nb, 1);                      // an empty range still hands non-null arrays to the writers
+      x.totl.resize(nb1); x.pass.resize(nb1); x.uniq.resize(nb1); x.ns.resize(nb1); x.bc.resize(nb1);
       for (int32_t k = 0; k < nb; ++k) {
         const int32_t c = order[(size_t)x.lo + k];
         x.pair_off[(size_t)k + 1] = x.pair_off[(size_t)k] + (pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]);
         x.read_off[(size_t)k + 1] = x.read_off[(size_t)k] + (pl.cell_read_off[c + 1] - pl.cell_read_off[c]);
+        x.totl[(size_t)k] = pl.rd_totl[c]; x.pass[(size_t)k] = pl.rd_pass[c]; x.uniq[(size_t)k] = pl.rd_uniq[c];
+        x.ns[(size_t)k] = nsnp[(size_t)c]; x.bc[(size_t)k] = bcs[(size_t)c];
       }
       x.snp.resize((size_t)x.pair_off[(size_t)nb]);
       x.nrd.resize((size_t)x.pair_off[(size_t)nb] * (size_t)pl.nrd_width + 4);
@@ -2263,55 +2293,55 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
       x.pl.n_cells = nb; x.pl.n_pairs = x.pair_off[(size_t)nb]; x.pl.n_reads = x.read_off[(size_t)nb];
       x.pl.cell_pair_off = x.pair_off.data(); x.pl.cell_read_off = x.read_off.data(); x.pl.pair_snp = x.snp.data();
       x.pl.pair_nrd = x.nrd.data(); x.pl.reads = x.reads.data();
-      x.pl.rd_totl = x.pl.rd_pass = x.pl.rd_uniq = nullptr;
+      x.pl.rd_totl = x.totl.data(); x.pl.rd_pass = x.pass.data(); x.pl.rd_uniq = x.uniq.data();
       use = &x.pl;
     }
-    dmx_engine_config cfg{};
-    cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior;
-    cfg.device = (job->device + i) % ndev; cfg.mode = DMX_MODE_STRICT;
-    if (int rc = dmx_engine_create(&cfg, &x.e)) return rc;
-    if (int rc = dmx_engine_set_genotypes(x.e, job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
-    if (int rc = dmx_engine_set_pileup(x.e, use)) return rc;
-  }
-  // ---- all shards compute concurrently (every engine has its own stream; launches are asynchronous)
-  for (Shard& x : sh) if (int rc = dmx_engine_run_singlet(x.e)) return rc;
-  const bool doublet_ok = V >= 2 && A >= 2;
-  if (doublet_ok) for (Shard& x : sh) if (int rc = dmx_engine_run_doublet(x.e)) return rc;
-
-  // ---- collect per-cell results on the host, back in cell-id order
-  std::vector<double> llks((size_t)B * V), llk0s((size_t)B);
-  std::vector<double> grid, l00;
-  if (doublet_ok) { grid.resize((size_t)B * nAB); l00.resize((size_t)B * A); }
-  for (Shard& x : sh) {
-    const int32_t nb = x.hi - x.lo;
-    if (nshard == 1) {
-      if (int rc = dmx_engine_get_singlet(x.e, llks.data(), llk0s.data())) return rc;
-      if (doublet_ok) if (int rc = dmx_engine_get_doublet(x.e, grid.data(), l00.data(), nullptr)) return rc;
-    } else {
-      std::vector<double> a((size_t)nb * V), b((size_t)nb), g2, z;
-      if (int rc = dmx_engine_get_singlet(x.e, a.data(), b.data())) return rc;
-      if (doublet_ok) { g2.resize((size_t)nb * nAB); z.resize((size_t)nb * A); if (int rc = dmx_engine_get_doublet(x.e, g2.data(), z.data(), nullptr)) return rc; }
-      for (int32_t k = 0; k < nb; ++k) {
-        const int32_t c = order[(size_t)x.lo + k];
-        std::memcpy(&llks[(size_t)c * V], &a[(size_t)k * V], sizeof(double) * (size_t)V);
-        llk0s[(size_t)c] = b[(size_t)k];
-        if (doublet_ok) {
-          std::memcpy(&grid[(size_t)c * nAB], &g2[(size_t)k * nAB], sizeof(double) * nAB);
-          std::memcpy(&l00[(size_t)c * A], &z[(size_t)k * A], sizeof(double) * (size_t)A);
-        }
-      }
+    dmx_engine* e = eng[(size_t)r % eng.size()];
+    if (int rc = dmx_engine_set_pileup(e, use)) return rc;
+    if (int rc = dmx_engine_run_singlet(e)) return rc;
+    if (doublet_ok) if (int rc = dmx_engine_run_doublet(e)) return rc;
+    return DMX_OK;
+  };
+  auto fetch = [&](int r) -> int {               // results of range r to the host (waits for its kernels)
+    Range& x = rg[(size_t)r];
+    const size_t nb = (size_t)(x.hi - x.lo);
+    dmx_engine* e = eng[(size_t)r % eng.size()];
+    x.llks.resize(std::max<size_t>(nb, 1) * (size_t)V); x.llk0s.resize(std::max<size_t>(nb, 1));
+    if (int rc = dmx_engine_get_singlet(e, x.llks.data(), x.llk0s.data())) return rc;
+    if (doublet_ok) {
+      x.grid.resize(std::max<size_t>(nb, 1) * nAB); x.l00.resize(std::max<size_t>(nb, 1) * (size_t)A);
+      if (int rc = dmx_engine_get_doublet(e, x.grid.data(), x.l00.data(), nullptr)) return rc;
     }
-  }
-  dmx_final_input fin{};
-  fin.n_cells = B; fin.n_samples = V; fin.n_alpha = A; fin.alpha = job->alpha; fin.doublet_prior = job->doublet_prior;
-  fin.min_total = job->min_total; fin.min_uniq = job->min_uniq; fin.min_snp = job->min_snp; fin.write_pair = job->write_pair;
-  fin.barcodes = bcs.data(); fin.sample_ids = job->sample_ids;
-  fin.rd_totl = pl.rd_totl; fin.rd_pass = pl.rd_pass; fin.rd_uniq = pl.rd_uniq; fin.n_snp = nsnp.data();
-  fin.llks = llks.data(); fin.llk0s = llk0s.data();
+    return DMX_OK;
+  };
   const std::string pre(job->out_prefix);
-  if (int rc = dmx_write_single(&fin, (pre + ".single").c_str())) return rc;
+  auto write = [&](int r) -> int {               // append range r's rows (rows of a range are sorted by the writers)
+    Range& x = rg[(size_t)r];
+    dmx_final_input fin{};
+    fin.n_cells = x.hi - x.lo; fin.n_samples = V; fin.n_alpha = A; fin.alpha = job->alpha; fin.doublet_prior = job->doublet_prior;
+    fin.min_total = job->min_total; fin.min_uniq = job->min_uniq; fin.min_snp = job->min_snp; fin.write_pair = job->write_pair;
+    fin.sample_ids = job->sample_ids;
+    if (R > 1) { fin.barcodes = x.bc.data(); fin.rd_totl = x.totl.data(); fin.rd_pass = x.pass.data(); fin.rd_uniq = x.uniq.data(); fin.n_snp = x.ns.data(); }
+    else { fin.barcodes = bcs.data(); fin.rd_totl = pl.rd_totl; fin.rd_pass = pl.rd_pass; fin.rd_uniq = pl.rd_uniq; fin.n_snp = nsnp.data(); }
+    fin.llks = x.llks.data(); fin.llk0s = x.llk0s.data();
+    if (int rc = dmx::write_single_impl(&fin, (pre + ".single").c_str(), r > 0)) return rc;
+    if (doublet_ok) {
+      fin.llksAB = x.grid.data(); fin.llks00 = x.l00.data();
+      if (job->arbiter) { fin.tie_pileup = (R > 1) ? &x.pl : &pl; fin.tie_g = job->g; }
+      if (int rc = dmx::write_doublet_impl(&fin, job->out_prefix, r > 0)) return rc;
+    }
+    x.release();
+    return DMX_OK;
+  };
+
+  const int per_wave = (int)eng.size(), waves = (R + per_wave - 1) / per_wave;
+  for (int r = 0; r < std::min(R, per_wave); ++r) if (int rc = launch(r)) return rc;
+  for (int w = 0; w < waves; ++w) {
+    const int r0 = w * per_wave, r1 = std::min(R, r0 + per_wave);
+    for (int r = r0; r < r1; ++r) if (int rc = fetch(r)) return rc;
+    for (int r = r1; r < std::min(R, r1 + per_wave); ++r) if (int rc = launch(r)) return rc;     // GPUs run wave w+1 ...
+    for (int r = r0; r < r1; ++r) if (int rc = write(r)) return rc;                               // ... while the host writes wave w
+  }
   if (!doublet_ok) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: the doublet stage needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
-  fin.llksAB = grid.data(); fin.llks00 = l00.data();
-  if (job->arbiter) { fin.tie_pileup = &pl; fin.tie_g = job->g; }
-  return dmx_write_doublet(&fin, job->out_prefix);
+  return DMX_OK;
 }

@@ -443,7 +443,7 @@ int check_common(const dmx_final_input* in, const char* who) {
 struct File {
   FILE* f = nullptr;
   ~File() { if (f) fclose(f); }
-  bool open(const std::string& path) { f = fopen(path.c_str(), "w"); return f != nullptr; }
+  bool open(const std::string& path, bool append = false) { f = fopen(path.c_str(), append ? "a" : "w"); return f != nullptr; }
 };
 
 // ---- rows are formatted by several host threads and written in barcode order ----------------------------------------
@@ -597,13 +597,15 @@ std::vector<int32_t> output_cells(const dmx_final_input* in, bool need_snps) {
 
 }  // namespace
 
-extern "C" int dmx_write_single(const dmx_final_input* in, const char* path) {
+extern "C" int dmx_write_single(const dmx_final_input* in, const char* path) { return dmx::write_single_impl(in, path, false); }
+
+int dmx::write_single_impl(const dmx_final_input* in, const char* path, bool append) {
   if (int rc = check_common(in, "dmx_write_single")) return rc;
   if (!path || !in->llks || !in->llk0s) return set_error(DMX_ERR_ARG, "dmx_write_single: null llks/llk0s/path");
   File w;
-  if (!w.open(path)) return set_error(DMX_ERR_IO, "Cannot create %s file", path);
+  if (!w.open(path, append)) return set_error(DMX_ERR_IO, "Cannot create %s file", path);
   const int32_t V = in->n_samples;
-  fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", w.f);                 // :470
+  if (!append) fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", w.f);    // :470
   const std::vector<int32_t> cells = output_cells(in, false);
   FILE* const files[kOutFiles] = {w.f, nullptr, nullptr};
   return format_in_order(cells.size(), std::max<size_t>(1, 8192 / (size_t)V), files, [&](size_t first, size_t last, Chunk& ck) {
@@ -630,18 +632,20 @@ extern "C" int dmx_write_single(const dmx_final_input* in, const char* path) {
   });
 }
 
-extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_prefix) {
+extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_prefix) { return dmx::write_doublet_impl(in, out_prefix, false); }
+
+int dmx::write_doublet_impl(const dmx_final_input* in, const char* out_prefix, bool append) {
   if (int rc = check_common(in, "dmx_write_doublet")) return rc;
   if (!out_prefix || !in->llksAB || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "dmx_write_doublet: null grid/alpha/prefix");
   const int32_t V = in->n_samples, A = in->n_alpha;
   if (V < 2 || A < 2) return set_error(DMX_ERR_ARG, "dmx_write_doublet: needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
   const std::string pre(out_prefix);
   File sing2, pairf, best;
-  if (!sing2.open(pre + ".sing2") || !best.open(pre + ".best") || (in->write_pair && !pairf.open(pre + ".pair")))
+  if (!sing2.open(pre + ".sing2", append) || !best.open(pre + ".best", append) || (in->write_pair && !pairf.open(pre + ".pair", append)))
     return set_error(DMX_ERR_IO, "Cannot create %s.single, %s.pair files", out_prefix, out_prefix);     // :535-536
-  fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", sing2.f);             // :533
-  if (pairf.f) fputs("BARCODE\tSM1.ID\tSM2.ID\tLLK12\tPOSTPRB\n", pairf.f);                              // :570 (5 names for 6 fields: reference quirk)
-  fputs("BARCODE\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tBEST\tSNG.1ST\tSNG.LLK1\tSNG.2ND\tSNG.LLK2\tSNG.LLK0\tDBL.1ST\tDBL.2ND\tALPHA\tLLK12\tLLK1\tLLK2\tLLK10\tLLK20\tLLK00\tPRB.DBL\tPRB.SNG1\n", best.f);  // :571
+  if (!append) fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", sing2.f);             // :533
+  if (pairf.f && !append) fputs("BARCODE\tSM1.ID\tSM2.ID\tLLK12\tPOSTPRB\n", pairf.f);                              // :570 (5 names for 6 fields: reference quirk)
+  if (!append) fputs("BARCODE\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tBEST\tSNG.1ST\tSNG.LLK1\tSNG.2ND\tSNG.LLK2\tSNG.LLK0\tDBL.1ST\tDBL.2ND\tALPHA\tLLK12\tLLK1\tLLK2\tLLK10\tLLK20\tLLK00\tPRB.DBL\tPRB.SNG1\n", best.f);  // :571
 
   const size_t ng = (size_t)V * V * A;
   const double prior = in->doublet_prior;

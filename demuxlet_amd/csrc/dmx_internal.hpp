@@ -31,4 +31,9 @@ struct GridReq { int32_t j, k, n; double value; };
 void exact_grid_entries(const dmx_pileup& pl, const float* g, int32_t V, int32_t A, const double* alpha,
                         const ReadLut& lut, int32_t cell, std::vector<GridReq>& reqs);
 
+// The writers behind dmx_write_single / dmx_write_doublet with an append mode: dmx_demuxlet_run streams contiguous ranges
+// of the sorted barcodes through the GPUs and appends each range's rows (append = true: no header, files opened "a").
+int write_single_impl(const dmx_final_input* in, const char* path, bool append);
+int write_doublet_impl(const dmx_final_input* in, const char* out_prefix, bool append);
+
 }  // namespace dmx

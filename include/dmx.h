@@ -217,10 +217,12 @@ typedef struct {
   const char*  out_prefix;
   int32_t      device;
   int32_t      arbiter;            /* 1 = run the tie arbiter (default in the CLI) */
-  int32_t      n_gpus;             /* 0 or 1: one GPU (`device`).  N > 1: the byte-wise sorted barcodes are cut into N contiguous
-                                      ranges of equal work, range i runs on device (device + i) mod (visible devices) with
-                                      its own engine and stream, all ranges concurrently; results are collected on the host.
-                                      Barcodes are independent (cmd_cram_demuxlet.cpp:576), so no collective is involved. */
+  int32_t      n_gpus;             /* 0 or 1: one GPU (`device`).  N > 1: one engine (own HIP stream) on each of devices
+                                      (device + i) mod (visible devices).  The byte-wise sorted barcodes are cut into contiguous
+                                      ranges of equal work — at least one per engine, more when a range's doublet grid would
+                                      exceed the byte budget (4 GiB, a third of the free device memory if that is less) — which go
+                                      through the engines in waves; the rows of a wave are formatted and appended on the host while
+                                      the next wave computes.  Barcodes are independent (cmd_cram_demuxlet.cpp:576): no collective. */
 } dmx_job;
 int dmx_demuxlet_run(const dmx_job*);
 

@@ -68,11 +68,17 @@ def test_golden_raw_arrays(eng, oracle, name):
     assert max(d1, d0, dg, d00) < TOL
 
 
-@pytest.mark.parametrize("n_gpus", [1, 3])
+@pytest.mark.parametrize("n_gpus,range_bytes", [(1, 0), (3, 0), (1, 3000), (2, 20000)])
 @pytest.mark.parametrize("name", CASES)
-def test_golden_files_end_to_end(eng, oracle, name, n_gpus, tmp_path):
+def test_golden_files_end_to_end(eng, oracle, name, n_gpus, range_bytes, tmp_path, monkeypatch):
     """Store -> engine -> finaliser with the tie arbiter == the reference's four files.  n_gpus = 3 shards the sorted
-    barcodes over three engines (all on device 0 on a 1-GPU box: same code path as three devices) and must not change a byte."""
+    barcodes over three engines (all on device 0 on a 1-GPU box: same code path as three devices) and must not change a byte;
+    DMX_RANGE_BYTES forces the doublet grid through the engines in many small ranges (several waves, rows appended range
+    by range while the next wave computes), which must not change a byte either."""
+    if range_bytes:
+        monkeypatch.setenv("DMX_RANGE_BYTES", str(range_bytes))
+    else:
+        monkeypatch.delenv("DMX_RANGE_BYTES", raising=False)
     gd = Golden(name)
     pb = gd.problem(oracle)
     st = build_store(eng, pb)
