@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--samples", type=int, default=0, help="override the number of samples (experiments; not the headline)")
     ap.add_argument("--field", default="", help="override the genotype field GT|GP|PL (experiments; not the headline)")
+    ap.add_argument("--alphas", default="", help="override the alpha grid, comma separated (experiments; not the headline)")
     args = ap.parse_args()
 
     import torch
@@ -170,8 +171,10 @@ def main():
         cfg["V"] = args.samples
     if args.field:
         cfg["field"] = args.field
-    if args.samples or args.field:
-        cfg["name"] += f" [override: V={cfg['V']}, field={cfg['field']}]"
+    if args.alphas:
+        cfg["alphas"] = tuple(float(x) for x in args.alphas.split(","))
+    if args.samples or args.field or args.alphas:
+        cfg["name"] += f" [override: V={cfg['V']}, field={cfg['field']}, alphas={list(cfg['alphas'])}]"
     B, S, V, A = cfg["B"], cfg["S"], cfg["V"], len(cfg["alphas"])
     rng = np.random.default_rng(0xD3A00000 + args.config)       # the panel is shared by all ranks
     raw, g = genotype_matrix(engine, synth, rng, S, V, cfg["field"])

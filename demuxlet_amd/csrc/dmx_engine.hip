@@ -1197,6 +1197,247 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// K2 for alpha grids of 3..8 entries: k_doublet_a2's ownership, order and arithmetic with AP (= A rounded up to 2, 4 or 8)
+// alphas per pair.  Phase 1 spreads the TP * AP (pair, alpha) lanes over all the cell's threads, in passes when the cell has
+// fewer than that; the one-max-across-ALL-alphas renormalisation (:626-639) is a butterfly over the AP lanes of a pair.
+// Phase 2 walks the alphas two at a time with their pG in registers, so an evaluation costs what it costs in k_doublet_a2.
+template <int TPC, int NK, int AP>
+__global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                         const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                         const double* __restrict__ alpha,
+                                                         const int32_t* __restrict__ sched, int32_t V, int32_t A, int32_t GS,
+                                                         double* __restrict__ grid, double* __restrict__ l00,
+                                                         uint8_t* __restrict__ flagged) {
+  static_assert(AP == 2 || AP == 4 || AP == 8, "alphas per pair padded to a power of two");
+  constexpr int TP = 32;
+  constexpr int CPW = kThreads / TPC;
+  constexpr int T00 = TP + 2;
+#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  __syncthreads();
+
+  const int cw = t / TPC, tid = t % TPC;
+  const size_t cell_bytes = (size_t)TP * AP * 9 * 8 + (size_t)TP * GS * 4 + (size_t)AP * T00 * 8 + TP * (4 + 4 + 8);
+  unsigned char* base = s_raw + (size_t)cw * cell_bytes;
+  double* s_pG = (double*)base;                                  // [TP][AP][9]
+  float* s_g = (float*)(base + (size_t)TP * AP * 9 * 8);         // [TP][GS]
+  double* s_t00 = (double*)((unsigned char*)s_g + (size_t)TP * GS * 4);   // [AP][T00]
+  int64_t* s_off = (int64_t*)(s_t00 + AP * T00);                 // [TP]
+  int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
+  uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
+
+  const int slot = blockIdx.x * CPW + cw;
+  if (TPC == 64 && slot >= pv.B) return;
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+
+  const int KB = (V + NK - 1) / NK;
+  const int JS = TPC / KB;
+  const int jl = tid / KB, kb = tid % KB;
+  const int j = (int)blockIdx.y * JS + jl;
+  const bool owner = jl < JS && j < V;
+  double acc[NK][AP];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+    for (int n = 0; n < AP; ++n) acc[kk][n] = 0.0;
+  bool ok = true;
+  double acc00 = 0.0;                            // lane tid < A owns llks00[tid]
+  const int row_len = V * 3;
+  constexpr int P1 = TP * AP;                    // phase-1 lanes per tile
+  constexpr int NPASS = (P1 + TPC - 1) / TPC;
+  const int n1 = tid % AP;                       // this thread's alpha in phase 1 (TPC is a multiple of AP)
+  const bool n_ok = n1 < A;
+  double wA[9], wR[9];
+  {
+    const double al = n_ok ? alpha[n1] : 0.0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * al;                       // :613
+        wA[l * 3 + m] = p;
+        wR[l * 3 + m] = 1.0 - p;
+      }
+  }
+
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_K2_SYNC();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    {
+      int r = tid % row_len, ti = tid / row_len;
+      const int dr = TPC % row_len, dt = TPC / row_len;
+      while (ti < tp) {
+        s_g[ti * GS + r] = g[(size_t)s_snp[ti] * row_len + r];
+        r += dr; ti += dt;
+        if (r >= row_len) { r -= row_len; ++ti; }
+      }
+    }
+    // ---- phase 1: lane u = (pair u / AP, alpha u % AP)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int u = tid + pass * TPC;
+      if (u >= P1) break;                          // uniform per wavefront (P1 and TPC are multiples of 64)
+      const int ti1 = u / AP;
+      const bool on = ti1 < tp && n_ok;
+      const uint32_t cnt = (ti1 < tp) ? s_cnt[ti1] : 0u;
+      const int64_t off = (ti1 < tp) ? s_off[ti1] : 0;
+      double pG[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt && n_ok;
+        const uint32_t byte = (r < cnt) ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+          }
+        }
+#pragma unroll
+        for (int d = 1; d < AP; d <<= 1) {                                  // one max across ALL alphas of the pair
+          const double o = __shfl_xor(mx, d);
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);       // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] /= mx;
+          }
+        }
+      }
+      double mx = 0.0;
+      if (n_ok) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          pG[i] += 1e-6;                                                     // :649
+          mx = (mx < pG[i]) ? pG[i] : mx;
+        }
+      }
+#pragma unroll
+      for (int d = 1; d < AP; d <<= 1) {
+        const double o = __shfl_xor(mx, d);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on) {
+        const double y = rcp_refined(mx);
+        const double* g0 = gp0 + (size_t)s_snp[ti1] * 3;
+        const double qq[3] = {g0[0], g0[1], g0[2]};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = div_by(pG[l * 3 + m], mx, y);                   // :656-663
+            s_pG[(ti1 * AP + n1) * 9 + l * 3 + m] = v;
+            sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
+          }
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+      }
+    }
+    DMX_K2_SYNC();
+    if (tid < A) {                                 // llks00[n]: lane n adds its alpha's terms in pair order
+      const double* row = &s_t00[tid * T00];
+      for (int i = 0; i < tp; ++i) acc00 += row[i];
+    }
+    // ---- phase 2
+    if (owner) {
+      for (int ti = 0; ti < tp; ++ti) {
+        const float* gr = &s_g[ti * GS];
+        const double aj[3] = {(double)gr[j * 3], (double)gr[j * 3 + 1], (double)gr[j * 3 + 2]};
+#pragma unroll
+        for (int ap = 0; ap < AP / 2; ++ap) {
+          if (2 * ap >= A) break;
+          const double* P = &s_pG[(ti * AP + 2 * ap) * 9];
+          if (2 * ap + 1 < A) {                    // two alphas share the nine products
+            double P0[9], P1v[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { P0[i] = P[i]; P1v[i] = P[9 + i]; }
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+              const int k = min(kb * NK + kk, V - 1);
+              const double bk[3] = {(double)gr[k * 3], (double)gr[k * 3 + 1], (double)gr[k * 3 + 2]};
+              double s0 = 0.0, s1 = 0.0;                                      // :674
+#pragma unroll
+              for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                  const double gp = aj[l] * bk[m];                            // :553 (exact)
+                  s0 += (gp * P0[l * 3 + m]);                                 // :677-679, l-major
+                  s1 += (gp * P1v[l * 3 + m]);
+                }
+              ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
+              acc[kk][2 * ap] += dmx_log_fast(s0, s_log);                     // :683
+              acc[kk][2 * ap + 1] += dmx_log_fast(s1, s_log);
+            }
+          } else {                                 // the last alpha of an odd-sized grid
+            double P0[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) P0[i] = P[i];
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+              const int k = min(kb * NK + kk, V - 1);
+              const double bk[3] = {(double)gr[k * 3], (double)gr[k * 3 + 1], (double)gr[k * 3 + 2]};
+              double s0 = 0.0;
+#pragma unroll
+              for (int l = 0; l < 3; ++l)
+#pragma unroll
+                for (int m = 0; m < 3; ++m) s0 += ((aj[l] * bk[m]) * P0[l * 3 + m]);
+              ok &= __builtin_amdgcn_class(s0, 0x100);
+              acc[kk][2 * ap] += dmx_log_fast(s0, s_log);
+            }
+          }
+        }
+      }
+    }
+    DMX_K2_SYNC();
+  }
+  if (cell_ok) {
+    if (owner) {
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const int k = kb * NK + kk;
+        if (k < V) {
+          double* o = grid + (((size_t)cell * V + j) * V + k) * A;
+#pragma unroll
+          for (int n = 0; n < AP; ++n) if (n < A) o[n] = acc[kk][n];
+        }
+      }
+    }
+    if (tid < A && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
+    if (!ok) flagged[cell] = 1;
+  }
+#undef DMX_K2_SYNC
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Genotype classes.  With --field GT every sample's probability row at a SNP is one of at most four float triplets
 // (the three one-hot rows and the HWE row shared by all missing genotypes, bcf_filtered_reader.cpp:381-400), so
 // log(sum_lm g_j[l] g_k[m] pG[l][m]) takes at most 16 distinct values per (pair, alpha) instead of V*V.  log and the
@@ -1923,6 +2164,38 @@ int launch_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
   const bool force_generic = getenv("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
   const bool use_cls = e->n_classes > 0 && !getenv("DMX_NO_CLASSES");
+  if (A >= 3 && A <= 8 && V <= 128 && !force_generic) {
+    // longer alpha grids: the A = 2 kernel's structure with AP alphas per pair
+    const int AP = A <= 4 ? 4 : 8;
+    const int GS = (V * 3 + 3) & ~3;
+    const size_t cell_bytes = (size_t)32 * AP * 9 * 8 + (size_t)32 * GS * 4 + (size_t)AP * 34 * 8 + 32 * (4 + 4 + 8);
+    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    const dim3 block(kThreads);
+    auto slabs = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
+    // gfx950 lets one workgroup use all 160 KB of a CU's LDS; above the traditional 64 KB the limit is raised explicitly
+#define DMX_K2N(TPC, NK, APP)                                                                                          \
+  do {                                                                                                                 \
+    const size_t lds = cell_bytes * (kThreads / TPC);                                                                  \
+    if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_an<TPC, NK, APP>),        \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+    hipLaunchKernelGGL((k_doublet_an<TPC, NK, APP>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs(TPC, NK)), \
+                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,                            \
+                       e->d_alpha, e->d_sched, V, A, GS, e->d_grid, e->d_l00, e->d_flag);                                \
+  } while (0)
+    if (AP == 4) {
+      if (V <= 8) DMX_K2N(64, 1, 4);
+      else if (V <= 16) DMX_K2N(64, 4, 4);
+      else if (V <= 32) DMX_K2N(256, 4, 4);
+      else DMX_K2N(256, 8, 4);
+    } else {
+      if (V <= 8) DMX_K2N(64, 1, 8);
+      else if (V <= 16) DMX_K2N(64, 4, 8);
+      else DMX_K2N(256, 4, 8);
+    }
+#undef DMX_K2N
+    HIP_TRY(hipGetLastError());
+    return launch_doublet_generic_w<true>(e);
+  }
   // wide panels: the class kernel's LDS grows by 32 bytes per sample, the general A = 2 kernel's by 384 (64 KB at V = 128)
   if (A != 2 || force_generic || V > (use_cls ? 1024 : 128)) {
     HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));

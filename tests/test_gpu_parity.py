@@ -414,3 +414,43 @@ def test_wide_panels_against_oracle(eng, oracle, V, field):
          np.abs(out["l00"] - ref.llks00).max()]
     print(f"V={V} {field}: max|d| = " + " ".join(f"{x:.2e}" for x in d))
     assert max(d) < TOL
+
+
+@pytest.mark.parametrize("V,alphas,field,B,S", [
+    (5, (0.0, 0.25, 0.5), "GT", 20, 400),                       # AP = 4, one wavefront per cell, one phase-1 pass of 2
+    (16, (0.0, 0.1, 0.3, 0.5), "GP", 12, 300),                  # AP = 4, four cells per workgroup
+    (12, (0.0, 0.1, 0.2, 0.3, 0.4, 0.5), "PL", 10, 300),        # AP = 8 (two padding alphas), four phase-1 passes
+    (32, (0.0, 0.2, 0.5), "GP", 6, 300),                        # 256 threads per cell
+    (64, (0.0, 0.1, 0.2, 0.3, 0.5), "GP", 4, 200),              # AP = 8, j-slabs
+    (100, (0.0, 0.25, 0.5), "GP", 3, 150),                      # AP = 4, NK = 8, j-slabs
+    (128, (0.0, 0.1, 0.2, 0.3, 0.4, 0.45, 0.48, 0.5), "GT", 2, 120),   # A = 8 exactly, the LDS maximum (72 KB per workgroup)
+])
+def test_longer_alpha_grids_against_oracle(eng, oracle, V, alphas, field, B, S):
+    """Alpha grids of 3..8 entries run k_doublet_an (the A = 2 kernel's structure with the alphas padded to 4 or 8 per
+    pair; the max across ALL alphas of a pair after every read, :626-639, is a butterfly over those lanes)."""
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(1300 + V + len(alphas))
+    raw = synth.make_raw_genotypes(rng, S, V)
+    if field == "GT":
+        g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    elif field == "GP":
+        gp = synth.raw_gp_from_alleles(rng, raw.alleles)
+        g = np.stack([eng.geno_from_gp(gp[s], 0.01) for s in range(S)])
+    else:
+        plv = synth.raw_pl_from_alleles(rng, raw.alleles)
+        g = np.stack([eng.geno_from_pl(plv[s]) for s in range(S)])
+    sp = synth.make_pileup(rng, raw.alleles, B, 0.4, 2.5, dense_layout=False, doublet_rate=0.3)
+    ref = oracle_from_pileup(oracle, sp, g, alphas, 0.5)
+    out = run_engine(eng, host_pileup(eng, sp), g, alphas, 0.5)
+    d = [np.abs(out["llks"] - ref.llks).max(), np.abs(out["llk0s"] - ref.llk0s).max(), np.abs(out["grid"] - ref.llksAB).max(),
+         np.abs(out["l00"] - ref.llks00).max()]
+    print(f"V={V} A={len(alphas)} {field}: max|d| = " + " ".join(f"{x:.2e}" for x in d))
+    assert max(d) < TOL
+    # K3 on the device grid: the reference's scans
+    from golden_util import summary_from_grid as ref_summary
+    for c in range(B):
+        if sp.cell_pair_off[c + 1] == sp.cell_pair_off[c]:
+            continue
+        want = ref_summary(out["grid"][c], out["l00"][c], alphas, 0.5, int(out["summ"][c]["n_pairs"]), out["summ"].dtype)
+        for f in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best"):
+            assert out["summ"][c][f] == want[f], (c, f)
