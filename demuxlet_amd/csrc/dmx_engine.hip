@@ -1716,6 +1716,238 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
 #undef DMX_K2_SYNC
 }
 
+// K2 over genotype classes for alpha grids of 3..8 entries: k_doublet_cls with k_doublet_an's phase 1.  The class table holds
+// T[pair][cj][ck][n] for the AP padded alphas; phase 2 is AP/2 16-byte lookups and A adds per (j, k).
+template <int TPC, int NK, int AP>
+__global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nrd_width, const float* __restrict__ rows,
+                                                           const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
+                                                           const double* __restrict__ tabs, const double* __restrict__ alpha,
+                                                           const int32_t* __restrict__ sched, int32_t V, int32_t A, int32_t VS,
+                                                           double* __restrict__ grid, double* __restrict__ l00,
+                                                           uint8_t* __restrict__ flagged) {
+  static_assert(AP == 4 || AP == 8, "alphas per pair padded to a power of two");
+  constexpr int TP = 32;
+  constexpr int CPW = kThreads / TPC;
+  constexpr int T00 = TP + 2;
+  constexpr int NT = kMaxCls * kMaxCls * AP;     // class-table entries per pair
+#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  __syncthreads();
+
+  const int cw = t / TPC, tid = t % TPC;
+  const size_t cell_bytes = (size_t)TP * AP * 9 * 8 + (size_t)TP * NT * 8 + (size_t)AP * T00 * 8 + TP * (4 + 4 + 8) + (size_t)TP * 12 * 4 + (size_t)TP * VS;
+  unsigned char* base = s_raw + (size_t)cw * ((cell_bytes + 15) & ~(size_t)15);
+  double* s_pG = (double*)base;                                  // [TP][AP][9]
+  double* s_T = s_pG + TP * AP * 9;                              // [TP][4][4][AP]
+  double* s_t00 = s_T + TP * NT;                                 // [AP][T00]
+  int64_t* s_off = (int64_t*)(s_t00 + AP * T00);                 // [TP]
+  int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
+  uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
+  float* s_rows = (float*)(s_cnt + TP);                          // [TP][4][3]
+  uint8_t* s_ids = (uint8_t*)(s_rows + TP * 12);                 // [TP][VS]
+
+  const int slot = blockIdx.x * CPW + cw;
+  if (TPC == 64 && slot >= pv.B) return;
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+
+  const int KB = (V + NK - 1) / NK;
+  const int JS = TPC / KB;
+  const int jl = tid / KB, kb = tid % KB;
+  const int j = (int)blockIdx.y * JS + jl;
+  const bool owner = jl < JS && j < V;
+  double acc[NK][AP];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+    for (int n = 0; n < AP; ++n) acc[kk][n] = 0.0;
+  bool ok = true;
+  double acc00 = 0.0;
+  constexpr int P1 = TP * AP;                    // phase-1 lanes per tile
+  constexpr int NPASS = (P1 + TPC - 1) / TPC;
+  const int n1 = tid % AP;                       // this thread's alpha in phase 1 (TPC is a multiple of AP)
+  const bool n_ok = n1 < A;
+  double wA[9], wR[9];
+  {
+    const double al = n_ok ? alpha[n1] : 0.0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * al;                       // :613
+        wA[l * 3 + m] = p;
+        wR[l * 3 + m] = 1.0 - p;
+      }
+  }
+
+
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_K2_SYNC();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    for (int e = tid; e < tp * 12; e += TPC) s_rows[e] = rows[(size_t)s_snp[e / 12] * 12 + (e % 12)];
+    {
+      const int wpr = VS / 4;
+      for (int e = tid; e < tp * wpr; e += TPC) {
+        const int ti = e / wpr, wq = e % wpr;
+        const uint8_t* src = ids + (size_t)s_snp[ti] * V + wq * 4;
+        uint32_t wv = 0;
+        for (int b = 0; b < 4; ++b) if (wq * 4 + b < V) wv |= (uint32_t)src[b] << (8 * b);
+        reinterpret_cast<uint32_t*>(s_ids)[ti * wpr + wq] = wv;
+      }
+    }
+    // ---- phase 1: lane u = (pair u / AP, alpha u % AP)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int u = tid + pass * TPC;
+      if (u >= P1) break;                          // uniform per wavefront (P1 and TPC are multiples of 64)
+      const int ti1 = u / AP;
+      const bool on = ti1 < tp && n_ok;
+      const uint32_t cnt = (ti1 < tp) ? s_cnt[ti1] : 0u;
+      const int64_t off = (ti1 < tp) ? s_off[ti1] : 0;
+      double pG[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt && n_ok;
+        const uint32_t byte = (r < cnt) ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+          }
+        }
+#pragma unroll
+        for (int d = 1; d < AP; d <<= 1) {                                  // one max across ALL alphas of the pair
+          const double o = __shfl_xor(mx, d);
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);       // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] /= mx;
+          }
+        }
+      }
+      double mx = 0.0;
+      if (n_ok) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          pG[i] += 1e-6;                                                     // :649
+          mx = (mx < pG[i]) ? pG[i] : mx;
+        }
+      }
+#pragma unroll
+      for (int d = 1; d < AP; d <<= 1) {
+        const double o = __shfl_xor(mx, d);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on) {
+        const double y = rcp_refined(mx);
+        const double* g0 = gp0 + (size_t)s_snp[ti1] * 3;
+        const double qq[3] = {g0[0], g0[1], g0[2]};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = div_by(pG[l * 3 + m], mx, y);                   // :656-663
+            s_pG[(ti1 * AP + n1) * 9 + l * 3 + m] = v;
+            sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
+          }
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+      }
+    }
+    DMX_K2_SYNC();
+    if (tid < A) {                                 // llks00[n]: lane n adds its alpha's terms in pair order
+      const double* row = &s_t00[tid * T00];
+      for (int i = 0; i < tp; ++i) acc00 += row[i];
+    }
+    // ---- phase 1b: the class table (padding alphas are skipped; their slots are never read)
+    for (int e = tid; e < tp * NT; e += TPC) {
+      const int ti = e / NT, cc = e % NT;
+      const int n = cc % AP, ck = (cc / AP) & 3, cj = cc / (AP * 4);
+      if (n >= A) continue;
+      const float* rj = &s_rows[ti * 12 + cj * 3];
+      const float* rk = &s_rows[ti * 12 + ck * 3];
+      const double* P = &s_pG[(ti * AP + n) * 9];
+      const double aj[3] = {(double)rj[0], (double)rj[1], (double)rj[2]};
+      const double bk[3] = {(double)rk[0], (double)rk[1], (double)rk[2]};
+      double sum = 0.0;                                                          // :674
+#pragma unroll
+      for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) sum += ((aj[l] * bk[m]) * P[l * 3 + m]);     // :553, :677-679
+      ok &= __builtin_amdgcn_class(sum, 0x100);
+      s_T[ti * NT + cc] = dmx_log_fast(sum, s_log);                              // the :683 term
+    }
+    DMX_K2_SYNC();
+    // ---- phase 2
+    if (owner) {
+      for (int ti = 0; ti < tp; ++ti) {
+        const uint8_t* idr = &s_ids[ti * VS];
+        const int cj = idr[j];
+        const double* Tj = &s_T[ti * NT + cj * 4 * AP];
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) {
+          const int k = min(kb * NK + kk, V - 1);
+          const double* Tk = &Tj[idr[k] * AP];
+#pragma unroll
+          for (int h = 0; h < AP / 2; ++h) {
+            if (2 * h >= A) break;
+            const double2 tv = *reinterpret_cast<const double2*>(&Tk[2 * h]);
+            acc[kk][2 * h] += tv.x;                                               // :683
+            if (2 * h + 1 < A) acc[kk][2 * h + 1] += tv.y;
+          }
+        }
+      }
+    }
+    DMX_K2_SYNC();
+  }
+  if (cell_ok) {
+    if (owner) {
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const int k = kb * NK + kk;
+        if (k < V) {
+          double* o = grid + (((size_t)cell * V + j) * V + k) * A;
+#pragma unroll
+          for (int n = 0; n < AP; ++n) if (n < A) o[n] = acc[kk][n];
+        }
+      }
+    }
+    if (tid < A && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
+    if (!ok) flagged[cell] = 1;
+  }
+#undef DMX_K2_SYNC
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K3.  One cell per workgroup over its finished grid.
 struct ArgMax { double v; int32_t i; };
@@ -2164,6 +2396,29 @@ int launch_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
   const bool force_generic = getenv("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
   const bool use_cls = e->n_classes > 0 && !getenv("DMX_NO_CLASSES");
+  if (A >= 3 && A <= 8 && use_cls && V <= 1024 && !force_generic) {
+    // GT inputs, longer alpha grids: the class kernel with AP alphas per pair.  One cell per workgroup (the class table is
+    // 4 x 4 x AP doubles per pair: 16-32 KB a tile); the k-block width follows the panel.
+    const int AP = A <= 4 ? 4 : 8;
+    const int VS = (V + 15) & ~15;
+    size_t cb = (size_t)32 * AP * 9 * 8 + (size_t)32 * 16 * AP * 8 + (size_t)AP * 34 * 8 + 32 * (4 + 4 + 8) + (size_t)32 * 12 * 4 + (size_t)32 * VS;
+    cb = (cb + 15) & ~(size_t)15;
+    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    auto slabs = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
+#define DMX_K2CN(NK, APP)                                                                                              \
+  do {                                                                                                                 \
+    if (cb > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_clsn<256, NK, APP>),       \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb));              \
+    hipLaunchKernelGGL((k_doublet_clsn<256, NK, APP>), dim3((unsigned)B, slabs(256, NK)), dim3(kThreads), cb, e->stream, \
+                       e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, A, VS,   \
+                       e->d_grid, e->d_l00, e->d_flag);                                                                  \
+  } while (0)
+    if (AP == 4) { if (V <= 16) DMX_K2CN(1, 4); else if (V <= 32) DMX_K2CN(4, 4); else DMX_K2CN(8, 4); }
+    else         { if (V <= 16) DMX_K2CN(1, 8); else DMX_K2CN(4, 8); }
+#undef DMX_K2CN
+    HIP_TRY(hipGetLastError());
+    return launch_doublet_generic_w<true>(e);
+  }
   if (A >= 3 && A <= 8 && V <= 128 && !force_generic) {
     // longer alpha grids: the A = 2 kernel's structure with AP alphas per pair
     const int AP = A <= 4 ? 4 : 8;

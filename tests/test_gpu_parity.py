@@ -317,7 +317,8 @@ def test_records_path_end_to_end(eng, oracle, name, tmp_path):
                                                  (100, 4, 200, 0.3, 0.05),     # wide panels: j-slabs (class: 3 slabs; general A=2: 3 slabs)
                                                  (128, 3, 150, 0.4, 0.0),      # 4 x 32 rows, the general kernel's LDS limit
                                                  (200, 2, 120, 0.4, 0.1)])     # class K2 in 11 slabs vs the generic slab kernel
-def test_genotype_class_kernel_is_bit_identical_to_the_general_one(eng, oracle, V, B, S, delta, missing):
+@pytest.mark.parametrize("alphas", [(0.0, 0.5), (0.0, 0.25, 0.5), (0.0, 0.1, 0.2, 0.3, 0.4, 0.5)])
+def test_genotype_class_kernel_is_bit_identical_to_the_general_one(eng, oracle, V, B, S, delta, missing, alphas):
     """--field GT gives <= 4 distinct probability rows per SNP; the class kernel evaluates log() once per distinct
     (row_j, row_k) and must reproduce the general kernel BIT FOR BIT (same operands, same operations, same add order)."""
     import os
@@ -328,16 +329,16 @@ def test_genotype_class_kernel_is_bit_identical_to_the_general_one(eng, oracle, 
     sp = synth.make_pileup(rng, np.where(raw.alleles < 0, 0, raw.alleles), B, delta, 1.5, dense_layout=(delta >= 1.0))
     pl = host_pileup(eng, sp)
     os.environ.pop("DMX_NO_CLASSES", None)
-    a = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    a = run_engine(eng, pl, g, alphas, 0.5)
     os.environ["DMX_NO_CLASSES"] = "1"
     try:
-        b = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+        b = run_engine(eng, pl, g, alphas, 0.5)
     finally:
         os.environ.pop("DMX_NO_CLASSES", None)
     assert np.array_equal(a["llks"], b["llks"]) and np.array_equal(a["llk0s"], b["llk0s"])      # K1 over classes
     assert np.array_equal(a["grid"], b["grid"]) and np.array_equal(a["l00"], b["l00"])            # K2 over classes
     assert np.array_equal(a["summ"], b["summ"])
-    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    ref = oracle_from_pileup(oracle, sp, g, alphas, 0.5)
     assert np.abs(a["grid"] - ref.llksAB).max() < TOL and np.abs(a["llks"] - ref.llks).max() < TOL
 
 
