@@ -604,7 +604,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet_clsw(PileupView pv, int
 #pragma unroll
   for (int d = T; d < 64; d <<= 1) max_np = max(max_np, __shfl_xor(max_np, d));
 
-  // chains: a = lane + 64*i over CW*(V+1) accumulators, a -> (cell a/(V+1), sample a%(V+1)); sample V is llk0
+  // chains: a = lane + 64*i over CW*(V+1) accumulators, a -> (cell a/(V+1), sample a%(V+1)); sample V is llk0.  A wavefront
+  // carries 256 chains; wider panels are cut into chain slabs over blockIdx.y, each repeating the five logs per pair.
   constexpr int MAXCH = 4;
   const int nchain = CW * (V + 1);
   double acc[MAXCH];
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet_clsw(PileupView pv, int
   int32_t ch_cell[MAXCH];
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
-    const int a = lane + 64 * i;
+    const int a = (int)blockIdx.y * 64 * MAXCH + lane + 64 * i;
     const bool okc = a < nchain && slot0 + a / (V + 1) < pv.B;
     const int ac = okc ? a / (V + 1) : 0;
     acc[i] = 0.0;
@@ -2315,9 +2316,10 @@ int launch_singlet(dmx_engine* e) {
   if (e->n_classes > 0 && !getenv("DMX_NO_CLASSES") && !getenv("DMX_NO_K1_CLASSES")) {
     // --field GT inputs: log() once per genotype class instead of once per sample (bit-identical, see k_singlet_cls)
     const int wide_v = getenv("DMX_K1_WIDE_V") ? atoi(getenv("DMX_K1_WIDE_V")) : 20;      // kernel experiments only
-    if (V >= wide_v && V + 1 <= 4 * 64) {        // wide panels: chains look the class terms up themselves, one pass per tile
+    if (V >= wide_v && V <= 1024) {              // wide panels: chains look the class terms up themselves, one pass per tile
       const size_t dynw = (size_t)(kThreads / 64) * 64 * ((V + 15) / 16) * sizeof(uint32_t);
-      const dim3 blkw(kThreads), grdw((unsigned)((B + (kThreads / 64) - 1) / (kThreads / 64)));
+      const dim3 blkw(kThreads), grdw((unsigned)((B + (kThreads / 64) - 1) / (kThreads / 64)), (unsigned)((V + 1 + 255) / 256));
+      if (dynw > 30 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_singlet_clsw<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynw));
       hipLaunchKernelGGL((k_singlet_clsw<1>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,
                          e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s);
       return DMX_OK;
