@@ -391,6 +391,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
                                                              const int32_t* __restrict__ sched, int32_t V,
                                                              double* __restrict__ llks, double* __restrict__ llk0s) {
   static_assert(KC == 8 || KC == 4, "a chunk's 2-bit class ids must sit inside one 32-bit id word");
+  constexpr int ablate = DMX_ABLATE;             // profiling builds only (tools/build_variant.sh); 0 in the product
   constexpr int T = 64 / CW;
   constexpr int TS = T + 2;
   constexpr int NC = KC + 1;
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
       const uint32_t b0 = cur.rd4 & 0xFFu;
       const double* f = g_final + 3 * (n ? b0 : 256u);
       G0 = f[0]; G1 = f[1]; G2 = f[2];
-      if (n >= 2) {
+      if (n >= 2 && !(ablate & 1)) {
         const double* f1 = g_first + 3 * b0;
         double g0_ = f1[0], g1_ = f1[1], g2_ = f1[2];
         const bool safe = n <= kSafeReads;
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
     for (int q = 0; q < nch; ++q) {
       const int k0 = q * KC;
       if (q > 0 && (k0 & 15) == 0) wcur = idrow[k0 >> 4];
-      if (valid) {
+      if (valid && !(ablate & 64)) {
         const uint32_t bits = wcur >> (2 * (k0 & 15));      // the chunk's KC class ids, 2 bits each
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk)
@@ -538,7 +539,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
       DMX_WAVE_LDS_ORDER();
       if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
         const int64_t left = a_np - tile * T;
-        const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
+        const int cnt = (ablate & 4) ? 1 : (left >= T ? T : (left > 0 ? (int)left : 0));
         const double* row = &term[lane * TS];
         double s = accs[q * (CW * NC) + lane];
         int i = 0;
