@@ -280,7 +280,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
                          "kernel_ms": dom_ms,
-                         "note": "FP64-VALU/log-bound path (SURVEY §8d): HBM fraction is reported as the metric asks; see fp64_valu"},
+                         "note": "FP64-VALU/log-bound path (SURVEY §8d): HBM fraction is reported as the metric asks; see roofline_valu. "
+                                 "traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of one launch (profiles/); above the algorithmic bytes it "
+                                 "contains the L2 misses of the GL seed-table gathers (DESIGN.md §6), not re-reads of the inputs"},
             "roofline_valu": valu,
             "fp64_valu": {"logical_log_terms_per_s": logs / ((k1_ms + k2_ms) * 1e-3), "kernel_ms": {"k_singlet": k1_ms, "k_doublet+k_reduce": k2_ms},
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS},

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <numeric>
 #include <vector>
 
@@ -63,6 +64,9 @@ constexpr int kLut = 3 * 128;   // mat | err/3 | 0.5-err/3
 constexpr int kTab = kLut + DMX_LOG_TABLE_DOUBLES;   // device table buffer: read LUT, then dmx_log's {invc,logc} table
 constexpr int kFirst = 256 * 3, kFinal = 257 * 3;     // then the singlet first-read tables (dmx::SingletTables)
 constexpr int kTabK1 = kTab + kFirst + kFinal;
+constexpr int kPair = 128 * 128 * 4;                    // then dmx::PairTables: second[16384][4] | final2[16384][4] (global memory only)
+constexpr int kTriple = dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes * 4;   // then dmx::TripleTables: third | final3
+constexpr int kTabAll = kTabK1 + 2 * kPair + 2 * kTriple;
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void k_gp0(const float* __restrict__ g, int32_t S, int32_t V, double* __restrict__ gp0) {
@@ -97,6 +101,65 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
 }
 
 constexpr uint32_t kSafeReads = 15;   // each read scales a likelihood by >= err(127)/3 > 2^-44: 15 reads stay above 2^-700
+
+// ---- genotype likelihoods of a (cell, SNP) pair (cmd_cram_demuxlet.cpp:427-452) -----------------------------------------
+// They start from a table entry chosen by the pair's read count and leading read bytes (dmx::SingletTables / PairTables /
+// TripleTables, host-computed with the reference's IEEE operations): the whole answer for 0-3 reads, the state after
+// three (two, one) reads for deeper pairs, whose loop then starts at read r0.  All tables live in one buffer (`tabs`), so
+// a 32-bit element offset selects the entry.  The K1 kernels issue this gather a whole tile ahead of its use.
+struct GlSeed { double g0, g1, g2; uint32_t r0; };     // r0: first read the loop still has to apply (>= n: none)
+__device__ __forceinline__ GlSeed gl_seed(const double* __restrict__ tabs, uint32_t n, uint32_t rd4) {
+  constexpr uint32_t oFirst = kTab, oFinal1 = kTab + kFirst, oSecond = kTabK1, oFinal2 = kTabK1 + kPair,
+                     oThird = kTabK1 + 2 * kPair, oFinal3 = kTabK1 + 2 * kPair + kTriple;
+  const uint32_t b0 = rd4 & 0xFFu, b1 = (rd4 >> 8) & 0xFFu, b2 = (rd4 >> 16) & 0xFFu;
+  const uint32_t q0 = b0 & 127u, q1 = b1 & 127u, q2 = b2 & 127u;
+  const bool two = n >= 2 && ((b0 | b1) & 0x40u) == 0;                          // both base qualities < 64: PairTables
+  const bool three = n >= 3 && max(max(q0, q1), q2) < (uint32_t)dmx::kTripleBq;  // all three < 48: TripleTables
+  const uint32_t i2 = ((((b0 & 0x80u) >> 1) | (b0 & 0x3Fu)) << 7) | (((b1 & 0x80u) >> 1) | (b1 & 0x3Fu));
+  const uint32_t c0 = ((b0 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q0, c1 = ((b1 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q1,
+                 c2 = ((b2 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q2;
+  const uint32_t i3 = __umul24(__umul24(c0, (uint32_t)dmx::kTripleCodes) + c1, (uint32_t)dmx::kTripleCodes) + c2;   // full-rate multiplies
+  uint32_t off = oFirst + 3u * b0;
+  off = two ? (n == 2 ? oFinal2 : oSecond) + 4u * i2 : off;
+  off = three ? (n == 3 ? oFinal3 : oThird) + 4u * i3 : off;
+  off = n == 1 ? oFinal1 + 3u * b0 : off;
+  off = n == 0 ? oFinal1 + 3u * 256u : off;
+  const double* p = tabs + off;
+  GlSeed sd;
+  sd.g0 = p[0]; sd.g1 = p[1]; sd.g2 = p[2];
+  sd.r0 = n < 2 ? n : (three ? 3u : (two ? 2u : 1u));
+  return sd;
+}
+// reads beyond the tables: continue the reference's loop from read r0, then the +1e-6 renormalisation
+__device__ __forceinline__ void gl_finish(const GlSeed& sd, uint32_t n, uint32_t rd4, const uint8_t* __restrict__ reads, int64_t off,
+                                          const double* __restrict__ lut, double& G0, double& G1, double& G2) {
+  G0 = sd.g0; G1 = sd.g1; G2 = sd.g2;
+  if (sd.r0 < n) {
+    double g0_ = G0, g1_ = G1, g2_ = G2;
+    const bool safe = n <= kSafeReads;
+    for (uint32_t r = sd.r0; r < n; ++r) {
+      const uint32_t byte = (r < 4) ? ((rd4 >> (8 * r)) & 0xFFu) : (uint32_t)reads[off + r];
+      const uint32_t bq = byte & 127u;
+      const bool alt = (byte >> 7) != 0;
+      const double m = lut[bq], e3 = lut[128 + bq], h = lut[256 + bq];
+      g0_ *= alt ? e3 : m;                                                   // :437
+      g1_ *= h;                                                              // :438
+      g2_ *= alt ? m : e3;                                                   // :439
+      const double tmp = g0_ + g1_ + g2_;                                    // :440
+      if (safe) {
+        const double y = rcp_refined(tmp);
+        g0_ = div_by(g0_, tmp, y); g1_ = div_by(g1_, tmp, y); g2_ = div_by(g2_, tmp, y);   // :441-443
+      } else {
+        g0_ /= tmp; g1_ /= tmp; g2_ /= tmp;
+      }
+    }
+    g0_ += 1e-6; g1_ += 1e-6; g2_ += 1e-6;                                   // :446-448
+    const double tmp = g0_ + g1_ + g2_;
+    const double y = rcp_refined(tmp);
+    G0 = div_by(g0_, tmp, y); G1 = div_by(g1_, tmp, y); G2 = div_by(g2_, tmp, y);          // :449-452
+  }
+}
+
 
 // the three singlet genotype likelihoods of one covered pair (:427-452): per read multiply, then renormalise to sum 1
 __device__ __forceinline__ void pair_gl(const uint8_t* __restrict__ rd, uint32_t n, const double* s_lut, double& G0,
@@ -407,8 +470,6 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
   __shared__ double s_scr[NW][64 * SD];
   const double* s_log = s_log_tab;
   const double* s_tab = tabs;                    // read LUT in global memory
-  const double* g_first = tabs + kTab;
-  const double* g_final = g_first + kFirst;
 
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const int nch = (V + KC - 1) / KC;
@@ -461,12 +522,17 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
     return h;
   };
 
-  Hdr nxt = prepare(issue(0));
-  Raw pre = issue(1);
+  Hdr h1 = prepare(issue(0));
+  Hdr h2 = prepare(issue(1));
+  Raw pre = issue(2);
+  GlSeed s1 = gl_seed(tabs, h1.n, h1.rd4);
   for (int64_t tile = 0; tile * T < max_np; ++tile) {
-    const Hdr cur = nxt;
-    nxt = prepare(pre);
-    pre = issue(tile + 2);
+    const Hdr cur = h1;
+    const GlSeed cs = s1;
+    h1 = h2;
+    s1 = gl_seed(tabs, h1.n, h1.rd4);              // tile+1: its read bytes were requested an iteration ago
+    h2 = prepare(pre);                             // tile+2: scan, request its read bytes
+    pre = issue(tile + 3);                         // tile+3: header loads in flight
     const bool valid = tile * T + ti < np;
 
     // class rows, llk0 row and the first id word of this lane's SNP (SNP-major: contiguous across a dense tile)
@@ -477,38 +543,8 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
     const uint32_t* idrow = idw + (size_t)cur.snp * nwd;
     uint32_t wcur = idrow[0];
 
-    double G0, G1, G2;                                                       // :427-452, as in k_singlet
-    {
-      const uint32_t n = cur.n;
-      const uint32_t b0 = cur.rd4 & 0xFFu;
-      const double* f = g_final + 3 * (n ? b0 : 256u);
-      G0 = f[0]; G1 = f[1]; G2 = f[2];
-      if (n >= 2 && !(ablate & 1)) {
-        const double* f1 = g_first + 3 * b0;
-        double g0_ = f1[0], g1_ = f1[1], g2_ = f1[2];
-        const bool safe = n <= kSafeReads;
-        for (uint32_t r = 1; r < n; ++r) {
-          const uint32_t byte = (r < 4) ? ((cur.rd4 >> (8 * r)) & 0xFFu) : (uint32_t)pv.reads[cur.off + r];
-          const uint32_t bq = byte & 127u;
-          const bool alt = (byte >> 7) != 0;
-          const double m = s_tab[bq], e3 = s_tab[128 + bq], h = s_tab[256 + bq];
-          g0_ *= alt ? e3 : m;
-          g1_ *= h;
-          g2_ *= alt ? m : e3;
-          const double tmp = g0_ + g1_ + g2_;
-          if (safe) {
-            const double y = rcp_refined(tmp);
-            g0_ = div_by(g0_, tmp, y); g1_ = div_by(g1_, tmp, y); g2_ = div_by(g2_, tmp, y);
-          } else {
-            g0_ /= tmp; g1_ /= tmp; g2_ /= tmp;
-          }
-        }
-        g0_ += 1e-6; g1_ += 1e-6; g2_ += 1e-6;
-        const double tmp = g0_ + g1_ + g2_;
-        const double y = rcp_refined(tmp);
-        G0 = div_by(g0_, tmp, y); G1 = div_by(g1_, tmp, y); G2 = div_by(g2_, tmp, y);
-      }
-    }
+    double G0, G1, G2;                                                       // :427-452
+    gl_finish(cs, (ablate & 1) ? min(cur.n, cs.r0) : cur.n, cur.rd4, pv.reads, cur.off, s_tab, G0, G1, G2);
     if (valid) {
       const double x0 = G0 * (double)r0.x + G1 * (double)r0.y + G2 * (double)r0.z;     // class 0   (:456)
       const double x1 = G0 * (double)r0.w + G1 * (double)r1.x + G2 * (double)r1.y;     // class 1
@@ -2143,7 +2179,7 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
   for (hipEvent_t& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
-  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTabK1));
+  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTabAll));
   HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
   HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
@@ -2189,6 +2225,13 @@ extern "C" int dmx_engine_set_phred_tables(dmx_engine* e, const double mat[256],
   dmx::SingletTables st;
   dmx::build_singlet_tables(lut, &st);
   HIP_TRY(hipMemcpy(e->d_lut + kTab, &st, sizeof st, hipMemcpyHostToDevice));
+  static_assert(sizeof(dmx::PairTables) == sizeof(double) * 2 * kPair, "table layout");
+  std::unique_ptr<dmx::PairTables> pt(new dmx::PairTables);
+  dmx::build_pair_tables(lut, st, pt.get());
+  HIP_TRY(hipMemcpy(e->d_lut + kTabK1, pt.get(), sizeof(dmx::PairTables), hipMemcpyHostToDevice));
+  const dmx::TripleTables& tt = dmx::build_triple_tables(lut, *pt);
+  HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair, tt.third.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair + kTriple, tt.final3.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
   return DMX_OK;
 }
 

@@ -61,6 +61,60 @@ void build_singlet_tables(const ReadLut& lut, SingletTables* out) {
   finish(ones, out->final1[256]);
 }
 
+void build_pair_tables(const ReadLut& lut, const SingletTables& st, PairTables* out) {
+  for (int c0 = 0; c0 < 128; ++c0)
+    for (int c1 = 0; c1 < 128; ++c1) {
+      const int byte0 = ((c0 >> 6) << 7) | (c0 & 63);
+      const int bq = c1 & 63;
+      const bool alt = (c1 >> 6) != 0;
+      double G0 = st.first[byte0][0], G1 = st.first[byte0][1], G2 = st.first[byte0][2];   // state after the first read
+      G0 *= alt ? lut.e3[bq] : lut.mat[bq];                          // :437
+      G1 *= lut.het[bq];                                             // :438
+      G2 *= alt ? lut.mat[bq] : lut.e3[bq];                          // :439
+      const double tmp = G0 + G1 + G2;                               // :440
+      double* s2 = out->second[c0 * 128 + c1];
+      s2[0] = G0 / tmp; s2[1] = G1 / tmp; s2[2] = G2 / tmp; s2[3] = 0.0;   // :441-443
+      const double a = s2[0] + 1e-6, b = s2[1] + 1e-6, c = s2[2] + 1e-6;   // :446-448
+      const double t2 = a + b + c;
+      double* f2 = out->final2[c0 * 128 + c1];
+      f2[0] = a / t2; f2[1] = b / t2; f2[2] = c / t2; f2[3] = 0.0;         // :449-452
+    }
+}
+
+const TripleTables& build_triple_tables(const ReadLut& lut, const PairTables& pt) {
+  static std::mutex mu;
+  static TripleTables cache;
+  static ReadLut cache_key;
+  static bool have = false;
+  std::lock_guard<std::mutex> lk(mu);
+  if (have && std::memcmp(&cache_key, &lut, sizeof lut) == 0) return cache;
+  const size_t n = (size_t)kTripleCodes * kTripleCodes * kTripleCodes;
+  cache.third.assign(n * 4, 0.0); cache.final3.assign(n * 4, 0.0);
+  for (int c0 = 0; c0 < kTripleCodes; ++c0)
+    for (int c1 = 0; c1 < kTripleCodes; ++c1) {
+      const int p0 = ((c0 / kTripleBq) << 6) | (c0 % kTripleBq), p1 = ((c1 / kTripleBq) << 6) | (c1 % kTripleBq);   // PairTables codes
+      const double* s2 = pt.second[p0 * 128 + p1];
+      for (int c2 = 0; c2 < kTripleCodes; ++c2) {
+        const int bq = c2 % kTripleBq;
+        const bool alt = c2 >= kTripleBq;
+        double G0 = s2[0], G1 = s2[1], G2 = s2[2];
+        G0 *= alt ? lut.e3[bq] : lut.mat[bq];                        // :437
+        G1 *= lut.het[bq];                                           // :438
+        G2 *= alt ? lut.mat[bq] : lut.e3[bq];                        // :439
+        const double tmp = G0 + G1 + G2;                             // :440
+        const size_t i = (((size_t)c0 * kTripleCodes + c1) * kTripleCodes + c2) * 4;
+        double* t3 = &cache.third[i];
+        t3[0] = G0 / tmp; t3[1] = G1 / tmp; t3[2] = G2 / tmp;        // :441-443
+        const double a = t3[0] + 1e-6, b = t3[1] + 1e-6, c = t3[2] + 1e-6;   // :446-448
+        const double t = a + b + c;
+        double* f3 = &cache.final3[i];
+        f3[0] = a / t; f3[1] = b / t; f3[2] = c / t;                 // :449-452
+      }
+    }
+  cache_key = lut; have = true;
+  return cache;
+}
+
 }  // namespace dmx
 
 using dmx::set_error;

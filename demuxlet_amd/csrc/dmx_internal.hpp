@@ -25,6 +25,22 @@ void build_read_lut(const double mat[256], const double err[256], ReadLut* out);
 struct SingletTables { double first[256][3]; double final1[257][3]; };
 void build_singlet_tables(const ReadLut& lut, SingletTables* out);
 
+// The same for the first TWO read bytes (both with base quality < 64, code c = (allele << 6) | bq, index c0 * 128 + c1;
+// 4 doubles per entry, the 4th is padding):
+//   second[c0][c1] = GL after two reads, renormalised after each (:437-443 twice) — start of the loop for pairs of >= 3 reads
+//   final2[c0][c1] = second + 1e-6, renormalised (:446-452)               — the whole answer for 2-read pairs
+struct PairTables { double second[128 * 128][4]; double final2[128 * 128][4]; };
+void build_pair_tables(const ReadLut& lut, const SingletTables& st, PairTables* out);
+
+// And for the first THREE read bytes, all with base quality < 48 (the CLI caps at --cap-BQ 40): code c = allele * 48 + bq,
+// index (c0 * 96 + c1) * 96 + c2, 4 doubles per entry:
+//   third[i]  = GL after three reads, renormalised after each — start of the loop for pairs of >= 4 reads
+//   final3[i] = third + 1e-6, renormalised                    — the whole answer for 3-read pairs
+// 2 x 28 MB; built once per process for a given phred table (build_triple_tables caches its last result).
+constexpr int kTripleCodes = 96, kTripleBq = 48;
+struct TripleTables { std::vector<double> third, final3; };       // [96*96*96][4] each
+const TripleTables& build_triple_tables(const ReadLut& lut, const PairTables& pt);
+
 // Host-side exact re-evaluation of selected doublet-grid entries of ONE cell, in the reference's operation order with
 // the host libm (tie arbiter; cmd_cram_demuxlet.cpp:595-684 restricted to the requested (j,k,n)).
 struct GridReq { int32_t j, k, n; double value; };
