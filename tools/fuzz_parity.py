@@ -1,0 +1,68 @@
+"""Randomised parity sweep on a GPU box: engine (every kernel-selection path) vs the oracle on small random problems.
+    python tools/fuzz_parity.py [n_cases] [seed]
+Prints the worst |delta| per case; exits non-zero on the first case above 1e-9 or with a K3 index mismatch."""
+import sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import torch  # noqa: F401
+from demuxlet_amd import build, engine, synth
+from oracle import oracle_py as O
+from golden_util import summary_from_grid
+
+build.build(); O.build()
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+worst_all = 0.0
+for case in range(n_cases):
+    V = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 20, 31, 32, 33, 48, 64, 65, 90, 128, 129, 160, 257]))
+    A = int(rng.choice([2, 2, 2, 3, 4, 5, 6, 8, 9]))
+    alphas = tuple([0.0] + sorted(rng.choice(np.arange(1, 50), size=A - 2, replace=False) / 100.0) + [0.5]) if A > 2 else (0.0, 0.5)
+    if rng.random() < 0.15:
+        alphas = tuple(sorted(rng.choice(np.arange(0, 51), size=A, replace=False) / 100.0))       # alpha[0] != 0, no 0.5
+    field = str(rng.choice(["GT", "GT", "GP", "PL"]))
+    dense = bool(rng.random() < 0.3)
+    S = int(rng.integers(5, 150 if V > 64 else 400))
+    B = int(rng.integers(1, 6 if V > 64 else 40))
+    delta = 1.0 if dense else float(rng.uniform(0.02, 0.6))
+    rbar = float(rng.choice([1.0, 1.25, 2.0, 4.0, 9.0]))
+    missing = float(rng.choice([0.0, 0.0, 0.1]))
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=missing if field == "GT" else 0.0)
+    al = np.where(raw.alleles < 0, 0, raw.alleles)
+    if field == "GT":
+        g = np.stack([engine.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    elif field == "GP":
+        gp = synth.raw_gp_from_alleles(rng, al)
+        g = np.stack([engine.geno_from_gp(gp[s], 0.01) for s in range(S)])
+    else:
+        plv = synth.raw_pl_from_alleles(rng, al)
+        g = np.stack([engine.geno_from_pl(plv[s]) for s in range(S)])
+    sp = synth.make_pileup(rng, al, B, delta, rbar, dense_layout=dense, doublet_rate=0.3)
+    if rng.random() < 0.3:                       # a wider range of base qualities than the generator's 13..40
+        sp.reads[:] = (sp.reads & 0x80) | rng.integers(0, 94, size=len(sp.reads)).astype(np.uint8)
+    pl = engine.HostPileup(B, S, sp.cell_pair_off, sp.cell_read_off, sp.pair_snp, sp.pair_nrd, sp.reads, sp.rd_totl, sp.rd_pass, sp.rd_uniq)
+    e = engine.Engine(V, alphas, 0.5, device=0)
+    e.set_genotypes(g); e.set_pileup(pl)
+    e.run_singlet(); e.run_doublet()
+    llks, llk0s = e.get_singlet()
+    grid, l00, summ = e.get_doublet()
+    e.close()
+    words = ((sp.reads >> 7).astype(np.uint32) << 24) | ((sp.reads & 0x7F).astype(np.uint32) << 16) | 1
+    pair_snp = sp.pair_snp if sp.pair_snp is not None else np.tile(np.arange(S, dtype=np.int32), B)
+    csr = O.Csr([f"c{i}" for i in range(B)], sp.cell_pair_off, pair_snp, np.concatenate([[0], np.cumsum(sp.pair_nrd.astype(np.int64))]),
+                words.astype(np.uint32), sp.rd_totl, sp.rd_pass, sp.rd_uniq)
+    ref = O.run_csr(csr, [f"s{j}" for j in range(V)], g, O.Params(alphas, 0.5))
+    proc = ref.processed.astype(bool)
+    d = max(np.abs(llks - ref.llks).max(), np.abs(llk0s - ref.llk0s).max(),
+            np.abs(grid[proc] - ref.llksAB[proc]).max() if proc.any() else 0.0, np.abs(l00[proc] - ref.llks00[proc]).max() if proc.any() else 0.0)
+    bad_idx = 0
+    for c in np.nonzero(proc)[0][:8]:
+        want = summary_from_grid(grid[c], l00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)
+        for f in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best"):
+            bad_idx += int(summ[c][f] != want[f])
+    worst_all = max(worst_all, d)
+    print(f"case {case:3d}: V={V:3d} A={A} {field} dense={int(dense)} B={B:2d} S={S:3d} rbar={rbar:4.2f} alphas[0]={alphas[0]:.2f}: max|d|={d:.2e} idx_mismatch={bad_idx}", flush=True)
+    if not (d < 1e-9) or bad_idx:
+        sys.exit(f"FAILED at case {case}")
+print(f"{n_cases} cases, worst |delta| = {worst_all:.3e}")
