@@ -142,6 +142,13 @@ def main():
     ap.add_argument("--alphas", default="", help="override the alpha grid, comma separated (experiments; not the headline)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON record.  Libraries that print banners from C (RCCL's version block is written
+    # to fd 1 and flushed at exit, i.e. AFTER anything Python printed) are sent to stderr: fd 1 is re-pointed at fd 2 for the
+    # whole run and the record goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from demuxlet_amd import build, engine, synth, synth_torch
@@ -304,7 +311,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 leg only
             out["cpu_baseline"] = cpu_baseline(dp, g, cfg)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         if rank == 0 and gathered is not None:
             assert len(gathered) == world and tuple(gathered[0].shape) == tuple(record_matrix().shape)
