@@ -1,5 +1,5 @@
 """Randomised parity sweep on a GPU box: engine (every kernel-selection path) vs the oracle on small random problems.
-    python tools/fuzz_parity.py [n_cases] [seed]
+    python tools/fuzz_parity.py [n_cases] [seed] [scale]      (scale multiplies the SNP and barcode ranges of narrow panels)
 Prints the worst |delta| per case; exits non-zero on the first case above 1e-9 or with a K3 index mismatch."""
 import sys
 from pathlib import Path
@@ -14,6 +14,7 @@ from golden_util import summary_from_grid
 build.build(); O.build()
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 worst_all = 0.0
 for case in range(n_cases):
     V = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 20, 31, 32, 33, 48, 64, 65, 90, 128, 129, 160, 257]))
@@ -23,8 +24,8 @@ for case in range(n_cases):
         alphas = tuple(sorted(rng.choice(np.arange(0, 51), size=A, replace=False) / 100.0))       # alpha[0] != 0, no 0.5
     field = str(rng.choice(["GT", "GT", "GP", "PL"]))
     dense = bool(rng.random() < 0.3)
-    S = int(rng.integers(5, 150 if V > 64 else 400))
-    B = int(rng.integers(1, 6 if V > 64 else 40))
+    S = int(rng.integers(5, 150 if V > 64 else 400 * (scale if V <= 32 else 1)))
+    B = int(rng.integers(1, 6 if V > 64 else 40 * (scale if V <= 32 else 1)))
     delta = 1.0 if dense else float(rng.uniform(0.02, 0.6))
     rbar = float(rng.choice([1.0, 1.25, 2.0, 4.0, 9.0]))
     missing = float(rng.choice([0.0, 0.0, 0.1]))
