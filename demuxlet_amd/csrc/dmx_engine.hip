@@ -536,11 +536,12 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
     const bool valid = tile * T + ti < np;
 
     // class rows, llk0 row and the first id word of this lane's SNP (SNP-major: contiguous across a dense tile)
-    const float4* rp = reinterpret_cast<const float4*>(rows + (size_t)cur.snp * 12);
+    const int32_t snp_l = (ablate & 256) ? (cur.snp & 63) : cur.snp;     // ablation: every row load an L1 hit
+    const float4* rp = reinterpret_cast<const float4*>(rows + (size_t)snp_l * 12);
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-    const double* g0 = gp0 + (size_t)cur.snp * 3;
+    const double* g0 = gp0 + (size_t)snp_l * 3;
     const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
-    const uint32_t* idrow = idw + (size_t)cur.snp * nwd;
+    const uint32_t* idrow = idw + (size_t)snp_l * nwd;
     uint32_t wcur = idrow[0];
 
     double G0, G1, G2;                                                       // :427-452
