@@ -20,6 +20,9 @@
 #include <cstring>
 #include <new>
 #include <memory>
+#include <functional>
+#include <thread>
+#include <string>
 #include <numeric>
 #include <vector>
 
@@ -2909,12 +2912,25 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     return DMX_OK;
   };
 
+  // the ranges of a wave belong to different engines: slice + stage (and later fetch) them on one host thread each, so that
+  // eight GPUs are not fed one after the other (slicing a 2.8 GB shard out of the CSR is ~0.5 s of host memcpy)
+  auto for_ranges = [&](int r0, int r1, const std::function<int(int)>& fn) -> int {
+    if (r1 - r0 <= 1) { for (int r = r0; r < r1; ++r) if (int rc = fn(r)) return rc; return DMX_OK; }
+    std::vector<int> rcs((size_t)(r1 - r0), DMX_OK);
+    std::vector<std::string> msgs((size_t)(r1 - r0));
+    std::vector<std::thread> th;
+    for (int r = r0; r < r1; ++r)
+      th.emplace_back([&, r] { const int rc = fn(r); rcs[(size_t)(r - r0)] = rc; if (rc) msgs[(size_t)(r - r0)] = dmx_last_error(); });
+    for (std::thread& t : th) t.join();
+    for (size_t i = 0; i < rcs.size(); ++i) if (rcs[i]) return set_error(rcs[i], "%s", msgs[i].c_str());   // the message is thread-local
+    return DMX_OK;
+  };
   const int per_wave = (int)eng.size(), waves = (R + per_wave - 1) / per_wave;
-  for (int r = 0; r < std::min(R, per_wave); ++r) if (int rc = launch(r)) return rc;
+  if (int rc = for_ranges(0, std::min(R, per_wave), launch)) return rc;
   for (int w = 0; w < waves; ++w) {
     const int r0 = w * per_wave, r1 = std::min(R, r0 + per_wave);
-    for (int r = r0; r < r1; ++r) if (int rc = fetch(r)) return rc;
-    for (int r = r1; r < std::min(R, r1 + per_wave); ++r) if (int rc = launch(r)) return rc;     // GPUs run wave w+1 ...
+    if (int rc = for_ranges(r0, r1, fetch)) return rc;
+    if (int rc = for_ranges(r1, std::min(R, r1 + per_wave), launch)) return rc;                   // GPUs run wave w+1 ...
     for (int r = r0; r < r1; ++r) if (int rc = write(r)) return rc;                               // ... while the host writes wave w
   }
   if (!doublet_ok) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: the doublet stage needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
