@@ -4,6 +4,7 @@
 // Reference lines are cited per function (paths relative to statgen/demuxlet).  Nothing here includes, links or calls
 // anything under oracle/.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -229,15 +230,20 @@ extern "C" int dmx_geno_from_gp(const float* gp, int32_t nv, double gt_error, fl
 // (sc_drop_seq.cpp:44,53,57), (ii) the per-cell counters (:39,:75 and cmd_cram_demuxlet.cpp:295), (iii) iteration order.
 // Here: an append-only observation log with an open-addressing index for the "seen before?" test, and one sort at
 // freeze time that emits the GPU's CSR directly.
+namespace { int host_threads(); }   // defined with the writers below
+
 struct dmx_store {
   struct Obs { int32_t cell, snp; uint32_t umi_off, umi_len; uint8_t allele, bq; uint32_t count; };
   std::vector<std::string> barcodes;
-  std::unordered_map<std::string, int32_t> barcode_id;
+  std::vector<uint64_t> bc_index;      // open addressing over barcodes: (hash's high 32 bits << 32) | cell id; looked up with
+                                       // the caller's C string as it is (no temporary std::string per read)
   std::vector<int32_t> totl, pass, uniq;
   int32_t n_snps = 0;
   std::vector<Obs> obs;
   std::string umi_pool;
-  std::vector<int64_t> index;          // open addressing over obs, -1 = empty
+  std::vector<uint64_t> index;         // open addressing over obs: (hash's high 32 bits << 32) | obs id; kEmpty = free.  The
+                                       // fingerprint settles almost every probe without touching obs (one cache miss per call)
+  static constexpr uint64_t kEmpty = ~0ull;
   // frozen CSR
   bool frozen = false;
   std::vector<int64_t> cell_pair_off, cell_read_off;
@@ -253,13 +259,32 @@ struct dmx_store {
     h ^= h >> 32;
     return h;
   }
+  static uint64_t hash_str(const char* z, size_t* len) {
+    uint64_t h = 0xCBF29CE484222325ULL;
+    size_t n = 0;
+    for (; z[n]; ++n) { h ^= (unsigned char)z[n]; h *= 0x100000001B3ULL; }
+    *len = n;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 32;
+    return h;
+  }
+  void bc_rehash(size_t cap) {
+    bc_index.assign(cap, kEmpty);
+    for (size_t i = 0; i < barcodes.size(); ++i) {
+      size_t len;
+      const uint64_t h = hash_str(barcodes[i].c_str(), &len);
+      size_t p = h & (cap - 1);
+      while (bc_index[p] != kEmpty) p = (p + 1) & (cap - 1);
+      bc_index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
+    }
+  }
   void rehash(size_t cap) {
-    index.assign(cap, -1);
+    index.assign(cap, kEmpty);
     for (size_t i = 0; i < obs.size(); ++i) {
       const Obs& o = obs[i];
-      size_t p = hash(o.cell, o.snp, umi_pool.data() + o.umi_off, o.umi_len) & (cap - 1);
-      while (index[p] >= 0) p = (p + 1) & (cap - 1);
-      index[p] = (int64_t)i;
+      const uint64_t h = hash(o.cell, o.snp, umi_pool.data() + o.umi_off, o.umi_len);
+      size_t p = h & (cap - 1);
+      while (index[p] != kEmpty) p = (p + 1) & (cap - 1);
+      index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
     }
   }
 };
@@ -268,6 +293,7 @@ extern "C" dmx_store* dmx_store_new(void) {
   dmx_store* s = new (std::nothrow) dmx_store;
   if (!s) { set_error(DMX_ERR_NOMEM, "dmx_store_new: out of memory"); return nullptr; }
   s->rehash(1 << 12);
+  s->bc_rehash(1 << 10);
   return s;
 }
 extern "C" void dmx_store_free(dmx_store* s) { delete s; }
@@ -278,11 +304,20 @@ extern "C" int32_t dmx_store_add_snp(dmx_store* s) {
 }
 extern "C" int32_t dmx_store_add_cell(dmx_store* s, const char* barcode) {       // sc_drop_seq.cpp:20-32
   if (!s || !barcode) return set_error(DMX_ERR_ARG, "dmx_store_add_cell: null argument");
-  auto it = s->barcode_id.find(barcode);
-  if (it != s->barcode_id.end()) return it->second;
+  size_t len;
+  const uint64_t h = dmx_store::hash_str(barcode, &len);
+  const size_t cap = s->bc_index.size();
+  size_t p = h & (cap - 1);
+  for (; s->bc_index[p] != dmx_store::kEmpty; p = (p + 1) & (cap - 1)) {
+    if ((s->bc_index[p] ^ h) >> 32) continue;
+    const std::string& b = s->barcodes[(size_t)(s->bc_index[p] & 0xFFFFFFFFull)];
+    if (b.size() == len && std::memcmp(b.data(), barcode, len) == 0) return (int32_t)(s->bc_index[p] & 0xFFFFFFFFull);
+  }
+  if (s->barcodes.size() >= 0x7FFFFFF0ull) return set_error(DMX_ERR_ARG, "dmx_store_add_cell: too many barcodes");
   const int32_t id = (int32_t)s->barcodes.size();
-  s->barcodes.emplace_back(barcode);
-  s->barcode_id.emplace(s->barcodes.back(), id);
+  s->barcodes.emplace_back(barcode, len);
+  s->bc_index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)id;
+  if (s->barcodes.size() * 2 > cap) s->bc_rehash(cap * 2);
   s->totl.push_back(0); s->pass.push_back(0); s->uniq.push_back(0);
   s->frozen = false;
   return id;
@@ -301,9 +336,12 @@ extern "C" int dmx_store_add_read(dmx_store* s, int32_t snp, int32_t cell, const
   ++s->pass[cell];                                                                 // sc_drop_seq.cpp:39
   const size_t len = std::strlen(umi);
   const size_t cap = s->index.size();
-  size_t p = dmx_store::hash(cell, snp, umi, len) & (cap - 1);
-  for (; s->index[p] >= 0; p = (p + 1) & (cap - 1)) {
-    dmx_store::Obs& o = s->obs[(size_t)s->index[p]];
+  const uint64_t h = dmx_store::hash(cell, snp, umi, len);
+  if (s->obs.size() >= 0xFFFFFFF0ull) return set_error(DMX_ERR_ARG, "dmx_store_add_read: more than 2^32 unique observations");
+  size_t p = h & (cap - 1);
+  for (; s->index[p] != dmx_store::kEmpty; p = (p + 1) & (cap - 1)) {
+    if ((s->index[p] ^ h) >> 32) continue;                                        // another key's fingerprint
+    dmx_store::Obs& o = s->obs[(size_t)(s->index[p] & 0xFFFFFFFFull)];
     if (o.cell == cell && o.snp == snp && o.umi_len == len && std::memcmp(s->umi_pool.data() + o.umi_off, umi, len) == 0) {
       ++o.count;                                                                   // :57 duplicate: only the count moves
       return 0;
@@ -311,7 +349,7 @@ extern "C" int dmx_store_add_read(dmx_store* s, int32_t snp, int32_t cell, const
   }
   dmx_store::Obs o{cell, snp, (uint32_t)s->umi_pool.size(), (uint32_t)len, (uint8_t)allele, (uint8_t)bq, 1u};
   s->umi_pool.append(umi, len);
-  s->index[p] = (int64_t)s->obs.size();
+  s->index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)s->obs.size();
   s->obs.push_back(o);
   if (s->obs.size() * 2 > cap) s->rehash(cap * 2);
   ++s->uniq[cell];                                                                 // :75
@@ -329,37 +367,69 @@ extern "C" int dmx_store_freeze(dmx_store* s, dmx_pileup* out) {
   if (!s || !out) return set_error(DMX_ERR_ARG, "dmx_store_freeze: null argument");
   const int32_t B = (int32_t)s->barcodes.size();
   if (!s->frozen) {
-    std::vector<uint32_t> ord(s->obs.size());
     if (s->obs.size() > 0xFFFFFFFFull) return set_error(DMX_ERR_ARG, "dmx_store_freeze: more than 2^32 unique observations");
-    std::iota(ord.begin(), ord.end(), 0u);
     const char* pool = s->umi_pool.data();
     const std::vector<dmx_store::Obs>& obs = s->obs;
-    // cell id, then SNP id, then UMI as unsigned bytes with the shorter string first on a common prefix
-    // (== std::string::operator<, the order of the reference's std::map<std::string,uint32_t>)
-    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+    const size_t n = obs.size();
+    // (1) stable counting sort by cell id: a cell's observations become one contiguous segment (still in arrival order, which
+    //     for a coordinate-sorted BAM is already nearly SNP order)
+    std::vector<int64_t> seg((size_t)B + 1, 0);
+    for (size_t i = 0; i < n; ++i) ++seg[(size_t)obs[i].cell + 1];
+    for (int32_t c = 0; c < B; ++c) seg[(size_t)c + 1] += seg[(size_t)c];
+    std::vector<uint32_t> ord(n);
+    {
+      std::vector<int64_t> at(seg.begin(), seg.end() - 1);
+      for (size_t i = 0; i < n; ++i) ord[(size_t)at[(size_t)obs[i].cell]++] = (uint32_t)i;
+    }
+    // (2) per cell, on all host threads: SNP id, then UMI as unsigned bytes with the shorter string first on a common prefix
+    //     (== std::string::operator<, the order of the reference's std::map<std::string,uint32_t>); then the cell's pair and
+    //     stored-read counts
+    auto less = [&](uint32_t a, uint32_t b) {
       const dmx_store::Obs &x = obs[a], &y = obs[b];
-      if (x.cell != y.cell) return x.cell < y.cell;
       if (x.snp != y.snp) return x.snp < y.snp;
       const int c = std::memcmp(pool + x.umi_off, pool + y.umi_off, std::min(x.umi_len, y.umi_len));
       if (c != 0) return c < 0;
       return x.umi_len < y.umi_len;
-    });
+    };
     s->cell_pair_off.assign((size_t)B + 1, 0);
     s->cell_read_off.assign((size_t)B + 1, 0);
-    s->pair_snp.clear(); s->reads.clear();
-    std::vector<uint32_t> nrd;
-    uint32_t max_nrd = 0;
-    for (size_t i = 0; i < ord.size(); ++i) {
-      const dmx_store::Obs& o = obs[ord[i]];
-      const bool new_pair = (i == 0) || obs[ord[i - 1]].cell != o.cell || obs[ord[i - 1]].snp != o.snp;
-      if (new_pair) { s->pair_snp.push_back(o.snp); nrd.push_back(0); ++s->cell_pair_off[(size_t)o.cell + 1]; }
-      if (o.allele != 2) {            // allele 2 never enters a likelihood (cmd_cram_demuxlet.cpp:435,:604)
-        s->reads.push_back((uint8_t)((o.allele << 7) | o.bq));
-        max_nrd = std::max(max_nrd, ++nrd.back());
-        ++s->cell_read_off[(size_t)o.cell + 1];
+    const int nthreads = std::max(1, std::min(host_threads(), B));
+    auto over_cells = [&](auto&& fn) {
+      std::atomic<int32_t> next{0};
+      auto work = [&]() { for (int32_t c0; (c0 = next.fetch_add(64)) < B;) for (int32_t c = c0; c < std::min(B, c0 + 64); ++c) fn(c); };
+      std::vector<std::thread> pool_t;
+      for (int t = 1; t < nthreads; ++t) pool_t.emplace_back(work);
+      work();
+      for (std::thread& t : pool_t) t.join();
+    };
+    over_cells([&](int32_t c) {
+      uint32_t* b0 = ord.data() + seg[(size_t)c];
+      uint32_t* b1 = ord.data() + seg[(size_t)c + 1];
+      if (!std::is_sorted(b0, b1, less)) std::sort(b0, b1, less);
+      int64_t np = 0, nr = 0;
+      for (uint32_t* q = b0; q < b1; ++q) {
+        if (q == b0 || obs[q[-1]].snp != obs[*q].snp) ++np;
+        if (obs[*q].allele != 2) ++nr;            // allele 2 never enters a likelihood (cmd_cram_demuxlet.cpp:435,:604)
       }
-    }
+      s->cell_pair_off[(size_t)c + 1] = np; s->cell_read_off[(size_t)c + 1] = nr;
+    });
     for (int32_t c = 0; c < B; ++c) { s->cell_pair_off[c + 1] += s->cell_pair_off[c]; s->cell_read_off[c + 1] += s->cell_read_off[c]; }
+    // (3) fill the CSR, again per cell
+    const size_t P = (size_t)s->cell_pair_off[(size_t)B], R = (size_t)s->cell_read_off[(size_t)B];
+    s->pair_snp.assign(P, 0); s->reads.assign(R, 0);
+    std::vector<uint32_t> nrd(P, 0);
+    over_cells([&](int32_t c) {
+      const uint32_t* b0 = ord.data() + seg[(size_t)c];
+      const uint32_t* b1 = ord.data() + seg[(size_t)c + 1];
+      int64_t p = s->cell_pair_off[(size_t)c] - 1, r = s->cell_read_off[(size_t)c];
+      for (const uint32_t* q = b0; q < b1; ++q) {
+        const dmx_store::Obs& o = obs[*q];
+        if (q == b0 || obs[q[-1]].snp != o.snp) s->pair_snp[(size_t)++p] = o.snp;
+        if (o.allele != 2) { s->reads[(size_t)r++] = (uint8_t)((o.allele << 7) | o.bq); ++nrd[(size_t)p]; }
+      }
+    });
+    uint32_t max_nrd = 0;
+    for (size_t p = 0; p < P; ++p) max_nrd = std::max(max_nrd, nrd[p]);
     s->nrd_width = max_nrd <= 0xFF ? 1 : (max_nrd <= 0xFFFF ? 2 : 4);
     s->pair_nrd_bytes.assign(nrd.size() * (size_t)s->nrd_width + 4, 0);
     for (size_t p = 0; p < nrd.size(); ++p) std::memcpy(&s->pair_nrd_bytes[p * (size_t)s->nrd_width], &nrd[p], (size_t)s->nrd_width); // little endian
