@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--samples", type=int, default=0, help="override the number of samples (experiments; not the headline)")
     ap.add_argument("--field", default="", help="override the genotype field GT|GP|PL (experiments; not the headline)")
+    ap.add_argument("--fast", action="store_true", help="DMX_MODE_FAST (bilinear doublet terms; opt-in, not the headline)")
     ap.add_argument("--alphas", default="", help="override the alpha grid, comma separated (experiments; not the headline)")
     args = ap.parse_args()
 
@@ -194,7 +195,9 @@ def main():
     # orders against it (the legacy NULL stream would not do: dmx_engine_set_stream(NULL) means "the engine's own")
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    eng = engine.Engine(V, cfg["alphas"], 0.5, device=local)
+    eng = engine.Engine(V, cfg["alphas"], 0.5, device=local, mode=engine.capi.DMX_MODE_FAST if args.fast else engine.capi.DMX_MODE_STRICT)
+    if args.fast:
+        cfg["name"] += " [DMX_MODE_FAST]"
     assert stream.cuda_stream != 0
     eng.set_stream(stream.cuda_stream)
     eng.set_genotypes(g)
@@ -282,7 +285,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"], "barcodes_per_gpu": B, "snps": S, "samples": V, "alphas": list(cfg["alphas"]),
-                       "covered_pairs_per_gpu": dp.n_pairs, "reads_per_gpu": dp.n_reads, "mode": "strict",
+                       "covered_pairs_per_gpu": dp.n_pairs, "reads_per_gpu": dp.n_reads, "mode": "fast" if args.fast else "strict",
                        "sharding": f"barcodes x{world}, one RCCL gather per step" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,

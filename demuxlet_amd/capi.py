@@ -17,6 +17,7 @@ LIB_PATH = Path(os.environ.get("DMX_LIB", Path(__file__).resolve().parent / "lib
 DMX_OK = 0
 DMX_MEM_HOST, DMX_MEM_DEVICE = 0, 1
 DMX_MODE_STRICT = 0
+DMX_MODE_FAST = 1
 
 # every symbol include/dmx.h declares (tests/test_abi.py checks the header against this list and the .so against both)
 SYMBOLS = [
@@ -90,7 +91,7 @@ class Job(C.Structure):
     _fields_ = [("store", C.c_void_p), ("g", C.c_void_p), ("n_samples", C.c_int32), ("sample_ids", C.c_void_p),
                 ("n_alpha", C.c_int32), ("alpha", C.c_void_p), ("doublet_prior", C.c_double),
                 ("min_total", C.c_int32), ("min_uniq", C.c_int32), ("min_snp", C.c_int32), ("write_pair", C.c_int32),
-                ("out_prefix", C.c_char_p), ("device", C.c_int32), ("arbiter", C.c_int32), ("n_gpus", C.c_int32)]
+                ("out_prefix", C.c_char_p), ("device", C.c_int32), ("arbiter", C.c_int32), ("n_gpus", C.c_int32), ("mode", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

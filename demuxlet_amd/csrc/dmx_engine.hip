@@ -1238,6 +1238,240 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
 #undef DMX_K2_SYNC
 }
 
+// K2, A = 2, FAST mode (dmx_engine_config.mode = DMX_MODE_FAST): k_doublet_a2 with the bilinear factoring of SURVEY H3.  Not the
+// reference's operation sequence inside a term (so not STRICT), but the same accumulation order; tests bound it by 1e-9.
+template <int TPC, int NK>
+__global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                         const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                         const double* __restrict__ alpha,
+                                                         const int32_t* __restrict__ sched, int32_t V, int32_t GS,
+                                                         double* __restrict__ grid, double* __restrict__ l00,
+                                                         uint8_t* __restrict__ flagged) {
+  constexpr int A = 2, TP = 32;
+  constexpr int CPW = kThreads / TPC;            // cells per workgroup
+  constexpr int T00 = TP + 2;
+#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  __syncthreads();
+
+  const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
+  // per-cell LDS regions
+  constexpr int SUB = 8;                         // pairs per u sub-tile
+  const int VU = V;                              // u row: [alpha][k][4 doubles] (4th pads the 3 to 32 bytes)
+  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * GS * 4 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)SUB * 2 * VU * 32;
+  unsigned char* base = s_raw + (size_t)cw * cell_bytes;
+  double* s_pG = (double*)base;                                  // [TP][2][9]
+  float* s_g = (float*)(base + (size_t)TP * 18 * 8);             // [TP][GS]   genotype rows of the tile's SNPs
+  double* s_t00 = (double*)((unsigned char*)s_g + (size_t)TP * GS * 4);   // [2][T00]   llks00 terms
+  int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                  // [TP]
+  int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
+  uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
+  double* s_u = (double*)(s_cnt + TP);                           // [SUB][2][V][4]   u[l] = sum_m pG[n][l][m] * g_k[m]
+
+  const int slot = blockIdx.x * CPW + cw;
+  if (TPC == 64 && slot >= pv.B) return;         // whole wavefront idle (no workgroup barriers below in this mode)
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+
+  // phase-2 identity.  A workgroup covers JS = TPC / KB rows j of the cell's grid; panels with more rows than that are cut
+  // into j-slabs, one workgroup (blockIdx.y) per slab, each repeating the cheap phases 0-1 for itself.
+  const int KB = (V + NK - 1) / NK;              // k-blocks per j
+  const int JS = TPC / KB;
+  const int jl = tid / KB, kb = tid % KB;
+  const int j = (int)blockIdx.y * JS + jl;
+  const bool owner = jl < JS && j < V;
+  double acc[NK][A];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
+  bool ok = true;
+  // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1; mixing weights of :613
+  const int ti1 = tid >> 1, n1 = tid & 1;
+  double wA[9], wR[9];
+  {
+    const double al = alpha[n1];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * al;
+        wA[l * 3 + m] = p;
+        wR[l * 3 + m] = 1.0 - p;
+      }
+  }
+  double acc00 = 0.0;                            // lane n1 == tid < 2 owns llks00[n]
+  const int row_len = V * 3;
+
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    // ---- headers of the tile's pairs (first 32 lanes of the cell)
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_K2_SYNC();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    // ---- genotype rows -> LDS (coalesced along the row)
+    {
+      int r = tid % row_len, ti = tid / row_len;
+      const int dr = TPC % row_len, dt = TPC / row_len;
+      while (ti < tp) {
+        s_g[ti * GS + r] = g[(size_t)s_snp[ti] * row_len + r];
+        r += dr; ti += dt;
+        if (r >= row_len) { r -= row_len; ++ti; }
+      }
+    }
+    // ---- phase 1
+    if (tid < 64) {
+      const bool on = ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      double pG[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt;
+        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+          }
+        }
+        {
+          const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);       // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] /= mx;
+          }
+        }
+      }
+      double mx = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        pG[i] += 1e-6;                                                       // :649
+        mx = (mx < pG[i]) ? pG[i] : mx;
+      }
+      {
+        const double o = __shfl_xor(mx, 1);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on) {
+        const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
+        const double* g0 = gp0 + (size_t)s_snp[ti1] * 3;
+        const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
+        const double qq[3] = {q0, q1, q2};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = div_by(pG[l * 3 + m], mx, y);                   // :656-663
+            s_pG[(ti1 * 2 + n1) * 9 + l * 3 + m] = v;
+            sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
+          }
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+      }
+    }
+    DMX_K2_SYNC();
+    // ---- llks00: lane n < 2 of the cell adds its alpha's terms in pair order
+    if (tid < 2) {
+      const double* row = &s_t00[tid * T00];
+      if (tp == TP) {                              // loads first (LDS latency paid once), then the ordered adds
+        double2 v[TP / 2];
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) v[i] = *reinterpret_cast<const double2*>(&row[2 * i]);
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+      } else {
+        for (int i = 0; i < tp; ++i) acc00 += row[i];
+      }
+    }
+    // ---- phase 2, in sub-tiles of SUB pairs.  FAST (bilinear) form: the nine-term sum g_j' pG[n] g_k is factored as
+    // g_j . u with u[l] = sum_m pG[n][l][m] g_k[m] formed ONCE per (pair, alpha, k) and shared through LDS by the rows j — three
+    // fused multiply-adds per evaluation instead of nine products and seventeen multiply/adds.  The value of a term moves by a
+    // few ulp (<= ~1e-15 absolute); the accumulation order is the reference's, so the result stays within ~1e-11 of STRICT.
+#pragma unroll 1
+    for (int sub = 0; sub < tp; sub += SUB) {
+      const int ns = min(SUB, tp - sub);
+#pragma unroll 1
+      for (int e = tid; e < ns * 2 * V; e += TPC) {
+        const int k = e % V, n = (e / V) & 1, pi = e / (2 * V);
+        const double* P = &s_pG[((sub + pi) * 2 + n) * 9];
+        const float* gr = &s_g[(sub + pi) * GS + k * 3];
+        const double b0 = (double)gr[0], b1 = (double)gr[1], b2 = (double)gr[2];
+        double* u = &s_u[(size_t)((pi * 2 + n) * VU + k) * 4];
+#pragma unroll
+        for (int l = 0; l < 3; ++l) u[l] = __builtin_fma(P[l * 3 + 2], b2, __builtin_fma(P[l * 3 + 1], b1, P[l * 3] * b0));
+      }
+      DMX_K2_SYNC();
+      if (owner) {
+#pragma unroll 1
+        for (int pi = 0; pi < ns; ++pi) {
+          const float* gr = &s_g[(sub + pi) * GS];
+          const double a0 = (double)gr[j * 3], a1 = (double)gr[j * 3 + 1], a2 = (double)gr[j * 3 + 2];
+          const double* u0 = &s_u[(size_t)((pi * 2 + 0) * VU) * 4];
+          const double* u1 = &s_u[(size_t)((pi * 2 + 1) * VU) * 4];
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk) {
+            const int k = min(kb * NK + kk, V - 1);
+            const double2 x01 = *reinterpret_cast<const double2*>(&u0[k * 4]);
+            const double x2 = u0[k * 4 + 2];
+            const double2 y01 = *reinterpret_cast<const double2*>(&u1[k * 4]);
+            const double y2 = u1[k * 4 + 2];
+            const double s0 = __builtin_fma(a2, x2, __builtin_fma(a1, x01.y, a0 * x01.x));
+            const double s1 = __builtin_fma(a2, y2, __builtin_fma(a1, y01.y, a0 * y01.x));
+            ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
+            acc[kk][0] += dmx_log_fast(s0, s_log);
+            acc[kk][1] += dmx_log_fast(s1, s_log);
+          }
+        }
+      }
+      DMX_K2_SYNC();
+    }
+    DMX_K2_SYNC();
+  }
+  if (cell_ok) {
+    if (owner) {
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const int k = kb * NK + kk;
+        if (k < V) {
+          double* o = grid + (((size_t)cell * V + j) * V + k) * A;
+          o[0] = acc[kk][0]; o[1] = acc[kk][1];
+        }
+      }
+    }
+    if (tid < 2 && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
+    if (!ok) flagged[cell] = 1;
+  }
+#undef DMX_K2_SYNC
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K2 for alpha grids of 3..8 entries: k_doublet_a2's ownership, order and arithmetic with AP (= A rounded up to 2, 4 or 8)
 // alphas per pair.  Phase 1 spreads the TP * AP (pair, alpha) lanes over all the cell's threads, in passes when the cell has
@@ -2166,7 +2400,7 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   if (!cfg || !out) return set_error(DMX_ERR_ARG, "dmx_engine_create: null argument");
   if (cfg->n_samples < 1 || cfg->n_samples > 4094) return set_error(DMX_ERR_ARG, "dmx_engine_create: n_samples %d not in [1,4094]", cfg->n_samples);
   if (cfg->n_alpha < 1 || cfg->n_alpha > 64 || !cfg->alpha) return set_error(DMX_ERR_ARG, "dmx_engine_create: n_alpha %d not in [1,64] or null grid", cfg->n_alpha);
-  if (cfg->mode != DMX_MODE_STRICT) return set_error(DMX_ERR_ARG, "dmx_engine_create: unknown mode %d", cfg->mode);
+  if (cfg->mode != DMX_MODE_STRICT && cfg->mode != DMX_MODE_FAST) return set_error(DMX_ERR_ARG, "dmx_engine_create: unknown mode %d", cfg->mode);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return set_error(DMX_ERR_NOGPU, "dmx_engine_create: no HIP device is visible (this library has no CPU fallback)");
@@ -2535,6 +2769,23 @@ int launch_doublet(dmx_engine* e) {
   hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
                      e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag)
+  if (e->mode == DMX_MODE_FAST && V > 16) {      // measured: the factored form wins from one-cell-per-workgroup panels (cfg3 1.33x), loses on V <= 16 (cfg5 0.7x)
+    const size_t fast_bytes = cell_bytes + (size_t)8 * 2 * V * 32;
+#define DMX_K2F(TPC, NK)                                                                                             \
+  do {                                                                                                               \
+    const size_t lds = fast_bytes * (kThreads / TPC);                                                                \
+    if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2f<TPC, NK>),          \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+    hipLaunchKernelGGL((k_doublet_a2f<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), \
+                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS,           \
+                       e->d_grid, e->d_l00, e->d_flag);                                                              \
+  } while (0)
+    if (V <= 32) DMX_K2F(256, 4);
+    else DMX_K2F(256, 16);
+#undef DMX_K2F
+    HIP_TRY(hipGetLastError());
+    return launch_doublet_generic_w<true>(e);
+  }
   if (V <= 8) DMX_K2A(64, 1);
   else if (V <= 16) DMX_K2A(64, 4);
   else if (V <= 32) DMX_K2A(256, 4);
@@ -2833,7 +3084,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   for (size_t i = 0; i < eng.size(); ++i) {
     dmx_engine_config cfg{};
     cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior;
-    cfg.device = (job->device + (int)i) % ndev; cfg.mode = DMX_MODE_STRICT;
+    cfg.device = (job->device + (int)i) % ndev; cfg.mode = job->mode;
     if (int rc = dmx_engine_create(&cfg, &eng[i])) return rc;
     if (int rc = dmx_engine_set_genotypes(eng[i], job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
   }

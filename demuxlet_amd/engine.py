@@ -133,13 +133,14 @@ class Store:
 class Engine:
     """The likelihood engine on one MI355X."""
 
-    def __init__(self, n_samples: int, alphas: Sequence[float] = (0.0, 0.5), doublet_prior: float = 0.5, device: int = 0):
+    def __init__(self, n_samples: int, alphas: Sequence[float] = (0.0, 0.5), doublet_prior: float = 0.5, device: int = 0,
+                 mode: int = capi.DMX_MODE_STRICT):
         self._L = capi.load()
         self.V = int(n_samples)
         self.alphas = np.ascontiguousarray(alphas, dtype=np.float64)
         self.A = len(self.alphas)
         self.prior = float(doublet_prior)
-        cfg = capi.EngineConfig(self.V, self.A, self.alphas.ctypes.data, self.prior, device, capi.DMX_MODE_STRICT)
+        cfg = capi.EngineConfig(self.V, self.A, self.alphas.ctypes.data, self.prior, device, mode)
         h = C.c_void_p()
         check(self._L.dmx_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -291,11 +292,11 @@ def write_doublet_summary(fa: FinalArgs, sing, l00, summary, out_prefix: str, ti
 
 def demuxlet_run(store: Store, g: np.ndarray, sample_ids: Sequence[str], alphas: Sequence[float], out_prefix: str,
                  doublet_prior: float = 0.5, min_total: int = 0, min_uniq: int = 0, min_snp: int = 0,
-                 write_pair: bool = False, device: int = 0, arbiter: bool = True, n_gpus: int = 1) -> None:
+                 write_pair: bool = False, device: int = 0, arbiter: bool = True, n_gpus: int = 1, mode: int = capi.DMX_MODE_STRICT) -> None:
     """cmd_cram_demuxlet.cpp:390-881 in one call (dmx_demuxlet_run)."""
     g = np.ascontiguousarray(g, dtype=np.float32)
     al = np.ascontiguousarray(alphas, dtype=np.float64)
     sm, keep = _cstrs(sample_ids)
     job = capi.Job(store.handle, g.ctypes.data, g.shape[1], C.cast(sm, C.c_void_p), len(al), al.ctypes.data, doublet_prior,
-                   min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter), n_gpus)
+                   min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter), n_gpus, mode)
     check(capi.load().dmx_demuxlet_run(C.byref(job)))

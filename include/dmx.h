@@ -106,10 +106,15 @@ typedef struct {
   const double* alpha;         /* [A] */
   double  doublet_prior;       /* --doublet-prior */
   int32_t device;              /* HIP device ordinal */
-  int32_t mode;                /* DMX_MODE_STRICT (0): reference operation order, no FMA contraction, IEEE division */
+  int32_t mode;                /* DMX_MODE_STRICT (0): reference operation order, no FMA contraction, IEEE division; or DMX_MODE_FAST */
   int32_t reserved[4];
 } dmx_engine_config;
-enum { DMX_MODE_STRICT = 0 };
+enum { DMX_MODE_STRICT = 0,
+       /* Opt-in.  Same ownership and accumulation order; inside a doublet term the nine-term sum of cmd_cram_demuxlet.cpp:677-679
+        * is factored as g_j . (pG[n] g_k) with fused multiply-adds.  A term moves by a few ulp, a log-likelihood
+        * by <= ~1e-11 (tests bound it by 1e-9 against the reference); .best stays identical with the tie arbiter.  Affects the
+        * general (soft-field) A = 2 doublet kernel only; every other path is the STRICT one. */
+       DMX_MODE_FAST = 1 };
 
 /* per-cell result of the device-side reduction (K3) — what :713-734 and :746-770,:799-828 derive from one cell's grid */
 typedef struct {
@@ -223,6 +228,7 @@ typedef struct {
                                       exceed the byte budget (4 GiB, a third of the free device memory if that is less) — which go
                                       through the engines in waves; the rows of a wave are formatted and appended on the host while
                                       the next wave computes.  Barcodes are independent (cmd_cram_demuxlet.cpp:576): no collective. */
+  int32_t      mode;               /* DMX_MODE_STRICT (0, default) or DMX_MODE_FAST */
 } dmx_job;
 int dmx_demuxlet_run(const dmx_job*);
 

@@ -88,7 +88,7 @@ def device_results(m, eng, B, V, A, doublet, rows=None):
     return out
 
 
-def run_full(m, cfg_id, n_sample, check_general, barcodes=0):
+def run_full(m, cfg_id, n_sample, check_general, barcodes=0, fast=False):
     torch, engine, bench = m["torch"], m["engine"], m["bench"]
     cfg = dict(bench.CONFIGS[cfg_id])
     if barcodes:
@@ -107,7 +107,7 @@ def run_full(m, cfg_id, n_sample, check_general, barcodes=0):
             old[k] = os.environ.get(k)
             os.environ[k] = val
         try:
-            e = engine.Engine(V, cfg["alphas"], 0.5, device=0)
+            e = engine.Engine(V, cfg["alphas"], 0.5, device=0, mode=engine.capi.DMX_MODE_FAST if fast else engine.capi.DMX_MODE_STRICT)
             e.set_genotypes(g)
             e.set_pileup_struct(pileup.as_struct(), keep=pileup)
             e.run_singlet()
@@ -192,3 +192,10 @@ def test_cfg4_full_depth_and_panel(mods):
     work 12.5x; the oracle needs 15 s per barcode here): 2 barcodes x 8.2e8 pair-evaluations through the oracle, class kernels
     == general kernels on all 1 000."""
     run_full(mods, 4, 2, check_general=True, barcodes=1000)
+
+
+def test_cfg3_full_size_fast_mode(mods):
+    """DMX_MODE_FAST at cfg3's full depth (50 k SNPs per barcode, |LLK| ~ 1e5): the factored doublet term keeps every sampled
+    log-likelihood within 1e-9 of the oracle, re-runs stay bit-identical, barcodes computed alone give the same bits."""
+    worst = run_full(mods, 3, 4, check_general=False, fast=True)
+    assert worst < 1e-9

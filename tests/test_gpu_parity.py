@@ -455,3 +455,78 @@ def test_longer_alpha_grids_against_oracle(eng, oracle, V, alphas, field, B, S):
         want = ref_summary(out["grid"][c], out["l00"][c], alphas, 0.5, int(out["summ"][c]["n_pairs"]), out["summ"].dtype)
         for f in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best"):
             assert out["summ"][c][f] == want[f], (c, f)
+
+
+@pytest.mark.parametrize("V,B,S,delta,field", [(8, 30, 800, 0.3, "GP"), (16, 20, 600, 1.0, "PL"), (32, 10, 500, 0.3, "GP"), (64, 4, 300, 0.3, "GP"),
+                                               (100, 3, 200, 0.3, "GP")])
+def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
+    """DMX_MODE_FAST (opt-in): the doublet term is g_j . (pG[n] g_k) with fused multiply-adds instead of the reference's nine-term
+    sum; the accumulation order is unchanged.  Every log-likelihood must stay within the 1e-9 of the north star (measured:
+    ~1e-13 at these depths), the singlet outputs are untouched (bit-equal to STRICT)."""
+    from demuxlet_amd import synth, capi
+    rng = np.random.default_rng(5150 + V)
+    raw = synth.make_raw_genotypes(rng, S, V)
+    if field == "GP":
+        gp = synth.raw_gp_from_alleles(rng, raw.alleles)
+        g = np.stack([eng.geno_from_gp(gp[s], 0.01) for s in range(S)])
+    else:
+        plv = synth.raw_pl_from_alleles(rng, raw.alleles)
+        g = np.stack([eng.geno_from_pl(plv[s]) for s in range(S)])
+    sp = synth.make_pileup(rng, raw.alleles, B, delta, 1.5, dense_layout=(delta >= 1.0), doublet_rate=0.3)
+    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    strict = run_engine(eng, host_pileup(eng, sp), g, (0.0, 0.5), 0.5)
+    e = eng.Engine(V, (0.0, 0.5), 0.5, mode=capi.DMX_MODE_FAST)
+    e.set_genotypes(g); e.set_pileup(host_pileup(eng, sp))
+    e.run_singlet(); e.run_doublet()
+    llks, llk0s = e.get_singlet()
+    grid, l00, summ = e.get_doublet()
+    e.close()
+    assert np.array_equal(llks, strict["llks"]) and np.array_equal(llk0s, strict["llk0s"]) and np.array_equal(l00, strict["l00"])
+    d_ref, d_strict = np.abs(grid - ref.llksAB).max(), np.abs(grid - strict["grid"]).max()
+    print(f"V={V} {field}: FAST vs reference {d_ref:.2e}, FAST vs STRICT {d_strict:.2e}")
+    assert d_ref < TOL and d_strict < 1e-10
+    if V > 16:
+        assert not np.array_equal(grid, strict["grid"])    # it IS a different operation sequence: keep the two modes honest
+    else:
+        assert np.array_equal(grid, strict["grid"])        # panels of <= 16 samples keep the STRICT kernel (it is the faster one there)
+
+
+def test_fast_mode_end_to_end_files(eng, oracle, tmp_path):
+    """dmx_demuxlet_run in DMX_MODE_FAST (with the tie arbiter) against the oracle's files on a soft-field 24-sample job: every
+    string field — barcodes, ids, the BEST call — identical, printed numbers equal up to their last digit."""
+    import os
+    from demuxlet_amd import synth, capi
+    rng = np.random.default_rng(777)
+    V, S, B = 24, 400, 30
+    raw = synth.make_raw_genotypes(rng, S, V)
+    g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+    sp = synth.make_pileup(rng, raw.alleles, B, 0.3, 1.5, dense_layout=False, doublet_rate=0.4)
+    bc, snp, umi, allele, bq, newread = synth.pileup_to_events(rng, sp)
+    sm = [f"SM{j:02d}" for j in range(V)]
+    params = oracle.Params((0.0, 0.5), 0.5, 0, 0, 0, True)
+    oracle.run_problem(oracle.Problem(sm, g, oracle.Events(bc, snp, umi, allele, bq, newread), params), str(tmp_path / "ref"))
+    st = eng.Store()
+    for _ in range(S):
+        st.add_snp()
+    for e in range(len(bc)):
+        c = st.add_cell(bc[e])
+        if newread[e]:
+            st.count_read(c)
+        if snp[e] >= 0:
+            st.add_read(int(snp[e]), c, umi[e], int(allele[e]), int(bq[e]))
+    eng.demuxlet_run(st, g, sm, (0.0, 0.5), str(tmp_path / "got"), 0.5, 0, 0, 0, True, arbiter=True, n_gpus=2, mode=capi.DMX_MODE_FAST)
+    ndiff = 0
+    for suf in ("single", "sing2", "best", "pair"):
+        got = (tmp_path / f"got.{suf}").read_text().splitlines()
+        want = (tmp_path / f"ref.{suf}").read_text().splitlines()
+        assert len(got) == len(want) and len(got) > 1, suf
+        for a, b in zip(got, want):
+            if a == b:
+                continue
+            fa, fb = a.split("\t"), b.split("\t")
+            assert len(fa) == len(fb)
+            for x, y in zip(fa, fb):
+                if x != y:
+                    assert abs(float(x) - float(y)) <= 1e-3 * max(1e-3, abs(float(y))) + 1.01e-4, (suf, a, b)
+                    ndiff += 1
+    print(f"FAST end to end: {ndiff} printed numbers differ in the last digit")
