@@ -2653,6 +2653,7 @@ int launch_doublet_generic(dmx_engine* e) {
   if (nacc > 0x7FFFFFFFll || V > 0xFFE) return set_error(DMX_ERR_ARG, "run_doublet: V*V*A = %lld accumulators per cell exceed this build's limit", (long long)nacc);
   const int slab_acc = 33;                        // accumulators per thread when the grid is cut into slabs
   const unsigned slabs = per <= 65 ? 1u : (unsigned)((nacc + (int64_t)slab_acc * kThreads - 1) / ((int64_t)slab_acc * kThreads));
+  if (slabs > 65535u) return set_error(DMX_ERR_ARG, "run_doublet: V*V*A = %lld accumulators per cell exceed this build's limit (5.5e8)", (long long)nacc);
   const dim3 grid((unsigned)B, slabs), block(kThreads);
 #define DMX_K2(NN)                                                                                                   \
   hipLaunchKernelGGL((k_doublet_generic<NRD, NN, FIXUP>), grid, block, 0, e->stream, e->pv, e->d_g, e->d_gp0, e->d_lut, \
