@@ -1,6 +1,7 @@
 """Randomised parity sweep on a GPU box: engine (every kernel-selection path) vs the oracle on small random problems.
     python tools/fuzz_parity.py [n_cases] [seed] [scale]      (scale multiplies the SNP and barcode ranges of narrow panels)
-Prints the worst |delta| per case; exits non-zero on the first case above 1e-9 or with a K3 index mismatch."""
+DMX_FUZZ_FAST=1 runs the engines in DMX_MODE_FAST.  Prints the worst |delta| per case; exits non-zero on the first case above 1e-9 or with a K3 index mismatch."""
+import os
 import sys
 from pathlib import Path
 import numpy as np
@@ -43,7 +44,7 @@ for case in range(n_cases):
     if rng.random() < 0.3:                       # a wider range of base qualities than the generator's 13..40
         sp.reads[:] = (sp.reads & 0x80) | rng.integers(0, 94, size=len(sp.reads)).astype(np.uint8)
     pl = engine.HostPileup(B, S, sp.cell_pair_off, sp.cell_read_off, sp.pair_snp, sp.pair_nrd, sp.reads, sp.rd_totl, sp.rd_pass, sp.rd_uniq)
-    e = engine.Engine(V, alphas, 0.5, device=0)
+    e = engine.Engine(V, alphas, 0.5, device=0, mode=engine.capi.DMX_MODE_FAST if os.environ.get("DMX_FUZZ_FAST") else engine.capi.DMX_MODE_STRICT)
     e.set_genotypes(g); e.set_pileup(pl)
     e.run_singlet(); e.run_doublet()
     llks, llk0s = e.get_singlet()
