@@ -530,3 +530,40 @@ def test_fast_mode_end_to_end_files(eng, oracle, tmp_path):
                     assert abs(float(x) - float(y)) <= 1e-3 * max(1e-3, abs(float(y))) + 1.01e-4, (suf, a, b)
                     ndiff += 1
     print(f"FAST end to end: {ndiff} printed numbers differ in the last digit")
+
+
+@pytest.mark.parametrize("V,field,dense", [(8, "GT", True), (8, "GP", True), (5, "GT", False), (16, "PL", False), (24, "GT", False), (40, "GP", True)])
+def test_every_launch_geometry_gives_the_same_bits(eng, oracle, V, field, dense, monkeypatch):
+    """The launchers pick cells-per-wavefront (1, 2, 4) by barcode count, the narrow or the wide class K1 by panel width, and the
+    specialised or the generic K2; the big-count choices are never reached by small tests.  Forcing each of them must not
+    change a bit of any output (every accumulator is owned by one lane and adds in SNP order whatever the geometry)."""
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(31 + V)
+    S, B = 700, 37
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=0.05 if field == "GT" else 0.0)
+    al = np.where(raw.alleles < 0, 0, raw.alleles)
+    if field == "GT":
+        g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    elif field == "GP":
+        g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, al)])
+    else:
+        g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, al)])
+    sp = synth.make_pileup(rng, al, B, 1.0 if dense else 0.3, 2.0, dense_layout=dense, doublet_rate=0.3)
+    pl = host_pileup(eng, sp)
+    for k in ("DMX_K1_CW", "DMX_K1_WIDE_V", "DMX_K2_GENERIC", "DMX_NO_CLASSES", "DMX_NO_K1_CLASSES"):
+        monkeypatch.delenv(k, raising=False)
+    base = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    assert np.abs(base["grid"] - ref.llksAB).max() < TOL and np.abs(base["llks"] - ref.llks).max() < TOL
+    variants = [{"DMX_K1_CW": "1"}, {"DMX_K1_CW": "2"}, {"DMX_K1_CW": "4"}, {"DMX_K1_WIDE_V": "2"}, {"DMX_K1_WIDE_V": "1000"},
+                {"DMX_K1_CW": "4", "DMX_NO_K1_CLASSES": "1"}, {"DMX_K1_CW": "2", "DMX_NO_K1_CLASSES": "1"}, {"DMX_K2_GENERIC": "1"},
+                {"DMX_NO_CLASSES": "1", "DMX_K1_CW": "4"}]
+    for env in variants:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+        for k in env:
+            monkeypatch.delenv(k)
+        for name in ("llks", "llk0s", "grid", "l00"):
+            assert np.array_equal(out[name], base[name]), (env, name)
+        assert np.array_equal(out["summ"], base["summ"]), env
