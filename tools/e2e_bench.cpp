@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
   std::vector<const char*> smp((size_t)V);
   for (int j = 0; j < V; ++j) smp[j] = sm[j].c_str();
 
+  const bool dry = getenv("E2E_DRY") != nullptr;      // generator only (its cost is part of the "store" time below)
   dmx_store* st = dmx_store_new();
   for (int s = 0; s < S; ++s) dmx_store_add_snp(st);
   // BAM order = SNP-major: for every SNP the reads of the cells that cover it
@@ -45,19 +46,20 @@ int main(int argc, char** argv) {
   for (int s = 0; s < S; ++s)
     for (int c = 0; c < B; ++c) {
       if (unif() >= delta) continue;
-      const int32_t ib = dmx_store_add_cell(st, bc[c].c_str());
+      const int32_t ib = dry ? c : dmx_store_add_cell(st, bc[c].c_str());
       const int src = c % V;
       int nr = 1; while (unif() < 0.2 && nr < 6) ++nr;
       for (int r = 0; r < nr; ++r) {
-        dmx_store_count_read(st, ib);
+        if (!dry) dmx_store_count_read(st, ib);
         const int bq = 13 + (int)(rnd() % 28);
         const bool alt = unif() < 0.5 * dos[(size_t)s * V + src];
         snprintf(umi, sizeof umi, "U%07llu", (unsigned long long)(rnd() % 10000000ull));
-        dmx_store_add_read(st, s, ib, umi, alt ? 1 : 0, bq);
+        if (!dry) dmx_store_add_read(st, s, ib, umi, alt ? 1 : 0, bq); else rng_state += (uint64_t)umi[3];
         ++n_obs;
       }
     }
   double t1 = now();
+  if (dry) { fprintf(stderr, "generator alone: %ld observations in %.2f s\n", n_obs, t1 - t0); return 0; }
   fprintf(stderr, "store: %ld observations in %.2f s = %.3e add_read/s (%d cells, %d SNPs)\n", n_obs, t1 - t0, n_obs / (t1 - t0), dmx_store_n_cells(st), S);
   dmx_pileup pl;
   dmx_store_freeze(st, &pl);
