@@ -309,6 +309,15 @@ def main():
                 rates.append(r.value)
             out["log_microkernel"] = {"dmx_log_per_s": rates[0], "ocml_log_per_s": rates[1],
                                       "path_logical_logs_over_dmx_log_ceiling": out["fp64_valu"]["logical_log_terms_per_s"] / rates[0]}
+            # ALGORITHMIC FP64 rate against the 78.6 TF vector peak, log() costed as 1 op and as C_log ops, where
+            # C_log = (peak wave-instructions/s x 64 lanes) / measured dmx_log/s issue slots, 2 flop each
+            rbar = dp.n_reads / max(dp.n_pairs, 1)
+            ops1 = dp.n_pairs * ((rbar * 11 + 8 + V * 7 + 7) + ((rbar * A * 54 + A * 18 + V * V * A * 20 + A * 20) if cfg["doublet"] else 0))
+            c_log = VALU_PEAK_WAVE_INSTS * 64 / rates[0] * 2
+            secs = (k1_ms + k2_ms) * 1e-3
+            out["fp64_valu"].update({"algorithmic_tflops_log_as_1_op": ops1 / secs / 1e12, "c_log_flops": c_log,
+                                     "algorithmic_tflops_log_as_c_log": (ops1 + logs * (c_log - 1)) / secs / 1e12,
+                                     "frac_of_peak_log_as_c_log": (ops1 + logs * (c_log - 1)) / secs / 1e12 / FP64_VALU_PEAK_TFLOPS})
         if cfg["doublet"]:
             out["pair_evals_per_s"] = total_pairs * V * V * A * args.steps / elapsed
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 leg only
