@@ -1260,9 +1260,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 
   const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
   // per-cell LDS regions
+  constexpr bool SHARE = TPC > 64;               // one-wavefront cells (V <= 16) form u in registers: no LDS tile, no extra syncs
   constexpr int SUB = 8;                         // pairs per u sub-tile
   const int VU = V;                              // u row: [alpha][k][4 doubles] (4th pads the 3 to 32 bytes)
-  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * GS * 4 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)SUB * 2 * VU * 32;
+  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * GS * 4 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (SHARE ? (size_t)SUB * 2 * VU * 32 : 0);
   unsigned char* base = s_raw + (size_t)cw * cell_bytes;
   double* s_pG = (double*)base;                                  // [TP][2][9]
   float* s_g = (float*)(base + (size_t)TP * 18 * 8);             // [TP][GS]   genotype rows of the tile's SNPs
@@ -1415,6 +1416,35 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
     // g_j . u with u[l] = sum_m pG[n][l][m] g_k[m] formed ONCE per (pair, alpha, k) and shared through LDS by the rows j — three
     // fused multiply-adds per evaluation instead of nine products and seventeen multiply/adds.  The value of a term moves by a
     // few ulp (<= ~1e-15 absolute); the accumulation order is the reference's, so the result stays within ~1e-11 of STRICT.
+    if (!SHARE) {
+      if (owner) {
+        for (int ti = 0; ti < tp; ++ti) {
+          const double* P = &s_pG[ti * 18];
+          double P0[9], P1[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) { P0[i] = P[i]; P1[i] = P[9 + i]; }
+          const float* gr = &s_g[ti * GS];
+          const double a0 = (double)gr[j * 3], a1 = (double)gr[j * 3 + 1], a2 = (double)gr[j * 3 + 2];
+#pragma unroll
+          for (int kk = 0; kk < NK; ++kk) {
+            const int k = min(kb * NK + kk, V - 1);
+            const double b0 = (double)gr[k * 3], b1 = (double)gr[k * 3 + 1], b2 = (double)gr[k * 3 + 2];
+            double x[3], y[3];
+#pragma unroll
+            for (int l = 0; l < 3; ++l) {
+              x[l] = __builtin_fma(P0[l * 3 + 2], b2, __builtin_fma(P0[l * 3 + 1], b1, P0[l * 3] * b0));
+              y[l] = __builtin_fma(P1[l * 3 + 2], b2, __builtin_fma(P1[l * 3 + 1], b1, P1[l * 3] * b0));
+            }
+            const double s0 = __builtin_fma(a2, x[2], __builtin_fma(a1, x[1], a0 * x[0]));
+            const double s1 = __builtin_fma(a2, y[2], __builtin_fma(a1, y[1], a0 * y[0]));
+            ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
+            acc[kk][0] += dmx_log_fast(s0, s_log);
+            acc[kk][1] += dmx_log_fast(s1, s_log);
+          }
+        }
+      }
+      DMX_K2_SYNC();
+    } else
 #pragma unroll 1
     for (int sub = 0; sub < tp; sub += SUB) {
       const int ns = min(SUB, tp - sub);
@@ -2770,8 +2800,9 @@ int launch_doublet(dmx_engine* e) {
   hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
                      e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag)
-  if (e->mode == DMX_MODE_FAST && V > 16) {      // measured: the factored form wins from one-cell-per-workgroup panels (cfg3 1.33x), loses on V <= 16 (cfg5 0.7x)
-    const size_t fast_bytes = cell_bytes + (size_t)8 * 2 * V * 32;
+  if (e->mode == DMX_MODE_FAST) {
+    // one-cell-per-workgroup panels share u through LDS (cfg3 1.33x); one-wavefront cells (V <= 16) form it in registers
+    const size_t fast_bytes = cell_bytes + (V > 16 ? (size_t)8 * 2 * V * 32 : 0);
 #define DMX_K2F(TPC, NK)                                                                                             \
   do {                                                                                                               \
     const size_t lds = fast_bytes * (kThreads / TPC);                                                                \
@@ -2781,7 +2812,9 @@ int launch_doublet(dmx_engine* e) {
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                              \
   } while (0)
-    if (V <= 32) DMX_K2F(256, 4);
+    if (V <= 8) DMX_K2F(64, 1);
+    else if (V <= 16) DMX_K2F(64, 4);
+    else if (V <= 32) DMX_K2F(256, 4);
     else DMX_K2F(256, 16);
 #undef DMX_K2F
     HIP_TRY(hipGetLastError());

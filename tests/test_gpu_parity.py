@@ -485,10 +485,7 @@ def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
     d_ref, d_strict = np.abs(grid - ref.llksAB).max(), np.abs(grid - strict["grid"]).max()
     print(f"V={V} {field}: FAST vs reference {d_ref:.2e}, FAST vs STRICT {d_strict:.2e}")
     assert d_ref < TOL and d_strict < 1e-10
-    if V > 16:
-        assert not np.array_equal(grid, strict["grid"])    # it IS a different operation sequence: keep the two modes honest
-    else:
-        assert np.array_equal(grid, strict["grid"])        # panels of <= 16 samples keep the STRICT kernel (it is the faster one there)
+    assert not np.array_equal(grid, strict["grid"])        # it IS a different operation sequence: keep the two modes honest
 
 
 def test_fast_mode_end_to_end_files(eng, oracle, tmp_path):
