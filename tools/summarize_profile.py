@@ -39,7 +39,7 @@ for k, cs in summ.items():
     if "WRITE_SIZE" in res[k]:
         res[k]["hbm_write_bytes"] = res[k]["WRITE_SIZE"] * 1024
 json.dump(res, open(out / f"{tag}_cfg{cfg}_pmc_summary.json", "w"), indent=1)
-dom = [k for k in res if ("k_doublet_a2" in k or "k_doublet_generic" in k)] or [k for k in res if "k_singlet" in k]
+dom = [k for k in res if "k_doublet" in k] or [k for k in res if "k_singlet" in k]
 dom = max(dom, key=lambda k: res[k].get("SQ_WAVE_CYCLES", 0))
 d = res[dom]
 bench = json.load(open(src / "bench.json"))
