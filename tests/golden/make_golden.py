@@ -167,11 +167,22 @@ def main():
         make_case("gt_v3_alpha_quirk", 105, B=12, S=150, V=3, alphas=(0.25, 0.5, 0.75, 0.1), field="GT", delta=0.5, rbar=3.0,
                   write_pair=True, doublet_prior=0.3, gt_error=0.0),
         make_case("gt_v5_dense", 106, B=8, S=300, V=5, alphas=(0.0, 0.5), field="GT", delta=1.0, rbar=1.25, min_total=1),
+        # wide panel x long alpha grid (j-slabs, alphas padded to 8 per pair), a 6-entry grid with --write-pair on a narrow
+        # panel, and deep pairs (6 reads on average: GL seed tables + the read loop) with missing genotypes
+        make_case("gp_v70_a5", 107, B=4, S=250, V=70, alphas=(0.0, 0.1, 0.25, 0.4, 0.5), field="GP", delta=0.3, rbar=1.5),
+        make_case("pl_v12_a6_pair", 108, B=14, S=300, V=12, alphas=(0.0, 0.1, 0.2, 0.3, 0.4, 0.5), field="PL", delta=0.3, rbar=3.0,
+                  write_pair=True, doublet_prior=0.2),
+        make_case("gt_v24_a2_deep", 109, B=10, S=200, V=24, alphas=(0.0, 0.5), field="GT", delta=0.5, rbar=6.0, write_pair=True,
+                  missing_rate=0.1),
     ]
+    only = set(sys.argv[1:])                 # python make_golden.py [case ...]: regenerate just these
+    if only:
+        cases = [c for c in cases if c[0] in only]
     with tempfile.TemporaryDirectory() as tmp:
         for name, pb in cases:
             save_case(name, pb, tmp)
-    phred_and_store_fixture()
+    if not only:
+        phred_and_store_fixture()
 
 
 if __name__ == "__main__":
