@@ -29,6 +29,8 @@ for case in range(n_cases):
     B = int(rng.integers(1, 6 if V > 64 else 40 * (scale if V <= 32 else 1)))
     delta = 1.0 if dense else float(rng.uniform(0.02, 0.6))
     rbar = float(rng.choice([1.0, 1.25, 2.0, 4.0, 9.0]))
+    if os.environ.get("DMX_FUZZ_DEEP") and V <= 16:            # hundreds of reads per pair: 16-bit counts, the plain-division path
+        rbar = float(rng.choice([40.0, 300.0])); S = min(S, 40); B = min(B, 6)
     missing = float(rng.choice([0.0, 0.0, 0.1]))
     raw = synth.make_raw_genotypes(rng, S, V, missing_rate=missing if field == "GT" else 0.0)
     al = np.where(raw.alleles < 0, 0, raw.alleles)
