@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the likelihood engine on synthetic pileups of the BASELINE.json configs.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|5] [--cells B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5|6] [--cells B] [--fast] [--only]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one resident batch: config 2 (the N=1 headline, BASELINE.json configs[1]):
-K1 singlet accumulation over 10k barcodes x 50k SNPs x 8 samples (dense, GT field); configs 3/5 add the doublet grid
-(K2) and the per-cell reduction (K3).  Inputs are generated in HBM before the timed region.  With N>1 every rank owns
-its own 10k-barcode shard (weak scaling: barcodes are independent, cmd_cram_demuxlet.cpp:576) and each step ends with
-the one RCCL gather of the per-cell records to rank 0.  Rank 0 prints ONE JSON line.
+A "step" is one pass of the hot path over one resident batch: K1 singlet accumulation (cmd_cram_demuxlet.cpp:412-461), then —
+for the doublet configs — K2 doublet grid (:576-710) and K3 per-cell reduction (:713-734,:746-758,:799-828).  Inputs are
+generated in HBM before the timed region.
+
+N = 1 (the driver's headline line): BASELINE.json configs[2] = cfg3, the heaviest single-GPU configuration and the one that
+exercises the whole metric (singlet + doublet), in STRICT mode (the reference's operation order).  The same run appends, as
+nested records under "also", cfg3 in FAST mode, cfg2 (singlet-only) and cfg5 (sparse PL) — each timed the same way with
+fewer steps.  `--only` skips them.
+
+N > 1: BASELINE.json configs[3] = cfg4 (100k barcodes x 100k SNPs x 64 samples, GT), STRONG scaling: the 100k barcodes are cut
+into N contiguous equal ranges (barcodes are independent, cmd_cram_demuxlet.cpp:576; dense pileup = equal work), rank r
+generates and owns range r, and every step ends with THE one collective of the job: the RCCL gather of the fixed-size
+per-barcode records to rank 0.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -30,8 +39,8 @@ CONFIGS = {
             name="cfg2: 10k barcodes x 50k SNPs x 8 samples, GT field, singlet-only, dense (delta=1, rbar=1.25)"),
     3: dict(B=10_000, S=50_000, V=32, field="GP", alphas=(0.0, 0.5), delta=1.0, rbar=1.25, doublet=True,
             name="cfg3: 10k barcodes x 50k SNPs x 32 samples, GP field, doublet grid alpha 0,0.5, dense"),
-    4: dict(B=12_500, S=100_000, V=64, field="GT", alphas=(0.0, 0.5), delta=1.0, rbar=1.25, doublet=True,
-            name="cfg4 (per-GPU shard): 12.5k of 100k barcodes x 100k SNPs x 64 samples, GT field, doublet grid, dense"),
+    4: dict(B=100_000, S=100_000, V=64, field="GT", alphas=(0.0, 0.5), delta=1.0, rbar=1.25, doublet=True,
+            name="cfg4: 100k barcodes x 100k SNPs x 64 samples, GT field, doublet grid alpha 0,0.5, dense"),
     5: dict(B=20_000, S=200_000, V=16, field="PL", alphas=(0.0, 0.5), delta=0.05, rbar=2.0, doublet=True,
             name="cfg5: 20k barcodes x 200k SNPs x 16 samples, PL field, doublet grid, sparse (delta=0.05, rbar=2)"),
     6: dict(B=20_000, S=100_000, V=16, field="GT", alphas=(0.0, 0.5), delta=0.02, rbar=1.25, doublet=True,
@@ -40,7 +49,9 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector peak (spec; half the 157.3 TF FP32 vector rate), FMA = 2 flop
-VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4   # FP64 wave64 instructions/s: 1024 SIMDs, 16 FP64 lanes/clk each (= 78.6 TF / 128)
+SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
+VALU_PEAK_WAVE_INSTS = SIMDS * CLOCK_HZ / 4   # FP64 wave64 instructions/s: 16 FP64 lanes/clk per SIMD (= 78.6 TF / 128)
+METRIC = "cell-SNP-sample triples/sec (singlet+doublet llk); HBM GB/s vs roofline"
 
 
 def genotype_matrix(engine, synth, rng, S, V, field):
@@ -58,6 +69,17 @@ def genotype_matrix(engine, synth, rng, S, V, field):
         for s in range(S):
             g[s] = engine.geno_from_pl(pl[s])
     return raw, g
+
+
+def host_cores():
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                    # a container's CPU quota is the real core count (cgroup v2: "quota period")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return cores
 
 
 def cpu_baseline(dp, g, cfg, target_s=12.0):
@@ -81,29 +103,23 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
             plan.execute()
         return time.perf_counter() - t0, plan.n_pairs * repeats
 
-    def run(ncells):
-        return execute(prepare(0, ncells))
-
     # size the sample from the oracle's measured cost on this class of host (~6 ns per singlet term, ~19 ns per doublet
     # pair-evaluation) so that ONE run lands near target_s
     A = len(cfg["alphas"])
     ns_per_pair = 6.0 * (V + 1) + (19.0 * (V * V * A + A) if cfg["doublet"] else 0.0)
     pairs_per_cell = max(1.0, dp.n_pairs / max(dp.n_cells, 1))
     n = int(max(1, min(dp.n_cells, round(target_s / (1e-9 * ns_per_pair * pairs_per_cell)))))
-    t, pairs = run(n)
+    t, pairs = execute(prepare(0, n))
     out = dict(value=pairs * V / t, unit="cell-SNP-sample triples/s", cores=1, kind="port",
                sample=f"first {n} barcodes of the same workload ({pairs} covered pairs), oracle/dmx_oracle.c "
-                      f"(gcc -O2 -ffp-contract=off), {t:.1f} s wall", seconds=t)
+                      f"(gcc -O2 -ffp-contract=off; a CSR walk of the reference's arithmetic — the reference's own std::map walk "
+                      f"is slower, so this baseline is conservative), {t:.1f} s wall", seconds=t)
+    if cfg["doublet"]:
+        out["pair_evals_per_s"] = pairs * V * V * A / t
     # the same code on all host cores at once (the reference itself is single-threaded, cmd_cram_demuxlet.cpp has no
     # parallelism; this is what `--group-list` sharding over cores would buy): one thread per core, each thread its own
     # barcodes of the same workload, host memory bounded to ~6 GB
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:                                    # a container's CPU quota is the real core count (cgroup v2: "quota period")
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            cores = max(1, min(cores, int(int(q) / int(per))))
-    except (OSError, ValueError):
-        pass
+    cores = host_cores()
     if cores > 1:
         import threading
         bytes_per_cell = pairs_per_cell * 24.0
@@ -129,75 +145,44 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
-    ap.add_argument("--cells", type=int, default=0, help="override barcodes per GPU (smaller = quicker run; not the headline)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--samples", type=int, default=0, help="override the number of samples (experiments; not the headline)")
-    ap.add_argument("--field", default="", help="override the genotype field GT|GP|PL (experiments; not the headline)")
-    ap.add_argument("--fast", action="store_true", help="DMX_MODE_FAST (bilinear doublet terms; opt-in, not the headline)")
-    ap.add_argument("--alphas", default="", help="override the alpha grid, comma separated (experiments; not the headline)")
-    args = ap.parse_args()
+def pmc_profile(cfgno, B, mode):
+    """HBM traffic and VALU instruction counts of one launch of the dominant kernel are properties of the workload; they come
+    from the committed rocprofv3 PMC passes of the SAME workload at the SAME size (profiles/, tools/profile_round.sh)."""
+    for name in (f"pmc_cfg{cfgno}_{mode}.json", f"pmc_cfg{cfgno}.json"):
+        p = ROOT / "profiles" / name
+        if p.exists():
+            pj = json.loads(p.read_text())
+            if pj.get("barcodes_per_gpu") == B and pj.get("mode", "strict") == mode:
+                return pj
+    return None
 
-    # stdout carries exactly one line, the JSON record.  Libraries that print banners from C (RCCL's version block is written
-    # to fd 1 and flushed at exit, i.e. AFTER anything Python printed) are sent to stderr: fd 1 is re-pointed at fd 2 for the
-    # whole run and the record goes to the saved descriptor.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
 
-    import torch
-    import torch.distributed as dist
-    from demuxlet_amd import build, engine, synth, synth_torch
+class Ctx:
+    pass
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    # DMX_BENCH_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (1-GPU boxes: exercises the gather)
-    use_dist = world > 1 or bool(os.environ.get("DMX_BENCH_FORCE_DIST"))
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
-    if rank == 0:
-        build.build()
-    if use_dist:
-        dist.barrier()
 
-    cfg = dict(CONFIGS[args.config])
-    if args.cells:
-        cfg["B"] = args.cells
-    if args.samples:
-        cfg["V"] = args.samples
-    if args.field:
-        cfg["field"] = args.field
-    if args.alphas:
-        cfg["alphas"] = tuple(float(x) for x in args.alphas.split(","))
-    if args.samples or args.field or args.alphas:
-        cfg["name"] += f" [override: V={cfg['V']}, field={cfg['field']}, alphas={list(cfg['alphas'])}]"
-    B, S, V, A = cfg["B"], cfg["S"], cfg["V"], len(cfg["alphas"])
-    rng = np.random.default_rng(0xD3A00000 + args.config)       # the panel is shared by all ranks
+def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log):
+    """Generate the workload of one configuration on this rank's GPU, time `steps` passes, return the record (rank 0)."""
+    torch, dist, engine, synth, synth_torch = cx.torch, cx.dist, cx.engine, cx.synth, cx.synth_torch
+    dev, world, rank, local = cx.dev, cx.world, cx.rank, cx.local
+    fast = mode == "fast"
+    B_total, S, V, A = cfg["B"], cfg["S"], cfg["V"], len(cfg["alphas"])
+    # strong scaling: rank r owns barcodes [lo, hi) of the B_total (contiguous, equal counts: equal work on a dense pileup)
+    lo, hi = (B_total * rank) // world, (B_total * (rank + 1)) // world
+    B = hi - lo
+    rng = np.random.default_rng(0xD3A00000 + cfgno)             # the panel is shared by all ranks
     raw, g = genotype_matrix(engine, synth, rng, S, V, cfg["field"])
     dosage = torch.from_numpy(np.clip(raw.alleles, 0, 1).sum(axis=2).astype(np.float32)).to(dev)
-    dp = synth_torch.make_device_pileup(dosage, B, cfg["delta"], cfg["rbar"], seed=0xD3A0 + 1000 * args.config + rank,
-                                        device=dev, cell_id_base=rank * B)
+    dp = synth_torch.make_device_pileup(dosage, B, cfg["delta"], cfg["rbar"], seed=0xD3A0 + 1000 * cfgno + rank,
+                                        device=dev, cell_id_base=lo)
+    del dosage
     torch.cuda.synchronize()
 
     # one explicit HIP stream for everything timed: the engine launches on it, torch events are recorded on it and RCCL
     # orders against it (the legacy NULL stream would not do: dmx_engine_set_stream(NULL) means "the engine's own")
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    eng = engine.Engine(V, cfg["alphas"], 0.5, device=local, mode=engine.capi.DMX_MODE_FAST if args.fast else engine.capi.DMX_MODE_STRICT)
-    if args.fast:
-        cfg["name"] += " [DMX_MODE_FAST]"
+    eng = engine.Engine(V, cfg["alphas"], 0.5, device=local, mode=engine.capi.DMX_MODE_FAST if fast else engine.capi.DMX_MODE_STRICT)
     assert stream.cuda_stream != 0
     eng.set_stream(stream.cuda_stream)
     eng.set_genotypes(g)
@@ -215,6 +200,7 @@ def main():
                      synth_torch.tensor_from_ptr(v.summary, (B, engine.capi.SUMMARY_DTYPE.itemsize // 8), torch.float64, dev)]
         return torch.cat(cols, dim=1)
 
+    counts = [(B_total * (r + 1)) // world - (B_total * r) // world for r in range(world)]
     gathered = None
 
     def step(ev=None):
@@ -224,83 +210,114 @@ def main():
         if ev: ev[1].record()
         if cfg["doublet"]:
             eng.run_doublet()
-            if ev: ev[2].record()
-        if use_dist:
-            # THE collective of the job: one fixed-size record per barcode -> rank 0 (RCCL gather over xGMI)
+        if ev: ev[2].record()
+        if cx.use_dist:
+            # THE collective of the job: one fixed-size record per barcode -> rank 0 (RCCL gather over xGMI).  Ranks may own
+            # B/N or B/N+1 barcodes, so the records are padded to the largest count (gather wants equal shapes).
             rec = record_matrix()
+            pad = max(counts) - B
+            if pad:
+                rec = torch.cat([rec, rec.new_zeros((pad, rec.shape[1]))], dim=0)
             outs = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
             dist.gather(rec, outs, dst=0)
             gathered = outs
+        if ev: ev[3].record()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    if use_dist:
+    if cx.use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(evs[i])
     torch.cuda.synchronize()
-    if use_dist:
+    own_elapsed = time.perf_counter() - t0          # this rank's own time (before waiting for the others)
+    if cx.use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if use_dist:
+    per_rank_ms = [1e3 * own_elapsed / steps]
+    if cx.use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        counts = torch.tensor([dp.n_pairs], dtype=torch.float64, device=dev)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        total_pairs = float(counts.item())
+        cnt = torch.tensor([dp.n_pairs], dtype=torch.float64, device=dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_pairs = float(cnt.item())
+        mine = torch.tensor([1e3 * own_elapsed / steps], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(x.item()) for x in allr]
     else:
         total_pairs = float(dp.n_pairs)
 
     k1_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     k2_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if cfg["doublet"] else 0.0
+    gather_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs])) if cx.use_dist else 0.0
+    out = None
     if rank == 0:
+        if cx.use_dist and gathered is not None:
+            assert len(gathered) == world and gathered[0].shape[0] == max(counts)
         triples = total_pairs * V
-        ms_per_step = 1e3 * elapsed / args.steps
+        ms_per_step = 1e3 * elapsed / steps
         dom_ms, dom_bytes, dom_name = (k2_ms, nbytes.doublet_bytes, "k_doublet") if cfg["doublet"] else (k1_ms, nbytes.singlet_bytes, "k_singlet")
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        # HBM traffic and VALU instruction counts of one launch of the dominant kernel are properties of the workload; they
-        # come from the committed rocprofv3 PMC passes of the same workload (profiles/, tools/profile_round.sh)
         traffic, valu = None, None
-        prof = ROOT / "profiles" / f"pmc_cfg{args.config}.json"
-        if prof.exists():
-            pj = json.loads(prof.read_text())
-            if pj.get("barcodes_per_gpu") == B:
-                traffic = pj.get("hbm_bytes_per_launch")
-                if pj.get("valu_wave_insts_per_launch"):
-                    rate = pj["valu_wave_insts_per_launch"] / (dom_ms * 1e-3)
-                    valu = {"bound": "fp64_valu", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave-instructions/s",
-                            "frac": rate / VALU_PEAK_WAVE_INSTS, "kernel": pj.get("kernel"),
-                            "note": "the binding roofline of this path: FP64 VALU issue (1024 SIMDs x 2.4 GHz / 4 cycles per wave64 FP64 "
-                                    "instruction); instruction count per launch from profiles/ PMC (SQ_INSTS_VALU), time live"}
-        logs = dp.n_pairs * ((V + 1) + (V * V * A + A if cfg["doublet"] else 0))
+        pj = pmc_profile(cfgno, B, mode)
+        if pj:
+            traffic = pj.get("hbm_bytes_per_launch")
+            if pj.get("issue_cycles_per_launch"):
+                # issue-cycle roofline: every wave64 VALU instruction occupies its SIMD's issue port for 4 cycles (FP64 and
+                # transcendental) or 2 cycles (FP32 / int / convert / move: MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc");
+                # 1024 SIMDs x 2.4 GHz cycles are available per second.  Counts per launch from profiles/ PMC, time live.
+                rate = pj["issue_cycles_per_launch"] / (dom_ms * 1e-3)
+                valu = {"bound": "valu_issue", "achieved": rate, "peak": SIMDS * CLOCK_HZ, "unit": "SIMD issue cycles/s",
+                        "frac": rate / (SIMDS * CLOCK_HZ), "kernel": pj.get("kernel"),
+                        "fp64_insts_per_launch": pj.get("fp64_insts_per_launch"), "other_valu_insts_per_launch": pj.get("other_valu_insts_per_launch"),
+                        "upper_bound_all_insts_at_4_cycles": pj.get("valu_wave_insts_per_launch", 0) / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS,
+                        "note": "the binding roofline of this path (SURVEY 8d): VALU issue. issue cycles = 4 x (FP64 + transcendental wave-"
+                                "instructions) + 2 x (all other VALU wave-instructions), per-type counts from profiles/ PMC"}
+            elif pj.get("valu_wave_insts_per_launch"):
+                rate = pj["valu_wave_insts_per_launch"] / (dom_ms * 1e-3)
+                valu = {"bound": "valu_issue", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave-instructions/s",
+                        "frac": rate / VALU_PEAK_WAVE_INSTS, "kernel": pj.get("kernel"),
+                        "note": "UPPER bound on FP64-pipe utilisation: every VALU instruction charged 4 cycles (SQ_INSTS_VALU also counts "
+                                "2-cycle int/FP32/convert instructions); instruction count per launch from profiles/ PMC, time live"}
+        logs = total_pairs * ((V + 1) + (V * V * A + A if cfg["doublet"] else 0))
         out = {
-            "metric": "cell-SNP-sample triples/sec (singlet+doublet llk); HBM GB/s vs roofline",
-            "value": triples * args.steps / elapsed, "unit": "triples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC,
+            "value": triples * steps / elapsed, "unit": "triples/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"], "barcodes_per_gpu": B, "snps": S, "samples": V, "alphas": list(cfg["alphas"]),
-                       "covered_pairs_per_gpu": dp.n_pairs, "reads_per_gpu": dp.n_reads, "mode": "fast" if args.fast else "strict",
-                       "sharding": f"barcodes x{world}, one RCCL gather per step" if world > 1 else "single GPU"},
+            "config": {"workload": cfg["name"] + (" [DMX_MODE_FAST]" if fast else ""), "barcodes_total": B_total, "barcodes_per_gpu": B,
+                       "snps": S, "samples": V, "alphas": list(cfg["alphas"]),
+                       "covered_pairs_per_gpu": dp.n_pairs, "reads_per_gpu": dp.n_reads, "mode": mode,
+                       "sharding": (f"{B_total} barcodes cut into {world} contiguous ranges, one per GPU (strong scaling); "
+                                    f"one RCCL gather of {max(counts)} x {record_matrix().shape[1] * 8} B records per rank per step")
+                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
                          "kernel_ms": dom_ms,
-                         "note": "FP64-VALU/log-bound path (SURVEY §8d): HBM fraction is reported as the metric asks; see roofline_valu. "
-                                 "traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of one launch (profiles/); above the algorithmic bytes it "
-                                 "contains the L2 misses of the GL seed-table gathers (DESIGN.md §6), not re-reads of the inputs"},
+                         "note": "VALU-issue/log-bound path (SURVEY §8d): HBM fraction is reported as the metric asks; see roofline_valu. "
+                                 "traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of one launch at this size (profiles/)"},
             "roofline_valu": valu,
-            "fp64_valu": {"logical_log_terms_per_s": logs / ((k1_ms + k2_ms) * 1e-3), "kernel_ms": {"k_singlet": k1_ms, "k_doublet+k_reduce": k2_ms},
-                          "peak_tflops": FP64_VALU_PEAK_TFLOPS},
+            "fp64_valu": {"logical_log_terms_per_s": logs / world / ((k1_ms + k2_ms) * 1e-3),
+                          "kernel_ms": {"k_singlet": k1_ms, "k_doublet+k_reduce": k2_ms}, "peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }
-        if world == 1:
+        if world > 1 or cx.use_dist:
+            out["ranks_seen"] = dist.get_world_size()
+            out["per_rank_ms_per_step"] = per_rank_ms
+            out["gather_ms"] = gather_ms
+        if cfg["doublet"]:
+            out["pair_evals_per_s"] = total_pairs * V * V * A * steps / elapsed
+        if with_log:
             # the device's log() ceiling from a register-resident microkernel, same run: what fraction of it the
-            # path's LOGICAL log terms amount to (the genotype-class kernels execute fewer logs than the reference's count,
-            # so this fraction can exceed 1 for GT inputs; it cannot for GP/PL inputs)
+            # path's LOGICAL log terms amount to (the genotype-class kernels and FAST mode execute fewer logs than the
+            # reference's count, so this fraction can exceed 1 there; it cannot for GP/PL inputs in STRICT mode)
             import ctypes
             rates = []
             for which in (0, 1):
@@ -318,15 +335,97 @@ def main():
             out["fp64_valu"].update({"algorithmic_tflops_log_as_1_op": ops1 / secs / 1e12, "c_log_flops": c_log,
                                      "algorithmic_tflops_log_as_c_log": (ops1 + logs * (c_log - 1)) / secs / 1e12,
                                      "frac_of_peak_log_as_c_log": (ops1 + logs * (c_log - 1)) / secs / 1e12 / FP64_VALU_PEAK_TFLOPS})
-        if cfg["doublet"]:
-            out["pair_evals_per_s"] = total_pairs * V * V * A * args.steps / elapsed
-        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 leg only
+        if with_cpu:                                     # the CPU baseline is a rank-0, N=1 leg only
             out["cpu_baseline"] = cpu_baseline(dp, g, cfg)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    eng.close()
+    del eng, dp, gathered
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(CONFIGS),
+                    help="0 = the driver's default: cfg3 (+ nested cfg3-fast/cfg2/cfg5 records) at N=1, cfg4 sharded at N>1")
+    ap.add_argument("--cells", type=int, default=0, help="override the TOTAL barcode count (smaller = quicker run; not the headline)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only", action="store_true", help="N=1: skip the nested records of the other configurations")
+    ap.add_argument("--samples", type=int, default=0, help="override the number of samples (experiments; not the headline)")
+    ap.add_argument("--field", default="", help="override the genotype field GT|GP|PL (experiments; not the headline)")
+    ap.add_argument("--fast", action="store_true", help="DMX_MODE_FAST for the main record (opt-in, not the headline)")
+    ap.add_argument("--alphas", default="", help="override the alpha grid, comma separated (experiments; not the headline)")
+    args = ap.parse_args()
+
+    # stdout carries exactly one line, the JSON record.  Libraries that print banners from C (RCCL's version block is written
+    # to fd 1 and flushed at exit, i.e. AFTER anything Python printed) are sent to stderr: fd 1 is re-pointed at fd 2 for the
+    # whole run and the record goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+    from demuxlet_amd import build, engine, synth, synth_torch
+
+    cx = Ctx()
+    cx.torch, cx.dist, cx.engine, cx.synth, cx.synth_torch = torch, dist, engine, synth, synth_torch
+    cx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    cx.rank = int(os.environ.get("RANK", "0"))
+    cx.local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(cx.local)
+    cx.dev = torch.device("cuda", cx.local)
+    # DMX_BENCH_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (1-GPU boxes: exercises the gather)
+    cx.use_dist = cx.world > 1 or bool(os.environ.get("DMX_BENCH_FORCE_DIST"))
+    if cx.use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
+    if cx.rank == 0:
+        build.build()
+    if cx.use_dist:
+        dist.barrier()
+
+    default_run = args.config == 0
+    cfgno = args.config or (3 if cx.world == 1 else 4)
+    cfg = dict(CONFIGS[cfgno])
+    if args.cells:
+        cfg["B"] = args.cells
+    if args.samples:
+        cfg["V"] = args.samples
+    if args.field:
+        cfg["field"] = args.field
+    if args.alphas:
+        cfg["alphas"] = tuple(float(x) for x in args.alphas.split(","))
+    if args.samples or args.field or args.alphas:
+        cfg["name"] += f" [override: V={cfg['V']}, field={cfg['field']}, alphas={list(cfg['alphas'])}]"
+    if args.cells:
+        cfg["name"] += f" [override: {args.cells} barcodes]"
+    single = cx.world == 1 and not cx.use_dist
+    out = run_config(cx, cfgno, cfg, "fast" if args.fast else "strict", args.steps, args.warmup,
+                     with_cpu=single and not args.no_cpu_baseline, with_log=single)
+    if single and default_run and not args.only:
+        # nested records of the same run: the other single-GPU BASELINE configurations and the opt-in mode, fewer steps each
+        also = []
+        k, w = max(2, min(args.steps, 5)), min(args.warmup, 1)
+        for no, mode in ((3, "fast"), (2, "strict"), (5, "strict"), (5, "fast")):
+            c = dict(CONFIGS[no])
+            if args.cells:
+                c["B"] = min(c["B"], args.cells)
+                c["name"] += f" [override: {c['B']} barcodes]"
+            r = run_config(cx, no, c, mode, k, w, with_cpu=False, with_log=False)
+            also.append({key: r[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu",
+                                                 "fp64_valu", "pair_evals_per_s") if key in r})
+        out["also"] = also
+    if cx.rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if use_dist:
-        if rank == 0 and gathered is not None:
-            assert len(gathered) == world and tuple(gathered[0].shape) == tuple(record_matrix().shape)
+    if cx.use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

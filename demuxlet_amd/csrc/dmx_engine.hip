@@ -2569,6 +2569,9 @@ extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
     HIP_TRY(hipMemcpy(h_off.data(), pl->cell_pair_off, sizeof(int64_t) * ((size_t)B + 1), hipMemcpyDeviceToHost));
     e->pv.cell_pair_off = pl->cell_pair_off; e->pv.cell_read_off = pl->cell_read_off; e->pv.pair_snp = pl->pair_snp;
     e->pv.pair_nrd = pl->pair_nrd; e->pv.reads = pl->reads;
+    if (!pl->pair_snp && pl->n_pairs == 0) {     // no pairs at all: never the dense layout (NULL would select it)
+      if (int rc = upload<int32_t>(e, nullptr, 0, &e->own[2], &e->pv.pair_snp)) return rc;
+    }
   } else {
     std::memcpy(h_off.data(), pl->cell_pair_off, sizeof(int64_t) * ((size_t)B + 1));
     if (pl->pair_snp) {   // host-side validation of what the kernels will index with
@@ -2577,7 +2580,9 @@ extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
     }
     if (int rc = upload<int64_t>(e, pl->cell_pair_off, (size_t)B + 1, &e->own[0], &e->pv.cell_pair_off)) return rc;
     if (int rc = upload<int64_t>(e, pl->cell_read_off, (size_t)B + 1, &e->own[1], &e->pv.cell_read_off)) return rc;
-    if (pl->pair_snp) { if (int rc = upload<int32_t>(e, pl->pair_snp, (size_t)pl->n_pairs, &e->own[2], &e->pv.pair_snp)) return rc; }
+    // NULL pair_snp = dense layout — but only when there are pairs: a pileup without any (no read overlaps a SNP, or a barcode
+    // range of uncovered cells) is a sparse pileup with empty cells, which the reference handles (.single rows only, :592)
+    if (pl->pair_snp || pl->n_pairs == 0) { if (int rc = upload<int32_t>(e, pl->pair_snp, (size_t)pl->n_pairs, &e->own[2], &e->pv.pair_snp)) return rc; }
     else e->pv.pair_snp = nullptr;
     const uint8_t* v = nullptr;
     if (int rc = upload<uint8_t>(e, pl->pair_nrd, (size_t)pl->n_pairs * (size_t)pl->nrd_width, &e->own[3], &v)) return rc;
@@ -2587,7 +2592,7 @@ extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
   if (h_off[0] != 0 || h_off[(size_t)B] != pl->n_pairs) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off does not span n_pairs");
   for (int32_t c = 0; c < B; ++c) {
     if (h_off[c + 1] < h_off[c]) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off not monotone at %d", c);
-    if (!pl->pair_snp && h_off[c + 1] - h_off[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: dense layout needs n_snps pairs per cell (cell %d)", c);
+    if (!e->pv.pair_snp && h_off[c + 1] - h_off[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: dense layout needs n_snps pairs per cell (cell %d)", c);
   }
   // dense pileups: SNP-minor copies of the genotype probabilities for the singlet kernel
   if (e->d_gT) { (void)hipFree(e->d_gT); e->d_gT = nullptr; }

@@ -233,7 +233,12 @@ extern "C" int dmx_geno_from_gp(const float* gp, int32_t nv, double gt_error, fl
 namespace { int host_threads(); }   // defined with the writers below
 
 struct dmx_store {
-  struct Obs { int32_t cell, snp; uint32_t umi_off, umi_len; uint8_t allele, bq; uint32_t count; };
+  // umi: offset into umi_pool in the low 40 bits (the pool passes 4 GiB at ~3.5e8 observations with 12-byte UMIs), length above
+  struct Obs {
+    int32_t cell, snp; uint64_t umi; uint8_t allele, bq; uint32_t count;
+    uint64_t umi_off() const { return umi & 0xFFFFFFFFFFull; }
+    uint32_t umi_len() const { return (uint32_t)(umi >> 40); }
+  };
   std::vector<std::string> barcodes;
   std::vector<uint64_t> bc_index;      // open addressing over barcodes: (hash's high 32 bits << 32) | cell id; looked up with
                                        // the caller's C string as it is (no temporary std::string per read)
@@ -281,7 +286,7 @@ struct dmx_store {
     index.assign(cap, kEmpty);
     for (size_t i = 0; i < obs.size(); ++i) {
       const Obs& o = obs[i];
-      const uint64_t h = hash(o.cell, o.snp, umi_pool.data() + o.umi_off, o.umi_len);
+      const uint64_t h = hash(o.cell, o.snp, umi_pool.data() + o.umi_off(), o.umi_len());
       size_t p = h & (cap - 1);
       while (index[p] != kEmpty) p = (p + 1) & (cap - 1);
       index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
@@ -342,12 +347,13 @@ extern "C" int dmx_store_add_read(dmx_store* s, int32_t snp, int32_t cell, const
   for (; s->index[p] != dmx_store::kEmpty; p = (p + 1) & (cap - 1)) {
     if ((s->index[p] ^ h) >> 32) continue;                                        // another key's fingerprint
     dmx_store::Obs& o = s->obs[(size_t)(s->index[p] & 0xFFFFFFFFull)];
-    if (o.cell == cell && o.snp == snp && o.umi_len == len && std::memcmp(s->umi_pool.data() + o.umi_off, umi, len) == 0) {
+    if (o.cell == cell && o.snp == snp && o.umi_len() == len && std::memcmp(s->umi_pool.data() + o.umi_off(), umi, len) == 0) {
       ++o.count;                                                                   // :57 duplicate: only the count moves
       return 0;
     }
   }
-  dmx_store::Obs o{cell, snp, (uint32_t)s->umi_pool.size(), (uint32_t)len, (uint8_t)allele, (uint8_t)bq, 1u};
+  if (len >= (1u << 24) || s->umi_pool.size() + len >= (1ull << 40)) return set_error(DMX_ERR_ARG, "dmx_store_add_read: UMI of %zu bytes / UMI pool over 1 TiB", len);
+  dmx_store::Obs o{cell, snp, (uint64_t)s->umi_pool.size() | ((uint64_t)len << 40), (uint8_t)allele, (uint8_t)bq, 1u};
   s->umi_pool.append(umi, len);
   s->index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)s->obs.size();
   s->obs.push_back(o);
@@ -387,9 +393,9 @@ extern "C" int dmx_store_freeze(dmx_store* s, dmx_pileup* out) {
     auto less = [&](uint32_t a, uint32_t b) {
       const dmx_store::Obs &x = obs[a], &y = obs[b];
       if (x.snp != y.snp) return x.snp < y.snp;
-      const int c = std::memcmp(pool + x.umi_off, pool + y.umi_off, std::min(x.umi_len, y.umi_len));
+      const int c = std::memcmp(pool + x.umi_off(), pool + y.umi_off(), std::min(x.umi_len(), y.umi_len()));
       if (c != 0) return c < 0;
-      return x.umi_len < y.umi_len;
+      return x.umi_len() < y.umi_len();
     };
     s->cell_pair_off.assign((size_t)B + 1, 0);
     s->cell_read_off.assign((size_t)B + 1, 0);
@@ -439,7 +445,8 @@ extern "C" int dmx_store_freeze(dmx_store* s, dmx_pileup* out) {
   out->n_cells = B; out->n_snps = s->n_snps;
   out->n_pairs = (int64_t)s->pair_snp.size(); out->n_reads = (int64_t)s->reads.size();
   out->cell_pair_off = s->cell_pair_off.data(); out->cell_read_off = s->cell_read_off.data();
-  out->pair_snp = s->pair_snp.data(); out->pair_nrd = s->pair_nrd_bytes.data(); out->nrd_width = s->nrd_width;
+  static const int32_t kNoPairs[1] = {0};       // a store without any pair still hands out the sparse layout (NULL = dense, dmx.h)
+  out->pair_snp = s->pair_snp.empty() ? kNoPairs : s->pair_snp.data(); out->pair_nrd = s->pair_nrd_bytes.data(); out->nrd_width = s->nrd_width;
   out->memory = DMX_MEM_HOST; out->reads = s->reads.data();
   out->rd_totl = s->totl.data(); out->rd_pass = s->pass.data(); out->rd_uniq = s->uniq.data();
   return DMX_OK;

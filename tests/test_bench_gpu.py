@@ -21,7 +21,7 @@ def run_bench(*extra):
 
 
 def test_bench_line_singlet():
-    d = run_bench("--cells", "1024")
+    d = run_bench("--config", "2", "--cells", "1024")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -41,3 +41,26 @@ def test_bench_line_doublet_configs():
     assert d["pair_evals_per_s"] > 0 and d["roofline"]["kernel"] == "k_doublet" and "cpu_baseline" not in d
     f = run_bench("--config", "3", "--cells", "64", "--no-cpu-baseline", "--fast")
     assert f["config"]["mode"] == "fast"
+
+
+def test_bench_default_line_is_cfg3_with_nested_records():
+    """The driver's N=1 command (no --config): cfg3 STRICT as the line, cfg3-FAST / cfg2 / cfg5 as nested records."""
+    d = run_bench("--cells", "64", "--no-cpu-baseline")
+    assert d["config"]["workload"].startswith("cfg3") and d["config"]["mode"] == "strict" and d["pair_evals_per_s"] > 0
+    assert d["roofline"]["kernel"] == "k_doublet" and d["scaling"] == "weak"
+    names = [(a["config"]["workload"][:4], a["config"]["mode"]) for a in d["also"]]
+    assert ("cfg3", "fast") in names and ("cfg2", "strict") in names and ("cfg5", "strict") in names
+    for a in d["also"]:
+        assert a["value"] > 0 and a["roofline"]["achieved"] > 0
+
+
+def test_bench_sharded_path_with_a_one_rank_group():
+    """The N>1 code path (cfg4 ranges + the end-of-step RCCL gather) on the one GPU this box has: a 1-rank process group."""
+    import os
+    env = dict(os.environ, DMX_BENCH_FORCE_DIST="1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "4",
+                        "--cells", "96"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert d["ranks_seen"] == 1 and len(d["per_rank_ms_per_step"]) == 1 and d["gather_ms"] >= 0
+    assert d["config"]["workload"].startswith("cfg4") and d["config"]["barcodes_total"] == 96
