@@ -1,6 +1,14 @@
 #!/usr/bin/env python3
-"""Condenses the rocprofv3 CSVs of tools/profile_round.sh into profiles/<tag>_cfg<N>_{kernel_stats.csv,pmc_summary.json}
-and writes profiles/pmc_cfg<N>.json (read by bench.py for roofline.traffic)."""
+"""Condenses the rocprofv3 CSVs of tools/profile_round.sh into profiles/<tag>_cfg<N>[_fast]_{kernel_stats.csv,pmc_summary.json,
+bench.json} and writes profiles/pmc_cfg<N>_<mode>.json (read by bench.py for roofline.traffic / roofline_valu).
+
+    python tools/summarize_profile.py gpurun_out/prof_r02_cfg3 r02 3
+
+Issue-cycle accounting: a wave64 VALU instruction holds its SIMD's issue port for 4 cycles when it is FP64
+(16 lanes/clk: add/mul/fma/transcendental incl. v_rcp_f64) and for 2 cycles otherwise (32 lanes/clk: int32, FP32, moves,
+compares, converts — MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc").  issue_cycles = 4 x FP64 + 2 x (SQ_INSTS_VALU - FP64).
+v_cvt_f64_f32 is priced at 2 here (conservative: if it runs at the FP64 rate the true utilisation is higher; `issue_cycles_cvt4`
+gives that variant)."""
 import collections
 import csv
 import json
@@ -12,8 +20,11 @@ tag = sys.argv[2]
 cfg = sys.argv[3]
 out = Path(__file__).resolve().parents[1] / "profiles"
 out.mkdir(exist_ok=True)
+bench = json.load(open(src / "bench.json"))
+mode = bench["config"].get("mode", "strict")
+sfx = "" if mode == "strict" else f"_{mode}"
 rows = [r for r in csv.DictReader(open(src / "kernel_stats.csv")) if "(anonymous namespace)::k_" in r["Name"]]
-with open(out / f"{tag}_cfg{cfg}_kernel_stats.csv", "w") as f:
+with open(out / f"{tag}_cfg{cfg}{sfx}_kernel_stats.csv", "w") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
     for r in rows:
@@ -24,29 +35,41 @@ for p in sorted(src.glob("pmc_*.csv")):
     for r in csv.DictReader(open(p)):
         if "(anonymous namespace)::k_" not in r["Kernel_Name"]:
             continue
-        k = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
+        k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         summ[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta[k] = dict(vgpr=r["VGPR_Count"], agpr=r["Accum_VGPR_Count"], sgpr=r["SGPR_Count"], lds=r["LDS_Block_Size"], grid=r["Grid_Size"], wg=r["Workgroup_Size"])
 res = {}
 for k, cs in summ.items():
-    res[k] = {c: sum(v) / len(v) for c, v in cs.items()}
-    res[k]["_dispatch"] = meta[k]
-    if "FETCH_SIZE" in res[k]:
+    d = res[k] = {c: sum(v) / len(v) for c, v in cs.items()}
+    d["_dispatch"] = meta[k]
+    if "FETCH_SIZE" in d:
         # rocprofv3 units: KiB.  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide
         # coalesced stream (x2 correction); narrower accesses are uncalibrated, so both figures are kept.
-        res[k]["hbm_read_bytes_raw"] = res[k]["FETCH_SIZE"] * 1024
-        res[k]["hbm_read_bytes_x2"] = res[k]["FETCH_SIZE"] * 2048
-    if "WRITE_SIZE" in res[k]:
-        res[k]["hbm_write_bytes"] = res[k]["WRITE_SIZE"] * 1024
-json.dump(res, open(out / f"{tag}_cfg{cfg}_pmc_summary.json", "w"), indent=1)
+        d["hbm_read_bytes_raw"] = d["FETCH_SIZE"] * 1024
+        d["hbm_read_bytes_x2"] = d["FETCH_SIZE"] * 2048
+    if "WRITE_SIZE" in d:
+        d["hbm_write_bytes"] = d["WRITE_SIZE"] * 1024
+    f64 = [d.get(f"SQ_INSTS_VALU_{x}_F64") for x in ("ADD", "MUL", "FMA", "TRANS")]
+    if all(v is not None for v in f64) and "SQ_INSTS_VALU" in d:
+        d["fp64_insts"] = sum(f64)
+        d["other_valu_insts"] = d["SQ_INSTS_VALU"] - d["fp64_insts"]
+        d["issue_cycles"] = 4 * d["fp64_insts"] + 2 * d["other_valu_insts"]
+        d["issue_cycles_cvt4"] = d["issue_cycles"] + 2 * d.get("SQ_INSTS_VALU_CVT", 0.0)
+json.dump(res, open(out / f"{tag}_cfg{cfg}{sfx}_pmc_summary.json", "w"), indent=1)
+json.dump(bench, open(out / f"{tag}_cfg{cfg}{sfx}_bench.json", "w"))
 dom = [k for k in res if "k_doublet" in k] or [k for k in res if "k_singlet" in k]
 dom = max(dom, key=lambda k: res[k].get("SQ_WAVE_CYCLES", 0))
 d = res[dom]
-bench = json.load(open(src / "bench.json"))
-json.dump({"kernel": dom, "barcodes_per_gpu": bench["config"]["barcodes_per_gpu"],
+json.dump({"kernel": dom, "barcodes_per_gpu": bench["config"]["barcodes_per_gpu"], "mode": mode,
            "valu_wave_insts_per_launch": d.get("SQ_INSTS_VALU"), "valu_busy_quadcycles_per_launch": d.get("SQ_ACTIVE_INST_VALU"),
+           "fp64_insts_per_launch": d.get("fp64_insts"), "other_valu_insts_per_launch": d.get("other_valu_insts"),
+           "issue_cycles_per_launch": d.get("issue_cycles"), "issue_cycles_cvt4_per_launch": d.get("issue_cycles_cvt4"),
+           "sq_inst_cycles_valu_per_launch": d.get("SQ_INST_CYCLES_VALU"),
+           "lds_insts_per_launch": d.get("SQ_INSTS_LDS"), "lds_active_quadcycles_per_launch": d.get("SQ_ACTIVE_INST_LDS"),
+           "lds_idx_active_per_launch": d.get("SQ_LDS_IDX_ACTIVE"), "lds_bank_conflict_per_launch": d.get("SQ_LDS_BANK_CONFLICT"),
+           "grbm_gui_active_per_launch": d.get("GRBM_GUI_ACTIVE"),
            "hbm_bytes_per_launch": d.get("hbm_read_bytes_x2", 0) + d.get("hbm_write_bytes", 0),
            "hbm_read_bytes_raw": d.get("hbm_read_bytes_raw"), "hbm_read_bytes_x2": d.get("hbm_read_bytes_x2"),
-           "hbm_write_bytes": d.get("hbm_write_bytes"), "source": f"profiles/{tag}_cfg{cfg}_pmc_summary.json"},
-          open(out / f"pmc_cfg{cfg}.json", "w"), indent=1)
-print(json.dumps(res, indent=1)[:3000])
+           "hbm_write_bytes": d.get("hbm_write_bytes"), "source": f"profiles/{tag}_cfg{cfg}{sfx}_pmc_summary.json"},
+          open(out / f"pmc_cfg{cfg}_{mode}.json", "w"), indent=1)
+print(json.dumps(res, indent=1)[:4000])
