@@ -1503,6 +1503,270 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// K2, FAST mode, alpha grid {0, 0.5} (demuxlet's default): only the grid entries demuxlet ever prints or decides on.
+//   * llksAB[j][k][0] for k != 0 is read by nothing but the maxLLK scan (cmd_cram_demuxlet.cpp:713-721; the printed uses of the
+//     alpha[0] entries are [j][0][0] only, :726,:749-757,:774-780,:816-825), and maxLLK cancels in every printed posterior
+//     (:726-733,:768,:780,:792,:827-828).  With alpha[0] == 0 the entry does not depend on k beyond float32 rounding of
+//     sum_m g_k[m].  They are not computed; the grid cells are filled with [j][0][0].
+//   * at alpha == 0.5 the mixture is symmetric: [k][j][1] is [j][k][1] up to the rounding of the nine-term sum (<= 3e-14 in the
+//     reference), .pair prints j < k only (:785) and the host tie arbiter settles which order .best names.  One
+//     evaluation per unordered pair {j,k}, mirrored into both cells.
+// Per covered pair that is V + V(V+1)/2 log terms instead of 2 V^2: 560 instead of 2048 at V = 32.  Everything else follows
+// k_doublet_a2f: the bilinear factoring g_j . u_k with u_k[l] = sum_m pG[1][l][m] g_k[m] formed once per (pair, k); every
+// accumulator is owned by one lane which adds its terms in ascending SNP order (what keeps the result within ~1e-11 of STRICT).
+// Entry e = tid + TPC*i of a lane: e < V*D (D = V/2 + 1): j = e % V, k = (j + e / V) % V at alpha 0.5 (the rotation makes the
+// lanes of a wavefront read consecutive u_k: conflict-free LDS); V*D <= e < V*D + V: the singlet entry [j][0][0], j = e - V*D.
+// For even V the offset d = V/2 is computed from both sides; only the j < k copy is stored.
+template <int TPC, int VMAX, int SUB, bool FIXJ>
+__global__ __launch_bounds__(kThreads, 3) void k_doublet_sym(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                          const int32_t* __restrict__ sched, int32_t V,
+                                                          double* __restrict__ grid, double* __restrict__ l00,
+                                                          uint8_t* __restrict__ flagged) {
+  constexpr int A = 2, TP = 32;
+  constexpr int CPW = kThreads / TPC;            // cells per workgroup
+  constexpr int T00 = TP + 2;
+  constexpr int NE = (VMAX * (VMAX / 2 + 1) + VMAX + TPC - 1) / TPC;   // entries per lane
+  constexpr int VUS = (VMAX + 2) & ~1;           // u row stride (V alpha-0.5 rows + the alpha-0 row of sample 0), even
+  constexpr int GSS = (3 * VMAX + 3) & ~3;       // genotype row stride (floats)
+#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  __shared__ double s_w[2][10];                  // mixing weights of :613 per alpha and distinct value: [n][0..4] = p (ALT), [n][5..9] = 1 - p
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  if (t < 10) {
+    // alpha 0: p = 0.5 l does not depend on m -> slots 0..2 hold l = 0..2 (slots 3, 4 repeat l = 2); alpha 0.5: p = 0.25 (l + m)
+    // -> slot = l + m.  Same operands, same operations as the nine entries of the reference: the values are bit-identical.
+    const int n = t / 5, q = t % 5;
+    const int l = n ? (q > 2 ? 2 : q) : min(q, 2), m = n ? q - l : 0;
+    const double p = 0.5 * l + (m - l) * 0.5 * (n ? 0.5 : 0.0);
+    s_w[n][q] = p;
+    s_w[n][5 + q] = 1.0 - p;
+  }
+  __syncthreads();
+
+  const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
+  constexpr size_t cell_bytes = (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)SUB * GSS * 4 + (size_t)SUB * 3 * VUS * 8;
+  unsigned char* base = s_raw + (size_t)cw * cell_bytes;
+  double* s_q1 = (double*)base;                                  // [TP][6]    pG of alpha 0.5: q[l+m], five distinct values
+  double* s_u0 = s_q1 + TP * 6;                                  // [TP][4]    u of (alpha 0, sample 0)
+  double* s_t00 = s_u0 + TP * 4;                                 // [2][T00]   llks00 terms
+  int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                  // [TP]
+  int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
+  uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
+  float* s_g = (float*)(s_cnt + TP);                             // [SUB][GSS] genotype rows of the sub-tile's SNPs
+  double* s_u = (double*)(s_g + SUB * GSS);                      // [SUB][3][VUS]
+
+  const int slot = blockIdx.x * CPW + cw;
+  if (TPC == 64 && slot >= pv.B) return;         // whole wavefront idle (no workgroup barriers below in this mode)
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+
+  // phase-2 identity: NE entries per lane
+  const int D = V / 2 + 1, VD = V * D;
+  int ek[NE], ej[NE];                            // u row (k, or V = the alpha-0 row) and sample j of each entry
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int e = tid + TPC * i;
+    if (e < VD) { const int j = e % V; int k = j + e / V; k = k >= V ? k - V : k; ej[i] = j; ek[i] = k; }
+    else if (e < VD + V) { ej[i] = e - VD; ek[i] = V; }
+    else { ej[i] = 0; ek[i] = V; }               // idle slot: computes the first singlet term, never stored
+  }
+  double acc[NE];
+#pragma unroll
+  for (int i = 0; i < NE; ++i) acc[i] = 0.0;
+  bool ok = true;
+  // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1
+  const int ti1 = tid >> 1, n1 = tid & 1;
+  double acc00 = 0.0;                            // lane n1 == tid < 2 owns llks00[n]
+  const int row_len = V * 3;
+
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    // ---- headers of the tile's pairs (first 32 lanes of the cell)
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_K2_SYNC();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    // ---- phase 1: pG[n][3][3] of the pair (:600-663), exactly as k_doublet_a2; kept: alpha 0.5's nine values, and for
+    //      alpha 0 the three u values of sample 0 (the only k the singlet column [j][0][0] needs)
+    if (tid < 64) {
+      const bool on = ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      const int32_t snp1 = on ? s_snp[ti1] : 0;
+      const float* g0r = g + (size_t)snp1 * row_len;             // sample 0's row (alpha-0 lanes use it)
+      const float gf0 = g0r[0], gf1 = g0r[1], gf2 = g0r[2];
+      double q[5], wA[5], wR[5];                                           // the weights live in registers during phase 1 only
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { q[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }   // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt;
+        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            q[i] *= (pR * wR[i] + pA * wA[i]);                              // :625
+            mx = (mx < q[i]) ? q[i] : mx;                                   // :626-627
+          }
+        }
+        {
+          const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] = div_by(q[i], mx, y);         // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] /= mx;
+          }
+        }
+      }
+      double mx = 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        q[i] += 1e-6;                                                        // :649
+        mx = (mx < q[i]) ? q[i] : mx;
+      }
+      {
+        const double o = __shfl_xor(mx, 1);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on) {
+        const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
+#pragma unroll
+        for (int i = 0; i < 5; ++i) q[i] = div_by(q[i], mx, y);              // :656-663
+        const double* g0 = gp0 + (size_t)snp1 * 3;
+        const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
+        const double qq[3] = {q0, q1, q2};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = n1 ? q[l + m] : q[l];                           // pG[n][l][m]
+            sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
+          }
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+        if (n1) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) s_q1[ti1 * 6 + i] = q[i];
+        } else {
+          const double b0 = (double)gf0, b1 = (double)gf1, b2 = (double)gf2;
+#pragma unroll
+          for (int l = 0; l < 3; ++l) s_u0[ti1 * 4 + l] = __builtin_fma(q[l], b2, __builtin_fma(q[l], b1, q[l] * b0));
+        }
+      }
+    }
+    DMX_K2_SYNC();
+    // ---- llks00: lane n < 2 of the cell adds its alpha's terms in pair order
+    if (tid < 2) {
+      const double* row = &s_t00[tid * T00];
+      if (tp == TP) {                              // loads first (LDS latency paid once), then the ordered adds
+        double2 v[TP / 2];
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) v[i] = *reinterpret_cast<const double2*>(&row[2 * i]);
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+      } else {
+        for (int i = 0; i < tp; ++i) acc00 += row[i];
+      }
+    }
+    // ---- phase 2 in sub-tiles of SUB pairs
+#pragma unroll 1
+    for (int sub = 0; sub < tp; sub += SUB) {
+      const int ns = min(SUB, tp - sub);
+      // genotype rows of the sub-tile -> LDS (coalesced along the row)
+      {
+        int r = tid % row_len, pi = tid / row_len;
+        const int dr = TPC % row_len, dt = TPC / row_len;
+        while (pi < ns) {
+          s_g[pi * GSS + r] = g[(size_t)s_snp[sub + pi] * row_len + r];
+          r += dr; pi += dt;
+          if (r >= row_len) { r -= row_len; ++pi; }
+        }
+      }
+      DMX_K2_SYNC();
+      // u[pi][l][k] = sum_m pG[1][l][m] g_k[m]  (k < V), and row V = the alpha-0 u of sample 0
+#pragma unroll 1
+      for (int e = tid; e < ns * (V + 1); e += TPC) {
+        const int k = e % (V + 1), pi = e / (V + 1);
+        double* u = &s_u[(size_t)pi * 3 * VUS + k];
+        if (k == V) {
+#pragma unroll
+          for (int l = 0; l < 3; ++l) u[l * VUS] = s_u0[(sub + pi) * 4 + l];
+        } else {
+          const double* P = &s_q1[(sub + pi) * 6];                 // pG[1][l][m] = P[l + m]
+          const float* gr = &s_g[pi * GSS + k * 3];
+          const double b0 = (double)gr[0], b1 = (double)gr[1], b2 = (double)gr[2];
+#pragma unroll
+          for (int l = 0; l < 3; ++l) u[l * VUS] = __builtin_fma(P[l + 2], b2, __builtin_fma(P[l + 1], b1, P[l] * b0));
+        }
+      }
+      DMX_K2_SYNC();
+#pragma unroll
+      for (int pi = 0; pi < SUB; ++pi) {
+        if (pi < ns) {
+          const float* gr = &s_g[pi * GSS];
+          const double* up = &s_u[pi * 3 * VUS];
+          double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+          if (FIXJ) { a0 = (double)gr[ej[0] * 3]; a1 = (double)gr[ej[0] * 3 + 1]; a2 = (double)gr[ej[0] * 3 + 2]; }
+#pragma unroll
+          for (int i = 0; i < NE; ++i) {
+            if (!FIXJ) { a0 = (double)gr[ej[i] * 3]; a1 = (double)gr[ej[i] * 3 + 1]; a2 = (double)gr[ej[i] * 3 + 2]; }
+            const double x0 = up[ek[i]], x1 = up[VUS + ek[i]], x2 = up[2 * VUS + ek[i]];
+            const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
+            ok &= __builtin_amdgcn_class(sj, 0x100);
+            acc[i] += dmx_log_fast(sj, s_log);
+          }
+        }
+      }
+      DMX_K2_SYNC();
+    }
+  }
+  if (cell_ok) {
+    double* G = grid + (size_t)cell * V * V * A;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = tid + TPC * i;
+      if (e < VD) {
+        const int j = ej[i], k = ek[i], d = e / V;
+        if (!(2 * d == V && j > k)) {              // d = V/2 is reached from both sides: the j < k lane stores
+          G[((size_t)j * V + k) * A + 1] = acc[i];
+          G[((size_t)k * V + j) * A + 1] = acc[i];
+        }
+      } else if (e < VD + V) {
+        const int j = ej[i];
+        for (int k = 0; k < V; ++k) G[((size_t)j * V + k) * A] = acc[i];
+      }
+    }
+    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (!ok) flagged[cell] = 1;
+  }
+#undef DMX_K2_SYNC
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K2 for alpha grids of 3..8 entries: k_doublet_a2's ownership, order and arithmetic with AP (= A rounded up to 2, 4 or 8)
 // alphas per pair.  Phase 1 spreads the TP * AP (pair, alpha) lanes over all the cell's threads, in passes when the cell has
 // fewer than that; the one-max-across-ALL-alphas renormalisation (:626-639) is a butterfly over the AP lanes of a pair.
@@ -2805,6 +3069,31 @@ int launch_doublet(dmx_engine* e) {
   hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
                      e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag)
+  if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 64 && !getenv("DMX_NO_SYM")) {
+    // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
+#define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
+  do {                                                                                                                \
+    constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1;                                                  \
+    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    const size_t lds = cb_ * (kThreads / TPC);                                                                         \
+    if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX>), \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+    hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
+                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V,           \
+                       e->d_grid, e->d_l00, e->d_flag);                                                                \
+  } while (0)
+    if (V <= 8) { if (64 % V == 0) DMX_K2S(64, 8, 4, true); else DMX_K2S(64, 8, 4, false); }
+    else if (V <= 14) DMX_K2S(64, 14, 4, false);
+    else if (V <= 17) { if (V == 16) DMX_K2S(64, 17, 4, true); else DMX_K2S(64, 17, 4, false); }
+    else if (V <= 23) DMX_K2S(64, 23, 4, false);
+    else if (V <= 27) DMX_K2S(64, 27, 4, false);
+    else if (V <= 32) { if (V == 32) DMX_K2S(64, 32, 4, true); else DMX_K2S(64, 32, 4, false); }
+    else if (V <= 48) DMX_K2S(256, 48, 8, false);
+    else { if (V == 64) DMX_K2S(256, 64, 8, true); else DMX_K2S(256, 64, 8, false); }
+#undef DMX_K2S
+    HIP_TRY(hipGetLastError());
+    return launch_doublet_generic_w<true>(e);
+  }
   if (e->mode == DMX_MODE_FAST) {
     // one-cell-per-workgroup panels share u through LDS (cfg3 1.33x); one-wavefront cells (V <= 16) form it in registers
     const size_t fast_bytes = cell_bytes + (V > 16 ? (size_t)8 * 2 * V * 32 : 0);

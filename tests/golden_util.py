@@ -65,3 +65,13 @@ def summary_from_grid(grid, l00, alphas, prior, n_pairs, summary_dtype):
     s["llk00_0"], s["llk00_best"] = l00[0], l00[nb]
     s["n_pairs"] = n_pairs
     return s
+
+
+def printed_mask(V, A):
+    """Grid entries demuxlet prints or decides on (cmd_cram_demuxlet.cpp:726-733,:746-797,:799-828): the singlet column
+    llksAB[j][0][0] and every entry of the doublet alphas n >= 1.  llksAB[j][k][0] for k != 0 is read by the maxLLK scan only
+    (:713-721) — DMX_MODE_FAST does not compute those (it stores [j][0][0] there)."""
+    m = np.zeros((V, V, A), dtype=bool)
+    m[:, 0, 0] = True
+    m[:, :, 1:] = True
+    return m
