@@ -2286,6 +2286,273 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
 #undef DMX_K2_SYNC
 }
 
+// K2 over genotype classes, FAST mode, alpha grid {0, 0.5}: k_doublet_sym's entry set (singlet column + one evaluation per
+// unordered pair) with k_doublet_cls's class table.  Lane (j, q) of a cell owns NED consecutive rotation offsets
+// d = q*NED .. q*NED+NED-1 of sample j, i.e. the pairs {j, (j+d) mod V}; lanes q = 0 also own the singlet entry [j][0][0].
+// Per tile of 32 pairs:
+//   stage    headers, class rows (4 x 3 float32), per-sample class ids (bytes) -> LDS; then the ids as a 2-bit stream over the
+//            DOUBLED sample sequence 0..V-1,0..V-1 so that a lane's NED consecutive (j+d) mod V never wrap inside its read
+//   phase 1  the five distinct pG values of alpha 0.5 and the three of alpha 0 (k_doublet_sym), the llks00 terms
+//   phase 1b T[pair][cj][ck] = log(row_cj . (pG[1] row_ck)) and T[pair][cj][4] = log(row_cj . (pG[0] row_c0)), c0 = class of sample 0
+//   phase 2  per pair and lane: one 64-bit read of its id window, then per entry one bit-field extract, one 8-byte LDS lookup
+//            (the 20-double class table of a pair sits in 40 distinct banks: conflict-free) and one FP64 add.
+template <int TPC, int NED>
+__global__ __launch_bounds__(kThreads, 3) void k_doublet_clsym(PileupView pv, int nrd_width, const float* __restrict__ rows,
+                                                            const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
+                                                            const double* __restrict__ tabs, const int32_t* __restrict__ sched,
+                                                            int32_t V, double* __restrict__ grid, double* __restrict__ l00,
+                                                            uint8_t* __restrict__ flagged) {
+  constexpr int A = 2, TP = 32;
+  constexpr int CPW = kThreads / TPC;
+  constexpr int T00 = TP + 2;
+  constexpr int VMAX = TPC == 64 ? 32 : 64;
+  constexpr int VS = VMAX;                        // id row stride (bytes)
+  constexpr int NW = (2 * VMAX + 16) / 16 + 2;    // words of the doubled 2-bit id stream per pair (+ slack for the last window)
+  constexpr int NT = 20;                          // class-table doubles per pair: [cj][ck = 0..3 | singlet]
+#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  __shared__ double s_w[2][10];                  // mixing weights per alpha and distinct value (see k_doublet_sym)
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  if (t < 10) {
+    const int n = t / 5, q = t % 5;
+    const int l = n ? (q > 2 ? 2 : q) : min(q, 2), m = n ? q - l : 0;
+    const double p = 0.5 * l + (m - l) * 0.5 * (n ? 0.5 : 0.0);
+    s_w[n][q] = p;
+    s_w[n][5 + q] = 1.0 - p;
+  }
+  __syncthreads();
+
+  const int cw = t / TPC, tid = t % TPC;
+  constexpr size_t cell_bytes = (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + (size_t)TP * NT * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) +
+                                (size_t)TP * 12 * 4 + (size_t)TP * NW * 4 + (size_t)TP * VS;
+  unsigned char* base = s_raw + (size_t)cw * ((cell_bytes + 15) & ~(size_t)15);
+  double* s_q1 = (double*)base;                                  // [TP][6]   pG of alpha 0.5: q[l+m]
+  double* s_q0 = s_q1 + TP * 6;                                  // [TP][4]   pG of alpha 0:   q[l]
+  double* s_T = s_q0 + TP * 4;                                   // [TP][4][5]
+  double* s_t00 = s_T + TP * NT;                                 // [2][T00]
+  int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                  // [TP]
+  int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
+  uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
+  float* s_rows = (float*)(s_cnt + TP);                          // [TP][4][3]
+  uint32_t* s_pk = (uint32_t*)(s_rows + TP * 12);                // [TP][NW]  2-bit ids of samples 0..V-1,0..V-1,...
+  uint8_t* s_ids = (uint8_t*)(s_pk + TP * NW);                   // [TP][VS]
+
+  const int slot = blockIdx.x * CPW + cw;
+  if (TPC == 64 && slot >= pv.B) return;
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+
+  // phase-2 identity
+  const int D = V / 2 + 1;                        // rotation offsets 0..V/2
+  const int j = tid % V, q = tid / V;
+  const int d0 = q * NED;
+  const bool lane_on = d0 < D && q * V + V <= TPC;   // the lane owns at least one offset (and is a complete (j,q) row)
+  const int p0 = lane_on ? j + d0 : 0;            // first position of its window in the doubled stream
+  const uint32_t w0 = (uint32_t)p0 >> 4, sh0 = ((uint32_t)p0 & 15u) * 2u;
+  const uint32_t wj = (uint32_t)j >> 4, shj = ((uint32_t)j & 15u) * 2u;
+  const bool sing_owner = tid < V;                // lanes q = 0
+  double acc[NED], accS = 0.0;
+#pragma unroll
+  for (int i = 0; i < NED; ++i) acc[i] = 0.0;
+  bool ok = true;
+  const int ti1 = tid >> 1, n1 = tid & 1;
+  double acc00 = 0.0;
+
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_K2_SYNC();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    // ---- class rows and id bytes -> LDS
+    for (int e = tid; e < tp * 12; e += TPC) s_rows[e] = rows[(size_t)s_snp[e / 12] * 12 + (e % 12)];
+    {
+      constexpr int wpr = VS / 4;                // id words per pair
+      for (int e = tid; e < tp * wpr; e += TPC) {
+        const int ti = e / wpr, wq = e % wpr;
+        const uint8_t* src = ids + (size_t)s_snp[ti] * V + wq * 4;
+        uint32_t wv = 0;
+        for (int b = 0; b < 4; ++b) if (wq * 4 + b < V) wv |= (uint32_t)src[b] << (8 * b);
+        reinterpret_cast<uint32_t*>(s_ids)[ti * wpr + wq] = wv;
+      }
+    }
+    // ---- phase 1 (k_doublet_sym's: five distinct values per alpha lane)
+    if (tid < 64) {
+      const bool on = ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      const int32_t snp1 = on ? s_snp[ti1] : 0;
+      double qv[5], wA[5], wR[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) { qv[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }   // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt;
+        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            qv[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+            mx = (mx < qv[i]) ? qv[i] : mx;                                 // :626-627
+          }
+        }
+        {
+          const double o = __shfl_xor(mx, 1);
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) qv[i] = div_by(qv[i], mx, y);       // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) qv[i] /= mx;
+          }
+        }
+      }
+      double mx = 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        qv[i] += 1e-6;                                                       // :649
+        mx = (mx < qv[i]) ? qv[i] : mx;
+      }
+      {
+        const double o = __shfl_xor(mx, 1);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on) {
+        const double y = rcp_refined(mx);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) qv[i] = div_by(qv[i], mx, y);            // :656-663
+        const double* g0 = gp0 + (size_t)snp1 * 3;
+        const double qq[3] = {g0[0], g0[1], g0[2]};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = n1 ? qv[l + m] : qv[l];                         // pG[n][l][m]
+            sum += ((qq[l] * qq[m]) * v);                                    // :555, :702-705
+          }
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);
+        if (n1) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) s_q1[ti1 * 6 + i] = qv[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) s_q0[ti1 * 4 + i] = qv[i];
+        }
+      }
+    }
+    DMX_K2_SYNC();
+    if (tid < 2) {
+      const double* row = &s_t00[tid * T00];
+      if (tp == TP) {
+        double2 v[TP / 2];
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) v[i] = *reinterpret_cast<const double2*>(&row[2 * i]);
+#pragma unroll
+        for (int i = 0; i < TP / 2; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+      } else {
+        for (int i = 0; i < tp; ++i) acc00 += row[i];
+      }
+    }
+    // ---- the doubled 2-bit id stream: word w of a pair holds the ids of samples (16 w + b) mod V, b = 0..15
+    for (int e = tid; e < tp * NW; e += TPC) {
+      const int ti = e / NW, w = e % NW;
+      const uint8_t* idr = &s_ids[ti * VS];
+      int k = (16 * w) % V;
+      uint32_t wv = 0;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) {
+        wv |= (uint32_t)idr[k] << (2 * b);
+        k = (k + 1 == V) ? 0 : k + 1;
+      }
+      s_pk[ti * NW + w] = wv;
+    }
+    // ---- phase 1b: the class table (bilinear form: row_cj . (pG row_ck))
+    for (int e = tid; e < tp * NT; e += TPC) {
+      const int ti = e / NT, c = e % NT;
+      const int cj = c / 5, ck = c % 5;
+      const float* rj = &s_rows[ti * 12 + cj * 3];
+      const double a0 = (double)rj[0], a1 = (double)rj[1], a2 = (double)rj[2];
+      double u0, u1, u2;
+      if (ck < 4) {
+        const float* rk = &s_rows[ti * 12 + ck * 3];
+        const double b0 = (double)rk[0], b1 = (double)rk[1], b2 = (double)rk[2];
+        const double* P = &s_q1[ti * 6];                                     // pG[1][l][m] = P[l + m]
+        u0 = __builtin_fma(P[2], b2, __builtin_fma(P[1], b1, P[0] * b0));
+        u1 = __builtin_fma(P[3], b2, __builtin_fma(P[2], b1, P[1] * b0));
+        u2 = __builtin_fma(P[4], b2, __builtin_fma(P[3], b1, P[2] * b0));
+      } else {
+        const float* rk = &s_rows[ti * 12 + (int)s_ids[ti * VS] * 3];      // sample 0's class row
+        const double b0 = (double)rk[0], b1 = (double)rk[1], b2 = (double)rk[2];
+        const double* P = &s_q0[ti * 4];                                     // pG[0][l][m] = P[l]
+        u0 = __builtin_fma(P[0], b2, __builtin_fma(P[0], b1, P[0] * b0));
+        u1 = __builtin_fma(P[1], b2, __builtin_fma(P[1], b1, P[1] * b0));
+        u2 = __builtin_fma(P[2], b2, __builtin_fma(P[2], b1, P[2] * b0));
+      }
+      const double sum = __builtin_fma(a2, u2, __builtin_fma(a1, u1, a0 * u0));
+      ok &= __builtin_amdgcn_class(sum, 0x100);
+      s_T[ti * NT + c] = dmx_log_fast(sum, s_log);
+    }
+    DMX_K2_SYNC();
+    // ---- phase 2
+    if (lane_on) {
+#pragma unroll 2
+      for (int ti = 0; ti < tp; ++ti) {
+        const uint32_t* pk = &s_pk[ti * NW];
+        const uint32_t cj = (pk[wj] >> shj) & 3u;
+        const uint32_t lo = pk[w0], hi = pk[w0 + 1];
+        const uint32_t bits = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh0);   // ids of (j + d0 + i) mod V, i = 0..15
+        const double* Tj = &s_T[ti * NT + cj * 5];
+#pragma unroll
+        for (int i = 0; i < NED; ++i) acc[i] += Tj[(bits >> (2 * i)) & 3u];
+        if (sing_owner) accS += Tj[4];
+      }
+    }
+    DMX_K2_SYNC();
+  }
+  if (cell_ok) {
+    double* G = grid + (size_t)cell * V * V * A;
+    if (lane_on) {
+#pragma unroll
+      for (int i = 0; i < NED; ++i) {
+        const int d = d0 + i;
+        if (d < D) {
+          int k = j + d; k = k >= V ? k - V : k;
+          if (!(2 * d == V && j > k)) {            // d = V/2 is reached from both sides: the j < k lane stores
+            G[((size_t)j * V + k) * A + 1] = acc[i];
+            G[((size_t)k * V + j) * A + 1] = acc[i];
+          }
+        }
+      }
+      if (sing_owner) for (int k = 0; k < V; ++k) G[((size_t)j * V + k) * A] = accS;
+    }
+    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (!ok) flagged[cell] = 1;
+  }
+#undef DMX_K2_SYNC
+}
+
 // K2 over genotype classes for alpha grids of 3..8 entries: k_doublet_cls with k_doublet_an's phase 1.  The class table holds
 // T[pair][cj][ck][n] for the AP padded alphas; phase 2 is AP/2 16-byte lookups and A adds per (j, k).
 template <int TPC, int NK, int AP>
@@ -3043,6 +3310,30 @@ int launch_doublet(dmx_engine* e) {
     return launch_doublet_generic_w<true>(e);
   }
   auto slabs_of = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
+  if (use_cls && e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 64 && !getenv("DMX_NO_SYM")) {
+    // GT inputs, default grid {0, 0.5}, FAST: class table + the printed entries only
+    const int TPCv = V <= 32 ? 64 : 256, D = V / 2 + 1, Q = TPCv / V;
+    const int need = (D + Q - 1) / Q;                                // consecutive offsets per lane
+    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+#define DMX_K2CS(TPC, NED)                                                                                             \
+  do {                                                                                                                 \
+    constexpr int VMAX_ = TPC == 64 ? 32 : 64, NW_ = (2 * VMAX_ + 16) / 16 + 2;                                          \
+    constexpr size_t cb_ = (((size_t)32 * 6 * 8 + 32 * 4 * 8 + 32 * 20 * 8 + 2 * 34 * 8 + 32 * 16 + 32 * 12 * 4 + 32 * NW_ * 4 + 32 * VMAX_) + 15) & ~(size_t)15; \
+    const size_t lds = cb_ * (kThreads / TPC);                                                                          \
+    if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_clsym<TPC, NED>),          \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+    hipLaunchKernelGGL((k_doublet_clsym<TPC, NED>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), dim3(kThreads), lds, \
+                       e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0, e->d_lut, e->d_sched, V, e->d_grid,  \
+                       e->d_l00, e->d_flag);                                                                             \
+  } while (0)
+#define DMX_K2CS_T(TPC) do { if (need <= 1) DMX_K2CS(TPC, 1); else if (need <= 2) DMX_K2CS(TPC, 2); else if (need <= 3) DMX_K2CS(TPC, 3); \
+                             else if (need <= 5) DMX_K2CS(TPC, 5); else DMX_K2CS(TPC, 9); } while (0)
+    if (TPCv == 64) DMX_K2CS_T(64); else DMX_K2CS_T(256);
+#undef DMX_K2CS_T
+#undef DMX_K2CS
+    HIP_TRY(hipGetLastError());
+    return launch_doublet_generic_w<true>(e);
+  }
   if (use_cls) {
     const int VS = (V <= 32) ? ((V + 3) & ~3) : ((V + 15) & ~15);   // id row stride: a whole number of k-blocks
     size_t cb = (size_t)32 * 18 * 8 + (size_t)32 * 32 * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8) + (size_t)32 * 12 * 4 + (size_t)32 * VS;

@@ -210,3 +210,16 @@ def test_cfg3_full_size_fast_mode(mods):
     log-likelihood within 1e-9 of the oracle, re-runs stay bit-identical, barcodes computed alone give the same bits."""
     worst = run_full(mods, 3, 4, check_general=False, fast=True)
     assert worst < 1e-9
+
+
+def test_cfg4_full_depth_fast_mode(mods):
+    """DMX_MODE_FAST on cfg4's depth and panel (100k SNPs x 64 samples, GT -> k_doublet_clsym): every printed entry of the two
+    sampled barcodes within 1e-9 of the oracle, the calls the oracle's, re-runs and other launch geometries bit-identical."""
+    worst = run_full(mods, 4, 2, check_general=False, barcodes=1000, fast=True)
+    assert worst < 1e-9
+
+
+def test_cfg5_full_size_fast_mode(mods):
+    """DMX_MODE_FAST on cfg5 (20k x 200k x 16, PL, sparse -> k_doublet_sym, one wavefront per barcode)."""
+    worst = run_full(mods, 5, 12, check_general=False, fast=True)
+    assert worst < 1e-9

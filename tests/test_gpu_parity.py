@@ -460,7 +460,12 @@ def test_longer_alpha_grids_against_oracle(eng, oracle, V, alphas, field, B, S):
 @pytest.mark.parametrize("V,B,S,delta,field", [(2, 30, 300, 0.5, "GP"), (3, 30, 300, 0.5, "PL"), (5, 30, 300, 0.5, "GP"), (8, 30, 800, 0.3, "GP"),
                                                (12, 20, 500, 0.4, "PL"), (16, 20, 600, 1.0, "PL"), (17, 12, 300, 0.4, "GP"), (21, 12, 300, 0.4, "GP"),
                                                (26, 12, 300, 0.4, "PL"), (29, 12, 300, 0.4, "GP"), (32, 10, 500, 0.3, "GP"), (33, 6, 300, 0.3, "GP"),
-                                               (48, 6, 300, 0.3, "PL"), (57, 4, 300, 0.3, "GP"), (64, 4, 300, 0.3, "GP"), (100, 3, 200, 0.3, "GP")])
+                                               (48, 6, 300, 0.3, "PL"), (57, 4, 300, 0.3, "GP"), (64, 4, 300, 0.3, "GP"), (100, 3, 200, 0.3, "GP"),
+                                               # GT inputs: the genotype-class form of the same entry set (k_doublet_clsym)
+                                               (2, 30, 300, 0.5, "GT"), (4, 30, 300, 0.5, "GT"), (7, 30, 300, 0.5, "GT"), (8, 30, 800, 0.3, "GT"),
+                                               (13, 20, 500, 0.4, "GT"), (16, 20, 600, 1.0, "GT"), (24, 12, 300, 0.4, "GT"), (31, 12, 300, 0.4, "GT"),
+                                               (32, 10, 500, 0.3, "GT"), (33, 6, 300, 0.3, "GT"), (48, 6, 300, 0.3, "GT"), (63, 4, 300, 0.3, "GT"),
+                                               (64, 4, 300, 1.0, "GT"), (100, 3, 200, 0.3, "GT")])
 def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
     """DMX_MODE_FAST (opt-in): the doublet term is g_j . (pG[n] g_k) with fused multiply-adds instead of the reference's nine-term
     sum; the accumulation order is unchanged.  Every log-likelihood must stay within the 1e-9 of the north star (measured:
@@ -471,6 +476,8 @@ def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
     if field == "GP":
         gp = synth.raw_gp_from_alleles(rng, raw.alleles)
         g = np.stack([eng.geno_from_gp(gp[s], 0.01) for s in range(S)])
+    elif field == "GT":
+        g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
     else:
         plv = synth.raw_pl_from_alleles(rng, raw.alleles)
         g = np.stack([eng.geno_from_pl(plv[s]) for s in range(S)])
@@ -489,7 +496,8 @@ def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
     d_ref, d_strict = np.abs(grid - ref.llksAB)[np.broadcast_to(m, grid.shape)].max(), np.abs(grid - strict["grid"])[np.broadcast_to(m, grid.shape)].max()
     print(f"V={V} {field}: FAST vs reference {d_ref:.2e}, FAST vs STRICT {d_strict:.2e} (printed entries)")
     assert d_ref < TOL and d_strict < 1e-10
-    assert not np.array_equal(grid, strict["grid"])        # it IS a different operation sequence: keep the two modes honest
+    if not (field == "GT" and V > 64):                      # wide GT panels keep the (bit-identical) STRICT class kernel
+        assert not np.array_equal(grid, strict["grid"])    # it IS a different operation sequence: keep the two modes honest
     if V <= 64:
         # alpha grid {0, 0.5}: one evaluation per unordered pair, mirrored; the never-printed [j][k != 0][0] hold [j][0][0]
         assert np.array_equal(grid[:, :, :, 1], grid[:, :, :, 1].transpose(0, 2, 1))
