@@ -103,6 +103,10 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
   return __builtin_fma(r, y, q);
 }
 
+// The plain IEEE division for the (rare) deep pairs, kept out of line: inlined five or nine times it is the register-pressure
+// peak of the FAST kernels, whose accumulators have to stay in registers across it.
+__device__ __attribute__((noinline)) double div_slow(double a, double b) { return a / b; }
+
 constexpr uint32_t kSafeReads = 15;   // each read scales a likelihood by >= err(127)/3 > 2^-44: 15 reads stay above 2^-700
 
 // ---- genotype likelihoods of a (cell, SNP) pair (cmd_cram_demuxlet.cpp:427-452) -----------------------------------------
@@ -1637,7 +1641,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_sym(PileupView pv, int 
             for (int i = 0; i < 5; ++i) q[i] = div_by(q[i], mx, y);         // :632-639
           } else {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) q[i] /= mx;
+            for (int i = 0; i < 5; ++i) q[i] = div_slow(q[i], mx);
           }
         }
       }
@@ -1682,12 +1686,15 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_sym(PileupView pv, int 
     // ---- llks00: lane n < 2 of the cell adds its alpha's terms in pair order
     if (tid < 2) {
       const double* row = &s_t00[tid * T00];
-      if (tp == TP) {                              // loads first (LDS latency paid once), then the ordered adds
-        double2 v[TP / 2];
+      if (tp == TP) {                              // eight terms at a time: loads first, then the ordered adds
+#pragma unroll 1
+        for (int h = 0; h < TP; h += 8) {
+          double2 v[4];
 #pragma unroll
-        for (int i = 0; i < TP / 2; ++i) v[i] = *reinterpret_cast<const double2*>(&row[2 * i]);
+          for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const double2*>(&row[h + 2 * i]);
 #pragma unroll
-        for (int i = 0; i < TP / 2; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+          for (int i = 0; i < 4; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+        }
       } else {
         for (int i = 0; i < tp; ++i) acc00 += row[i];
       }
@@ -2019,7 +2026,8 @@ constexpr int kMaxCls = 4;
 
 __global__ void k_build_classes(const float* __restrict__ g, int32_t S, int32_t V, float* __restrict__ rows /*[S][4][3]*/,
                                 uint8_t* __restrict__ ids /*[S][V]*/, uint32_t* __restrict__ idw /*[S][ceil(V/16)] 2 bits per sample*/,
-                                int32_t* __restrict__ max_cls) {
+                                uint32_t* __restrict__ idd /*[S][nwd2]: word w = ids of samples (16 w + b) mod V, b = 0..15 (k_doublet_clsym)*/,
+                                int32_t nwd2, int32_t* __restrict__ max_cls) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   const uint32_t* gr = reinterpret_cast<const uint32_t*>(g + (size_t)s * V * 3);
@@ -2041,6 +2049,12 @@ __global__ void k_build_classes(const float* __restrict__ g, int32_t S, int32_t 
     uint32_t wv = 0;
     for (int b = 0; b < 16 && wq * 16 + b < V; ++b) wv |= (uint32_t)ids[(size_t)s * V + wq * 16 + b] << (2 * b);
     idw[(size_t)s * nwd + wq] = wv;
+  }
+  for (int wq = 0; wq < nwd2; ++wq) {
+    uint32_t wv = 0;
+    int k = (16 * wq) % V;
+    for (int b = 0; b < 16; ++b) { wv |= (uint32_t)ids[(size_t)s * V + k] << (2 * b); k = (k + 1 == V) ? 0 : k + 1; }
+    idd[(size_t)s * nwd2 + wq] = wv;
   }
   uint32_t* ro = reinterpret_cast<uint32_t*>(rows + (size_t)s * kMaxCls * 3);
   for (int d = 0; d < kMaxCls; ++d) {
@@ -2287,30 +2301,31 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
 }
 
 // K2 over genotype classes, FAST mode, alpha grid {0, 0.5}: k_doublet_sym's entry set (singlet column + one evaluation per
-// unordered pair) with k_doublet_cls's class table.  Lane (j, q) of a cell owns NED consecutive rotation offsets
-// d = q*NED .. q*NED+NED-1 of sample j, i.e. the pairs {j, (j+d) mod V}; lanes q = 0 also own the singlet entry [j][0][0].
-// Per tile of 32 pairs:
-//   stage    headers, class rows (4 x 3 float32), per-sample class ids (bytes) -> LDS; then the ids as a 2-bit stream over the
-//            DOUBLED sample sequence 0..V-1,0..V-1 so that a lane's NED consecutive (j+d) mod V never wrap inside its read
+// unordered pair) with k_doublet_cls's class table.  ONE WAVEFRONT PER BARCODE (four independent barcodes per workgroup, no
+// workgroup barrier after the table staging): lane (j, q) owns NED consecutive rotation offsets d = q*NED .. q*NED+NED-1 of
+// sample j, i.e. the pairs {j, (j+d) mod V}; lanes q = 0 also own the singlet entry [j][0][0].  Per tile of 32 pairs:
+//   stage    headers, class rows (4 x 3 float32) and the pairs' 2-bit class ids as a stream over the periodic sample sequence
+//            0..V-1,0..V-1,... (built once per SNP by k_build_classes) so that a lane's consecutive (j+d) mod V never wrap
 //   phase 1  the five distinct pG values of alpha 0.5 and the three of alpha 0 (k_doublet_sym), the llks00 terms
-//   phase 1b T[pair][cj][ck] = log(row_cj . (pG[1] row_ck)) and T[pair][cj][4] = log(row_cj . (pG[0] row_c0)), c0 = class of sample 0
-//   phase 2  per pair and lane: one 64-bit read of its id window, then per entry one bit-field extract, one 8-byte LDS lookup
-//            (the 20-double class table of a pair sits in 40 distinct banks: conflict-free) and one FP64 add.
-template <int TPC, int NED>
-__global__ __launch_bounds__(kThreads, 3) void k_doublet_clsym(PileupView pv, int nrd_width, const float* __restrict__ rows,
-                                                            const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
-                                                            const double* __restrict__ tabs, const int32_t* __restrict__ sched,
-                                                            int32_t V, double* __restrict__ grid, double* __restrict__ l00,
-                                                            uint8_t* __restrict__ flagged) {
-  constexpr int A = 2, TP = 32;
+//   per sub-tile of 8 pairs:
+//   phase 1b T[pair][cj][ck] = log(row_cj . (pG[1] row_ck)) for cj <= ck (mirrored), T[pair][cj][4] = log(row_cj . (pG[0] row_c0)),
+//            c0 = class of sample 0; 64-byte rows: a pair's table occupies the 64 LDS banks exactly once (conflict-free lookups)
+//   phase 2  per pair and lane: its id window (2-4 words), then per entry one bit-field extract, one address op, one 8-byte LDS
+//            lookup and one FP64 add.
+template <int NED, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv, int nrd_width, const float* __restrict__ rows,
+                                                               const uint32_t* __restrict__ idd, int32_t nwd2,
+                                                               const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                               const int32_t* __restrict__ sched, int32_t V,
+                                                               double* __restrict__ grid, double* __restrict__ l00,
+                                                               uint8_t* __restrict__ flagged) {
+  constexpr int A = 2, TP = 32, TPC = 64, SUBT = 8;
   constexpr int CPW = kThreads / TPC;
   constexpr int T00 = TP + 2;
-  constexpr int VMAX = TPC == 64 ? 32 : 64;
-  constexpr int VS = VMAX;                        // id row stride (bytes)
-  constexpr int NW = (2 * VMAX + 16) / 16 + 2;    // words of the doubled 2-bit id stream per pair (+ slack for the last window)
-  constexpr int NT = 20;                          // class-table doubles per pair: [cj][ck = 0..3 | singlet]
-#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  constexpr int NW = 10;                          // id-stream words per pair (V <= 64: nwd2 <= 10)
+  constexpr int NRW = (2 * NED + 30) / 32 + 1;    // words a lane's window can span
+  constexpr int NT = 32;                          // class-table doubles per pair: [cj][8]: ck = 0..3 | singlet | pad
+  extern __shared__ __attribute__((aligned(64))) unsigned char s_raw[];
   __shared__ double s_tab[kTab];
   __shared__ double s_w[2][10];                  // mixing weights per alpha and distinct value (see k_doublet_sym)
   const double* s_log = s_tab + kLut;
@@ -2326,37 +2341,37 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_clsym(PileupView pv, in
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;
-  constexpr size_t cell_bytes = (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + (size_t)TP * NT * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) +
-                                (size_t)TP * 12 * 4 + (size_t)TP * NW * 4 + (size_t)TP * VS;
-  unsigned char* base = s_raw + (size_t)cw * ((cell_bytes + 15) & ~(size_t)15);
-  double* s_q1 = (double*)base;                                  // [TP][6]   pG of alpha 0.5: q[l+m]
+  constexpr size_t cell_bytes = ((size_t)SUBT * NT * 8 + (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) +
+                                 (size_t)TP * 12 * 4 + (size_t)TP * NW * 4 + 63) & ~(size_t)63;
+  unsigned char* base = s_raw + (size_t)cw * cell_bytes;
+  double* s_T = (double*)base;                                   // [SUBT][4][8]  (a pair's 256 contiguous bytes = each of the 64 banks once)
+  double* s_q1 = s_T + SUBT * NT;                                // [TP][6]   pG of alpha 0.5: q[l+m]
   double* s_q0 = s_q1 + TP * 6;                                  // [TP][4]   pG of alpha 0:   q[l]
-  double* s_T = s_q0 + TP * 4;                                   // [TP][4][5]
-  double* s_t00 = s_T + TP * NT;                                 // [2][T00]
+  double* s_t00 = s_q0 + TP * 4;                                 // [2][T00]
   int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                  // [TP]
   int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
   uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
   float* s_rows = (float*)(s_cnt + TP);                          // [TP][4][3]
   uint32_t* s_pk = (uint32_t*)(s_rows + TP * 12);                // [TP][NW]  2-bit ids of samples 0..V-1,0..V-1,...
-  uint8_t* s_ids = (uint8_t*)(s_pk + TP * NW);                   // [TP][VS]
 
   const int slot = blockIdx.x * CPW + cw;
-  if (TPC == 64 && slot >= pv.B) return;
-  const bool cell_ok = slot < pv.B;
-  const int32_t cell = cell_ok ? sched[slot] : 0;
-  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
-  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
-  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+  if (slot >= pv.B) return;                      // whole wavefront idle (no workgroup barriers below)
+  const int32_t cell = sched[slot];
+  const int64_t p_beg = pv.cell_pair_off[cell];
+  const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
+  int64_t rd_base = pv.cell_read_off[cell];
 
   // phase-2 identity
   const int D = V / 2 + 1;                        // rotation offsets 0..V/2
+  // Panels whose D offsets do not fit one wavefront's (64 / V) x NED are cut into slabs of offsets, one wavefront (blockIdx.y)
+  // each, which repeat the cheap phases 1 and 1b for themselves: no barrier, and more, shorter wavefronts per barcode.
   const int j = tid % V, q = tid / V;
-  const int d0 = q * NED;
+  const int d0 = ((int)blockIdx.y * (TPC / V) + q) * NED;
   const bool lane_on = d0 < D && q * V + V <= TPC;   // the lane owns at least one offset (and is a complete (j,q) row)
-  const int p0 = lane_on ? j + d0 : 0;            // first position of its window in the doubled stream
+  const int p0 = lane_on ? j + d0 : 0;            // first position of its window in the id stream
   const uint32_t w0 = (uint32_t)p0 >> 4, sh0 = ((uint32_t)p0 & 15u) * 2u;
   const uint32_t wj = (uint32_t)j >> 4, shj = ((uint32_t)j & 15u) * 2u;
-  const bool sing_owner = tid < V;                // lanes q = 0
+  const bool sing_owner = tid < V && blockIdx.y == 0;   // lanes q = 0 of the first slab
   double acc[NED], accS = 0.0;
 #pragma unroll
   for (int i = 0; i < NED; ++i) acc[i] = 0.0;
@@ -2374,22 +2389,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_clsym(PileupView pv, in
       s_off[tid] = rd_base + (int64_t)(incl - n);
       s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
     }
-    DMX_K2_SYNC();
+    DMX_WAVE_LDS_ORDER();
     rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
-    // ---- class rows and id bytes -> LDS
+    // ---- class rows and id streams -> LDS
     for (int e = tid; e < tp * 12; e += TPC) s_rows[e] = rows[(size_t)s_snp[e / 12] * 12 + (e % 12)];
-    {
-      constexpr int wpr = VS / 4;                // id words per pair
-      for (int e = tid; e < tp * wpr; e += TPC) {
-        const int ti = e / wpr, wq = e % wpr;
-        const uint8_t* src = ids + (size_t)s_snp[ti] * V + wq * 4;
-        uint32_t wv = 0;
-        for (int b = 0; b < 4; ++b) if (wq * 4 + b < V) wv |= (uint32_t)src[b] << (8 * b);
-        reinterpret_cast<uint32_t*>(s_ids)[ti * wpr + wq] = wv;
-      }
+    for (int e = tid; e < tp * NW; e += TPC) {
+      const int ti = e / NW, w = e % NW;
+      s_pk[e] = w < nwd2 ? idd[(size_t)s_snp[ti] * nwd2 + w] : 0u;
     }
     // ---- phase 1 (k_doublet_sym's: five distinct values per alpha lane)
-    if (tid < 64) {
+    {
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
@@ -2423,7 +2432,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_clsym(PileupView pv, in
             for (int i = 0; i < 5; ++i) qv[i] = div_by(qv[i], mx, y);       // :632-639
           } else {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) qv[i] /= mx;
+            for (int i = 0; i < 5; ++i) qv[i] = div_slow(qv[i], mx);
           }
         }
       }
@@ -2462,76 +2471,96 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_clsym(PileupView pv, in
         }
       }
     }
-    DMX_K2_SYNC();
+    DMX_WAVE_LDS_ORDER();
     if (tid < 2) {
       const double* row = &s_t00[tid * T00];
-      if (tp == TP) {
-        double2 v[TP / 2];
+      if (tp == TP) {                              // eight terms at a time: loads first, then the ordered adds
+#pragma unroll 1
+        for (int h = 0; h < TP; h += 8) {
+          double2 v[4];
 #pragma unroll
-        for (int i = 0; i < TP / 2; ++i) v[i] = *reinterpret_cast<const double2*>(&row[2 * i]);
+          for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const double2*>(&row[h + 2 * i]);
 #pragma unroll
-        for (int i = 0; i < TP / 2; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+          for (int i = 0; i < 4; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+        }
       } else {
         for (int i = 0; i < tp; ++i) acc00 += row[i];
       }
     }
-    // ---- the doubled 2-bit id stream: word w of a pair holds the ids of samples (16 w + b) mod V, b = 0..15
-    for (int e = tid; e < tp * NW; e += TPC) {
-      const int ti = e / NW, w = e % NW;
-      const uint8_t* idr = &s_ids[ti * VS];
-      int k = (16 * w) % V;
-      uint32_t wv = 0;
-#pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        wv |= (uint32_t)idr[k] << (2 * b);
-        k = (k + 1 == V) ? 0 : k + 1;
-      }
-      s_pk[ti * NW + w] = wv;
-    }
-    // ---- phase 1b: the class table (bilinear form: row_cj . (pG row_ck))
-    for (int e = tid; e < tp * NT; e += TPC) {
-      const int ti = e / NT, c = e % NT;
-      const int cj = c / 5, ck = c % 5;
-      const float* rj = &s_rows[ti * 12 + cj * 3];
-      const double a0 = (double)rj[0], a1 = (double)rj[1], a2 = (double)rj[2];
-      double u0, u1, u2;
-      if (ck < 4) {
+#pragma unroll 1
+    for (int sub = 0; sub < tp; sub += SUBT) {
+      const int ns = min(SUBT, tp - sub);
+      // ---- phase 1b: the class table of the sub-tile's pairs (bilinear form row_cj . (pG row_ck)); 14 items per pair:
+      //      ten unordered class pairs cj <= ck (stored to both [cj][ck] and [ck][cj]) and the four singlet entries
+      for (int e = tid; e < ns * 14; e += TPC) {
+        const int pi = e / 14, c = e % 14;
+        const int ti = sub + pi;
+        const int cj = c < 10 ? (int)((0x3221110000ull >> (4 * c)) & 15u) : c - 10;        // (0,0)(0,1)(0,2)(0,3)(1,1)(1,2)(1,3)(2,2)(2,3)(3,3)
+        const int ck = c < 10 ? (int)((0x3323213210ull >> (4 * c)) & 15u) : (int)(s_pk[ti * NW] & 3u);   // singlet: sample 0's class
+        const float* rj = &s_rows[ti * 12 + cj * 3];
         const float* rk = &s_rows[ti * 12 + ck * 3];
+        const double a0 = (double)rj[0], a1 = (double)rj[1], a2 = (double)rj[2];
         const double b0 = (double)rk[0], b1 = (double)rk[1], b2 = (double)rk[2];
-        const double* P = &s_q1[ti * 6];                                     // pG[1][l][m] = P[l + m]
-        u0 = __builtin_fma(P[2], b2, __builtin_fma(P[1], b1, P[0] * b0));
-        u1 = __builtin_fma(P[3], b2, __builtin_fma(P[2], b1, P[1] * b0));
-        u2 = __builtin_fma(P[4], b2, __builtin_fma(P[3], b1, P[2] * b0));
-      } else {
-        const float* rk = &s_rows[ti * 12 + (int)s_ids[ti * VS] * 3];      // sample 0's class row
-        const double b0 = (double)rk[0], b1 = (double)rk[1], b2 = (double)rk[2];
-        const double* P = &s_q0[ti * 4];                                     // pG[0][l][m] = P[l]
-        u0 = __builtin_fma(P[0], b2, __builtin_fma(P[0], b1, P[0] * b0));
-        u1 = __builtin_fma(P[1], b2, __builtin_fma(P[1], b1, P[1] * b0));
-        u2 = __builtin_fma(P[2], b2, __builtin_fma(P[2], b1, P[2] * b0));
+        double u0, u1, u2;
+        if (c < 10) {
+          const double* P = &s_q1[ti * 6];                                   // pG[1][l][m] = P[l + m]
+          u0 = __builtin_fma(P[2], b2, __builtin_fma(P[1], b1, P[0] * b0));
+          u1 = __builtin_fma(P[3], b2, __builtin_fma(P[2], b1, P[1] * b0));
+          u2 = __builtin_fma(P[4], b2, __builtin_fma(P[3], b1, P[2] * b0));
+        } else {
+          const double* P = &s_q0[ti * 4];                                   // pG[0][l][m] = P[l]
+          u0 = __builtin_fma(P[0], b2, __builtin_fma(P[0], b1, P[0] * b0));
+          u1 = __builtin_fma(P[1], b2, __builtin_fma(P[1], b1, P[1] * b0));
+          u2 = __builtin_fma(P[2], b2, __builtin_fma(P[2], b1, P[2] * b0));
+        }
+        const double sum = __builtin_fma(a2, u2, __builtin_fma(a1, u1, a0 * u0));
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        const double lv = dmx_log_fast(sum, s_log);
+        if (c < 10) { s_T[pi * NT + cj * 8 + ck] = lv; s_T[pi * NT + ck * 8 + cj] = lv; }
+        else s_T[pi * NT + cj * 8 + 4] = lv;
       }
-      const double sum = __builtin_fma(a2, u2, __builtin_fma(a1, u1, a0 * u0));
-      ok &= __builtin_amdgcn_class(sum, 0x100);
-      s_T[ti * NT + c] = dmx_log_fast(sum, s_log);
-    }
-    DMX_K2_SYNC();
-    // ---- phase 2
-    if (lane_on) {
-#pragma unroll 2
-      for (int ti = 0; ti < tp; ++ti) {
-        const uint32_t* pk = &s_pk[ti * NW];
-        const uint32_t cj = (pk[wj] >> shj) & 3u;
-        const uint32_t lo = pk[w0], hi = pk[w0 + 1];
-        const uint32_t bits = (uint32_t)((((uint64_t)hi << 32) | lo) >> sh0);   // ids of (j + d0 + i) mod V, i = 0..15
-        const double* Tj = &s_T[ti * NT + cj * 5];
+      DMX_WAVE_LDS_ORDER();
+      // ---- phase 2.  LDS byte address of an entry's table cell = (row base of this pair and this lane's class cj, a multiple of
+      //      64) | (ck << 3): one shift and one and-or per entry.  Entries go in groups of GRP (their loads in flight together).
+      if (lane_on) {
+        constexpr int GRP = NED <= 12 ? NED : (NED + 2) / 3;
+        using lds_cd = const __attribute__((address_space(3))) double*;
+        using lds_cu = const __attribute__((address_space(3))) uint32_t*;
+        const uint32_t t_base = (uint32_t)(uintptr_t)(lds_cd)s_T;            // 64-byte aligned (checked by the launcher's layout)
+        const uint32_t pk_lane = (uint32_t)(uintptr_t)(lds_cu)s_pk + 4u * w0, pk_j = (uint32_t)(uintptr_t)(lds_cu)s_pk + 4u * wj;
+#pragma unroll (NED >= 12 ? 1 : 2)
+        for (int pi = 0; pi < ns; ++pi) {
+          const uint32_t po = (uint32_t)((sub + pi) * NW * 4);
+          const uint32_t cj = (*(lds_cu)(uintptr_t)(pk_j + po) >> shj) & 3u;
+          uint32_t wd[NRW];
 #pragma unroll
-        for (int i = 0; i < NED; ++i) acc[i] += Tj[(bits >> (2 * i)) & 3u];
-        if (sing_owner) accS += Tj[4];
+          for (int r = 0; r < NRW; ++r) wd[r] = *(lds_cu)(uintptr_t)(pk_lane + po + 4u * r);
+          const uint32_t row = t_base + (uint32_t)(pi * NT * 8) + (cj << 6);
+          uint32_t bits[(NED + 15) / 16];
+#pragma unroll
+          for (int r = 0; r < (NED + 15) / 16; ++r)     // ids of (j + d0 + i) mod V: 16 per funnel-shifted word
+            bits[r] = (r + 1 < NRW) ? __builtin_amdgcn_alignbit(wd[r + 1], wd[r], sh0) : (wd[r] >> sh0);
+#pragma unroll
+          for (int g0 = 0; g0 < NED; g0 += GRP) {
+            double tv[GRP];
+#pragma unroll
+            for (int i = g0; i < g0 + GRP && i < NED; ++i) {
+              const int sh = 2 * (i % 16) - 3;           // ck << 3
+              const uint32_t b = bits[i / 16];
+              const uint32_t a = row | ((sh >= 0 ? (b >> sh) : (b << -sh)) & 24u);
+              tv[i - g0] = *(lds_cd)(uintptr_t)a;
+            }
+#pragma unroll
+            for (int i = g0; i < g0 + GRP && i < NED; ++i) acc[i] += tv[i - g0];
+            if (g0 + GRP < NED) __builtin_amdgcn_sched_barrier(0);
+          }
+          if (sing_owner) accS += *(lds_cd)(uintptr_t)(row + 32u);
+        }
       }
+      DMX_WAVE_LDS_ORDER();
     }
-    DMX_K2_SYNC();
   }
-  if (cell_ok) {
+  {
     double* G = grid + (size_t)cell * V * V * A;
     if (lane_on) {
 #pragma unroll
@@ -2547,10 +2576,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_clsym(PileupView pv, in
       }
       if (sing_owner) for (int k = 0; k < V; ++k) G[((size_t)j * V + k) * A] = accS;
     }
-    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (tid < 2 && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
     if (!ok) flagged[cell] = 1;
   }
-#undef DMX_K2_SYNC
 }
 
 // K2 over genotype classes for alpha grids of 3..8 entries: k_doublet_cls with k_doublet_an's phase 1.  The class table holds
@@ -2906,7 +2934,7 @@ struct dmx_engine {
   double* d_alpha = nullptr;
   // genotypes
   const float* d_g = nullptr; float* d_g_own = nullptr; int32_t S = 0; double* d_gp0 = nullptr; float* d_gT = nullptr; double* d_g0T = nullptr;
-  float* d_rows = nullptr; uint8_t* d_ids = nullptr; uint32_t* d_idw = nullptr; int32_t n_classes = 0;   // genotype classes (0 = not usable)
+  float* d_rows = nullptr; uint8_t* d_ids = nullptr; uint32_t* d_idw = nullptr; uint32_t* d_idd = nullptr; int32_t nwd2 = 0; int32_t n_classes = 0;   // genotype classes (0 = not usable)
   // pileup
   PileupView pv{}; int32_t nrd_width = 1; int64_t P = 0, R = 0; bool have_pileup = false;
   void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -3000,6 +3028,7 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_rows) (void)hipFree(e->d_rows);
   if (e->d_ids) (void)hipFree(e->d_ids);
   if (e->d_idw) (void)hipFree(e->d_idw);
+  if (e->d_idd) (void)hipFree(e->d_idd);
   if (e->d_lut) (void)hipFree(e->d_lut);
   if (e->d_alpha) (void)hipFree(e->d_alpha);
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
@@ -3062,23 +3091,26 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
   if (e->d_rows) { (void)hipFree(e->d_rows); e->d_rows = nullptr; }
   if (e->d_ids) { (void)hipFree(e->d_ids); e->d_ids = nullptr; }
   if (e->d_idw) { (void)hipFree(e->d_idw); e->d_idw = nullptr; }
+  if (e->d_idd) { (void)hipFree(e->d_idd); e->d_idd = nullptr; }
   e->n_classes = 0;
   if (n_snps > 0) {
     int32_t* d_max = nullptr;
     HIP_TRY(hipMalloc((void**)&e->d_rows, (size_t)n_snps * kMaxCls * 3 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&e->d_ids, (size_t)n_snps * e->V + 16));
     HIP_TRY(hipMalloc((void**)&e->d_idw, (size_t)n_snps * ((e->V + 15) / 16) * sizeof(uint32_t) + 16));
+    e->nwd2 = ((e->V + e->V / 2 - 1) >> 4) + 5;                     // last window start (V-1 + V/2) >> 4, plus a window of <= 4 words, plus one
+    HIP_TRY(hipMalloc((void**)&e->d_idd, (size_t)n_snps * e->nwd2 * sizeof(uint32_t) + 16));
     HIP_TRY(hipMalloc((void**)&d_max, sizeof(int32_t)));
     HIP_TRY(hipMemsetAsync(d_max, 0, sizeof(int32_t), e->stream));
     hipLaunchKernelGGL(k_build_classes, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_g, n_snps, e->V,
-                       e->d_rows, e->d_ids, e->d_idw, d_max);
+                       e->d_rows, e->d_ids, e->d_idw, e->d_idd, e->nwd2, d_max);
     HIP_TRY(hipGetLastError());
     int32_t h_max = 0;
     HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     (void)hipFree(d_max);
     e->n_classes = (h_max >= 1 && h_max <= kMaxCls) ? h_max : 0;
-    if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); (void)hipFree(e->d_idw); e->d_rows = nullptr; e->d_ids = nullptr; e->d_idw = nullptr; }
+    if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); (void)hipFree(e->d_idw); (void)hipFree(e->d_idd); e->d_rows = nullptr; e->d_ids = nullptr; e->d_idw = nullptr; e->d_idd = nullptr; }
   }
   HIP_TRY(hipStreamSynchronize(e->stream));   // the host buffer may go away after return
   return DMX_OK;
@@ -3311,25 +3343,22 @@ int launch_doublet(dmx_engine* e) {
   }
   auto slabs_of = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
   if (use_cls && e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 64 && !getenv("DMX_NO_SYM")) {
-    // GT inputs, default grid {0, 0.5}, FAST: class table + the printed entries only
-    const int TPCv = V <= 32 ? 64 : 256, D = V / 2 + 1, Q = TPCv / V;
-    const int need = (D + Q - 1) / Q;                                // consecutive offsets per lane
+    // GT inputs, default grid {0, 0.5}, FAST: class table + the printed entries only, one wavefront per barcode
+    const int D = V / 2 + 1, Q = 64 / V;
+    // offsets per lane NED and slabs NS with Q * NED * NS >= D: as few slabs as 17 accumulators per lane allow (more do not fit
+    // the register file beside the kernel's invariants at 3 wavefronts per SIMD), then the smallest NED
+    int NS = (D + Q * 17 - 1) / (Q * 17);
+    if (const char* env = getenv("DMX_CLSYM_NED")) NS = (D + Q * atoi(env) - 1) / (Q * atoi(env));   // kernel experiments only
+    const int need = (D + Q * NS - 1) / (Q * NS);
     HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
-#define DMX_K2CS(TPC, NED)                                                                                             \
-  do {                                                                                                                 \
-    constexpr int VMAX_ = TPC == 64 ? 32 : 64, NW_ = (2 * VMAX_ + 16) / 16 + 2;                                          \
-    constexpr size_t cb_ = (((size_t)32 * 6 * 8 + 32 * 4 * 8 + 32 * 20 * 8 + 2 * 34 * 8 + 32 * 16 + 32 * 12 * 4 + 32 * NW_ * 4 + 32 * VMAX_) + 15) & ~(size_t)15; \
-    const size_t lds = cb_ * (kThreads / TPC);                                                                          \
-    if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_clsym<TPC, NED>),          \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-    hipLaunchKernelGGL((k_doublet_clsym<TPC, NED>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), dim3(kThreads), lds, \
-                       e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0, e->d_lut, e->d_sched, V, e->d_grid,  \
-                       e->d_l00, e->d_flag);                                                                             \
-  } while (0)
-#define DMX_K2CS_T(TPC) do { if (need <= 1) DMX_K2CS(TPC, 1); else if (need <= 2) DMX_K2CS(TPC, 2); else if (need <= 3) DMX_K2CS(TPC, 3); \
-                             else if (need <= 5) DMX_K2CS(TPC, 5); else DMX_K2CS(TPC, 9); } while (0)
-    if (TPCv == 64) DMX_K2CS_T(64); else DMX_K2CS_T(256);
-#undef DMX_K2CS_T
+    constexpr size_t cb = ((size_t)8 * 32 * 8 + 32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + 32 * 12 * 4 + 32 * 10 * 4 + 63) & ~(size_t)63;
+    static_assert(cb % 64 == 0, "a barcode's LDS block keeps its class table 64-byte aligned (k_doublet_clsym ORs the class offset in)");
+#define DMX_K2CS(NED, MINW)                                                                                            \
+  hipLaunchKernelGGL((k_doublet_clsym<NED, MINW>), dim3((unsigned)((B + 3) / 4), (unsigned)NS), dim3(kThreads), cb * 4, e->stream, e->pv, \
+                     e->nrd_width, e->d_rows, e->d_idd, e->nwd2, e->d_gp0, e->d_lut, e->d_sched, V, e->d_grid, e->d_l00, e->d_flag)
+    if (need <= 1) DMX_K2CS(1, 4); else if (need <= 2) DMX_K2CS(2, 4); else if (need <= 3) DMX_K2CS(3, 4); else if (need <= 5) DMX_K2CS(5, 4);
+    else if (need <= 7) DMX_K2CS(7, 3); else if (need <= 9) DMX_K2CS(9, 3); else if (need <= 11) DMX_K2CS(11, 3);
+    else if (need <= 13) DMX_K2CS(13, 3); else if (need <= 15) DMX_K2CS(15, 3); else DMX_K2CS(17, 3);
 #undef DMX_K2CS
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
