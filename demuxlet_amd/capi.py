@@ -56,12 +56,12 @@ class CellSummary(C.Structure):
                 ("llk12", C.c_double), ("llk1", C.c_double), ("llk2", C.c_double), ("llk10", C.c_double), ("llk20", C.c_double),
                 ("llk00_0", C.c_double), ("llk00_best", C.c_double),
                 ("i_sing1", C.c_int32), ("i_sing2", C.c_int32), ("j_best", C.c_int32), ("k_best", C.c_int32),
-                ("n_best", C.c_int32), ("n_pairs", C.c_int32)]
+                ("n_best", C.c_int32), ("n_pairs", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 SUMMARY_DTYPE = np.dtype([(n, np.float64) for n in ("max_llk", "sum_single", "sum_double", "sing_llk1", "sing_llk2", "llk12",
                                                     "llk1", "llk2", "llk10", "llk20", "llk00_0", "llk00_best")] +
-                         [(n, np.int32) for n in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best", "n_pairs")])
+                         [(n, np.int32) for n in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best", "n_pairs", "flags", "reserved")])
 assert SUMMARY_DTYPE.itemsize == C.sizeof(CellSummary)
 
 
@@ -91,7 +91,14 @@ class Job(C.Structure):
     _fields_ = [("store", C.c_void_p), ("g", C.c_void_p), ("n_samples", C.c_int32), ("sample_ids", C.c_void_p),
                 ("n_alpha", C.c_int32), ("alpha", C.c_void_p), ("doublet_prior", C.c_double),
                 ("min_total", C.c_int32), ("min_uniq", C.c_int32), ("min_snp", C.c_int32), ("write_pair", C.c_int32),
-                ("out_prefix", C.c_char_p), ("device", C.c_int32), ("arbiter", C.c_int32), ("n_gpus", C.c_int32), ("mode", C.c_int32)]
+                ("out_prefix", C.c_char_p), ("device", C.c_int32), ("arbiter", C.c_int32), ("n_gpus", C.c_int32), ("mode", C.c_int32),
+                ("pileup", C.c_void_p), ("barcodes", C.c_void_p), ("timing", C.c_void_p)]
+
+
+class JobTiming(C.Structure):
+    _fields_ = [("freeze_s", C.c_double), ("setup_s", C.c_double), ("stage_s", C.c_double), ("wait_s", C.c_double),
+                ("write_s", C.c_double), ("total_s", C.c_double), ("kernel_ms", C.c_double),
+                ("n_ranges", C.c_int32), ("n_engines", C.c_int32), ("n_cells_grid_fetched", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -15,7 +15,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -2528,7 +2530,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
         using lds_cu = const __attribute__((address_space(3))) uint32_t*;
         const uint32_t t_base = (uint32_t)(uintptr_t)(lds_cd)s_T;            // 64-byte aligned (checked by the launcher's layout)
         const uint32_t pk_lane = (uint32_t)(uintptr_t)(lds_cu)s_pk + 4u * w0, pk_j = (uint32_t)(uintptr_t)(lds_cu)s_pk + 4u * wj;
-#pragma unroll (NED >= 12 ? 1 : 2)
+        constexpr int UNR = NED >= 12 ? 1 : 2;
+#pragma unroll UNR
         for (int pi = 0; pi < ns; ++pi) {
           const uint32_t po = (uint32_t)((sub + pi) * NW * 4);
           const uint32_t cj = (*(lds_cu)(uintptr_t)(pk_j + po) >> shj) & 3u;
@@ -2900,6 +2903,36 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
   }
   const int32_t i2 = (s_i[0] == 0x7FFFFFFF) ? -1 : s_i[0];
 
+  // (5) decisions within 1e-7 of an alternative (other than the alpha = 0.5 mirror of the best doublet, which every cell has):
+  //     the host fetches the grid of such a cell and lets the tie arbiter re-evaluate the contenders (DESIGN.md "Ties")
+  int32_t flags = 0;
+  {
+    const double tol = 1e-7;
+    bool near_d = false;
+    if (qbest != 0x7FFFFFFF) {
+      const double best = G[qbest];
+      const int32_t nb = qbest % A, jkb = qbest / A, jb = jkb / V, kb = jkb % V;
+      const int32_t qmir = (alpha[nb] == 0.5) ? ((kb * V + jb) * A + nb) : -1;
+      for (int32_t q = t; q < nAB; q += kThreads) {
+        const int32_t n = q % A, jk = q / A, j = jk / V, k = jk % V;
+        if (j != k && n >= 1 && q != qbest && q != qmir && G[q] >= best - tol) near_d = true;
+      }
+    }
+    int cnt = 0;
+    const double s1v = (i1 != 0x7FFFFFFF) ? G[(size_t)i1 * V * A] : 0.0, s2v = (i2 >= 0) ? G[(size_t)i2 * V * A] : -1e300;
+    for (int32_t j = t; j < V; j += kThreads) if (G[(size_t)j * V * A] >= s2v - tol) ++cnt;
+    const int any_d = __syncthreads_or(near_d ? 1 : 0);
+    s_i[t] = cnt;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+      if (t < s) s_i[t] += s_i[t + s];
+      __syncthreads();
+    }
+    const int n_near_s = s_i[0];
+    if (any_d) flags |= DMX_CELL_NEAR_DOUBLET;
+    if (i2 >= 0 && (n_near_s > 2 || s1v - s2v < tol)) flags |= DMX_CELL_NEAR_SINGLET;
+  }
+
   if (t == 0) {
     // NaN likelihoods (e.g. a GP record with a missing sample poisons the whole SNP, bcf_filtered_reader.cpp:431-448) make
     // every `<` of the reference's scans false: it then indexes with -1 (:816-825, undefined behaviour).  Here the
@@ -2917,7 +2950,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
     r.llk1 = hasb ? G[(size_t)jb * V * A] : kNaN; r.llk2 = hasb ? G[(size_t)kb * V * A] : kNaN;
     r.llk10 = hasb ? G[(size_t)jb * V * A + nb] : kNaN; r.llk20 = hasb ? G[(size_t)kb * V * A + nb] : kNaN;    // :824-825
     r.llk00_0 = l00[(size_t)cell * A]; r.llk00_best = l00[(size_t)cell * A + nb];
-    r.n_pairs = npairs;
+    r.n_pairs = npairs; r.flags = flags; r.reserved = 0;
     out[cell] = r;
   }
 }
@@ -3665,18 +3698,33 @@ extern "C" int dmx_debug_device_log(const double* x, double* y, int64_t n, int32
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// cmd_cram_demuxlet.cpp:390-881 in one call: store + genotype matrix in, four text files out.
+// cmd_cram_demuxlet.cpp:390-881 in one call: store (or a frozen pileup) + genotype matrix in, four text files out.
 extern "C" int dmx_demuxlet_run(const dmx_job* job) {
-  if (!job || !job->store || !job->g || !job->sample_ids || !job->alpha || !job->out_prefix)
+  if (!job || (!job->store && !(job->pileup && job->barcodes)) || !job->g || !job->sample_ids || !job->alpha || !job->out_prefix)
     return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: null argument");
+  using clk = std::chrono::steady_clock;
+  auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const clk::time_point t_begin = clk::now();
+  dmx_job_timing tm{};
   dmx_pileup pl;
-  if (int rc = dmx_store_freeze(job->store, &pl)) return rc;
+  if (job->store) { if (int rc = dmx_store_freeze(job->store, &pl)) return rc; }
+  else {
+    pl = *job->pileup;
+    if (pl.memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup must be host memory");
+    if (!pl.rd_totl || !pl.rd_pass || !pl.rd_uniq) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup needs the per-cell read counters");
+  }
+  tm.freeze_s = secs(t_begin, clk::now());
+  const clk::time_point t_setup = clk::now();
   const int32_t B = pl.n_cells, V = job->n_samples, A = job->n_alpha;
   const size_t nAB = (size_t)V * V * A;
   const bool doublet_ok = V >= 2 && A >= 2;
+  const bool dense = pl.pair_snp == nullptr && pl.n_pairs > 0;
   std::vector<const char*> bcs((size_t)B);
   std::vector<int32_t> nsnp((size_t)B);
-  for (int32_t c = 0; c < B; ++c) { bcs[c] = dmx_store_barcode(job->store, c); nsnp[c] = (int32_t)(pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]); }
+  for (int32_t c = 0; c < B; ++c) {
+    bcs[c] = job->store ? dmx_store_barcode(job->store, c) : job->barcodes[c];
+    nsnp[c] = (int32_t)(pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]);
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return set_error(DMX_ERR_NOGPU, "dmx_demuxlet_run: no HIP device is visible (this library has no CPU fallback)");
@@ -3684,7 +3732,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   // ---- ranges: contiguous runs of the byte-wise sorted barcodes (= output order, cmd_cram_demuxlet.cpp:472,:576) with equal
   // work.  One engine per GPU; a range is what one engine holds at a time, sized so that its doublet grid stays inside a
   // byte budget (the grid, nb * V*V*A doubles, is the only thing that grows with the panel).  Ranges go through the engines
-  // in waves; while the host formats and appends the rows of wave w, the GPUs already compute wave w + 1.
+  // in waves; while the host arbitrates, formats and appends the rows of wave w, the GPUs already compute wave w + 1 — so a
+  // job that is big enough is cut into at least four ranges per engine even when memory does not ask for it.
   const int ngpu = std::max(1, std::min(job->n_gpus > 0 ? job->n_gpus : 1, std::max(B, 1)));
   size_t budget = (size_t)4 << 30;                                   // bytes of grid per range (host holds two waves of them)
   if (const char* env = getenv("DMX_RANGE_BYTES")) budget = (size_t)std::max(1ll, atoll(env));   // tests: force many ranges
@@ -3693,41 +3742,55 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     HIP_TRY(hipSetDevice(job->device % ndev));
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < budget) budget = std::max<size_t>(free_b / 3, 1);
   }
+  const double per_pair = (double)(V + 1) + (doublet_ok ? (double)nAB + A : 0.0);
+  double work_total = 0;
+  for (int32_t c = 0; c < B; ++c) work_total += nsnp[c] * per_pair + 1.0;
   const double grid_total = doublet_ok ? (double)B * (double)nAB * 8.0 : 0.0;
   const int by_mem = (int)std::min<double>((double)std::max(B, 1), std::ceil(grid_total / (double)budget));
-  int R = std::max(ngpu, by_mem);
+  int by_overlap = 1;                                                // ranges per engine wanted for host/GPU overlap
+  if (const char* env = getenv("DMX_RANGES_PER_GPU")) by_overlap = std::max(1, atoi(env));
+  else if (doublet_ok && work_total / ngpu > 2e11 && B / ngpu >= 8 * 1024) by_overlap = 4;   // >= ~0.3 s of GPU work per engine
+  int R = std::max(ngpu * by_overlap, by_mem);
   R = ((R + ngpu - 1) / ngpu) * ngpu;                                 // whole waves
   R = std::max(1, std::min(R, std::max(B, 1)));
+  const size_t cell_cap = doublet_ok ? std::max<size_t>(1, budget / (nAB * 8)) : (size_t)B + 1;   // a range never holds more cells than its grid budget
   std::vector<int32_t> order((size_t)B);
   std::iota(order.begin(), order.end(), 0);
-  if (R > 1) std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return std::strcmp(bcs[a], bcs[b]) < 0; });
-  std::vector<int32_t> cut((size_t)R + 1, 0);
+  const bool sliced = R > 1;
+  if (sliced) std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return std::strcmp(bcs[a], bcs[b]) < 0; });
+  std::vector<int32_t> cut;
+  cut.push_back(0);
   {
-    const double per_pair = (double)(V + 1) + (double)nAB + A;
-    double total = 0;
-    for (int32_t c = 0; c < B; ++c) total += nsnp[c] * per_pair + 1.0;
     double run = 0;
     int r = 1;
-    for (int32_t i = 0; i < B && r < R; ++i) {
+    for (int32_t i = 0; i < B; ++i) {
       run += nsnp[order[i]] * per_pair + 1.0;
-      while (r < R && run >= total * r / R) cut[(size_t)r++] = i + 1;
+      const bool by_work = r < R && run >= work_total * r / R;
+      const bool by_cap = (size_t)(i + 1 - cut.back()) >= cell_cap;
+      if ((by_work || by_cap) && i + 1 < B) { cut.push_back(i + 1); if (by_work) ++r; }
     }
-    for (; r <= R; ++r) cut[(size_t)r] = B;
-    cut[(size_t)R] = B;
+    cut.push_back(B);
+    if (B == 0) cut.assign({0, 0});
   }
+  R = (int)cut.size() - 1;
+  tm.n_ranges = R;
 
   struct Range {
     std::vector<int64_t> pair_off, read_off;
     std::vector<int32_t> snp, totl, pass, uniq, ns;
     std::vector<uint8_t> nrd, reads;
     std::vector<const char*> bc;
-    std::vector<double> llks, llk0s, grid, l00;
+    std::vector<double> llks, llk0s, grid, l00, sing;
+    std::vector<dmx_cell_summary> summ;
+    std::vector<std::vector<double>> flagged_grid;
+    std::vector<const double*> cell_grid;
     dmx_pileup pl{};
     int32_t lo = 0, hi = 0;
     void release() { *this = Range(); }
   };
   std::vector<Range> rg((size_t)R);
   std::vector<dmx_engine*> eng((size_t)std::min(ngpu, R), nullptr);
+  tm.n_engines = (int32_t)eng.size();
   struct Guard { std::vector<dmx_engine*>* e; ~Guard() { for (dmx_engine* x : *e) if (x) dmx_engine_destroy(x); } } guard{&eng};
   for (size_t i = 0; i < eng.size(); ++i) {
     dmx_engine_config cfg{};
@@ -3736,13 +3799,18 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     if (int rc = dmx_engine_create(&cfg, &eng[i])) return rc;
     if (int rc = dmx_engine_set_genotypes(eng[i], job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
   }
+  tm.setup_s = secs(t_setup, clk::now());
+  std::mutex tm_mu;
+  double stage_s = 0, wait_s = 0, write_s = 0, kernel_ms = 0;
+  int32_t n_fetched = 0;
 
   auto launch = [&](int r) -> int {              // stage range r on its engine and start its kernels (asynchronous)
+    const clk::time_point t0 = clk::now();
     Range& x = rg[(size_t)r];
     x.lo = cut[(size_t)r]; x.hi = cut[(size_t)r + 1];
     const int32_t nb = x.hi - x.lo;
     const dmx_pileup* use = &pl;
-    if (R > 1) {                                 // slice the CSR: cells order[lo..hi) become cells 0..nb-1 of the range
+    if (sliced) {                                // slice the CSR: cells order[lo..hi) become cells 0..nb-1 of the range
       x.pair_off.assign((size_t)nb + 1, 0); x.read_off.assign((size_t)nb + 1, 0);
       const size_t nb1 = (size_t)std::max(nb, 1);                      // an empty range still hands non-null arrays to the writers
       x.totl.resize(nb1); x.pass.resize(nb1); x.uniq.resize(nb1); x.ns.resize(nb1); x.bc.resize(nb1);
@@ -3753,14 +3821,14 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
         x.totl[(size_t)k] = pl.rd_totl[c]; x.pass[(size_t)k] = pl.rd_pass[c]; x.uniq[(size_t)k] = pl.rd_uniq[c];
         x.ns[(size_t)k] = nsnp[(size_t)c]; x.bc[(size_t)k] = bcs[(size_t)c];
       }
-      x.snp.resize((size_t)x.pair_off[(size_t)nb]);
+      if (!dense) x.snp.resize((size_t)x.pair_off[(size_t)nb] + 1);
       x.nrd.resize((size_t)x.pair_off[(size_t)nb] * (size_t)pl.nrd_width + 4);
       x.reads.resize((size_t)x.read_off[(size_t)nb] + 4);
       for (int32_t k = 0; k < nb; ++k) {
         const int32_t c = order[(size_t)x.lo + k];
         const int64_t np = pl.cell_pair_off[c + 1] - pl.cell_pair_off[c], nr = pl.cell_read_off[c + 1] - pl.cell_read_off[c];
         if (np) {
-          std::memcpy(&x.snp[(size_t)x.pair_off[(size_t)k]], pl.pair_snp + pl.cell_pair_off[c], sizeof(int32_t) * (size_t)np);
+          if (!dense) std::memcpy(&x.snp[(size_t)x.pair_off[(size_t)k]], pl.pair_snp + pl.cell_pair_off[c], sizeof(int32_t) * (size_t)np);
           std::memcpy(&x.nrd[(size_t)x.pair_off[(size_t)k] * (size_t)pl.nrd_width],
                       (const uint8_t*)pl.pair_nrd + (size_t)pl.cell_pair_off[c] * (size_t)pl.nrd_width, (size_t)np * (size_t)pl.nrd_width);
         }
@@ -3768,7 +3836,9 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
       }
       x.pl = pl;
       x.pl.n_cells = nb; x.pl.n_pairs = x.pair_off[(size_t)nb]; x.pl.n_reads = x.read_off[(size_t)nb];
-      x.pl.cell_pair_off = x.pair_off.data(); x.pl.cell_read_off = x.read_off.data(); x.pl.pair_snp = x.snp.data();
+      x.pl.cell_pair_off = x.pair_off.data(); x.pl.cell_read_off = x.read_off.data();
+      x.pl.pair_snp = (dense && x.pl.n_pairs > 0) ? nullptr : x.snp.data();      // a dense job stays dense; an all-empty range is sparse
+      if (!x.pl.pair_snp && x.pl.n_pairs == 0) { x.snp.resize(1); x.pl.pair_snp = x.snp.data(); }
       x.pl.pair_nrd = x.nrd.data(); x.pl.reads = x.reads.data();
       x.pl.rd_totl = x.totl.data(); x.pl.rd_pass = x.pass.data(); x.pl.rd_uniq = x.uniq.data();
       use = &x.pl;
@@ -3777,37 +3847,67 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     if (int rc = dmx_engine_set_pileup(e, use)) return rc;
     if (int rc = dmx_engine_run_singlet(e)) return rc;
     if (doublet_ok) if (int rc = dmx_engine_run_doublet(e)) return rc;
+    { std::lock_guard<std::mutex> lk(tm_mu); stage_s += secs(t0, clk::now()); }
     return DMX_OK;
   };
   auto fetch = [&](int r) -> int {               // results of range r to the host (waits for its kernels)
+    const clk::time_point t0 = clk::now();
     Range& x = rg[(size_t)r];
-    const size_t nb = (size_t)(x.hi - x.lo);
+    const size_t nb = (size_t)(x.hi - x.lo), nb1 = std::max<size_t>(nb, 1);
     dmx_engine* e = eng[(size_t)r % eng.size()];
-    x.llks.resize(std::max<size_t>(nb, 1) * (size_t)V); x.llk0s.resize(std::max<size_t>(nb, 1));
+    x.llks.resize(nb1 * (size_t)V); x.llk0s.resize(nb1);
     if (int rc = dmx_engine_get_singlet(e, x.llks.data(), x.llk0s.data())) return rc;
+    int32_t fetched = 0;
     if (doublet_ok) {
-      x.grid.resize(std::max<size_t>(nb, 1) * nAB); x.l00.resize(std::max<size_t>(nb, 1) * (size_t)A);
-      if (int rc = dmx_engine_get_doublet(e, x.grid.data(), x.l00.data(), nullptr)) return rc;
+      x.l00.resize(nb1 * (size_t)A);
+      if (job->write_pair) {                     // .pair prints the grid: bring all of it
+        x.grid.resize(nb1 * nAB);
+        if (int rc = dmx_engine_get_doublet(e, x.grid.data(), x.l00.data(), nullptr)) return rc;
+      } else {                                   // otherwise the K3 records say everything, except for cells flagged as near-ties
+        x.sing.resize(nb1 * (size_t)V); x.summ.resize(nb1);
+        if (int rc = dmx_engine_get_doublet(e, nullptr, x.l00.data(), x.summ.data())) return rc;
+        if (int rc = dmx_engine_get_sing(e, x.sing.data())) return rc;
+        x.cell_grid.assign(nb1, nullptr);
+        if (job->arbiter) {
+          for (size_t c = 0; c < nb; ++c) if (x.summ[c].flags && x.summ[c].n_pairs > 0) {
+            x.flagged_grid.emplace_back(nAB);
+            HIP_TRY(hipSetDevice(e->device));
+            HIP_TRY(hipMemcpyAsync(x.flagged_grid.back().data(), e->d_grid + c * nAB, sizeof(double) * nAB, hipMemcpyDeviceToHost, e->stream));
+            ++fetched;
+          }
+          HIP_TRY(hipStreamSynchronize(e->stream));
+          size_t f = 0;
+          for (size_t c = 0; c < nb; ++c) if (x.summ[c].flags && x.summ[c].n_pairs > 0) x.cell_grid[c] = x.flagged_grid[f++].data();
+        }
+      }
     }
+    dmx_kernel_times kt{};
+    (void)dmx_engine_last_kernel_times(e, &kt);
+    { std::lock_guard<std::mutex> lk(tm_mu); wait_s += secs(t0, clk::now()); kernel_ms += kt.singlet_ms + kt.doublet_ms + kt.reduce_ms; n_fetched += fetched; }
     return DMX_OK;
   };
   const std::string pre(job->out_prefix);
   auto write = [&](int r) -> int {               // append range r's rows (rows of a range are sorted by the writers)
+    const clk::time_point t0 = clk::now();
     Range& x = rg[(size_t)r];
     dmx_final_input fin{};
     fin.n_cells = x.hi - x.lo; fin.n_samples = V; fin.n_alpha = A; fin.alpha = job->alpha; fin.doublet_prior = job->doublet_prior;
     fin.min_total = job->min_total; fin.min_uniq = job->min_uniq; fin.min_snp = job->min_snp; fin.write_pair = job->write_pair;
     fin.sample_ids = job->sample_ids;
-    if (R > 1) { fin.barcodes = x.bc.data(); fin.rd_totl = x.totl.data(); fin.rd_pass = x.pass.data(); fin.rd_uniq = x.uniq.data(); fin.n_snp = x.ns.data(); }
+    if (sliced) { fin.barcodes = x.bc.data(); fin.rd_totl = x.totl.data(); fin.rd_pass = x.pass.data(); fin.rd_uniq = x.uniq.data(); fin.n_snp = x.ns.data(); }
     else { fin.barcodes = bcs.data(); fin.rd_totl = pl.rd_totl; fin.rd_pass = pl.rd_pass; fin.rd_uniq = pl.rd_uniq; fin.n_snp = nsnp.data(); }
     fin.llks = x.llks.data(); fin.llk0s = x.llk0s.data();
     if (int rc = dmx::write_single_impl(&fin, (pre + ".single").c_str(), r > 0)) return rc;
     if (doublet_ok) {
-      fin.llksAB = x.grid.data(); fin.llks00 = x.l00.data();
-      if (job->arbiter) { fin.tie_pileup = (R > 1) ? &x.pl : &pl; fin.tie_g = job->g; }
-      if (int rc = dmx::write_doublet_impl(&fin, job->out_prefix, r > 0)) return rc;
+      fin.llks00 = x.l00.data();
+      if (job->arbiter) { fin.tie_pileup = sliced ? &x.pl : &pl; fin.tie_g = job->g; }
+      dmx::DoubletSource src{};
+      if (job->write_pair) { fin.llksAB = x.grid.data(); src.grid_all = x.grid.data(); }
+      else { src.sing = x.sing.data(); src.summary = x.summ.data(); src.cell_grid = x.cell_grid.data(); }
+      if (int rc = dmx::write_doublet_core(&fin, src, job->out_prefix, r > 0, "dmx_demuxlet_run")) return rc;
     }
     x.release();
+    { std::lock_guard<std::mutex> lk(tm_mu); write_s += secs(t0, clk::now()); }
     return DMX_OK;
   };
 
@@ -3832,6 +3932,13 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     if (int rc = for_ranges(r1, std::min(R, r1 + per_wave), launch)) return rc;                   // GPUs run wave w+1 ...
     for (int r = r0; r < r1; ++r) if (int rc = write(r)) return rc;                               // ... while the host writes wave w
   }
+  tm.stage_s = stage_s; tm.wait_s = wait_s; tm.write_s = write_s; tm.kernel_ms = kernel_ms; tm.n_cells_grid_fetched = n_fetched;
+  tm.total_s = secs(t_begin, clk::now());
+  if (job->timing) *job->timing = tm;
+  if (getenv("DMX_E2E_TIMING"))
+    fprintf(stderr, "{\"dmx_demuxlet_run\": {\"freeze_s\": %.4f, \"setup_s\": %.4f, \"stage_s\": %.4f, \"wait_s\": %.4f, \"write_s\": %.4f, \"total_s\": %.4f, "
+                    "\"kernel_ms\": %.3f, \"ranges\": %d, \"engines\": %d, \"cells_grid_fetched\": %d}}\n",
+            tm.freeze_s, tm.setup_s, tm.stage_s, tm.wait_s, tm.write_s, tm.total_s, tm.kernel_ms, tm.n_ranges, tm.n_engines, tm.n_cells_grid_fetched);
   if (!doublet_ok) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: the doublet stage needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
   return DMX_OK;
 }

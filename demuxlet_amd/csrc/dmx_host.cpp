@@ -463,10 +463,25 @@ static inline uint32_t nrd_at(const dmx_pileup& pl, int64_t p) {
   return v;
 }
 
-void exact_grid_entries(const dmx_pileup& pl, const float* g, int32_t V, int32_t A, const double* alpha,
-                        const ReadLut& lut, int32_t cell, std::vector<GridReq>& reqs) {
-  for (GridReq& r : reqs) r.value = 0.0;
-  std::vector<double> pG((size_t)A * 9), mixR((size_t)A * 9), mixA((size_t)A * 9);
+// pG[A][3][3] of one pair from its stored read bytes: cmd_cram_demuxlet.cpp:597-663, operation for operation
+static inline void mix_pair(const uint8_t* rd, uint32_t nr, const ReadLut& lut, const double* mixR, const double* mixA, size_t n9, double* pG) {
+  for (size_t q = 0; q < n9; ++q) pG[q] = 1.0;                                                                          // :597
+  for (uint32_t r = 0; r < nr; ++r) {
+    const uint8_t b = rd[r];
+    const int al = b >> 7, bq = b & 127;
+    const double pR = (al == 0) ? lut.mat[bq] : lut.e3[bq];      // :606
+    const double pA = (al == 1) ? lut.mat[bq] : lut.e3[bq];      // :607
+    double mx = 0;
+    for (size_t q = 0; q < n9; ++q) { pG[q] *= (pR * mixR[q] + pA * mixA[q]); if (mx < pG[q]) mx = pG[q]; }             // :625-627
+    for (size_t q = 0; q < n9; ++q) pG[q] /= mx;                                                                        // :632-639
+  }
+  double mx = 0;
+  for (size_t q = 0; q < n9; ++q) { pG[q] += 1e-6; if (mx < pG[q]) mx = pG[q]; }                                        // :643-654
+  for (size_t q = 0; q < n9; ++q) pG[q] /= mx;                                                                          // :656-663
+}
+
+static void mix_weights(int32_t A, const double* alpha, std::vector<double>& mixR, std::vector<double>& mixA) {
+  mixR.assign((size_t)A * 9, 0.0); mixA.assign((size_t)A * 9, 0.0);
   for (int32_t n = 0; n < A; ++n)
     for (int l = 0; l < 3; ++l)
       for (int m = 0; m < 3; ++m) {
@@ -474,33 +489,53 @@ void exact_grid_entries(const dmx_pileup& pl, const float* g, int32_t V, int32_t
         mixA[(size_t)n * 9 + l * 3 + m] = p;
         mixR[(size_t)n * 9 + l * 3 + m] = 1.0 - p;
       }
+}
+
+void build_mix_tables(const ReadLut& lut, int32_t A, const double* alpha, MixTables* out) {
+  std::vector<double> mixR, mixA;
+  mix_weights(A, alpha, mixR, mixA);
+  const size_t n9 = (size_t)A * 9;
+  out->A = A;
+  out->none.assign(n9, 0.0);
+  mix_pair(nullptr, 0, lut, mixR.data(), mixA.data(), n9, out->none.data());
+  out->one.assign(256 * n9, 0.0);
+  for (int b = 0; b < 256; ++b) { const uint8_t rd[1] = {(uint8_t)b}; mix_pair(rd, 1, lut, mixR.data(), mixA.data(), n9, &out->one[(size_t)b * n9]); }
+  out->two.assign((size_t)128 * 128 * n9, 0.0);
+  for (int c0 = 0; c0 < 128; ++c0)
+    for (int c1 = 0; c1 < 128; ++c1) {
+      const uint8_t rd[2] = {(uint8_t)(((c0 & 64) << 1) | (c0 & 63)), (uint8_t)(((c1 & 64) << 1) | (c1 & 63))};
+      mix_pair(rd, 2, lut, mixR.data(), mixA.data(), n9, &out->two[((size_t)c0 * 128 + c1) * n9]);
+    }
+}
+
+void exact_grid_entries(const dmx_pileup& pl, const float* g, int32_t V, int32_t A, const double* alpha,
+                        const ReadLut& lut, const MixTables* mix, int32_t cell, std::vector<GridReq>& reqs) {
+  for (GridReq& r : reqs) r.value = 0.0;
+  const size_t n9 = (size_t)A * 9;
+  std::vector<double> pG(n9), mixR, mixA;
+  mix_weights(A, alpha, mixR, mixA);
+  if (mix && mix->A != A) mix = nullptr;
   int64_t rd = pl.cell_read_off[cell];
   const int64_t p0 = pl.cell_pair_off[cell], p1 = pl.cell_pair_off[cell + 1];
   for (int64_t p = p0; p < p1; ++p) {
     const int32_t snp = pl.pair_snp ? pl.pair_snp[p] : (int32_t)(p - p0);
     const uint32_t nr = nrd_at(pl, p);
-    std::fill(pG.begin(), pG.end(), 1.0);
-    for (uint32_t r = 0; r < nr; ++r) {
-      const uint8_t b = pl.reads[rd + r];
-      const int al = b >> 7, bq = b & 127;
-      const double pR = (al == 0) ? lut.mat[bq] : lut.e3[bq];      // :606
-      const double pA = (al == 1) ? lut.mat[bq] : lut.e3[bq];      // :607
-      double mx = 0;
-      for (size_t q = 0; q < pG.size(); ++q) { pG[q] *= (pR * mixR[q] + pA * mixA[q]); if (mx < pG[q]) mx = pG[q]; }   // :625-627
-      for (size_t q = 0; q < pG.size(); ++q) pG[q] /= mx;                                                              // :632-639
-    }
+    const uint8_t* rb = pl.reads + rd;
+    const double* P;
+    if (mix && nr == 0) P = mix->none.data();
+    else if (mix && nr == 1) P = &mix->one[(size_t)rb[0] * n9];
+    else if (mix && nr == 2 && !((rb[0] | rb[1]) & 0x40))
+      P = &mix->two[((size_t)(((rb[0] & 0x80) >> 1) | (rb[0] & 0x3F)) * 128 + (((rb[1] & 0x80) >> 1) | (rb[1] & 0x3F))) * n9];
+    else { mix_pair(rb, nr, lut, mixR.data(), mixA.data(), n9, pG.data()); P = pG.data(); }
     rd += nr;
-    double mx = 0;
-    for (size_t q = 0; q < pG.size(); ++q) { pG[q] += 1e-6; if (mx < pG[q]) mx = pG[q]; }                              // :643-654
-    for (size_t q = 0; q < pG.size(); ++q) pG[q] /= mx;                                                                // :656-663
     const float* gs = g + (size_t)snp * V * 3;
     for (GridReq& r : reqs) {
       const float* gj = gs + 3 * r.j;
       const float* gk = gs + 3 * r.k;
-      const double* P = &pG[(size_t)r.n * 9];
+      const double* Pn = P + (size_t)r.n * 9;
       double sum = 0;
       for (int l = 0; l < 3; ++l)
-        for (int m = 0; m < 3; ++m) sum += ((double)gj[l] * (double)gk[m]) * P[l * 3 + m];                             // :553,:677-679
+        for (int m = 0; m < 3; ++m) sum += ((double)gj[l] * (double)gk[m]) * Pn[l * 3 + m];                             // :553,:677-679
       r.value += std::log(sum);                                                                                         // :683
     }
   }
@@ -768,8 +803,29 @@ extern "C" int dmx_write_doublet(const dmx_final_input* in, const char* out_pref
 int dmx::write_doublet_impl(const dmx_final_input* in, const char* out_prefix, bool append) {
   if (int rc = check_common(in, "dmx_write_doublet")) return rc;
   if (!out_prefix || !in->llksAB || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "dmx_write_doublet: null grid/alpha/prefix");
+  dmx::DoubletSource src{};
+  src.grid_all = in->llksAB;
+  return dmx::write_doublet_core(in, src, out_prefix, append, "dmx_write_doublet");
+}
+
+// .sing2 and .best from the per-cell records of the device reduction (K3) — the multi-GPU path gathers exactly these.
+extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double* sing, const dmx_cell_summary* summary,
+                                         const char* out_prefix) {
+  if (int rc = check_common(in, "dmx_write_doublet_summary")) return rc;
+  if (!out_prefix || !sing || !summary || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: null sing/summary/llks00/alpha/prefix");
+  if (in->write_pair) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: .pair rows need the full grid (use dmx_write_doublet)");
+  dmx::DoubletSource src{};
+  src.sing = sing; src.summary = summary;
+  return dmx::write_doublet_core(in, src, out_prefix, false, "dmx_write_doublet_summary");
+}
+
+// The doublet-stage writers (.sing2, .best, optionally .pair).  A cell's rows come either from its grid — the whole
+// llksAB array (src.grid_all) or a per-cell pointer (src.cell_grid[c], the cells K3 flagged as near-ties) — or, without one,
+// from its K3 record (src.sing / src.summary).
+int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src, const char* out_prefix, bool append, const char* who) {
   const int32_t V = in->n_samples, A = in->n_alpha;
-  if (V < 2 || A < 2) return set_error(DMX_ERR_ARG, "dmx_write_doublet: needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
+  if (V < 2 || A < 2) return set_error(DMX_ERR_ARG, "%s: needs >= 2 samples and >= 2 alphas (got %d, %d)", who, V, A);
+  if (in->write_pair && !src.grid_all) return set_error(DMX_ERR_ARG, "%s: .pair rows need the full grid", who);
   const std::string pre(out_prefix);
   File sing2, pairf, best;
   if (!sing2.open(pre + ".sing2", append) || !best.open(pre + ".best", append) || (in->write_pair && !pairf.open(pre + ".pair", append)))
@@ -783,69 +839,111 @@ int dmx::write_doublet_impl(const dmx_final_input* in, const char* out_prefix, b
   const double tol = in->tie_tol > 0 ? in->tie_tol : 1e-7;
   const bool arbiter = in->tie_pileup && in->tie_g;
   dmx::ReadLut lut;
+  std::unique_ptr<dmx::MixTables> mix;
   if (arbiter) {
-    if (in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "dmx_write_doublet: the tie arbiter needs a HOST pileup");
+    if (in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "%s: the tie arbiter needs a HOST pileup", who);
     double mat[256], err[256];
     dmx_phred_tables(mat, err);
     dmx::build_read_lut(mat, err, &lut);
+    mix.reset(new dmx::MixTables);
+    dmx::build_mix_tables(lut, A, in->alpha, mix.get());
   }
   const std::vector<int32_t> cells = output_cells(in, true);
   FILE* const files[kOutFiles] = {sing2.f, pairf.f, best.f};
   std::vector<std::string> alpha_txt((size_t)A);                           // "\t%.3lf\t" of every alpha
   for (int32_t a = 0; a < A; ++a) { alpha_txt[(size_t)a].push_back('\t'); put_fixed(alpha_txt[(size_t)a], in->alpha[a], 3); alpha_txt[(size_t)a].push_back('\t'); }
   const size_t rows_per_cell = (size_t)V + (pairf.f ? (size_t)V * V * (A - 1) : 0);
-  return format_in_order(cells.size(), std::max<size_t>(1, 16384 / rows_per_cell), files, [&](size_t first, size_t last, Chunk& ck) {
+  // the arbiter walks a cell's whole pileup: keep chunks small enough that every host thread gets work
+  const size_t per_chunk = arbiter ? std::max<size_t>(1, std::min<size_t>(16384 / rows_per_cell, (cells.size() + 4 * (size_t)host_threads() - 1) / (4 * (size_t)host_threads())))
+                                   : std::max<size_t>(1, 16384 / rows_per_cell);
+  return format_in_order(cells.size(), per_chunk, files, [&](size_t first, size_t last, Chunk& ck) {
   std::vector<double> scratch;
   std::vector<dmx::GridReq> reqs;
   for (size_t q = first; q < last; ++q) {
     const int32_t c = cells[q];
-    const double* grid = in->llksAB + (size_t)c * ng;
+    const double* grid = src.grid_all ? src.grid_all + (size_t)c * ng : (src.cell_grid ? src.cell_grid[c] : nullptr);
     const double* l00 = in->llks00 + (size_t)c * A;
-    if (arbiter) {
-      // Which entries sit within tol of a decision?  top-2 singlets (:746-758) and the best doublet (:799-814).
-      reqs.clear();
-      double s1 = -1e300, s2 = -1e300;
-      for (int32_t j = 0; j < V; ++j) { const double v = grid[(size_t)j * V * A]; if (v > s1) { s2 = s1; s1 = v; } else if (v > s2) s2 = v; }
-      int near2 = 0;
-      for (int32_t j = 0; j < V; ++j) if (grid[(size_t)j * V * A] >= s2 - tol) ++near2;
-      if (near2 > 2 || s1 - s2 < tol)
-        for (int32_t j = 0; j < V; ++j) if (grid[(size_t)j * V * A] >= s2 - tol) reqs.push_back({j, 0, 0, 0.0});
-      double mab = -1e300;
-      for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) if (j != k) for (int32_t a = 1; a < A; ++a) mab = std::max(mab, grid[((size_t)j * V + k) * A + a]);
-      size_t nd0 = reqs.size();
-      for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) if (j != k) for (int32_t a = 1; a < A; ++a)
-        if (grid[((size_t)j * V + k) * A + a] >= mab - tol) reqs.push_back({j, k, a, 0.0});
-      if (reqs.size() - nd0 == 1) reqs.pop_back();
-      if (!reqs.empty()) {
-        dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, c, reqs);
-        scratch.assign(grid, grid + ng);
-        for (const dmx::GridReq& r : reqs) scratch[((size_t)r.j * V + r.k) * A + r.n] = r.value;
-        grid = scratch.data();
-      }
-    }
-    CellCall cc = call_cell(grid, V, A, in->alpha, prior);
-    // NaN likelihoods leave the reference's scans without a winner and it indexes with -1 (undefined behaviour, :816-825);
-    // we fall back to index 0 so that the row is still printable (its numbers are NaN).
-    if (cc.i_sing1 < 0) cc.i_sing1 = 0;
-    if (cc.i_sing2 < 0) cc.i_sing2 = 0;
-    if (cc.j_best < 0) { cc.j_best = 0; cc.k_best = 0; cc.n_best = 0; }
     const char* bc = in->barcodes[c];
     const int32_t t = in->rd_totl[c], p = in->rd_pass[c], u = in->rd_uniq[c], ns = in->n_snp[c];
-
     std::string head, mid, l0s;                                            // constant parts of this cell's rows, once
     head.append(bc).push_back('\t');
     mid.push_back('\t'); put_int(mid, t); mid.push_back('\t'); put_int(mid, p); mid.push_back('\t'); put_int(mid, u);
     mid.push_back('\t'); put_int(mid, ns); mid.push_back('\t');
     put_fixed(l0s, l00[0], 4);
+
+    // ---- the scalars every row is built from: from the grid with the reference's scans, or from the K3 record
+    double max_llk, sum_single, sum_double, sing1, sing2v, l12, l1, l2, l10, l20;
+    int32_t i_sing1, i_sing2, jb, kb, nb;
+    const double* sg = nullptr;                                            // singlet column when there is no grid
+    if (grid) {
+      if (arbiter) {
+        // Which entries sit within tol of a decision?  top-2 singlets (:746-758) and the best doublet (:799-814).
+        reqs.clear();
+        double s1 = -1e300, s2 = -1e300;
+        for (int32_t j = 0; j < V; ++j) { const double v = grid[(size_t)j * V * A]; if (v > s1) { s2 = s1; s1 = v; } else if (v > s2) s2 = v; }
+        int near2 = 0;
+        for (int32_t j = 0; j < V; ++j) if (grid[(size_t)j * V * A] >= s2 - tol) ++near2;
+        if (near2 > 2 || s1 - s2 < tol)
+          for (int32_t j = 0; j < V; ++j) if (grid[(size_t)j * V * A] >= s2 - tol) reqs.push_back({j, 0, 0, 0.0});
+        double mab = -1e300;
+        for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) if (j != k) for (int32_t a = 1; a < A; ++a) mab = std::max(mab, grid[((size_t)j * V + k) * A + a]);
+        size_t nd0 = reqs.size();
+        for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) if (j != k) for (int32_t a = 1; a < A; ++a)
+          if (grid[((size_t)j * V + k) * A + a] >= mab - tol) reqs.push_back({j, k, a, 0.0});
+        if (reqs.size() - nd0 == 1) reqs.pop_back();
+        if (!reqs.empty()) {
+          dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), c, reqs);
+          scratch.assign(grid, grid + ng);
+          for (const dmx::GridReq& r : reqs) scratch[((size_t)r.j * V + r.k) * A + r.n] = r.value;
+          grid = scratch.data();
+        }
+      }
+      CellCall cc = call_cell(grid, V, A, in->alpha, prior);
+      // NaN likelihoods leave the reference's scans without a winner and it indexes with -1 (undefined behaviour, :816-825);
+      // we fall back to index 0 so that the row is still printable (its numbers are NaN).
+      if (cc.i_sing1 < 0) cc.i_sing1 = 0;
+      if (cc.i_sing2 < 0) cc.i_sing2 = 0;
+      if (cc.j_best < 0) { cc.j_best = 0; cc.k_best = 0; cc.n_best = 0; }
+      max_llk = cc.max_llk; sum_single = cc.sum_single; sum_double = cc.sum_double;
+      i_sing1 = cc.i_sing1; i_sing2 = cc.i_sing2; jb = cc.j_best; kb = cc.k_best; nb = cc.n_best;
+      sing1 = grid[(size_t)i_sing1 * V * A]; sing2v = grid[(size_t)i_sing2 * V * A];
+      l12 = grid[((size_t)jb * V + kb) * A + nb];
+      l1 = grid[(size_t)jb * V * A]; l2 = grid[(size_t)kb * V * A];
+      l10 = grid[(size_t)jb * V * A + nb];                                 // :824 pairs with sample 0 (reference quirk)
+      l20 = grid[(size_t)kb * V * A + nb];                                 // :825
+    } else {
+      dmx_cell_summary sm = src.summary[c];
+      if (sm.i_sing1 < 0) sm.i_sing1 = 0;         // NaN likelihoods: see above
+      if (sm.i_sing2 < 0) sm.i_sing2 = 0;
+      if (sm.j_best < 0) { sm.j_best = 0; sm.k_best = 0; sm.n_best = 0; }
+      sg = src.sing + (size_t)c * V;
+      max_llk = sm.max_llk; sum_single = sm.sum_single; sum_double = sm.sum_double;
+      i_sing1 = sm.i_sing1; i_sing2 = sm.i_sing2; jb = sm.j_best; kb = sm.k_best; nb = sm.n_best;
+      sing1 = sg[i_sing1]; sing2v = sg[i_sing2];
+      l12 = sm.llk12; l1 = sm.llk1; l2 = sm.llk2; l10 = sm.llk10; l20 = sm.llk20;
+      if (arbiter && in->alpha[nb] == 0.5) {
+        // (j,k) and (k,j) are one doublet at alpha = 0.5 and differ only by rounding: re-evaluate both in the
+        // reference's operation order and let its strict-< scan decide, which visits the smaller first index first.
+        const int32_t a = std::min(jb, kb), b = std::max(jb, kb);
+        reqs.assign({{a, b, nb, 0.0}, {b, a, nb, 0.0}});
+        dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), c, reqs);
+        const bool swap_to_ba = reqs[0].value < reqs[1].value;
+        const int32_t nj = swap_to_ba ? b : a, nk = swap_to_ba ? a : b;
+        if (nj != jb) { std::swap(l1, l2); std::swap(l10, l20); }
+        jb = nj; kb = nk;
+        l12 = swap_to_ba ? reqs[1].value : reqs[0].value;
+      }
+    }
+
     for (int32_t j = 0; j < V; ++j) {                                      // :746-770 (.sing2) "%s\t%s\t%d\t%d\t%d\t%d\t%.4lf\t%.4lf\t%.3lg\n"
-      const double v = grid[(size_t)j * V * A];
+      const double v = grid ? grid[(size_t)j * V * A] : sg[j];
       std::string& o = ck.out[0];
       o.append(head).append(in->sample_ids[j]).append(mid);
       put_fixed(o, v, 4); o.push_back('\t'); o.append(l0s); o.push_back('\t');
-      put_general(o, std::exp(v - cc.max_llk) * (1. - prior) / V / cc.sum_single, 3); o.push_back('\n');
+      put_general(o, std::exp(v - max_llk) * (1. - prior) / V / sum_single, 3); o.push_back('\n');
     }
     if (pairf.f) {                                                         // :772-797 (.pair) "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n"
-      const double tot = cc.sum_single + cc.sum_double;
+      const double tot = sum_single + sum_double;
       std::string& o = ck.out[1];
       for (int32_t j = 0; j < V; ++j) {
         const double vs = grid[(size_t)j * V * A];
@@ -853,7 +951,7 @@ int dmx::write_doublet_impl(const dmx_final_input* in, const char* out_prefix, b
         hj.append(head).append(in->sample_ids[j]).push_back('\t');
         o.append(hj).append(in->sample_ids[j]).append(alpha_txt[0]);
         put_fixed(o, vs, 5); o.push_back('\t');
-        put_general(o, std::exp(vs - cc.max_llk) * (1. - prior) / V / tot, 5); o.push_back('\n');
+        put_general(o, std::exp(vs - max_llk) * (1. - prior) / V / tot, 5); o.push_back('\n');
         for (int32_t k = 0; k < V; ++k)
           for (int32_t a = 1; a < A; ++a) {
             if (j == k) continue;
@@ -861,110 +959,25 @@ int dmx::write_doublet_impl(const dmx_final_input* in, const char* out_prefix, b
             const double v = grid[((size_t)j * V + k) * A + a];
             o.append(hj).append(in->sample_ids[k]).append(alpha_txt[(size_t)a]);
             put_fixed(o, v, 5); o.push_back('\t');
-            put_general(o, std::exp(v - cc.max_llk) * prior / V / (V - 1) / (A - 1) / tot, 5); o.push_back('\n');
+            put_general(o, std::exp(v - max_llk) * prior / V / (V - 1) / (A - 1) / tot, 5); o.push_back('\n');
           }
       }
     }
     // :816-874 (.best)
-    const double sing1 = grid[(size_t)cc.i_sing1 * V * A], sing2v = grid[(size_t)cc.i_sing2 * V * A], sing0 = l00[0];
-    const double l12 = grid[((size_t)cc.j_best * V + cc.k_best) * A + cc.n_best];
-    const double l1 = grid[(size_t)cc.j_best * V * A], l2 = grid[(size_t)cc.k_best * V * A];
-    const double l10 = grid[(size_t)cc.j_best * V * A + cc.n_best];        // :824 pairs with sample 0 (reference quirk)
-    const double l20 = grid[(size_t)cc.k_best * V * A + cc.n_best];        // :825
-    const double l00b = l00[cc.n_best];
-    const double post_dbl = cc.sum_double / (cc.sum_single + cc.sum_double);
-    const double post_sng = std::exp(sing1 - cc.max_llk) * (1. - prior) / V / cc.sum_single;
+    const double sing0 = l00[0], l00b = l00[nb];
+    const double post_dbl = sum_double / (sum_single + sum_double);
+    const double post_sng = std::exp(sing1 - max_llk) * (1. - prior) / V / sum_single;
     appendf(ck.out[2], "%s\t%d\t%d\t%d\t%d\t", bc, t, p, u, ns);
     if ((l12 > l1) && (l12 > l2) && (l12 > sing1 + 2))                     // :837
-      appendf(ck.out[2], "DBL-%s-%s-%.3lf", in->sample_ids[cc.j_best], in->sample_ids[cc.k_best], in->alpha[cc.n_best]);
+      appendf(ck.out[2], "DBL-%s-%s-%.3lf", in->sample_ids[jb], in->sample_ids[kb], in->alpha[nb]);
     else if (sing1 > sing2v + 2)                                           // :844
-      appendf(ck.out[2], "SNG-%s", in->sample_ids[cc.i_sing1]);
+      appendf(ck.out[2], "SNG-%s", in->sample_ids[i_sing1]);
     else
-      appendf(ck.out[2], "AMB-%s-%s-%s/%s", in->sample_ids[cc.i_sing1], in->sample_ids[cc.i_sing2], in->sample_ids[cc.j_best], in->sample_ids[cc.k_best]);
-    appendf(ck.out[2], "\t%s\t%.4lf", in->sample_ids[cc.i_sing1], sing1);
-    appendf(ck.out[2], "\t%s\t%.4lf\t%.4lf", in->sample_ids[cc.i_sing2], sing2v, sing0);
-    appendf(ck.out[2], "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[cc.j_best],
-            in->sample_ids[cc.k_best], in->alpha[cc.n_best], l12, l1, l2, l10, l20, l00b, post_dbl, post_sng);
-  }
-  });
-}
-
-
-// .sing2 and .best from the per-cell records of the device reduction (K3) — the multi-GPU path gathers exactly these.
-extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double* sing, const dmx_cell_summary* summary,
-                                         const char* out_prefix) {
-  if (int rc = check_common(in, "dmx_write_doublet_summary")) return rc;
-  if (!out_prefix || !sing || !summary || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: null sing/summary/llks00/alpha/prefix");
-  if (in->write_pair) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: .pair rows need the full grid (use dmx_write_doublet)");
-  const int32_t V = in->n_samples, A = in->n_alpha;
-  if (V < 2 || A < 2) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
-  const std::string pre(out_prefix);
-  File sing2, best;
-  if (!sing2.open(pre + ".sing2") || !best.open(pre + ".best")) return set_error(DMX_ERR_IO, "Cannot create %s.single, %s.pair files", out_prefix, out_prefix);
-  fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", sing2.f);
-  fputs("BARCODE\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tBEST\tSNG.1ST\tSNG.LLK1\tSNG.2ND\tSNG.LLK2\tSNG.LLK0\tDBL.1ST\tDBL.2ND\tALPHA\tLLK12\tLLK1\tLLK2\tLLK10\tLLK20\tLLK00\tPRB.DBL\tPRB.SNG1\n", best.f);
-  const double prior = in->doublet_prior;
-  const bool arbiter = in->tie_pileup && in->tie_g;
-  dmx::ReadLut lut;
-  if (arbiter) {
-    if (in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: the tie arbiter needs a HOST pileup");
-    double mat[256], err[256];
-    dmx_phred_tables(mat, err);
-    dmx::build_read_lut(mat, err, &lut);
-  }
-  const std::vector<int32_t> cells = output_cells(in, true);
-  FILE* const files[kOutFiles] = {sing2.f, nullptr, best.f};
-  return format_in_order(cells.size(), std::max<size_t>(1, 8192 / (size_t)V), files, [&](size_t first, size_t last, Chunk& ck) {
-  std::vector<dmx::GridReq> reqs;
-  for (size_t q = first; q < last; ++q) {
-    const int32_t c = cells[q];
-    dmx_cell_summary sm = summary[c];
-    if (sm.i_sing1 < 0) sm.i_sing1 = 0;         // NaN likelihoods: see dmx_write_doublet
-    if (sm.i_sing2 < 0) sm.i_sing2 = 0;
-    if (sm.j_best < 0) { sm.j_best = 0; sm.k_best = 0; sm.n_best = 0; }
-    const double* sg = sing + (size_t)c * V;
-    const double* l00 = in->llks00 + (size_t)c * A;
-    int32_t jb = sm.j_best, kb = sm.k_best;
-    double l12 = sm.llk12, l1 = sm.llk1, l2 = sm.llk2, l10 = sm.llk10, l20 = sm.llk20;
-    if (arbiter && in->alpha[sm.n_best] == 0.5) {
-      // (j,k) and (k,j) are one doublet at alpha = 0.5 and differ only by rounding: re-evaluate both in the
-      // reference's operation order and let its strict-< scan decide, which visits the smaller first index first.
-      const int32_t a = std::min(jb, kb), b = std::max(jb, kb);
-      reqs.assign({{a, b, sm.n_best, 0.0}, {b, a, sm.n_best, 0.0}});
-      dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, c, reqs);
-      const bool swap_to_ba = reqs[0].value < reqs[1].value;
-      const int32_t nj = swap_to_ba ? b : a, nk = swap_to_ba ? a : b;
-      if (nj != jb) { std::swap(l1, l2); std::swap(l10, l20); }
-      jb = nj; kb = nk;
-      l12 = swap_to_ba ? reqs[1].value : reqs[0].value;
-    }
-    const char* bc = in->barcodes[c];
-    const int32_t t = in->rd_totl[c], p = in->rd_pass[c], u = in->rd_uniq[c], ns = in->n_snp[c];
-    std::string head, mid, l0s;
-    head.append(bc).push_back('\t');
-    mid.push_back('\t'); put_int(mid, t); mid.push_back('\t'); put_int(mid, p); mid.push_back('\t'); put_int(mid, u);
-    mid.push_back('\t'); put_int(mid, ns); mid.push_back('\t');
-    put_fixed(l0s, l00[0], 4);
-    for (int32_t j = 0; j < V; ++j) {                                      // "%s\t%s\t%d\t%d\t%d\t%d\t%.4lf\t%.4lf\t%.3lg\n"
-      std::string& o = ck.out[0];
-      o.append(head).append(in->sample_ids[j]).append(mid);
-      put_fixed(o, sg[j], 4); o.push_back('\t'); o.append(l0s); o.push_back('\t');
-      put_general(o, std::exp(sg[j] - sm.max_llk) * (1. - prior) / V / sm.sum_single, 3); o.push_back('\n');
-    }
-    const double sing1 = sg[sm.i_sing1], sing2v = sg[sm.i_sing2];
-    const double post_dbl = sm.sum_double / (sm.sum_single + sm.sum_double);
-    const double post_sng = std::exp(sing1 - sm.max_llk) * (1. - prior) / V / sm.sum_single;
-    appendf(ck.out[2], "%s\t%d\t%d\t%d\t%d\t", bc, t, p, u, ns);
-    if ((l12 > l1) && (l12 > l2) && (l12 > sing1 + 2))
-      appendf(ck.out[2], "DBL-%s-%s-%.3lf", in->sample_ids[jb], in->sample_ids[kb], in->alpha[sm.n_best]);
-    else if (sing1 > sing2v + 2)
-      appendf(ck.out[2], "SNG-%s", in->sample_ids[sm.i_sing1]);
-    else
-      appendf(ck.out[2], "AMB-%s-%s-%s/%s", in->sample_ids[sm.i_sing1], in->sample_ids[sm.i_sing2], in->sample_ids[jb], in->sample_ids[kb]);
-    appendf(ck.out[2], "\t%s\t%.4lf", in->sample_ids[sm.i_sing1], sing1);
-    appendf(ck.out[2], "\t%s\t%.4lf\t%.4lf", in->sample_ids[sm.i_sing2], sing2v, l00[0]);
-    appendf(ck.out[2], "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[jb], in->sample_ids[kb],
-            in->alpha[sm.n_best], l12, l1, l2, l10, l20, l00[sm.n_best], post_dbl, post_sng);
+      appendf(ck.out[2], "AMB-%s-%s-%s/%s", in->sample_ids[i_sing1], in->sample_ids[i_sing2], in->sample_ids[jb], in->sample_ids[kb]);
+    appendf(ck.out[2], "\t%s\t%.4lf", in->sample_ids[i_sing1], sing1);
+    appendf(ck.out[2], "\t%s\t%.4lf\t%.4lf", in->sample_ids[i_sing2], sing2v, sing0);
+    appendf(ck.out[2], "\t%s\t%s\t%.3lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.4lf\t%.3lg\t%.3lg\n", in->sample_ids[jb],
+            in->sample_ids[kb], in->alpha[nb], l12, l1, l2, l10, l20, l00b, post_dbl, post_sng);
   }
   });
 }

@@ -44,8 +44,27 @@ const TripleTables& build_triple_tables(const ReadLut& lut, const PairTables& pt
 // Host-side exact re-evaluation of selected doublet-grid entries of ONE cell, in the reference's operation order with
 // the host libm (tie arbiter; cmd_cram_demuxlet.cpp:595-684 restricted to the requested (j,k,n)).
 struct GridReq { int32_t j, k, n; double value; };
+// pG[A][3][3] of a pair (cmd_cram_demuxlet.cpp:597-663, every IEEE operation of the reference) as a function of its read bytes,
+// tabulated for pairs of 0, 1 and 2 (base quality < 64) reads: what exact_grid_entries needs per pair without the per-read
+// divisions.  97 % of the pairs of a 10x-like pileup have at most two reads.
+struct MixTables {
+  int32_t A = 0;
+  std::vector<double> none;     // [A*9]
+  std::vector<double> one;      // [256][A*9]        index = read byte (allele << 7) | bq
+  std::vector<double> two;      // [128*128][A*9]    index = c0 * 128 + c1, c = (allele << 6) | bq, bq < 64
+};
+void build_mix_tables(const ReadLut& lut, int32_t A, const double* alpha, MixTables* out);
 void exact_grid_entries(const dmx_pileup& pl, const float* g, int32_t V, int32_t A, const double* alpha,
-                        const ReadLut& lut, int32_t cell, std::vector<GridReq>& reqs);
+                        const ReadLut& lut, const MixTables* mix, int32_t cell, std::vector<GridReq>& reqs);
+
+// Where the doublet-stage writers take a cell's numbers from: the whole grid, a per-cell grid pointer, or the K3 records.
+struct DoubletSource {
+  const double* grid_all = nullptr;              // [n_cells][V][V][A]
+  const double* const* cell_grid = nullptr;      // [n_cells] -> [V][V][A] or NULL
+  const double* sing = nullptr;                  // [n_cells][V]
+  const dmx_cell_summary* summary = nullptr;     // [n_cells]
+};
+int write_doublet_core(const dmx_final_input* in, const DoubletSource& src, const char* out_prefix, bool append, const char* who);
 
 // The writers behind dmx_write_single / dmx_write_doublet with an append mode: dmx_demuxlet_run streams contiguous ranges
 // of the sorted barcodes through the GPUs and appends each range's rows (append = true: no header, files opened "a").

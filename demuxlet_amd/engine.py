@@ -290,13 +290,26 @@ def write_doublet_summary(fa: FinalArgs, sing, l00, summary, out_prefix: str, ti
     check(capi.load().dmx_write_doublet_summary(C.byref(fin), sing.ctypes.data, summary.ctypes.data, out_prefix.encode()))
 
 
-def demuxlet_run(store: Store, g: np.ndarray, sample_ids: Sequence[str], alphas: Sequence[float], out_prefix: str,
+def demuxlet_run(store, g: np.ndarray, sample_ids: Sequence[str], alphas: Sequence[float], out_prefix: str,
                  doublet_prior: float = 0.5, min_total: int = 0, min_uniq: int = 0, min_snp: int = 0,
-                 write_pair: bool = False, device: int = 0, arbiter: bool = True, n_gpus: int = 1, mode: int = capi.DMX_MODE_STRICT) -> None:
-    """cmd_cram_demuxlet.cpp:390-881 in one call (dmx_demuxlet_run)."""
+                 write_pair: bool = False, device: int = 0, arbiter: bool = True, n_gpus: int = 1, mode: int = capi.DMX_MODE_STRICT,
+                 barcodes: Optional[Sequence[str]] = None, timing: bool = False):
+    """cmd_cram_demuxlet.cpp:390-881 in one call (dmx_demuxlet_run).  `store` is a Store, or a frozen HostPileup together with
+    `barcodes` (dmx_job.pileup).  With timing=True returns the stage seconds (dmx_job_timing) as a dict."""
     g = np.ascontiguousarray(g, dtype=np.float32)
     al = np.ascontiguousarray(alphas, dtype=np.float64)
     sm, keep = _cstrs(sample_ids)
-    job = capi.Job(store.handle, g.ctypes.data, g.shape[1], C.cast(sm, C.c_void_p), len(al), al.ctypes.data, doublet_prior,
-                   min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter), n_gpus, mode)
+    tm = capi.JobTiming()
+    if isinstance(store, HostPileup):
+        st = store.as_struct()
+        bc, keep_b = _cstrs(barcodes)
+        job = capi.Job(None, g.ctypes.data, g.shape[1], C.cast(sm, C.c_void_p), len(al), al.ctypes.data, doublet_prior,
+                       min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter), n_gpus, mode,
+                       C.addressof(st), C.cast(bc, C.c_void_p), C.addressof(tm) if timing else None)
+    else:
+        job = capi.Job(store.handle, g.ctypes.data, g.shape[1], C.cast(sm, C.c_void_p), len(al), al.ctypes.data, doublet_prior,
+                       min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter), n_gpus, mode,
+                       None, None, C.addressof(tm) if timing else None)
     check(capi.load().dmx_demuxlet_run(C.byref(job)))
+    if timing:
+        return {name: getattr(tm, name) for name, _ in capi.JobTiming._fields_}

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 1
+#define DMX_ABI_VERSION 2
 
 typedef enum {
   DMX_OK = 0,
@@ -127,7 +127,11 @@ typedef struct {
   int32_t i_sing1, i_sing2;    /* :746-758 (first maximum wins; second = first maximum of the rest) */
   int32_t j_best, k_best, n_best;            /* :799-814 (strict <: lowest (j,k,n) scan index among equal maxima) */
   int32_t n_pairs;             /* N.SNP of the cell; 0 => the cell has no .best row (:592) */
+  int32_t flags;               /* DMX_CELL_* : decisions that sit within 1e-7 of an alternative other than the (j,k)/(k,j) mirror */
+  int32_t reserved;
 } dmx_cell_summary;
+enum { DMX_CELL_NEAR_DOUBLET = 1,   /* another doublet entry (not the alpha = 0.5 mirror of the best one) within 1e-7 of the best */
+       DMX_CELL_NEAR_SINGLET = 2 }; /* the best two singlets within 1e-7 of each other, or a third within 1e-7 of the second */
 
 int dmx_engine_create(const dmx_engine_config*, dmx_engine** out);
 int dmx_engine_destroy(dmx_engine*);
@@ -229,7 +233,23 @@ typedef struct {
                                       through the engines in waves; the rows of a wave are formatted and appended on the host while
                                       the next wave computes.  Barcodes are independent (cmd_cram_demuxlet.cpp:576): no collective. */
   int32_t      mode;               /* DMX_MODE_STRICT (0, default) or DMX_MODE_FAST */
+  /* Optional (ABI 2): a pileup that is already frozen (host memory, sparse or dense layout) instead of `store` (then NULL), with
+   * its barcodes by cell id — what a caller that builds the CSR itself hands over (tools/e2e_bench.cpp, the benchmarks). */
+  const dmx_pileup*  pileup;
+  const char* const* barcodes;
+  /* Optional (ABI 2): wall-clock seconds of the stages of this call, written on return (NULL = not wanted). */
+  struct dmx_job_timing* timing;
 } dmx_job;
+typedef struct dmx_job_timing {
+  double freeze_s;                 /* dmx_store_freeze */
+  double setup_s;                  /* engine creation, genotype upload, class detection */
+  double stage_s;                  /* slicing the CSR into ranges + H2D (host time, all ranges) */
+  double wait_s;                   /* host blocked on the GPUs (kernels not hidden behind host work) + D2H of the results */
+  double write_s;                  /* tie arbiter + row formatting + file writes (all ranges) */
+  double total_s;
+  double kernel_ms;                /* sum over ranges of the K1 + K2 + K3 HIP-event times (device time, all engines) */
+  int32_t n_ranges, n_engines, n_cells_grid_fetched, reserved;
+} dmx_job_timing;
 int dmx_demuxlet_run(const dmx_job*);
 
 #ifdef __cplusplus

@@ -86,3 +86,44 @@ def test_nan_likelihoods_do_not_crash(tmp_path):
     assert r.returncode == 0, r.stderr[-500:]
     for suf in ("single", "sing2", "best", "pair"):
         assert (tmp_path / f"o.{suf}").stat().st_size > 100
+
+
+def test_cfg1_tutorial_vcf_through_the_binary_on_the_gpu(oracle, tmp_path):
+    """BASELINE config 1 on the HIP path: the reference tutorial's VCF (tutorial/README.MD; first 4 000 records, a data fixture —
+    the tutorial BAM is not in the reference repository) + a synthetic 500-barcode SAM laid over it, `--field GT --alpha 0
+    --alpha 0.5` through the `demuxlet` binary on the GPU, against the oracle's four files for the same scan."""
+    import gzip
+    from demuxlet_amd import build
+    build.build()
+    vcf = ROOT / "tests" / "golden" / "tutorial_jurkat_293T_first4000.vcf.gz"
+    recs, contigs = [], []
+    for line in gzip.open(vcf, "rt"):
+        if line.startswith("##contig=<ID="):
+            name = line[13:].split(",")[0].rstrip(">\n")
+            ln = int(line.split("length=")[1].split(">")[0].split(",")[0]) if "length=" in line else 250000000
+            contigs.append((name, ln))
+        elif not line.startswith("#"):
+            t = line.rstrip("\n").split("\t")
+            recs.append(dict(chrom=t[0], pos=int(t[1]) - 1, ref=t[3], alt=t[4], fields=t[9:]))
+    rng = np.random.default_rng(20)
+    used = [c for c in contigs if c[0] in {r["chrom"] for r in recs}]
+    samples = ["jurkat", "293T_RTG"]
+    reads = sv.make_reads(rng, used, recs, 40000, [f"CELL{i:03d}-1" for i in range(500)], tmp_path / "r.sam", tmp_path / "r.bam")
+    out = tmp_path / "o"
+    subprocess.run([str(CLI), "--sam", str(tmp_path / "r.bam"), "--vcf", str(vcf), "--field", "GT", "--alpha", "0", "--alpha", "0.5",
+                    "--out", str(out)], check=True, stderr=subprocess.DEVNULL)
+    snps, events, gts, sm_cols = sv.scan(reads, recs, used, samples)
+    assert len(snps) > 500
+    g = np.stack([oracle.geno_from_gt(np.array(a), 0.01) for a in gts])
+    ev = oracle.Events([e[0] for e in events], np.array([e[1] for e in events], dtype=np.int32), [e[2] for e in events],
+                       np.array([e[3] for e in events], dtype=np.uint8), np.array([e[4] for e in events], dtype=np.uint8),
+                       np.array([e[5] for e in events], dtype=np.uint8))
+    oracle.run_problem(oracle.Problem(samples, g.astype(np.float32), ev, oracle.Params()), str(tmp_path / "orc"))
+    for suf in ("single", "sing2", "best"):
+        compare_files(f"{out}.{suf}", tmp_path / f"orc.{suf}")
+    got = [l.split("\t") for l in Path(f"{out}.best").read_text().splitlines()]
+    want = [l.split("\t") for l in (tmp_path / "orc.best").read_text().splitlines()]
+    assert len(got) > 300 and [r[5] for r in got] == [r[5] for r in want]         # every BEST call
+    assert [r[:5] for r in got] == [r[:5] for r in want]                            # barcodes and read/SNP counters
+    calls = {r[5][:3] for r in got[1:]}
+    assert "SNG" in calls                                                          # the job is not degenerate

@@ -223,3 +223,61 @@ def test_cfg5_full_size_fast_mode(mods):
     """DMX_MODE_FAST on cfg5 (20k x 200k x 16, PL, sparse -> k_doublet_sym, one wavefront per barcode)."""
     worst = run_full(mods, 5, 12, check_general=False, fast=True)
     assert worst < 1e-9
+
+
+def test_cfg4_slice_streamed_with_write_pair(mods, tmp_path, monkeypatch):
+    """A slice of cfg4's per-GPU shard (2 000 of its barcodes x 100 k SNPs x 64 samples, GT, dense) through dmx_demuxlet_run with
+    `--write-pair` and a forced 16 MiB range budget: the barcodes stream through the engine in ~8 ranges of the sorted order, the
+    4.2 M rows are appended range by range.  Three sampled barcodes are pushed through the oracle at full depth: their rows of all
+    four files must be the oracle's (strings and BEST identical, numbers to the last printed digit)."""
+    torch, engine, bench, O = mods["torch"], mods["engine"], mods["bench"], mods["O"]
+    cfg = dict(bench.CONFIGS[4])
+    B, S, V = 2000, cfg["S"], cfg["V"]
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0xD3A00000 + 4)
+    raw, g = bench.genotype_matrix(engine, mods["synth"], rng, S, V, cfg["field"])
+    dosage = torch.from_numpy(np.clip(raw.alleles, 0, 1).sum(axis=2).astype(np.float32)).to(dev)
+    dp = mods["st"].make_device_pileup(dosage, B, cfg["delta"], cfg["rbar"], seed=0xD3A0 + 4000, device=dev)
+    h = dp.host_slice(0, B)
+    nrd = h["pair_nrd"].astype(np.int64)
+    per_cell_reads = np.diff(h["cell_read_off"]).astype(np.int32)
+    pl = engine.HostPileup(B, S, h["cell_pair_off"], h["cell_read_off"], None, h["pair_nrd"], h["reads"], per_cell_reads, per_cell_reads,
+                           per_cell_reads)
+    barcodes = [f"BC{(i * 7919) % B:05d}-1" for i in range(B)]          # sorted order != id order
+    sm = [f"SM{j:02d}" for j in range(V)]
+    del dp, dosage
+    torch.cuda.empty_cache()
+    monkeypatch.setenv("DMX_RANGE_BYTES", str(16 << 20))
+    tm = engine.demuxlet_run(pl, g, sm, cfg["alphas"], str(tmp_path / "o"), write_pair=True, arbiter=True, barcodes=barcodes, timing=True)
+    assert tm["n_ranges"] >= 8
+    print("cfg4 slice, --write-pair, streamed:", {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()})
+    cells = np.array([3, 977, 1999])
+    pidx = np.concatenate([np.arange(h["cell_pair_off"][c], h["cell_pair_off"][c + 1]) for c in cells])
+    ridx = np.concatenate([np.arange(h["cell_read_off"][c], h["cell_read_off"][c + 1]) for c in cells])
+    reads = h["reads"][ridx]
+    words = ((reads >> 7).astype(np.uint32) << 24) | ((reads & 0x7F).astype(np.uint32) << 16) | 1
+    z = np.zeros(1, dtype=np.int64)
+    csr = O.Csr([barcodes[c] for c in cells], np.concatenate([z, np.cumsum(np.full(len(cells), S, dtype=np.int64))]),
+                np.tile(np.arange(S, dtype=np.int32), len(cells)), np.concatenate([z, np.cumsum(nrd[pidx])]), words,
+                per_cell_reads[cells], per_cell_reads[cells], per_cell_reads[cells])
+    O.run_csr(csr, sm, g, O.Params(tuple(cfg["alphas"]), 0.5, 0, 0, 0, True), str(tmp_path / "r"))
+    want_bc = {barcodes[c] for c in cells}
+    for suf in ("single", "sing2", "best", "pair"):
+        got_all = (tmp_path / f"o.{suf}").read_text().splitlines()
+        want = (tmp_path / f"r.{suf}").read_text().splitlines()
+        assert got_all[0] == want[0]
+        keys = [r.split("\t")[0] for r in got_all[1:]]
+        assert keys == sorted(keys)                                      # ascending barcode order across the appended ranges
+        got = [got_all[0]] + [r for r in got_all[1:] if r.split("\t")[0] in want_bc]
+        assert len(got) == len(want), suf
+        for a, b in zip(got[1:], want[1:]):
+            fa, fb = a.split("\t"), b.split("\t")
+            assert len(fa) == len(fb)
+            for x, y in zip(fa, fb):
+                try:
+                    fx, fy = float(x), float(y)
+                    assert abs(fx - fy) <= 1e-3 * max(1e-3, abs(fy)) + 1.01e-4, (suf, a, b)
+                except ValueError:
+                    assert x == y, (suf, a, b)
+    n_pair_rows = sum(1 for _ in open(tmp_path / "o.pair")) - 1
+    assert n_pair_rows == B * (V + V * (V - 1) // 2)

@@ -190,3 +190,91 @@ def test_row_formatter_equals_printf(eng, tmp_path, monkeypatch):
         eng.write_single(fa, vals.reshape(B, 1), -vals, path)
         got = open(path).read()
         assert got == want, next((a, b) for a, b in zip(got.split("\n"), want.split("\n")) if a != b)
+
+
+def test_geno_transforms_hand_vectors(eng, oracle):
+    """Row a3 is unpinned by the reference (parse_posteriors needs htslib), so beyond product == oracle it is pinned on values
+    derived by hand from bcf_filtered_reader.cpp:186-242 (allele counts), :381-400 (GT), :255-311 (PL, 10 EM rounds) and
+    :421-448 (GP) — exact rationals or 50-digit arithmetic where an EM is involved, compared after rounding to float32."""
+    import mpmath
+    f32 = np.float32
+    MISS = np.iinfo(np.int32).min                      # bcf_int32_missing; toProb(uint32) sends it to phred2Prob[255] (PhredHelper.h:40)
+    # ---- GT (:381-400).  called genotype g: 1-e on g, e/2 elsewhere, as float32
+    assert np.array_equal(eng.geno_from_gt(np.array([[1, 1]]), 0.0), [[0.0, 0.0, 1.0]])
+    assert np.array_equal(eng.geno_from_gt(np.array([[0, 0]]), 0.1), np.array([[f32(0.9), f32(0.05), f32(0.05)]]))
+    assert np.array_equal(eng.geno_from_gt(np.array([[1, 0]]), 0.01), np.array([[f32(0.005), f32(0.99), f32(0.005)]]))   # 1|0 is a het too
+    # a column in which EVERY genotype is missing: an = 0, ac = (0, 0) -> (0 + 1/2)/(0 + 1) per allele -> HWE (1/4, 1/2, 1/4)
+    g = eng.geno_from_gt(np.array([[-1, -1], [-1, -1], [-1, -1]]), 0.01)
+    assert np.array_equal(g, np.tile(np.array([[0.25, 0.5, 0.25]], dtype=f32), (3, 1)))
+    # half-missing (0/.) counts its called allele (an = 1, ac = (1, 0)) and is itself "missing" (bcf_filtered_reader.h:144-149):
+    #   l0 = (1.5/2)^2, l1 = 2 (0.5/2)(1.5/2), l2 = (0.5/2)^2, evaluated left to right in binary64
+    g = eng.geno_from_gt(np.array([[0, -1]]), 0.01)
+    want = [f32(1.0 * 1.5 / 2.0 * 1.5 / 2.0), f32(2.0 * 0.5 / 2.0 * 1.5 / 2.0), f32(1.0 * 0.5 / 2.0 * 0.5 / 2.0)]
+    assert np.array_equal(g[0], want) and np.array_equal(g[0], np.array([0.5625, 0.375, 0.0625], dtype=f32))
+    # 0/0, 0/0, 0/1, ./. : an = 6, ac = (5, 1) -> missing row ((5.5/7)^2, 2 (1.5/7)(5.5/7), (1.5/7)^2)
+    g = eng.geno_from_gt(np.array([[0, 0], [0, 0], [0, 1], [-1, -1]]), 0.01)
+    want = np.array([f32(1.0 * 5.5 / 7.0 * 5.5 / 7.0), f32(2.0 * 1.5 / 7.0 * 5.5 / 7.0), f32(1.0 * 1.5 / 7.0 * 1.5 / 7.0)])
+    assert np.array_equal(g[3], want) and abs(float(g[3].sum()) - 1.0) < 1e-6
+    assert np.array_equal(g[2], np.array([f32(0.005), f32(0.99), f32(0.005)]))
+    # 0/0, 0/1, 1/1, ./. : an = 6, ac = (3, 3) -> (3.5/7)^2 = 1/4 etc.: exact
+    g = eng.geno_from_gt(np.array([[0, 0], [0, 1], [1, 1], [-1, -1]]), 0.01)
+    assert np.array_equal(g[3], np.array([0.25, 0.5, 0.25], dtype=f32))
+
+    # ---- PL (:255-311): 10 EM rounds from af = (1/2, 1/2); the LAST round's posteriors are kept
+    def em_pl(pl_rows):                               # 50-digit arithmetic, no float rounding anywhere
+        mpmath.mp.dps = 50
+        L = [[mpmath.mpf(10) ** (-mpmath.mpf(min(p, 255) if p >= 0 else 255) / 10) for p in row] for row in pl_rows]
+        af = [mpmath.mpf(1) / 2, mpmath.mpf(1) / 2]
+        out = None
+        for _ in range(10):
+            new, out = [mpmath.mpf(0), mpmath.mpf(0)], []
+            for Ls in L:
+                gp = [af[0] * af[0] * Ls[0], 2 * af[1] * af[0] * Ls[1], af[1] * af[1] * Ls[2]]
+                s = sum(gp)
+                gp = [x / s for x in gp]
+                new[0] += 2 * gp[0] + gp[1]
+                new[1] += gp[1] + 2 * gp[2]
+                out.append(gp)
+            af = [x / (2 * len(L)) for x in new]
+        return np.array([[float(x) for x in r] for r in out])
+    # every PL missing: the three likelihoods are equal, af stays (1/2, 1/2): (1/4, 1/2, 1/4) exactly
+    assert np.array_equal(eng.geno_from_pl(np.array([[MISS, MISS, MISS]], dtype=np.int32)), np.array([[0.25, 0.5, 0.25]], dtype=f32))
+    # PL above 255 is read as 255
+    assert np.array_equal(eng.geno_from_pl(np.array([[0, 300, 1000]], dtype=np.int32)), eng.geno_from_pl(np.array([[0, 255, 255]], dtype=np.int32)))
+    for rows in ([[0, 30, 60], [60, 30, 0]], [[0, 255, 255]], [[232, 14, 0], [MISS, MISS, MISS]], [[10, 0, 10], [0, 3, 30], [40, 0, 25], [MISS, 5, 0]]):
+        got = eng.geno_from_pl(np.array(rows, dtype=np.int32))
+        want = em_pl(rows)
+        assert np.allclose(got, want.astype(f32), rtol=3e-7, atol=1e-30), (rows, got, want)
+    # --geno-error does not touch the PL path (cmd_cram_demuxlet.cpp passes it, parse_likelihoods ignores it): one entry point, no error argument
+
+    # ---- GP (:421-448): per-sample float32 normalisation, pseudo-sample HWE(1/2), mean over (n + 1) with an INTEGER divisor, mix
+    gp = np.array([[0.2, 0.3, 0.5]], dtype=f32)
+    s = f32(f32(f32(0) + gp[0, 0]) + gp[0, 1]) + gp[0, 2]
+    norm = gp[0] / s                                   # float32 divisions
+    assert np.array_equal(eng.geno_from_gp(gp, 0.0), [norm])                      # gt_error = 0: (1.0) * gp + 0.0 * mean = gp
+    two = np.array([[1, 0, 0], [0, 0, 1]], dtype=f32)
+    mean = np.array([f32(f32(0.25) + f32(1)) / f32(3), f32(0.5) / f32(3), f32(f32(0.25) + f32(1)) / f32(3)], dtype=f32)   # float / (int32_t)(2 + 1.0)
+    want = np.array([[f32((1.0 - 0.1) * 1.0 + 0.1 * float(mean[0])), f32(0.1 * float(mean[1])), f32(0.1 * float(mean[2]))],
+                     [f32(0.1 * float(mean[0])), f32(0.1 * float(mean[1])), f32((1.0 - 0.1) * 1.0 + 0.1 * float(mean[2]))]])
+    assert np.array_equal(eng.geno_from_gp(two, 0.1), want)
+    # unnormalised input (2, 2, 4) == (0.25, 0.25, 0.5)
+    assert np.array_equal(eng.geno_from_gp(np.array([[2, 2, 4]], dtype=f32), 0.01), eng.geno_from_gp(np.array([[0.25, 0.25, 0.5]], dtype=f32), 0.01))
+
+    # ---- the tutorial VCF's first records (tutorial/README.MD; FORMAT GT:GQ:DP:PL:AD, samples jurkat / 293T_RTG), by hand:
+    #   1:700513  0/1:3:14:232,14,0   .:.:.:.:.      1:713914  0/1:2:4:54,3,0   .     1:761606  0/1:2:18:261,2,0   .
+    import gzip
+    from golden_util import GOLDEN
+    recs = [l.rstrip("\n").split("\t") for l in gzip.open(GOLDEN / "tutorial_jurkat_293T_first4000.vcf.gz", "rt") if not l.startswith("#")][:4]
+    assert [r[1] for r in recs] == ["700513", "713914", "714061", "761606"] and recs[0][9].startswith("0/1:3:14:232,14,0") and recs[0][10].startswith(".")
+    for r, pl in ((recs[0], [232, 14, 0]), (recs[1], [54, 3, 0]), (recs[3], [261, 2, 0])):
+        assert r[9].split(":")[3] == ",".join(map(str, pl)) and r[9].split(":")[0] == "0/1"
+        # GT: jurkat het, 293T missing: an = 2, ac = (1, 1) -> 293T gets ((1.5/3)^2, 2 (1.5/3)^2, (1.5/3)^2) = (1/4, 1/2, 1/4)
+        g = eng.geno_from_gt(np.array([[0, 1], [-1, -1]]), 0.01)
+        assert np.array_equal(g, np.array([[f32(0.005), f32(0.99), f32(0.005)], [0.25, 0.5, 0.25]], dtype=f32))
+        # PL: jurkat's three likelihoods against a sample whose PL is missing
+        got = eng.geno_from_pl(np.array([pl, [MISS, MISS, MISS]], dtype=np.int32))
+        assert np.allclose(got, em_pl([pl, [MISS, MISS, MISS]]).astype(f32), rtol=3e-7, atol=1e-30)
+        assert got[0, 2] > got[0, 1] > got[0, 0]       # PL ... ,0: hom-alt is the most likely genotype of jurkat here
+    # the oracle restatement agrees on all of the above (it is what the GPU tests check the product against)
+    for a, e in ((np.array([[0, -1]]), 0.01), (np.array([[0, 0], [0, 0], [0, 1], [-1, -1]]), 0.01)):
+        assert np.array_equal(eng.geno_from_gt(a, e), oracle.geno_from_gt(a, e))
