@@ -18,6 +18,7 @@ DMX_OK = 0
 DMX_MEM_HOST, DMX_MEM_DEVICE = 0, 1
 DMX_MODE_STRICT = 0
 DMX_MODE_FAST = 1
+DMX_CELL_NEAR_DOUBLET, DMX_CELL_NEAR_SINGLET, DMX_CELL_ORDER_CERTIFIED = 1, 2, 4
 
 # every symbol include/dmx.h declares (tests/test_abi.py checks the header against this list and the .so against both)
 SYMBOLS = [
@@ -28,7 +29,7 @@ SYMBOLS = [
     "dmx_engine_set_genotypes", "dmx_engine_set_pileup", "dmx_engine_run_singlet", "dmx_engine_run_doublet",
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
-    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_write_doublet_summary",
+    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_write_doublet_summary", "dmx_debug_log_dd",
 ]
 
 
@@ -137,6 +138,7 @@ def load() -> C.CDLL:
         "dmx_engine_get_sing": [vp, vp], "dmx_write_doublet_summary": [vp, vp, vp, C.c_char_p],
         "dmx_debug_device_div": [vp, vp, vp, C.c_int64, i32],
         "dmx_debug_log_rate": [i32, i32, i32, vp],
+        "dmx_debug_log_dd": [vp, vp, vp, vp, vp, C.c_int64],
     }
     for name, args in sig.items():
         f = getattr(L, name)

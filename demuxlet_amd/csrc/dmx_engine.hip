@@ -72,6 +72,8 @@ constexpr int kTabK1 = kTab + kFirst + kFinal;
 constexpr int kPair = 128 * 128 * 4;                    // then dmx::PairTables: second[16384][4] | final2[16384][4] (global memory only)
 constexpr int kTriple = dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes * 4;   // then dmx::TripleTables: third | final3
 constexpr int kTabAll = kTabK1 + 2 * kPair + 2 * kTriple;
+constexpr int kTabLogLo = kTabAll;                      // then dmx_log_dd's second-order table (128 doubles)
+constexpr int kTabTotal = kTabAll + 128;
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void k_gp0(const float* __restrict__ g, int32_t S, int32_t V, double* __restrict__ gp0) {
@@ -2955,11 +2957,166 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
   }
 }
 
+// K3b — the tie-order certificate (DESIGN.md "Ties").  At alpha = 0.5 the reference's llksAB[j][k] and llksAB[k][j] are one number
+// mathematically and differ by the rounding noise of its own evaluation order; its strict-< scan then names the doublet
+// "a-b" or "b-a" by that noise.  To print the same order one has to know BOTH accumulators as the reference computes them, bit for
+// bit.  Every operation of the reference except log() is an IEEE operation the device reproduces exactly; for log() the device
+// evaluates hi + lo = log(x) in double-double and knows which double(s) a libm with < 0.55 ulp error can return
+// (dmx_log_bracket).  One wavefront per barcode re-walks the barcode's pairs for its best alpha = 0.5 pair {a, b} only and
+// accumulates, in the reference's order, a LOWER and an UPPER bound of each of the two accumulators (IEEE addition is monotone in
+// both operands).  When lower == upper for both, they ARE the reference's values and the order is decided here — for any such
+// libm; the host tie arbiter (which calls the host's log()) is left with the barcodes where a bracket stayed open, about one in
+// ten.  Requires A = 2 (phase 1 is k_doublet_a2's) and no other doublet entry within 1e-7 of the best (K3's flag).
+__global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                      const double* __restrict__ tabs, const double* __restrict__ alpha,
+                                                      int32_t V, dmx_cell_summary* __restrict__ summ) {
+  constexpr int TP = 32, T00 = TP + 2, TPC = 64, CPW = kThreads / TPC;
+  __shared__ double s_tab[kTab];
+  __shared__ double s_lo[128];
+  __shared__ __attribute__((aligned(16))) double s_t[CPW][4][T00];   // [ab_lo | ab_hi | ba_lo | ba_hi][pair]
+  __shared__ int64_t s_offs[CPW][TP];
+  __shared__ int32_t s_snps[CPW][TP];
+  __shared__ uint32_t s_cnts[CPW][TP];
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  if (t < 128) s_lo[t] = tabs[kTabLogLo + t];
+  __syncthreads();
+  const double* s_log = s_tab + kLut;
+  const int cw = t / TPC, tid = t % TPC;
+  const int32_t cell = blockIdx.x * CPW + cw;
+  if (cell >= pv.B) return;
+  const dmx_cell_summary sm = summ[cell];
+  if (sm.n_pairs <= 0 || sm.j_best < 0 || sm.k_best < 0 || sm.n_best != 1 || alpha[1] != 0.5 || (sm.flags & DMX_CELL_NEAR_DOUBLET)) return;
+  const int32_t ia = min(sm.j_best, sm.k_best), ib = max(sm.j_best, sm.k_best);
+  int64_t* s_off = s_offs[cw]; int32_t* s_snp = s_snps[cw]; uint32_t* s_cnt = s_cnts[cw];
+  const int64_t p_beg = pv.cell_pair_off[cell];
+  const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
+  int64_t rd_base = pv.cell_read_off[cell];
+  const int ti1 = tid >> 1, n1 = tid & 1;
+  double wA[9], wR[9];
+  {
+    const double al = alpha[n1];
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * al;
+        wA[l * 3 + m] = p;
+        wR[l * 3 + m] = 1.0 - p;
+      }
+  }
+  bool ok = true;
+  double acc = 0.0;                              // lanes 0..3: lower/upper bound of the (a,b) accumulator, of the (b,a) accumulator
+  const int row_len = V * 3;
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_WAVE_LDS_ORDER();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    {
+      const bool on = ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      const int32_t snp1 = on ? s_snp[ti1] : 0;
+      const float* gr = g + (size_t)snp1 * row_len;
+      const float fa0 = gr[ia * 3], fa1 = gr[ia * 3 + 1], fa2 = gr[ia * 3 + 2], fb0 = gr[ib * 3], fb1 = gr[ib * 3 + 1], fb2 = gr[ib * 3 + 2];
+      double pG[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt;
+        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+          }
+        }
+        {
+          const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+          mx = (mx < o) ? o : mx;
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);       // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] = div_slow(pG[i], mx);
+          }
+        }
+      }
+      double mx = 0.0;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        pG[i] += 1e-6;                                                       // :649
+        mx = (mx < pG[i]) ? pG[i] : mx;
+      }
+      {
+        const double o = __shfl_xor(mx, 1);
+        mx = (mx < o) ? o : mx;
+      }
+      if (on && n1 == 1) {
+        const double y = rcp_refined(mx);
+        const double aj[3] = {(double)fa0, (double)fa1, (double)fa2}, bk[3] = {(double)fb0, (double)fb1, (double)fb2};
+        double sab = 0.0, sba = 0.0;                                         // :674
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = div_by(pG[l * 3 + m], mx, y);                   // :656-663
+            sab += ((aj[l] * bk[m]) * v);                                    // llksAB[a][b]: :553, :677-679
+            sba += ((bk[l] * aj[m]) * v);                                    // llksAB[b][a]
+          }
+        ok &= __builtin_amdgcn_class(sab, 0x100) && __builtin_amdgcn_class(sba, 0x100);
+        double lo1, hi1, lo2, hi2;
+        dmx_log_bracket((uint32_t)__double2hiint(sab), (uint32_t)__double2loint(sab), s_log, s_lo, &lo1, &hi1);
+        dmx_log_bracket((uint32_t)__double2hiint(sba), (uint32_t)__double2loint(sba), s_log, s_lo, &lo2, &hi2);
+        s_t[cw][0][ti1] = lo1; s_t[cw][1][ti1] = hi1; s_t[cw][2][ti1] = lo2; s_t[cw][3][ti1] = hi2;
+      }
+    }
+    DMX_WAVE_LDS_ORDER();
+    if (tid < 4) {
+      const double* row = &s_t[cw][tid][0];
+      for (int i = 0; i < tp; ++i) acc += row[i];                            // :683, in pair order
+    }
+    DMX_WAVE_LDS_ORDER();
+  }
+  const bool all_ok = __all(ok ? 1 : 0) != 0;
+  const double ab_lo = __shfl(acc, 0), ab_hi = __shfl(acc, 1), ba_lo = __shfl(acc, 2), ba_hi = __shfl(acc, 3);
+  if (tid == 0 && all_ok && ab_lo == ab_hi && ba_lo == ba_hi) {
+    // the reference's scan (:799-814, strict <) meets (a,b) before (b,a): it keeps (a,b) unless (b,a) is strictly larger
+    const bool ba = ab_lo < ba_lo;
+    dmx_cell_summary r = sm;
+    const int32_t nj = ba ? ib : ia, nk = ba ? ia : ib;
+    if (nj != sm.j_best) { r.llk1 = sm.llk2; r.llk2 = sm.llk1; r.llk10 = sm.llk20; r.llk20 = sm.llk10; }
+    r.j_best = nj; r.k_best = nk;
+    r.llk12 = ba ? ba_lo : ab_lo;
+    r.flags = sm.flags | DMX_CELL_ORDER_CERTIFIED;
+    summ[cell] = r;
+  }
+}
+
 }  // namespace
 
 // =====================================================================================================================
 struct dmx_engine {
   int32_t V = 0, A = 0, device = 0, mode = 0;
+  bool certify = false;        // run k_certify (the host libm's log() was found inside dmx_log_bracket's brackets)
   double prior = 0.5;
   std::vector<double> alpha;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -3039,8 +3196,10 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
   for (hipEvent_t& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
-  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTabAll));
+  HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTabTotal));
   HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_lut + kTabLogLo, dmx_log_table_lo_host, sizeof(double) * 128, hipMemcpyHostToDevice));
+  e->certify = !getenv("DMX_NO_CERTIFY") && dmx::libm_log_within_brackets();
   HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
   HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
   double mat[256], err[256];
@@ -3513,6 +3672,11 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)B), dim3(kThreads), 0, e->stream, e->d_grid, e->d_l00, e->pv.cell_pair_off,
                      e->d_alpha, e->V, e->A, e->prior, e->d_sum, e->d_sing);
   HIP_TRY(hipGetLastError());
+  if (e->certify && e->A == 2 && e->alpha[1] == 0.5) {
+    hipLaunchKernelGGL(k_certify, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_lut,
+                       e->d_alpha, e->V, e->d_sum);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipEventRecord(e->ev[6], e->stream));
   e->timed[2] = e->timed[3] = true; e->have_grid = true;
   return DMX_OK;

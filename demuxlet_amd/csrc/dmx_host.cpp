@@ -18,6 +18,7 @@
 #include <unordered_map>
 
 #include "dmx_internal.hpp"
+#include "dmx_log.hpp"
 
 namespace dmx {
 
@@ -121,6 +122,44 @@ const TripleTables& build_triple_tables(const ReadLut& lut, const PairTables& pt
 using dmx::set_error;
 
 extern "C" int dmx_abi_version(void) { return DMX_ABI_VERSION; }
+
+bool dmx::libm_log_within_brackets() {
+  static const bool ok = [] {
+    uint64_t st = 0x243F6A8885A308D3ull;
+    auto next = [&] { uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+    for (int i = 0; i < 400000; ++i) {
+      const double u = (next() >> 11) * (1.0 / 9007199254740992.0);
+      double x;
+      switch (i & 3) {                           // likelihood-like arguments: near 1, (0.3, 1), tiny, and across many binades
+        case 0: x = 0.93 + 0.14 * u; break;
+        case 1: x = 0.3 + 0.7 * u; break;
+        case 2: x = std::ldexp(0.5 + 0.5 * u, -(int)(next() % 60)); break;
+        default: x = 1e-6 + u * 1e-3; break;
+      }
+      uint64_t b;
+      std::memcpy(&b, &x, sizeof b);
+      double lo, hi;
+      dmx_log_bracket((uint32_t)(b >> 32), (uint32_t)b, dmx_log_table_host, dmx_log_table_lo_host, &lo, &hi);
+      const double y = std::log(x);
+      if (!(y >= lo && y <= hi)) return false;
+    }
+    return true;
+  }();
+  return ok;
+}
+
+extern "C" int dmx_debug_log_dd(const double* x, double* hi, double* lo, double* t_lo, double* t_hi, int64_t n) {
+  if (!x || !hi || !lo || !t_lo || !t_hi || n < 0) return set_error(DMX_ERR_ARG, "dmx_debug_log_dd: bad arguments");
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t b;
+    std::memcpy(&b, &x[i], sizeof b);
+    const uint32_t hw = (uint32_t)(b >> 32), lw = (uint32_t)b;
+    if ((hw - 0x00100000u) >= 0x7FE00000u) return set_error(DMX_ERR_ARG, "dmx_debug_log_dd: x[%lld] is not a normal positive number", (long long)i);
+    dmx_log_dd(hw, lw, dmx_log_table_host, dmx_log_table_lo_host, &hi[i], &lo[i]);
+    dmx_log_bracket(hw, lw, dmx_log_table_host, dmx_log_table_lo_host, &t_lo[i], &t_hi[i]);
+  }
+  return DMX_OK;
+}
 extern "C" const char* dmx_last_error(void) { return dmx::g_last_error.c_str(); }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -921,7 +960,7 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
       i_sing1 = sm.i_sing1; i_sing2 = sm.i_sing2; jb = sm.j_best; kb = sm.k_best; nb = sm.n_best;
       sing1 = sg[i_sing1]; sing2v = sg[i_sing2];
       l12 = sm.llk12; l1 = sm.llk1; l2 = sm.llk2; l10 = sm.llk10; l20 = sm.llk20;
-      if (arbiter && in->alpha[nb] == 0.5) {
+      if (arbiter && in->alpha[nb] == 0.5 && !(sm.flags & DMX_CELL_ORDER_CERTIFIED)) {
         // (j,k) and (k,j) are one doublet at alpha = 0.5 and differ only by rounding: re-evaluate both in the
         // reference's operation order and let its strict-< scan decide, which visits the smaller first index first.
         const int32_t a = std::min(jb, kb), b = std::max(jb, kb);

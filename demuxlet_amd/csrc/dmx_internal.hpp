@@ -64,6 +64,8 @@ struct DoubletSource {
   const double* sing = nullptr;                  // [n_cells][V]
   const dmx_cell_summary* summary = nullptr;     // [n_cells]
 };
+// true when the host libm's log() stays inside dmx_log_bracket()'s brackets on a fixed sample of arguments (checked once)
+bool libm_log_within_brackets();
 int write_doublet_core(const dmx_final_input* in, const DoubletSource& src, const char* out_prefix, bool append, const char* who);
 
 // The writers behind dmx_write_single / dmx_write_doublet with an append mode: dmx_demuxlet_run streams contiguous ranges

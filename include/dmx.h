@@ -131,7 +131,9 @@ typedef struct {
   int32_t reserved;
 } dmx_cell_summary;
 enum { DMX_CELL_NEAR_DOUBLET = 1,   /* another doublet entry (not the alpha = 0.5 mirror of the best one) within 1e-7 of the best */
-       DMX_CELL_NEAR_SINGLET = 2 }; /* the best two singlets within 1e-7 of each other, or a third within 1e-7 of the second */
+       DMX_CELL_NEAR_SINGLET = 2,   /* the best two singlets within 1e-7 of each other, or a third within 1e-7 of the second */
+       DMX_CELL_ORDER_CERTIFIED = 4 /* the order (j_best, k_best) of an alpha = 0.5 best doublet and llk12 are the reference's, bit for
+                                       bit (device certificate, DESIGN.md "Ties"): the host tie arbiter has nothing left to decide */ };
 
 int dmx_engine_create(const dmx_engine_config*, dmx_engine** out);
 int dmx_engine_destroy(dmx_engine*);
@@ -212,6 +214,11 @@ int dmx_debug_log_rate(int32_t which, int32_t iters, int32_t device, double* log
 /* Diagnostics: q[i] = a[i] / b[i] through the kernels' shared-reciprocal division (must equal IEEE division bit for bit
  * for 2^-700 < a,b < 2^700). */
 int dmx_debug_device_div(const double* a, const double* b, double* q, int64_t n, int32_t device);
+
+/* Diagnostics (host evaluation of the code the device runs): the double-double logarithm behind the tie-order certificate
+ * (csrc/dmx_log.hpp, DESIGN.md "Ties").  hi[i] + lo[i] = log(x[i]) to ~2^-75; [t_lo[i], t_hi[i]] = the doubles a libm with
+ * < 0.53 ulp error can return for log(x[i]) (one double, or the two neighbours of a rounding midpoint). */
+int dmx_debug_log_dd(const double* x, double* hi, double* lo, double* t_lo, double* t_hi, int64_t n);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * One call for the whole of cmd_cram_demuxlet.cpp:390-881: store + genotype matrix + options in, four files out. */

@@ -113,3 +113,36 @@ def test_device_shared_reciprocal_division_is_ieee():
     q = np.empty_like(a)
     capi.check(L.dmx_debug_device_div(a.ctypes.data, b.ctypes.data, q.ctypes.data, len(a), 0))
     assert np.array_equal(q, a / b), f"{np.sum(q != a / b)} of {len(a)} quotients differ from IEEE division"
+
+
+def test_double_double_log_and_libm_brackets():
+    """dmx_log_dd / dmx_log_bracket (csrc/dmx_log.hpp; host evaluation of the code the device runs): hi + lo = log(x) to better
+    than 2^-65 relative (50-digit check), and the bracket [t_lo, t_hi] — what a libm with < 0.55 ulp error (0.67 ulp in glibc's
+    near-1 interval) can return — contains both the correctly rounded value and THIS host's log(), on likelihood-like arguments.
+    It is what lets the device certify the reference's accumulators bit for bit (DESIGN.md "Ties")."""
+    import mpmath
+    from demuxlet_amd import build, capi
+    build.build()
+    L = capi.load()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(0.93, 1.07, 300000), rng.uniform(0.3, 1.0, 300000), rng.uniform(1e-6, 1e-3, 200000),
+                        np.ldexp(rng.uniform(0.5, 1.0, 200000), -rng.integers(0, 60, 200000))])
+    n = len(x)
+    hi, lo, tl, th = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
+    capi.check(L.dmx_debug_log_dd(x.ctypes.data, hi.ctypes.data, lo.ctypes.data, tl.ctypes.data, th.ctypes.data, n))
+    y = np.log(x)
+    assert ((y >= tl) & (y <= th)).all()                            # the host libm never leaves the bracket
+    assert (tl <= hi).all() and (hi <= th).all()                      # nor does the correctly rounded value
+    amb = tl != th
+    assert (np.abs(th[amb] - tl[amb]) <= 1.0001 * np.spacing(np.minimum(np.abs(tl[amb]), np.abs(th[amb])))).all()    # neighbours
+    assert 0.02 < amb.mean() < 0.30
+    mpmath.mp.prec = 200
+    worst = -999.0
+    for i in rng.choice(n, 2000, replace=False):
+        t = mpmath.log(mpmath.mpf(float(x[i])))
+        err = abs(mpmath.mpf(float(hi[i])) + mpmath.mpf(float(lo[i])) - t)
+        if err > 0:
+            worst = max(worst, float(mpmath.log(err / abs(t), 2)))
+        assert float(t) == hi[i] or abs(abs(lo[i]) - 0.5 * np.spacing(abs(hi[i]))) < 1e-3 * np.spacing(abs(hi[i]))    # hi = RN(log x)
+    print(f"dmx_log_dd: worst relative error 2^{worst:.1f}; {100 * amb.mean():.1f} % of the arguments leave two candidates")
+    assert worst < -65

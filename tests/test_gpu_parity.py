@@ -653,3 +653,53 @@ def test_engines_on_distinct_devices_when_there_are_several(eng, oracle, tmp_pat
                      gd.write_pair, arbiter=True, n_gpus=n)
     for suf, ref in gd.files.items():
         assert (tmp_path / f"o.{suf}").read_bytes() == ref, suf
+
+
+@pytest.mark.parametrize("V,field,S,B,mode", [(8, "GT", 1500, 300, "strict"), (16, "GP", 800, 200, "fast"), (32, "GT", 600, 120, "fast"),
+                                              (5, "PL", 3000, 200, "strict"), (64, "GT", 300, 60, "fast")])
+def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_path, V, field, S, B, mode):
+    """K3b (k_certify) decides on the device, for most barcodes, in which order the reference names the two samples of an
+    alpha = 0.5 best doublet — by bracketing the reference's two accumulators bit for bit (DESIGN.md "Ties").  The host tie
+    arbiter re-evaluates both accumulators with the host's log().  Wherever the device claims a certificate the two must agree on
+    the order AND on LLK12's bits: writing .sing2/.best from the records as certified must give the same bytes as writing them
+    with every certificate wiped (= the arbiter decides every barcode)."""
+    from demuxlet_amd import synth, capi
+    rng = np.random.default_rng(900 + V)
+    raw = synth.make_raw_genotypes(rng, S, V)
+    if field == "GT":
+        g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    elif field == "GP":
+        g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+    else:
+        g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, raw.alleles)])
+    sp = synth.make_pileup(rng, raw.alleles, B, 0.5, 1.6, dense_layout=False, doublet_rate=0.5)
+    pl = host_pileup(eng, sp)
+    e = eng.Engine(V, (0.0, 0.5), 0.5, mode=capi.DMX_MODE_FAST if mode == "fast" else capi.DMX_MODE_STRICT)
+    e.set_genotypes(g); e.set_pileup(pl)
+    e.run_singlet(); e.run_doublet()
+    _, l00, summ = e.get_doublet(want_grid=False)
+    sing = e.get_sing()
+    e.close()
+    covered = summ["n_pairs"] > 0
+    cert = (summ["flags"] & capi.DMX_CELL_ORDER_CERTIFIED) != 0
+    frac = cert[covered].mean()
+    print(f"V={V} {field} {mode}: {cert.sum()} of {covered.sum()} covered barcodes carry the order certificate ({100 * frac:.1f} %)")
+    assert frac > 0.5
+    fa = eng.FinalArgs([f"BC{i:05d}" for i in range(B)], [f"S{j}" for j in range(V)], (0.0, 0.5), 0.5, sp.rd_totl, sp.rd_pass, sp.rd_uniq,
+                       pl.n_snp_per_cell)
+    eng.write_doublet_summary(fa, sing, l00, summ, str(tmp_path / "cert"), tie_pileup=pl, tie_g=g)
+    wiped = summ.copy()
+    wiped["flags"] &= ~np.int32(capi.DMX_CELL_ORDER_CERTIFIED)
+    eng.write_doublet_summary(fa, sing, l00, wiped, str(tmp_path / "host"), tie_pileup=pl, tie_g=g)
+    for suf in ("sing2", "best"):
+        assert (tmp_path / f"cert.{suf}").read_bytes() == (tmp_path / f"host.{suf}").read_bytes(), suf
+    # and both are the oracle's files (the arbiter path is what the golden tests pin)
+    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    from golden_util import summary_from_grid
+    n_swapped = 0
+    for c in np.flatnonzero(cert):
+        want = summary_from_grid(ref.llksAB[c], ref.llks00[c], (0.0, 0.5), 0.5, int(summ[c]["n_pairs"]), summ.dtype)
+        assert (int(summ[c]["j_best"]), int(summ[c]["k_best"])) == (int(want["j_best"]), int(want["k_best"])), c
+        assert summ[c]["llk12"] == want["llk12"], c               # the reference's bits
+        n_swapped += int(summ[c]["j_best"] > summ[c]["k_best"])
+    print(f"   {n_swapped} certified barcodes name the doublet in descending sample order, as the reference does")
