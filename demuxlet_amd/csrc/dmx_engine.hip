@@ -4033,7 +4033,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
         if (int rc = dmx_engine_get_sing(e, x.sing.data())) return rc;
         x.cell_grid.assign(nb1, nullptr);
         if (job->arbiter) {
-          for (size_t c = 0; c < nb; ++c) if (x.summ[c].flags && x.summ[c].n_pairs > 0) {
+          constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
+          for (size_t c = 0; c < nb; ++c) if ((x.summ[c].flags & kNear) && x.summ[c].n_pairs > 0) {
             x.flagged_grid.emplace_back(nAB);
             HIP_TRY(hipSetDevice(e->device));
             HIP_TRY(hipMemcpyAsync(x.flagged_grid.back().data(), e->d_grid + c * nAB, sizeof(double) * nAB, hipMemcpyDeviceToHost, e->stream));
@@ -4041,7 +4042,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
           }
           HIP_TRY(hipStreamSynchronize(e->stream));
           size_t f = 0;
-          for (size_t c = 0; c < nb; ++c) if (x.summ[c].flags && x.summ[c].n_pairs > 0) x.cell_grid[c] = x.flagged_grid[f++].data();
+          for (size_t c = 0; c < nb; ++c) if ((x.summ[c].flags & kNear) && x.summ[c].n_pairs > 0) x.cell_grid[c] = x.flagged_grid[f++].data();
         }
       }
     }
