@@ -161,7 +161,7 @@ class Ctx:
     pass
 
 
-def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log):
+def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e=False):
     """Generate the workload of one configuration on this rank's GPU, time `steps` passes, return the record (rank 0)."""
     torch, dist, engine, synth, synth_torch = cx.torch, cx.dist, cx.engine, cx.synth, cx.synth_torch
     dev, world, rank, local = cx.dev, cx.world, cx.rank, cx.local
@@ -335,6 +335,26 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log):
             out["fp64_valu"].update({"algorithmic_tflops_log_as_1_op": ops1 / secs / 1e12, "c_log_flops": c_log,
                                      "algorithmic_tflops_log_as_c_log": (ops1 + logs * (c_log - 1)) / secs / 1e12,
                                      "frac_of_peak_log_as_c_log": (ops1 + logs * (c_log - 1)) / secs / 1e12 / FP64_VALU_PEAK_TFLOPS})
+        if with_e2e and cfg["doublet"]:
+            # The same workload through the one-call C-ABI entry (dmx_demuxlet_run: frozen host pileup -> H2D -> K1/K2/K3(+K3b) ->
+            # tie arbiter -> .single/.sing2/.best), stage seconds from dmx_job_timing.  Outside the timed region; host -> device
+            # copies included (this is the PCIe-inclusive picture DESIGN.md asks for).
+            import tempfile
+            h = dp.host_slice(0, B)
+            nreads = np.diff(h["cell_read_off"]).astype(np.int32)
+            hp = engine.HostPileup(B, S, h["cell_pair_off"], h["cell_read_off"], h["pair_snp"], h["pair_nrd"], h["reads"], nreads, nreads, nreads)
+            bcs = [f"BC{i:07d}-1" for i in range(B)]
+            sms = [f"SM{j:02d}" for j in range(V)]
+            e2e = {"what": "dmx_demuxlet_run on this workload from a frozen HOST pileup (no --write-pair, tie arbiter on, 1 GPU): wall seconds per stage"}
+            with tempfile.TemporaryDirectory() as td:
+                for name, md in (("strict", engine.capi.DMX_MODE_STRICT), ("fast", engine.capi.DMX_MODE_FAST)):
+                    tm = engine.demuxlet_run(hp, g, sms, cfg["alphas"], os.path.join(td, name), barcodes=bcs, timing=True, mode=md)
+                    tm.pop("reserved", None)
+                    tm["arbiter_format_write_frac"] = tm["write_s"] / tm["total_s"]
+                    tm["triples_per_s"] = dp.n_pairs * V / tm["total_s"]
+                    e2e[name] = tm
+            out["end_to_end"] = e2e
+            del hp, h
         if with_cpu:                                     # the CPU baseline is a rank-0, N=1 leg only
             out["cpu_baseline"] = cpu_baseline(dp, g, cfg)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
@@ -409,7 +429,7 @@ def main():
         cfg["name"] += f" [override: {args.cells} barcodes]"
     single = cx.world == 1 and not cx.use_dist
     out = run_config(cx, cfgno, cfg, "fast" if args.fast else "strict", args.steps, args.warmup,
-                     with_cpu=single and not args.no_cpu_baseline, with_log=single)
+                     with_cpu=single and not args.no_cpu_baseline, with_log=single, with_e2e=single and default_run and not args.only)
     if single and default_run and not args.only:
         # nested records of the same run: the other single-GPU BASELINE configurations and the opt-in mode, fewer steps each
         also = []
@@ -423,6 +443,12 @@ def main():
             also.append({key: r[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu",
                                                  "fp64_valu", "pair_evals_per_s") if key in r})
         out["also"] = also
+    if cx.world > 1 and default_run and not args.only:
+        # the sharded job once more in the opt-in FAST mode (every rank takes part: it ends with the same gather)
+        r = run_config(cx, cfgno, cfg, "fast", max(2, min(args.steps, 5)), min(args.warmup, 1), with_cpu=False, with_log=False)
+        if cx.rank == 0:
+            out["also"] = [{key: r[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu", "fp64_valu",
+                                                    "pair_evals_per_s", "ranks_seen", "per_rank_ms_per_step", "gather_ms") if key in r}]
     if cx.rank == 0:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if cx.use_dist:

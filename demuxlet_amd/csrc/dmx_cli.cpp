@@ -94,14 +94,104 @@ bool check_double(const char* s) {
   return *end == 0;
 }
 
-void print_help(const std::vector<OptDef>& defs) {
-  fprintf(stderr, "\nDetailed instructions of parameters are available. Ones with \"[]\" are in effect:\n\nAvailable Options:\n");
+// ---- the reference's option printouts (params.cpp) --------------------------------------------------------------------
+// paramList::Read prints the help (params.cpp:306-405,:527-550) on -h/--help and exits 1; paramList::Status (:188-303,:552-574)
+// echoes every run's effective options.  Both are reproduced character for character for the reference's own options (the
+// group and name column widths follow the longest group title and option name, :96-104; this build's extra group is shorter
+// than either, so it does not move a column).
+std::string opt_state(const OptDef& d, bool help) {
+  char buf[64];
+  std::string st;
+  auto dbl = [&](double v) { if (v == 0.0 || v >= 0.01) snprintf(buf, sizeof buf, "%.*f", 2, v); else snprintf(buf, sizeof buf, "%.1e", v); return std::string(buf); };   // precision = 2 (:111)
+  switch (d.type) {
+    case O_BOOL: st = help ? (*(bool*)d.ptr ? "[FLG: ON]" : "[FLG: OFF]") : (*(bool*)d.ptr ? "[ON]" : ""); break;
+    case O_INT: {
+      const int v = *(int*)d.ptr;
+      if (v == 0) st = help ? "[INT: 0]" : "";
+      else { snprintf(buf, sizeof buf, help ? "[INT: %d]" : "[%d]", v); st = buf; }
+      break;
+    }
+    case O_DOUBLE: {
+      const double v = *(double*)d.ptr;
+      if (v != v) st = help ? "[FLT: NaN]" : "";
+      else st = std::string(help ? "[FLT: " : "[") + dbl(v) + "]";
+      break;
+    }
+    case O_STRING: {
+      const std::string& v = *(std::string*)d.ptr;
+      st = v.empty() ? (help ? "[STR: ]" : "") : std::string(help ? "[STR: " : "[") + v + "]";
+      break;
+    }
+    case O_MULTI_DOUBLE: {
+      const std::vector<double>& v = *(std::vector<double>*)d.ptr;
+      if (v.empty()) { st = help ? "[V_FLT: ]" : ""; break; }
+      st = help ? "[V_FLT: " : "[";
+      for (size_t i = 0; i < v.size(); ++i) { if (i) st += ", "; st += dbl(v[i]); }
+      st += "]";
+      break;
+    }
+    case O_MULTI_STRING: {
+      const std::vector<std::string>& v = *(std::vector<std::string>*)d.ptr;
+      if (v.empty()) { st = help ? "[V_STR: ]" : ""; break; }
+      st = help ? "[V_STR: " : "[";
+      for (size_t i = 0; i < v.size(); ++i) { if (i) st += ", "; st += v[i]; }
+      st += "]";
+      break;
+    }
+  }
+  return st.empty() ? st : " " + st;
+}
+
+void column_widths(const std::vector<OptDef>& defs, int& group_len, int& name_len) {
+  group_len = name_len = 0;
+  for (const OptDef& d : defs) { group_len = std::max(group_len, (int)strlen(d.group)); name_len = std::max(name_len, (int)strlen(d.name)); }
+}
+
+void print_help(const std::vector<OptDef>& defs) {                                 // paramList::HelpMessage, longParams::HelpMessage
+  int group_len, name_len;
+  column_widths(defs, group_len, name_len);
+  fprintf(stderr, "\nDetailed instructions of parameters are available. Ones with \"[]\" are in effect:\n");
+  fprintf(stderr, "\nAvailable Options\n\n");
   const char* grp = nullptr;
   for (const OptDef& d : defs) {
-    if (!grp || strcmp(grp, d.group)) { fprintf(stderr, "\n== %s ==\n", d.group); grp = d.group; }
-    fprintf(stderr, "   --%-14s %s\n", d.name, d.help);
+    if (!grp || strcmp(grp, d.group)) { fprintf(stderr, "\n%s\n", d.group); grp = d.group; }
+    fprintf(stderr, "  --%-*s%-*s%s%s\n", name_len, d.name, 20, opt_state(d, true).c_str(), " : ", d.help);          // helpCol = 20 (:31)
   }
-  fprintf(stderr, "\nNOTES:\nWhen --help was included in the argument. The program prints the help message but do not actually run\n");
+  fprintf(stderr, "\n\n");
+  fprintf(stderr, "NOTES:\nWhen --help was included in the argument. The program prints the help message but do not actually run\n");
+}
+
+void print_status(const std::vector<OptDef>& defs) {                               // paramList::Status, longParams::Status
+  int group_len, name_len;
+  column_widths(defs, group_len, name_len);
+  fprintf(stderr, "\nAvailable Options\n\n");
+  fprintf(stderr, "The following parameters are available. Ones with \"[]\" are in effect:\n");
+  const int line_start = group_len ? group_len + 5 : 0;
+  bool need_a_comma = false;
+  int line_len = 0;
+  const char* grp = nullptr;
+  for (const OptDef& d : defs) {
+    if (!grp || strcmp(grp, d.group)) {
+      fprintf(stderr, "%s %*s :", need_a_comma ? "\n" : "", group_len + 2, d.group);
+      need_a_comma = false;
+      line_len = line_start;
+      grp = d.group;
+    }
+    const std::string state = opt_state(d, false);
+    int item_len = 3 + (int)strlen(d.name) + (need_a_comma ? 1 : 0) + (int)state.size();
+    if (item_len + line_len > 78 && line_len > line_start) {
+      line_len = line_start;
+      fprintf(stderr, "%s\n%*s", need_a_comma ? "," : "", line_len, "");
+      need_a_comma = false;
+      item_len -= 1;
+    }
+    fprintf(stderr, "%s --%s%s", need_a_comma ? "," : "", d.name, state.c_str());
+    need_a_comma = true;
+    line_len += item_len;
+  }
+  fprintf(stderr, "\n");
+  fprintf(stderr, "\nRun with --help for more detailed help messages of each argument.\n");
+  fprintf(stderr, "\n");
 }
 
 void parse_options(int argc, char** argv, Options& o) {
@@ -165,6 +255,7 @@ void parse_options(int argc, char** argv, Options& o) {
       snprintf(ebuf, sizeof ebuf, "Cannot correspond command line parameter %s (#%d) to any of the options\n", a, i); errors += ebuf;
     }
   }
+  print_status(defs);                                                                                                // params.cpp:552-560
   if (!errors.empty()) fatal("Problems encountered parsing command line:\n\n%s", errors.c_str());                   // params.cpp:562-567
 }
 
@@ -443,19 +534,25 @@ struct VcfReader {
       v.n_allele = (f[4] == "." ? 1 : 1 + (int)alts.size());
       v.ref0 = v.ref.empty() ? 'N' : v.ref[0];
       v.alt0 = (v.n_allele > 1 && !alts[0].empty()) ? alts[0][0] : '.';
+      // passed_vfilter returns true before ANY check when neither --min-mac nor --min-callrate asks for genotypes
+      // (require_GT = false, bcf_filtered_reader.cpp:507; cmd_cram_demuxlet.cpp:104-105 sets it from those two options)
+      const bool require_gt = (min_mac > 0) || (min_callrate > 0);
+      // (multi-allelic records stay skipped in that case too: the reference lets them through and then reads its 6-genotype
+      //  layout as if it had 3 per sample, cmd_cram_demuxlet.cpp:227-231 — garbage this build does not reproduce)
       if (v.n_allele > max_alleles) { ++n_skip; continue; }                                    // :534
       // FORMAT keys
       const auto keys = split(f[8], ':');
       int i_gt = -1, i_fld = -1;
       for (size_t k = 0; k < keys.size(); ++k) { if (keys[k] == "GT") i_gt = (int)k; if (keys[k] == field) i_fld = (int)k; }
-      if (i_gt < 0) fatal("[E:%s] Cannot find the field GT from the VCF file at position %s:%lld", __func__, f[0].c_str(), (long long)v.pos + 1);   // :548-549
+      if (i_gt < 0 && (require_gt || field == "GT")) fatal("[E:%s] Cannot find the field GT from the VCF file at position %s:%lld", __func__, f[0].c_str(), (long long)v.pos + 1);   // :548-549
       const int nv = nsamples();
       std::vector<int32_t> alleles((size_t)nv * 2, -1);
       std::vector<std::vector<std::string>> sf((size_t)nv);
       int an = 0; std::vector<int> acs((size_t)std::max(v.n_allele, 2), 0);
       for (int i = 0; i < nv; ++i) {
         sf[i] = split(f[9 + sm_icols[i]], ':');
-        const std::string& gt = sf[i][i_gt < (int)sf[i].size() ? i_gt : 0];
+        static const std::string kMissingGt = ".";
+        const std::string& gt = (i_gt >= 0 && i_gt < (int)sf[i].size()) ? sf[i][i_gt] : kMissingGt;
         // diploid GT "a/b" or "a|b"; '.' = missing allele (bcf_gt_allele < 0); haploid "a" leaves the second allele missing
         size_t sep = gt.find_first_of("/|");
         const std::string a1 = gt.substr(0, sep), a2 = sep == std::string::npos ? "." : gt.substr(sep + 1);
@@ -463,9 +560,9 @@ struct VcfReader {
         alleles[2 * i] = al(a1); alleles[2 * i + 1] = al(a2);
         for (int h = 0; h < 2; ++h) { const int x = alleles[2 * i + h]; if (x >= 0 && x < (int)acs.size()) { ++an; ++acs[x]; } }   // :230-240
       }
-      if (min_callrate > (double)an / (2.0 * (double)nv)) { ++n_skip; continue; }              // :554
+      if (require_gt && min_callrate > (double)an / (2.0 * (double)nv)) { ++n_skip; continue; }   // :554
       const int ac = an - acs[0];
-      if ((ac < min_mac) || (an - ac < min_mac)) { ++n_skip; continue; }                       // :565
+      if (require_gt && ((ac < min_mac) || (an - ac < min_mac))) { ++n_skip; continue; }       // :565
       // parse_posteriors (:360-454) through the library's a3 transforms
       v.gps.assign((size_t)nv * 3, 0.f);
       if (field == "GT") {
@@ -655,7 +752,10 @@ struct SamReader {
       o += 3;
       size_t len = 0;
       if (ty == 'Z' || ty == 'H') {
-        const char* s = (const char*)&b[o]; len = strlen(s) + 1;
+        const char* s = (const char*)&b[o];
+        const void* nul = o < b.size() ? memchr(s, 0, b.size() - o) : nullptr;          // the string must end inside the record
+        if (!nul) fatal("[E:%s] corrupt BAM record: unterminated %c%c:%c aux field", __func__, t0, t1, ty);
+        len = (size_t)((const char*)nul - s) + 1;
         if (ty == 'Z') {
           if (gtag[0] && t0 == gtag[0] && t1 == gtag[1]) { r.cb = s; r.has_cb = true; }
           if (utag[0] && t0 == utag[0] && t1 == utag[1]) { r.ub = s; r.has_ub = true; }
@@ -664,10 +764,13 @@ struct SamReader {
       else if (ty == 's' || ty == 'S') len = 2;
       else if (ty == 'i' || ty == 'I' || ty == 'f') len = 4;
       else if (ty == 'B') {
+        if (o + 5 > b.size()) fatal("[E:%s] corrupt BAM record: truncated B aux field", __func__);
         const char sub = (char)b[o]; int32_t cnt; memcpy(&cnt, &b[o + 1], 4);
+        if (cnt < 0) fatal("[E:%s] corrupt BAM record: negative B array length", __func__);
         const size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
         len = 5 + es * (size_t)cnt;
       } else fatal("[E:%s] unknown BAM aux type %c", __func__, ty);
+      if (len > b.size() - o) fatal("[E:%s] corrupt BAM record: aux field %c%c runs past the record", __func__, t0, t1);
       o += len;
     }
     return true;

@@ -187,3 +187,90 @@ def test_tutorial_vcf_plumbing(cli, oracle, tmp_path):
     assert len(dump["snps"]) == len(snps) and len(snps) > 500
     assert sum(len(c["pairs"]) for c in dump["cells"]) > 500
     check_dump_against_scan(oracle, dump, snps, events, gts, recs, sm_cols, "GT")
+
+
+HELP_HEAD = """
+Detailed instructions of parameters are available. Ones with "[]" are in effect:
+
+Available Options
+
+
+Options for input SAM/BAM/CRAM
+  --sam           [STR: ]             : Input SAM/BAM/CRAM file. Must be sorted by coordinates and indexed
+  --tag-group     [STR: CB]           : Tag representing readgroup or cell barcodes, in the case to partition the BAM file into multiple groups. For 10x genomics, use CB
+  --tag-UMI       [STR: UB]           : Tag representing UMIs. For 10x genomiucs, use UB
+
+Options for input VCF/BCF
+  --vcf           [STR: ]             : Input VCF/BCF file, containing the individual genotypes (GT), posterior probability (GP), or genotype likelihood (PL)
+  --field         [STR: GP]           : FORMAT field to extract the genotype, likelihood, or posterior from
+  --geno-error    [FLT: 0.01]         : Genotype error rate (must be used with --field GT)
+  --min-mac       [INT: 1]            : Minimum minor allele frequency
+  --min-callrate  [FLT: 0.50]         : Minimum call rate
+  --sm            [V_STR: ]           : List of sample IDs to compare to (default: use all)
+  --sm-list       [STR: ]             : File containing the list of sample IDs to compare
+
+Output Options
+  --out           [STR: ]             : Output file prefix
+  --alpha         [V_FLT: ]           : Grid of alpha to search for (default is 0, 0.5)
+  --write-pair    [FLG: OFF]          : Writing the (HUGE) pair file
+  --doublet-prior [FLT: 0.50]         : Prior of doublet
+  --sam-verbose   [INT: 1000000]      : Verbose message frequency for SAM/BAM/CRAM
+  --vcf-verbose   [INT: 10000]        : Verbose message frequency for VCF/BCF
+
+Read filtering Options
+  --cap-BQ        [INT: 40]           : Maximum base quality (higher BQ will be capped)
+  --min-BQ        [INT: 13]           : Minimum base quality to consider (lower BQ will be skipped)
+  --min-MQ        [INT: 20]           : Minimum mapping quality to consider (lower MQ will be ignored)
+  --min-TD        [INT: 0]            : Minimum distance to the tail (lower will be ignored)
+  --excl-flag     [INT: 3844]         : SAM/BAM FLAGs to be excluded
+
+Cell/droplet filtering options
+  --group-list    [STR: ]             : List of tag readgroup/cell barcode to consider in this run. All other barcodes will be ignored. This is useful for parallelized run
+  --min-total     [INT: 0]            : Minimum number of total reads for a droplet/cell to be considered
+  --min-uniq      [INT: 0]            : Minimum number of unique reads (determined by UMI/SNP pair) for a droplet/cell to be considered
+  --min-snp       [INT: 0]            : Minimum number of SNPs with coverage for a droplet/cell to be considered
+"""
+
+STATUS_HEAD = """
+Available Options
+
+The following parameters are available. Ones with "[]" are in effect:
+   Options for input SAM/BAM/CRAM : --sam [r.sam], --tag-group [CB],
+                                    --tag-UMI [UB]
+        Options for input VCF/BCF : --vcf [v.vcf], --field [GT],
+                                    --geno-error [1.0e-03], --min-mac [1],
+                                    --min-callrate [0.50], --sm [smA, smC],
+                                    --sm-list
+                   Output Options : --out [o], --alpha [0.00, 0.25, 0.50],
+                                    --write-pair [ON], --doublet-prior [0.50],
+                                    --sam-verbose [1000000],
+                                    --vcf-verbose [10000]
+           Read filtering Options : --cap-BQ [40], --min-BQ [13],
+                                    --min-MQ [20], --min-TD,
+                                    --excl-flag [3844]
+   Cell/droplet filtering options : --group-list, --min-total, --min-uniq,
+                                    --min-snp [5]
+"""
+
+
+def test_help_and_status_text_are_the_reference_layout(cli, tmp_path):
+    """f4: `--help` (paramList::HelpMessage + longParams::HelpMessage, params.cpp:306-405,:527-550) and the status echo every run
+    prints (paramList::Status + longParams::Status, :188-303,:552-574), compared with literal text laid out by hand from those
+    functions: "  --%-*s%-*s : help" with the name column = longest option name (13, doublet-prior) and a 20-column state, groups
+    right-aligned to the longest group title + 2, items wrapped at 78 columns with a continuation indent of group_len + 5,
+    doubles "%.2f" (or "%.1e" below 0.01), zero / empty values echoed without brackets.  This build's own options form one more
+    group after the reference's; it is shorter than either column and does not move them."""
+    r = subprocess.run([cli, "--help"], capture_output=True, text=True)
+    assert r.returncode == 1 and r.stdout == ""
+    assert r.stderr.startswith(HELP_HEAD + "\nMI355X build\n"), r.stderr[:400]
+    assert r.stderr.endswith("\n\n\nNOTES:\nWhen --help was included in the argument. The program prints the help message but do not actually run\n")
+    (tmp_path / "r.sam").write_text("@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:1\tLN:1000\n")
+    (tmp_path / "v.vcf").write_text("##fileformat=VCFv4.2\n##contig=<ID=1,length=1000>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsmA\tsmC\n")
+    r = subprocess.run([cli, "--sam", "r.sam", "--vcf", "v.vcf", "--field", "GT", "--geno-error", "0.001", "--sm", "smA", "--sm", "smC", "--out", "o",
+                        "--alpha", "0", "--alpha", "0.25", "--alpha", "0.5", "--write-pair", "--min-snp", "5", "--pileup-only"],
+                       capture_output=True, text=True, cwd=tmp_path)
+    assert r.stderr.startswith(STATUS_HEAD + "                     MI355X build : --gpu, --gpus [1], --pileup-only [ON],\n"), r.stderr[:1500]
+    assert "\n\nRun with --help for more detailed help messages of each argument.\n\n" in r.stderr
+    # parse errors are reported AFTER the status echo, as paramList::Status does (:562-567)
+    r = subprocess.run([cli, "--sam", "r.sam", "--bogus"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode != 0 and r.stderr.index("Run with --help") < r.stderr.index("Command line parameter --bogus (#3) not recognized")
