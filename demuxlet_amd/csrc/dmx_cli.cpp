@@ -77,7 +77,8 @@ struct Options {
   int gpu = 0, gpus = 1;
   bool pileup_only = false;      // stop after the scan and write <out>.pileup.txt (no GPU needed)
   bool no_arbiter = false;
-  bool fast = false;
+  bool fast = false;       // accepted for compatibility with round-1 command lines: FAST is the default now
+  bool strict = false;
 };
 
 enum OptType { O_BOOL, O_INT, O_DOUBLE, O_STRING, O_MULTI_DOUBLE, O_MULTI_STRING };
@@ -225,7 +226,8 @@ void parse_options(int argc, char** argv, Options& o) {
       {"gpus", O_INT, &o.gpus, "[MI355X build] number of GPUs to shard the barcodes over (starting at --gpu)", "MI355X build"},
       {"pileup-only", O_BOOL, &o.pileup_only, "[MI355X build] stop after the BAM x VCF scan and write <out>.pileup.txt", "MI355X build"},
       {"no-arbiter", O_BOOL, &o.no_arbiter, "[MI355X build] skip the host tie arbiter (DESIGN.md, Ties)", "MI355X build"},
-      {"fast", O_BOOL, &o.fast, "[MI355X build] DMX_MODE_FAST: factored doublet terms (log-likelihoods within 1e-9, same calls)", "MI355X build"},
+      {"strict", O_BOOL, &o.strict, "[MI355X build] DMX_MODE_STRICT: every grid entry in the reference's operation order (default: DMX_MODE_FAST, the printed entries only, log-likelihoods within 1e-9, same calls)", "MI355X build"},
+      {"fast", O_BOOL, &o.fast, "[MI355X build] DMX_MODE_FAST (the default; kept for older command lines)", "MI355X build"},
   };
   std::set<std::string> touched;
   std::string errors;
@@ -1058,7 +1060,7 @@ int main(int argc, char** argv) {
   job.store = scl; job.g = G.data(); job.n_samples = nv; job.sample_ids = sm.data();
   job.n_alpha = (int32_t)o.alpha.size(); job.alpha = o.alpha.data(); job.doublet_prior = o.doublet_prior;
   job.min_total = o.min_total; job.min_uniq = o.min_uniq; job.min_snp = o.min_snp; job.write_pair = o.write_pair;
-  job.out_prefix = o.out.c_str(); job.device = o.gpu; job.arbiter = o.no_arbiter ? 0 : 1; job.n_gpus = o.gpus; job.mode = o.fast ? DMX_MODE_FAST : DMX_MODE_STRICT;
+  job.out_prefix = o.out.c_str(); job.device = o.gpu; job.arbiter = o.no_arbiter ? 0 : 1; job.n_gpus = o.gpus; job.mode = o.strict ? DMX_MODE_STRICT : DMX_MODE_FAST;
   if (dmx_demuxlet_run(&job) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
   notice("Finished writing output files");                                                                 // :876
   dmx_store_free(scl);

@@ -269,7 +269,8 @@ def test_help_and_status_text_are_the_reference_layout(cli, tmp_path):
     r = subprocess.run([cli, "--sam", "r.sam", "--vcf", "v.vcf", "--field", "GT", "--geno-error", "0.001", "--sm", "smA", "--sm", "smC", "--out", "o",
                         "--alpha", "0", "--alpha", "0.25", "--alpha", "0.5", "--write-pair", "--min-snp", "5", "--pileup-only"],
                        capture_output=True, text=True, cwd=tmp_path)
-    assert r.stderr.startswith(STATUS_HEAD + "                     MI355X build : --gpu, --gpus [1], --pileup-only [ON],\n"), r.stderr[:1500]
+    assert r.stderr.startswith(STATUS_HEAD + "                     MI355X build : --gpu, --gpus [1], --pileup-only [ON],\n"
+                                             "                                    --no-arbiter, --strict, --fast\n"), r.stderr[:1500]
     assert "\n\nRun with --help for more detailed help messages of each argument.\n\n" in r.stderr
     # parse errors are reported AFTER the status echo, as paramList::Status does (:562-567)
     r = subprocess.run([cli, "--sam", "r.sam", "--bogus"], capture_output=True, text=True, cwd=tmp_path)
