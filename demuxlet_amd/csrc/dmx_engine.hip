@@ -1525,8 +1525,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 // Entry e = tid + TPC*i of a lane: e < V*D (D = V/2 + 1): j = e % V, k = (j + e / V) % V at alpha 0.5 (the rotation makes the
 // lanes of a wavefront read consecutive u_k: conflict-free LDS); V*D <= e < V*D + V: the singlet entry [j][0][0], j = e - V*D.
 // For even V the offset d = V/2 is computed from both sides; only the j < k copy is stored.
-template <int TPC, int VMAX, int SUB, bool FIXJ>
-__global__ __launch_bounds__(kThreads, 3) void k_doublet_sym(PileupView pv, int nrd_width, const float* __restrict__ g,
+template <int TPC, int VMAX, int SUB, bool FIXJ, int MINW = 3>
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                           const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                           const int32_t* __restrict__ sched, int32_t V,
                                                           double* __restrict__ grid, double* __restrict__ l00,
@@ -1735,7 +1735,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_sym(PileupView pv, int 
         }
       }
       DMX_K2_SYNC();
-#pragma unroll
+      constexpr int UPI = MINW >= 4 ? 1 : SUB;       // pairs unrolled together (register budget)
+#pragma unroll UPI
       for (int pi = 0; pi < SUB; ++pi) {
         if (pi < ns) {
           const float* gr = &s_g[pi * GSS];
@@ -3594,14 +3595,32 @@ int launch_doublet(dmx_engine* e) {
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
+#define DMX_K2SV(TPC, VMAX, SUB, FIX, MINW)                                                                            \
+  do {                                                                                                                \
+    constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1;                                                  \
+    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    const size_t lds = cb_ * (kThreads / TPC);                                                                         \
+    if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+    hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
+                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V,           \
+                       e->d_grid, e->d_l00, e->d_flag);                                                                \
+  } while (0)
     if (V <= 8) { if (64 % V == 0) DMX_K2S(64, 8, 4, true); else DMX_K2S(64, 8, 4, false); }
     else if (V <= 14) DMX_K2S(64, 14, 4, false);
     else if (V <= 17) { if (V == 16) DMX_K2S(64, 17, 4, true); else DMX_K2S(64, 17, 4, false); }
     else if (V <= 23) DMX_K2S(64, 23, 4, false);
     else if (V <= 27) DMX_K2S(64, 27, 4, false);
-    else if (V <= 32) { if (V == 32) DMX_K2S(64, 32, 4, true); else DMX_K2S(64, 32, 4, false); }
+    else if (V <= 32) {
+      if (V == 32) {
+        const int var = getenv("DMX_SYM_VARIANT") ? atoi(getenv("DMX_SYM_VARIANT")) : 0;      // kernel experiments only
+        if (var == 1) DMX_K2SV(64, 32, 2, true, 4); else if (var == 2) DMX_K2SV(64, 32, 4, true, 4); else if (var == 3) DMX_K2SV(64, 32, 8, true, 3);
+        else if (var == 4) DMX_K2SV(64, 32, 2, true, 3); else if (var == 5) DMX_K2SV(64, 32, 8, true, 2); else DMX_K2S(64, 32, 4, true);
+      } else DMX_K2S(64, 32, 4, false);
+    }
     else if (V <= 48) DMX_K2S(256, 48, 8, false);
     else { if (V == 64) DMX_K2S(256, 64, 8, true); else DMX_K2S(256, 64, 8, false); }
+#undef DMX_K2SV
 #undef DMX_K2S
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);

@@ -148,8 +148,12 @@ def run_full(m, cfg_id, n_sample, check_general, barcodes=0, fast=False):
             ref = summary_from_grid(full["grid"][c], full["l00"][c], cfg["alphas"], 0.5, int(sm["n_pairs"]),
                                     m["engine"].capi.SUMMARY_DTYPE)
             assert sm["max_llk"] == ref["max_llk"]
-            for f in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best"):
+            for f in ("i_sing1", "i_sing2", "n_best"):
                 assert sm[f] == ref[f], (c, f)
+            if sm["flags"] & m["engine"].capi.DMX_CELL_ORDER_CERTIFIED:      # K3b may have turned the pair into the reference's order
+                assert {int(sm["j_best"]), int(sm["k_best"])} == {int(ref["j_best"]), int(ref["k_best"])}, c
+            else:
+                assert (sm["j_best"], sm["k_best"]) == (ref["j_best"], ref["k_best"]), c
         # ... and the calls they lead to are the ORACLE's calls: same best/next singlet, same doublet pair (its two samples may
         # come in either order at alpha = 0.5, which is what the host tie arbiter settles, DESIGN.md "Ties"), same alpha
         for i, c in enumerate(cells):
@@ -157,6 +161,9 @@ def run_full(m, cfg_id, n_sample, check_general, barcodes=0, fast=False):
             want_s = summary_from_grid(want.llksAB[i], want.llks00[i], cfg["alphas"], 0.5, int(sm["n_pairs"]), m["engine"].capi.SUMMARY_DTYPE)
             assert (sm["i_sing1"], sm["i_sing2"], sm["n_best"]) == (want_s["i_sing1"], want_s["i_sing2"], want_s["n_best"]), c
             assert {int(sm["j_best"]), int(sm["k_best"])} == {int(want_s["j_best"]), int(want_s["k_best"])}, c
+            if sm["flags"] & m["engine"].capi.DMX_CELL_ORDER_CERTIFIED:      # certified: the oracle's order and LLK12 bits
+                assert (int(sm["j_best"]), int(sm["k_best"])) == (int(want_s["j_best"]), int(want_s["k_best"])), c
+                assert sm["llk12"] == want_s["llk12"], c
     # (2) a second run is bit-identical
     e2 = run(dp)
     again = device_results(m, e2, B, V, A, cfg["doublet"])
