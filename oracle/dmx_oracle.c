@@ -9,7 +9,8 @@
  *     (byte-identical .single/.sing2/.best/.pair and bit-identical raw llks/llk0s/llksAB/llks00, tests/golden/),
  *   - oracle/_ref/libref_units.so    = sc_drop_seq.cpp + PhredHelper.cpp compiled alone (rows a1, a2).
  *   Row a3 (genotype-field transforms) needs htslib to run in the reference and is therefore PARITY-UNPINNED by any
- *   reference output; it is pinned only by hand-derived vectors (tests/test_geno_transform.py).
+ *   reference output; it is pinned only by hand-derived vectors (tests/test_host_units.py: test_geno_transforms_match_oracle,
+ *   test_geno_transforms_hand_vectors).
  *
  * Build: gcc -O2 -ffp-contract=off -std=c11 (no FMA contraction: the reference is built -O2 for baseline x86-64,
  * Makefile.am:6, and FMA contraction changes .best rows — SURVEY.md F6).

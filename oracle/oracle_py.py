@@ -2,7 +2,7 @@
 reference slice harness (oracle/_ref/ref_slice_harness, dev container only).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module. Nothing under
-demuxlet_amd/ may import it (tests/test_layout.py enforces that)."""
+demuxlet_amd/ may import it (tests/test_abi.py::test_product_never_touches_the_oracle enforces that)."""
 from __future__ import annotations
 
 import ctypes as C

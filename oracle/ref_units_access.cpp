@@ -2,7 +2,8 @@
 // g++ from /root/reference and need no stand-in of any kind:
 //   PhredHelper.cpp  (global phredConv, ctor PhredHelper.cpp:24-40)            -> pins SURVEY §8a row a2
 //   sc_drop_seq.cpp  (sc_dropseq_lib_t::add_snp/add_cell/add_read, :3-77)      -> pins SURVEY §8a row a1
-// Used by tests/golden/make_golden.py to generate fixtures, and by tests/test_oracle_vs_ref.py when oracle/_ref exists.
+// Used by tests/golden/make_golden.py to generate the fixture tests/golden/ref_units.npz (checked by tests/test_host_units.py and
+// tests/test_oracle_golden.py).
 #include <cstring>
 #include <string>
 #include <vector>

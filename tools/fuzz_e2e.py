@@ -51,7 +51,8 @@ for case in range(n_cases):
         else: os.environ.pop("DMX_RANGE_BYTES", None)
         os.environ["DMX_THREADS"] = str(int(rng.choice([1, 3, 8])))
         engine.demuxlet_run(st, g, sm, alphas, os.path.join(td, "got"), params.doublet_prior, params.min_total, params.min_uniq, params.min_snp,
-                            params.write_pair, arbiter=True, n_gpus=n_gpus)
+                            params.write_pair, arbiter=True, n_gpus=n_gpus,
+                            mode=engine.capi.DMX_MODE_FAST if os.environ.get("DMX_FUZZ_FAST") else engine.capi.DMX_MODE_STRICT)
         ndiff = 0
         for suf in ("single", "sing2", "best") + (("pair",) if params.write_pair else ()):
             got = open(os.path.join(td, f"got.{suf}")).read().splitlines()

@@ -58,13 +58,22 @@ for case in range(n_cases):
                 words.astype(np.uint32), sp.rd_totl, sp.rd_pass, sp.rd_uniq)
     ref = O.run_csr(csr, [f"s{j}" for j in range(V)], g, O.Params(alphas, 0.5))
     proc = ref.processed.astype(bool)
-    d = max(np.abs(llks - ref.llks).max(), np.abs(llk0s - ref.llk0s).max(),
-            np.abs(grid[proc] - ref.llksAB[proc]).max() if proc.any() else 0.0, np.abs(l00[proc] - ref.llks00[proc]).max() if proc.any() else 0.0)
+    dgrid = np.abs(grid[proc] - ref.llksAB[proc]) if proc.any() else np.zeros(1)
+    if os.environ.get("DMX_FUZZ_FAST") and tuple(alphas) == (0.0, 0.5) and proc.any():     # FAST computes the printed entries
+        m = np.zeros((V, V, A), dtype=bool); m[:, 0, 0] = True; m[:, :, 1:] = True
+        dgrid = dgrid[np.broadcast_to(m[None], dgrid.shape)]
+    d = max(np.abs(llks - ref.llks).max(), np.abs(llk0s - ref.llk0s).max(), dgrid.max(), np.abs(l00[proc] - ref.llks00[proc]).max() if proc.any() else 0.0)
     bad_idx = 0
     for c in np.nonzero(proc)[0][:8]:
         want = summary_from_grid(grid[c], l00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)
-        for f in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best"):
+        for f in ("i_sing1", "i_sing2", "n_best"):
             bad_idx += int(summ[c][f] != want[f])
+        bad_idx += int({int(summ[c]["j_best"]), int(summ[c]["k_best"])} != {int(want["j_best"]), int(want["k_best"])})   # K3b may order the pair
+        want_ref = summary_from_grid(ref.llksAB[c], ref.llks00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)    # ... and the calls are the oracle's
+        bad_idx += int((summ[c]["i_sing1"], summ[c]["i_sing2"], summ[c]["n_best"]) != (want_ref["i_sing1"], want_ref["i_sing2"], want_ref["n_best"]))
+        bad_idx += int({int(summ[c]["j_best"]), int(summ[c]["k_best"])} != {int(want_ref["j_best"]), int(want_ref["k_best"])})
+        if summ[c]["flags"] & 4:                                                             # certified: the oracle's order and bits
+            bad_idx += int((summ[c]["j_best"], summ[c]["k_best"]) != (want_ref["j_best"], want_ref["k_best"])) + int(summ[c]["llk12"] != want_ref["llk12"])
     worst_all = max(worst_all, d)
     print(f"case {case:3d}: V={V:3d} A={A} {field} dense={int(dense)} B={B:2d} S={S:3d} rbar={rbar:4.2f} alphas[0]={alphas[0]:.2f}: max|d|={d:.2e} idx_mismatch={bad_idx}", flush=True)
     if not (d < 1e-9) or bad_idx:
