@@ -3071,23 +3071,30 @@ __global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_wid
         const double o = __shfl_xor(mx, 1);
         mx = (mx < o) ? o : mx;
       }
-      if (on && n1 == 1) {
+      // the alpha = 0.5 lane finishes its nine values (:656-663) and hands a copy to its alpha = 0 neighbour (which only had to
+      // contribute to the shared maxima): the two lanes of a pair then take one accumulator each
+      double v[9];
+      {
         const double y = rcp_refined(mx);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v[i] = div_by(pG[i], mx, y);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { const double o = __shfl_xor(v[i], 1); v[i] = n1 ? v[i] : o; }
+      }
+      if (on) {
         const double aj[3] = {(double)fa0, (double)fa1, (double)fa2}, bk[3] = {(double)fb0, (double)fb1, (double)fb2};
-        double sab = 0.0, sba = 0.0;                                         // :674
+        double sx = 0.0;                                                     // :674
 #pragma unroll
         for (int l = 0; l < 3; ++l)
 #pragma unroll
           for (int m = 0; m < 3; ++m) {
-            const double v = div_by(pG[l * 3 + m], mx, y);                   // :656-663
-            sab += ((aj[l] * bk[m]) * v);                                    // llksAB[a][b]: :553, :677-679
-            sba += ((bk[l] * aj[m]) * v);                                    // llksAB[b][a]
+            const double gp = n1 ? (bk[l] * aj[m]) : (aj[l] * bk[m]);       // lane 0: llksAB[a][b], lane 1: llksAB[b][a]   (:553)
+            sx += (gp * v[l * 3 + m]);                                       // :677-679
           }
-        ok &= __builtin_amdgcn_class(sab, 0x100) && __builtin_amdgcn_class(sba, 0x100);
-        double lo1, hi1, lo2, hi2;
-        dmx_log_bracket((uint32_t)__double2hiint(sab), (uint32_t)__double2loint(sab), s_log, s_lo, &lo1, &hi1);
-        dmx_log_bracket((uint32_t)__double2hiint(sba), (uint32_t)__double2loint(sba), s_log, s_lo, &lo2, &hi2);
-        s_t[cw][0][ti1] = lo1; s_t[cw][1][ti1] = hi1; s_t[cw][2][ti1] = lo2; s_t[cw][3][ti1] = hi2;
+        ok &= __builtin_amdgcn_class(sx, 0x100);
+        double lo1, hi1;
+        dmx_log_bracket((uint32_t)__double2hiint(sx), (uint32_t)__double2loint(sx), s_log, s_lo, &lo1, &hi1);
+        s_t[cw][2 * n1][ti1] = lo1; s_t[cw][2 * n1 + 1][ti1] = hi1;
       }
     }
     DMX_WAVE_LDS_ORDER();
@@ -3923,7 +3930,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipSetDevice(job->device % ndev));
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < budget) budget = std::max<size_t>(free_b / 3, 1);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 6 < budget) budget = std::max<size_t>(free_b / 6, 1);   // two ranges per GPU in flight
   }
   const double per_pair = (double)(V + 1) + (doublet_ok ? (double)nAB + A : 0.0);
   double work_total = 0;
@@ -3932,7 +3939,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   const int by_mem = (int)std::min<double>((double)std::max(B, 1), std::ceil(grid_total / (double)budget));
   int by_overlap = 1;                                                // ranges per engine wanted for host/GPU overlap
   if (const char* env = getenv("DMX_RANGES_PER_GPU")) by_overlap = std::max(1, atoi(env));
-  else if (doublet_ok && work_total / ngpu > 2e11 && B / ngpu >= 8 * 1024) by_overlap = 4;   // >= ~0.3 s of GPU work per engine
+  else if (doublet_ok && work_total / ngpu > 3e10 && B / ngpu >= 8 * 1024) by_overlap = 4;   // >= ~50 ms of GPU work per engine
   int R = std::max(ngpu * by_overlap, by_mem);
   R = ((R + ngpu - 1) / ngpu) * ngpu;                                 // whole waves
   R = std::max(1, std::min(R, std::max(B, 1)));
@@ -3972,13 +3979,19 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     void release() { *this = Range(); }
   };
   std::vector<Range> rg((size_t)R);
-  std::vector<dmx_engine*> eng((size_t)std::min(ngpu, R), nullptr);
+  // Engines: one per GPU and wave slot.  When the job takes several waves, every GPU gets TWO engines (own stream, own buffers)
+  // that alternate between waves, so that the slicing + H2D of wave w + 2 overlaps the kernels of wave w + 1 (the copy engine
+  // runs beside the compute units) while the host arbitrates and writes wave w.
+  const int per_wave = std::min(ngpu, R);
+  const int waves = (R + per_wave - 1) / per_wave;
+  const int nset = (waves >= 2 && !getenv("DMX_ONE_ENGINE_PER_GPU")) ? 2 : 1;
+  std::vector<dmx_engine*> eng((size_t)per_wave * nset, nullptr);
   tm.n_engines = (int32_t)eng.size();
   struct Guard { std::vector<dmx_engine*>* e; ~Guard() { for (dmx_engine* x : *e) if (x) dmx_engine_destroy(x); } } guard{&eng};
   for (size_t i = 0; i < eng.size(); ++i) {
     dmx_engine_config cfg{};
     cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior;
-    cfg.device = (job->device + (int)i) % ndev; cfg.mode = job->mode;
+    cfg.device = (job->device + (int)(i % (size_t)per_wave)) % ndev; cfg.mode = job->mode;
     if (int rc = dmx_engine_create(&cfg, &eng[i])) return rc;
     if (int rc = dmx_engine_set_genotypes(eng[i], job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
   }
@@ -3987,6 +4000,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   double stage_s = 0, wait_s = 0, write_s = 0, kernel_ms = 0;
   int32_t n_fetched = 0;
 
+  auto eng_of = [&](int r) -> dmx_engine* { return eng[(size_t)(((r / per_wave) % nset) * per_wave + r % per_wave)]; };
   auto launch = [&](int r) -> int {              // stage range r on its engine and start its kernels (asynchronous)
     const clk::time_point t0 = clk::now();
     Range& x = rg[(size_t)r];
@@ -4026,7 +4040,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
       x.pl.rd_totl = x.totl.data(); x.pl.rd_pass = x.pass.data(); x.pl.rd_uniq = x.uniq.data();
       use = &x.pl;
     }
-    dmx_engine* e = eng[(size_t)r % eng.size()];
+    dmx_engine* e = eng_of(r);
     if (int rc = dmx_engine_set_pileup(e, use)) return rc;
     if (int rc = dmx_engine_run_singlet(e)) return rc;
     if (doublet_ok) if (int rc = dmx_engine_run_doublet(e)) return rc;
@@ -4037,7 +4051,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     const clk::time_point t0 = clk::now();
     Range& x = rg[(size_t)r];
     const size_t nb = (size_t)(x.hi - x.lo), nb1 = std::max<size_t>(nb, 1);
-    dmx_engine* e = eng[(size_t)r % eng.size()];
+    dmx_engine* e = eng_of(r);
     x.llks.resize(nb1 * (size_t)V); x.llk0s.resize(nb1);
     if (int rc = dmx_engine_get_singlet(e, x.llks.data(), x.llk0s.data())) return rc;
     int32_t fetched = 0;
@@ -4108,13 +4122,12 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     for (size_t i = 0; i < rcs.size(); ++i) if (rcs[i]) return set_error(rcs[i], "%s", msgs[i].c_str());   // the message is thread-local
     return DMX_OK;
   };
-  const int per_wave = (int)eng.size(), waves = (R + per_wave - 1) / per_wave;
-  if (int rc = for_ranges(0, std::min(R, per_wave), launch)) return rc;
+  auto wave_lo = [&](int w) { return std::min(R, w * per_wave); };
+  for (int w = 0; w < std::min(waves, nset); ++w) if (int rc = for_ranges(wave_lo(w), wave_lo(w + 1), launch)) return rc;
   for (int w = 0; w < waves; ++w) {
-    const int r0 = w * per_wave, r1 = std::min(R, r0 + per_wave);
-    if (int rc = for_ranges(r0, r1, fetch)) return rc;
-    if (int rc = for_ranges(r1, std::min(R, r1 + per_wave), launch)) return rc;                   // GPUs run wave w+1 ...
-    for (int r = r0; r < r1; ++r) if (int rc = write(r)) return rc;                               // ... while the host writes wave w
+    if (int rc = for_ranges(wave_lo(w), wave_lo(w + 1), fetch)) return rc;
+    if (w + nset < waves) if (int rc = for_ranges(wave_lo(w + nset), wave_lo(w + nset + 1), launch)) return rc;   // the freed engines stage wave w + nset ...
+    for (int r = wave_lo(w); r < wave_lo(w + 1); ++r) if (int rc = write(r)) return rc;           // ... while the host writes wave w and the GPUs run w + 1
   }
   tm.stage_s = stage_s; tm.wait_s = wait_s; tm.write_s = write_s; tm.kernel_ms = kernel_ms; tm.n_cells_grid_fetched = n_fetched;
   tm.total_s = secs(t_begin, clk::now());

@@ -233,12 +233,13 @@ typedef struct {
   const char*  out_prefix;
   int32_t      device;
   int32_t      arbiter;            /* 1 = run the tie arbiter (default in the CLI) */
-  int32_t      n_gpus;             /* 0 or 1: one GPU (`device`).  N > 1: one engine (own HIP stream) on each of devices
-                                      (device + i) mod (visible devices).  The byte-wise sorted barcodes are cut into contiguous
-                                      ranges of equal work — at least one per engine, more when a range's doublet grid would
-                                      exceed the byte budget (4 GiB, a third of the free device memory if that is less) — which go
-                                      through the engines in waves; the rows of a wave are formatted and appended on the host while
-                                      the next wave computes.  Barcodes are independent (cmd_cram_demuxlet.cpp:576): no collective. */
+  int32_t      n_gpus;             /* 0 or 1: one GPU (`device`).  N > 1: devices (device + i) mod (visible devices).  The byte-wise
+                                      sorted barcodes are cut into contiguous ranges of equal work — at least one per GPU, four for jobs
+                                      worth overlapping, more when a range's doublet grid would exceed the byte budget (4 GiB, or a sixth of
+                                      the free device memory) — which go through the GPUs in waves.  With several waves every GPU runs two
+                                      engines (own HIP stream each) that alternate: the H2D of wave w + 2 overlaps the kernels of wave w + 1
+                                      while the host arbitrates, formats and appends the rows of wave w.  Barcodes are independent
+                                      (cmd_cram_demuxlet.cpp:576): no collective. */
   int32_t      mode;               /* DMX_MODE_STRICT (0, default) or DMX_MODE_FAST */
   /* Optional (ABI 2): a pileup that is already frozen (host memory, sparse or dense layout) instead of `store` (then NULL), with
    * its barcodes by cell id — what a caller that builds the CSR itself hands over (tools/e2e_bench.cpp, the benchmarks). */
