@@ -490,7 +490,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
   __syncthreads();                               // the only workgroup barrier
 
   double* term = s_term[w];
-  double* scr = &s_scr[w][lane * SD];
+  double* scr = &s_scr[w][lane];                 // class-major [d][lane]: a lane's four terms sit 512 bytes apart, i.e. in the SAME
+                                                 // bank pair, and the 32 lanes of an LDS cycle in 32 different ones whatever class each
+                                                 // of them looks up (lane-major [lane][d] made every lookup a 4-way bank conflict)
   double* accs = s_dyn + (size_t)w * nch * CW * NC;
   const int slot0 = (blockIdx.x * NW + w) * CW;
   if (slot0 >= pv.B) return;
@@ -567,11 +569,11 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
                            __builtin_amdgcn_class(x3, 0x100) && __builtin_amdgcn_class(x4, 0x100);
       double* t0 = &term[(c * NC + KC) * TS + ti];   // the llk0 chain's slot of this pair
       if (__builtin_expect(fast_ok, 1)) {
-        scr[0] = dmx_log_fast(x0, s_log); scr[1] = dmx_log_fast(x1, s_log); scr[2] = dmx_log_fast(x2, s_log);
-        scr[3] = dmx_log_fast(x3, s_log); *t0 = dmx_log_fast(x4, s_log);
+        scr[0] = dmx_log_fast(x0, s_log); scr[64] = dmx_log_fast(x1, s_log); scr[128] = dmx_log_fast(x2, s_log);
+        scr[192] = dmx_log_fast(x3, s_log); *t0 = dmx_log_fast(x4, s_log);
       } else {                                     // never for real likelihoods; keeps log(0) / log(nan) semantics
-        scr[0] = x0; scr[1] = x1; scr[2] = x2; scr[3] = x3; *t0 = x4;
-        for (int d = 0; d < SD; ++d) scr[d] = log(scr[d]);
+        scr[0] = x0; scr[64] = x1; scr[128] = x2; scr[192] = x3; *t0 = x4;
+        for (int d = 0; d < SD; ++d) scr[64 * d] = log(scr[64 * d]);
         *t0 = log(*t0);
       }
     }
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
         const uint32_t bits = wcur >> (2 * (k0 & 15));      // the chunk's KC class ids, 2 bits each
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk)
-          term[(c * NC + kk) * TS + ti] = scr[(bits >> (2 * kk)) & 3u];     // sample k0+kk's term (slots past V-1 are never summed)
+          term[(c * NC + kk) * TS + ti] = scr[((bits >> (2 * kk)) & 3u) << 6];     // sample k0+kk's term (slots past V-1 are never summed)
       }
       DMX_WAVE_LDS_ORDER();
       if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
