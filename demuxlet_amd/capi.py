@@ -57,12 +57,14 @@ class CellSummary(C.Structure):
                 ("llk12", C.c_double), ("llk1", C.c_double), ("llk2", C.c_double), ("llk10", C.c_double), ("llk20", C.c_double),
                 ("llk00_0", C.c_double), ("llk00_best", C.c_double),
                 ("i_sing1", C.c_int32), ("i_sing2", C.c_int32), ("j_best", C.c_int32), ("k_best", C.c_int32),
-                ("n_best", C.c_int32), ("n_pairs", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("n_best", C.c_int32), ("n_pairs", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
+                ("llk_ab", C.c_double), ("llk_ba", C.c_double)]
 
 
 SUMMARY_DTYPE = np.dtype([(n, np.float64) for n in ("max_llk", "sum_single", "sum_double", "sing_llk1", "sing_llk2", "llk12",
                                                     "llk1", "llk2", "llk10", "llk20", "llk00_0", "llk00_best")] +
-                         [(n, np.int32) for n in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best", "n_pairs", "flags", "reserved")])
+                         [(n, np.int32) for n in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best", "n_pairs", "flags", "reserved")] +
+                         [(n, np.float64) for n in ("llk_ab", "llk_ba")])
 assert SUMMARY_DTYPE.itemsize == C.sizeof(CellSummary)
 
 

@@ -2955,7 +2955,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
     r.llk1 = hasb ? G[(size_t)jb * V * A] : kNaN; r.llk2 = hasb ? G[(size_t)kb * V * A] : kNaN;
     r.llk10 = hasb ? G[(size_t)jb * V * A + nb] : kNaN; r.llk20 = hasb ? G[(size_t)kb * V * A + nb] : kNaN;    // :824-825
     r.llk00_0 = l00[(size_t)cell * A]; r.llk00_best = l00[(size_t)cell * A + nb];
-    r.n_pairs = npairs; r.flags = flags; r.reserved = 0;
+    r.n_pairs = npairs; r.flags = flags; r.reserved = 0; r.llk_ab = 0.0; r.llk_ba = 0.0;
     out[cell] = r;
   }
 }
@@ -3116,6 +3116,7 @@ __global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_wid
     if (nj != sm.j_best) { r.llk1 = sm.llk2; r.llk2 = sm.llk1; r.llk10 = sm.llk20; r.llk20 = sm.llk10; }
     r.j_best = nj; r.k_best = nk;
     r.llk12 = ba ? ba_lo : ab_lo;
+    r.llk_ab = ab_lo; r.llk_ba = ba_lo;
     r.flags = sm.flags | DMX_CELL_ORDER_CERTIFIED;
     summ[cell] = r;
   }
@@ -4060,8 +4061,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     if (doublet_ok) {
       x.l00.resize(nb1 * (size_t)A);
       if (job->write_pair) {                     // .pair prints the grid: bring all of it
-        x.grid.resize(nb1 * nAB);
-        if (int rc = dmx_engine_get_doublet(e, x.grid.data(), x.l00.data(), nullptr)) return rc;
+        x.grid.resize(nb1 * nAB); x.summ.resize(nb1);
+        if (int rc = dmx_engine_get_doublet(e, x.grid.data(), x.l00.data(), x.summ.data())) return rc;
       } else {                                   // otherwise the K3 records say everything, except for cells flagged as near-ties
         x.sing.resize(nb1 * (size_t)V); x.summ.resize(nb1);
         if (int rc = dmx_engine_get_doublet(e, nullptr, x.l00.data(), x.summ.data())) return rc;
@@ -4102,7 +4103,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
       fin.llks00 = x.l00.data();
       if (job->arbiter) { fin.tie_pileup = sliced ? &x.pl : &pl; fin.tie_g = job->g; }
       dmx::DoubletSource src{};
-      if (job->write_pair) { fin.llksAB = x.grid.data(); src.grid_all = x.grid.data(); }
+      if (job->write_pair) { fin.llksAB = x.grid.data(); src.grid_all = x.grid.data(); src.summary = x.summ.data(); }
       else { src.sing = x.sing.data(); src.summary = x.summ.data(); src.cell_grid = x.cell_grid.data(); }
       if (int rc = dmx::write_doublet_core(&fin, src, job->out_prefix, r > 0, "dmx_demuxlet_run")) return rc;
     }

@@ -915,7 +915,17 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
     int32_t i_sing1, i_sing2, jb, kb, nb;
     const double* sg = nullptr;                                            // singlet column when there is no grid
     if (grid) {
-      if (arbiter) {
+      constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
+      if (arbiter && src.summary && (src.summary[c].flags & DMX_CELL_ORDER_CERTIFIED) && !(src.summary[c].flags & kNear)) {
+        // the device certified both accumulators of the best alpha = 0.5 pair (K3b) and K3 saw no other near-tie: the two
+        // entries the arbiter would re-evaluate are known, bit for bit
+        const dmx_cell_summary& sm = src.summary[c];
+        const int32_t a = std::min(sm.j_best, sm.k_best), b = std::max(sm.j_best, sm.k_best);
+        scratch.assign(grid, grid + ng);
+        scratch[((size_t)a * V + b) * A + sm.n_best] = sm.llk_ab;
+        scratch[((size_t)b * V + a) * A + sm.n_best] = sm.llk_ba;
+        grid = scratch.data();
+      } else if (arbiter) {
         // Which entries sit within tol of a decision?  top-2 singlets (:746-758) and the best doublet (:799-814).
         reqs.clear();
         double s1 = -1e300, s2 = -1e300;

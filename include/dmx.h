@@ -129,6 +129,8 @@ typedef struct {
   int32_t n_pairs;             /* N.SNP of the cell; 0 => the cell has no .best row (:592) */
   int32_t flags;               /* DMX_CELL_* : decisions that sit within 1e-7 of an alternative other than the (j,k)/(k,j) mirror */
   int32_t reserved;
+  double  llk_ab, llk_ba;      /* with DMX_CELL_ORDER_CERTIFIED: llksAB[a][b][n_best] and llksAB[b][a][n_best], a = min(j_best, k_best),
+                                  b = max, exactly as the reference computes them (what the host tie arbiter would re-evaluate) */
 } dmx_cell_summary;
 enum { DMX_CELL_NEAR_DOUBLET = 1,   /* another doublet entry (not the alpha = 0.5 mirror of the best one) within 1e-7 of the best */
        DMX_CELL_NEAR_SINGLET = 2,   /* the best two singlets within 1e-7 of each other, or a third within 1e-7 of the second */
