@@ -1031,8 +1031,8 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 //           :553), the nine-term l-major sums for both alphas (:677-679), log, add (:683).
 // log() arguments outside the normal positive range cannot occur for genuine likelihoods; if one does, the cell is
 // flagged and recomputed by k_doublet_generic<FIXUP> with ocml's log().
-template <int TPC, int NK>
-__global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
+template <int TPC, int NK, int MINW = 1>
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                          const double* __restrict__ alpha,
                                                          const int32_t* __restrict__ sched, int32_t V, int32_t GS,
@@ -1044,9 +1044,17 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab];
+  __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha: [n][0..8] = p (ALT), [n][9..17] = 1 - p; in LDS so
+                                                 // that they occupy registers only while phase 1 runs (36 VGPRs otherwise)
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
   for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  if (t < 18) {
+    const int n = t / 9, l = (t % 9) / 3, m = t % 3;
+    const double p = 0.5 * l + (m - l) * 0.5 * alpha[n];
+    s_w[n][t % 9] = p;
+    s_w[n][9 + t % 9] = 1.0 - p;
+  }
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
@@ -1081,18 +1089,6 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
   bool ok = true;
   // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1; mixing weights of :613
   const int ti1 = tid >> 1, n1 = tid & 1;
-  double wA[9], wR[9];
-  {
-    const double al = alpha[n1];
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const double p = 0.5 * l + (m - l) * 0.5 * al;
-        wA[l * 3 + m] = p;
-        wR[l * 3 + m] = 1.0 - p;
-      }
-  }
   double acc00 = 0.0;                            // lane n1 == tid < 2 owns llks00[n]
   const int row_len = V * 3;
 
@@ -1124,9 +1120,9 @@ __global__ __launch_bounds__(kThreads) void k_doublet_a2(PileupView pv, int nrd_
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
-      double pG[9];
+      double pG[9], wA[9], wR[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
+      for (int i = 0; i < 9; ++i) { pG[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][9 + i]; }   // :597
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
         const uint32_t byte = live ? pv.reads[off + r] : 0u;
@@ -3657,7 +3653,13 @@ int launch_doublet(dmx_engine* e) {
   }
   if (V <= 8) DMX_K2A(64, 1);
   else if (V <= 16) DMX_K2A(64, 4);
-  else if (V <= 32) DMX_K2A(256, 4);
+  else if (V <= 32) {
+    // 4 wavefronts per SIMD (128 VGPRs, a few spills outside the hot loop) measured 2.8 % faster than 3 (158 VGPRs) on cfg3
+    if (!getenv("DMX_A2_MINW1"))
+      hipLaunchKernelGGL((k_doublet_a2<256, 4, 4>), dim3((unsigned)B, slabs_of(256, 4)), block, cell_bytes, e->stream, e->pv, e->nrd_width, e->d_g,
+                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
+    else DMX_K2A(256, 4);
+  }
   else DMX_K2A(256, 16);
 #undef DMX_K2A
   HIP_TRY(hipGetLastError());
