@@ -1210,14 +1210,17 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
           const int k = min(kb * NK + kk, V - 1);
           const double b0 = (double)gr[k * 3], b1 = (double)gr[k * 3 + 1], b2 = (double)gr[k * 3 + 2];
           const double bk[3] = {b0, b1, b2};
-          double s0 = 0.0, s1 = 0.0;                                          // :674
+          // :674-679, l-major.  The reference starts from 0 and adds nine products; 0 + x is x for these non-negative
+          // products (no -0 can occur), so the first product initialises the sum: same bits, one add fewer per term.
+          double s0 = (aj[0] * bk[0]) * P0[0], s1 = (aj[0] * bk[0]) * P1[0];
 #pragma unroll
           for (int l = 0; l < 3; ++l)
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
+              if (l == 0 && m == 0) continue;
               const double gp = aj[l] * bk[m];                                // :553 (exact)
-              s0 += (gp * P0[l * 3 + m]);                                     // :677-679, l-major, alpha 0
-              s1 += (gp * P1[l * 3 + m]);                                     //                    alpha 1
+              s0 += (gp * P0[l * 3 + m]);                                     // alpha 0
+              s1 += (gp * P1[l * 3 + m]);                                     // alpha 1
             }
           ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
           acc[kk][0] += dmx_log_fast(s0, s_log);                              // :683
