@@ -116,6 +116,9 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
                       f"is slower, so this baseline is conservative), {t:.1f} s wall", seconds=t)
     if cfg["doublet"]:
         out["pair_evals_per_s"] = pairs * V * V * A / t
+    ref = reference_slice_leg(dp, g, cfg)
+    if ref:
+        out["reference_slice"] = ref
     # the same code on all host cores at once (the reference itself is single-threaded, cmd_cram_demuxlet.cpp has no
     # parallelism; this is what `--group-list` sharding over cores would buy): one thread per core, each thread its own
     # barcodes of the same workload, host memory bounded to ~6 GB
@@ -143,6 +146,49 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
         out["all_cores"] = dict(value=tot * V / wall, unit="cell-SNP-sample triples/s", cores=cores,
                                 sample=f"{cores} threads x {n_mt} barcodes x {reps} passes ({tot} covered pairs), {wall:.1f} s wall")
     return out
+
+
+def reference_slice_leg(dp, g, cfg, n_cells=24, n_snps=2000):
+    """the reference's OWN lines (cmd_cram_demuxlet.cpp:390-881 compiled verbatim into oracle/_ref/ref_slice_harness,
+    std::map store, materialised pair tables, text writers) timed on a corner of the same workload: the first n_cells barcodes
+    restricted to the first n_snps SNPs.  Only where the prebuilt harness travelled with the repo; it reads nothing else."""
+    import subprocess
+    import tempfile
+    from oracle import oracle_py as O
+    if not O.have_ref() or not cfg["doublet"]:
+        return None
+    V = cfg["V"]
+    n_cells = min(n_cells, dp.n_cells)
+    n_snps = min(n_snps, dp.n_snps)
+    h = dp.host_slice(0, n_cells)
+    po, ro = h["cell_pair_off"], h["cell_read_off"]
+    bc, snp, umi, al, bq, nr = [], [], [], [], [], []
+    pairs = 0
+    for c in range(n_cells):
+        r = int(ro[c])
+        for p in range(int(po[c]), int(po[c + 1])):
+            s = int(h["pair_snp"][p]) if h["pair_snp"] is not None else p - int(po[c])
+            n = int(h["pair_nrd"][p])
+            if s < n_snps:
+                pairs += 1
+                for q in range(n):
+                    b = int(h["reads"][r + q])
+                    bc.append(f"BC{c:05d}"); snp.append(s); umi.append(f"U{q:03d}"); al.append(b >> 7); bq.append(b & 127); nr.append(1)
+            r += n
+    ev = O.Events(bc, np.array(snp, dtype=np.int32), umi, np.array(al, dtype=np.uint8), np.array(bq, dtype=np.uint8), np.array(nr, dtype=np.uint8))
+    pb = O.Problem([f"s{j}" for j in range(V)], g[:n_snps], ev, O.Params(tuple(cfg["alphas"]), 0.5))
+    with tempfile.TemporaryDirectory() as td:
+        spec = os.path.join(td, "spec.txt")
+        O.write_spec(pb, spec)
+        r = subprocess.run([str(O.REF_HARNESS), spec, os.path.join(td, "ref"), "--no-raw"], capture_output=True, text=True)
+    secs = [float(l.split()[1]) for l in r.stderr.splitlines() if l.startswith("SLICE_SECONDS")]
+    if r.returncode != 0 or not secs:
+        return None
+    A = len(cfg["alphas"])
+    return dict(value=pairs * V / secs[0], unit="cell-SNP-sample triples/s", pair_evals_per_s=pairs * V * V * A / secs[0], cores=1, seconds=secs[0],
+                kind="reference lines 390-881, verbatim, behind I/O stand-ins (oracle/_ref/ref_slice_harness; see DESIGN.md §3)",
+                sample=f"first {n_cells} barcodes x first {n_snps} SNPs of the same workload ({pairs} covered pairs), incl. the reference's "
+                       f"S*V^2*9 pair-table precompute and its four text files")
 
 
 def pmc_profile(cfgno, B, mode):

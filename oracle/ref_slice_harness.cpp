@@ -36,6 +36,7 @@
 #include <set>
 #include <algorithm>
 #include <stdint.h>
+#include <time.h>
 
 #include "sc_drop_seq.h"
 #include "PhredHelper.h"
@@ -118,7 +119,12 @@ int main(int argc, char** argv) {
     g_dump_ab = fopen("/dev/null", "wb"); g_dump_00 = fopen("/dev/null", "wb"); g_dump_id = fopen("/dev/null", "wb");
   }
 
+  // wall-clock of the reference's lines alone (bench.py's cpu_baseline "reference_slice" leg reads this line)
+  struct timespec ts0, ts1;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
 #include DMX_REF_SLICE
+  clock_gettime(CLOCK_MONOTONIC, &ts1);
+  fprintf(stderr, "SLICE_SECONDS %.6f\n", (double)(ts1.tv_sec - ts0.tv_sec) + 1e-9 * (double)(ts1.tv_nsec - ts0.tv_nsec));
 
   if (raw) {
     FILE* f = fopen((outPrefix + ".raw.llks").c_str(), "wb");
