@@ -203,11 +203,11 @@ __device__ __forceinline__ void pair_gl(const uint8_t* __restrict__ rd, uint32_t
 // four row-shift adds give the scan inside each 16-lane row, row_bcast:15 / row_bcast:31 carry the row totals.
 template <int T>
 __device__ __forceinline__ uint32_t seg_scan_incl(uint32_t v) {
-  static_assert(T == 16 || T == 32 || T == 64, "segment width");
+  static_assert(T == 8 || T == 16 || T == 32 || T == 64, "segment width (8: the segment must start a 16-lane row)");
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1 (0 past the row start)
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
   v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
-  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  if (T >= 16) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
   if (T >= 32) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
   if (T >= 64) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
   return v;
@@ -1532,13 +1532,18 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
                                                           const int32_t* __restrict__ sched, int32_t V,
                                                           double* __restrict__ grid, double* __restrict__ l00,
                                                           uint8_t* __restrict__ flagged) {
-  constexpr int A = 2, TP = 32;
+  // Narrow panels put SEVERAL barcodes in one wavefront (TPC = 32: two, TPC = 16: four): their entries fill the lanes (V = 16: 160
+  // entries = 5 per lane of 32; V = 8: 48 = 3 per lane of 16) and the per-tile phases 0-1 are shared instruction-wise.  The tile is
+  // what one pass of phase 1 covers: two lanes per pair.
+  static_assert(TPC == 16 || TPC == 32 || TPC == 64 || TPC == 256, "threads per barcode");
+  constexpr int A = 2, TP = TPC >= 64 ? 32 : TPC / 2;
+  static_assert(SUB <= TP && TP % 8 == 0, "sub-tile");
   constexpr int CPW = kThreads / TPC;            // cells per workgroup
   constexpr int T00 = TP + 2;
   constexpr int NE = (VMAX * (VMAX / 2 + 1) + VMAX + TPC - 1) / TPC;   // entries per lane
   constexpr int VUS = (VMAX + 2) & ~1;           // u row stride (V alpha-0.5 rows + the alpha-0 row of sample 0), even
   constexpr int GSS = (3 * VMAX + 3) & ~3;       // genotype row stride (floats)
-#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+#define DMX_K2_SYNC() do { if (TPC <= 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab];
   __shared__ double s_w[2][10];                  // mixing weights of :613 per alpha and distinct value: [n][0..4] = p (ALT), [n][5..9] = 1 - p
@@ -1570,7 +1575,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 
   const int slot = blockIdx.x * CPW + cw;
   if (TPC == 64 && slot >= pv.B) return;         // whole wavefront idle (no workgroup barriers below in this mode)
-  const bool cell_ok = slot < pv.B;
+  const bool cell_ok = slot < pv.B;              // (sub-wavefront barcodes past the end stay in the wavefront with zero pairs)
   const int32_t cell = cell_ok ? sched[slot] : 0;
   const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
   const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
@@ -1601,7 +1606,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
     if (tid < TP) {
       const bool v = tid < tp;
       const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
-      const uint32_t incl = seg_scan_incl<32>(n);
+      const uint32_t incl = seg_scan_incl<TP>(n);
       s_cnt[tid] = n;
       s_off[tid] = rd_base + (int64_t)(incl - n);
       s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
@@ -1610,7 +1615,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
     rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
     // ---- phase 1: pG[n][3][3] of the pair (:600-663), exactly as k_doublet_a2; kept: alpha 0.5's nine values, and for
     //      alpha 0 the three u values of sample 0 (the only k the singlet column [j][0][0] needs)
-    if (tid < 64) {
+    if (tid < 2 * TP) {
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
@@ -3595,8 +3600,8 @@ int launch_doublet(dmx_engine* e) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do {                                                                                                                \
-    constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1;                                                  \
-    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
+    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
@@ -3606,8 +3611,8 @@ int launch_doublet(dmx_engine* e) {
   } while (0)
 #define DMX_K2SV(TPC, VMAX, SUB, FIX, MINW)                                                                            \
   do {                                                                                                                \
-    constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1;                                                  \
-    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
+    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
@@ -3615,8 +3620,10 @@ int launch_doublet(dmx_engine* e) {
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
-    if (V <= 8) { if (64 % V == 0) DMX_K2S(64, 8, 4, true); else DMX_K2S(64, 8, 4, false); }
-    else if (V <= 14) DMX_K2S(64, 14, 4, false);
+    const bool wide_cells = getenv("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
+    if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
+    else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
+    else if (V <= 8) { if (64 % V == 0) DMX_K2S(64, 8, 4, true); else DMX_K2S(64, 8, 4, false); }
     else if (V <= 17) { if (V == 16) DMX_K2S(64, 17, 4, true); else DMX_K2S(64, 17, 4, false); }
     else if (V <= 23) DMX_K2S(64, 23, 4, false);
     else if (V <= 27) DMX_K2S(64, 27, 4, false);
