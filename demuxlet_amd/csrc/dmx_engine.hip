@@ -223,6 +223,16 @@ __device__ __forceinline__ uint32_t seg_last(uint32_t v, int lane) {
   return (uint32_t)__shfl((int)v, T - 1, T);
 }
 
+// The first four stored read bytes of a pair as one (unaligned) 32-bit load; bytes past the pair's reads are never interpreted.
+__device__ __forceinline__ uint32_t load_rd4(const PileupView& pv, int64_t off, uint32_t cnt) {
+  uint32_t rd4 = 0;
+  if (cnt > 0) {
+    if (off + 4 <= pv.R) __builtin_memcpy(&rd4, pv.reads + off, 4);
+    else for (int64_t i = off; i < pv.R; ++i) rd4 |= (uint32_t)pv.reads[i] << (8 * (int)(i - off));
+  }
+  return rd4;
+}
+
 __device__ __forceinline__ uint32_t load_nrd(const void* __restrict__ base, int64_t p, int width) {
   if (width == 1) return ((const uint8_t*)base)[p];
   if (width == 2) return ((const uint16_t*)base)[p];
@@ -926,12 +936,13 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
       const bool on = lane1 && ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
       double pG[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) pG[i] = 1.0;                              // :597
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
-        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
         const uint32_t bq = byte & 127u;
         const bool alt = (byte >> 7) != 0;
         const double pR = alt ? s_lut[128 + bq] : s_lut[bq];               // :606
@@ -1120,12 +1131,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
       double pG[9], wA[9], wR[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) { pG[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][9 + i]; }   // :597
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
-        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
         const uint32_t bq = byte & 127u;
         const bool alt = (byte >> 7) != 0;
         const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
@@ -1346,12 +1358,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
       double pG[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
-        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
         const uint32_t bq = byte & 127u;
         const bool alt = (byte >> 7) != 0;
         const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
@@ -1600,16 +1613,30 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   double acc00 = 0.0;                            // lane n1 == tid < 2 owns llks00[n]
   const int row_len = V * 3;
 
+  // Narrow panels (short tiles, several barcodes per wavefront) request a tile's header one tile ahead; the wide forms have no
+  // register to spare for it (9 entries per lane at 167 VGPRs) and hide that latency behind their longer phase 2.
+  constexpr bool PREFETCH = TPC < 64;
+  uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
+  if (PREFETCH && tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
     const int tp = (int)min((int64_t)TP, np - tbase);
     // ---- headers of the tile's pairs (first 32 lanes of the cell)
     if (tid < TP) {
-      const bool v = tid < tp;
-      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      uint32_t n; int32_t sn;
+      if (PREFETCH) {                              // this tile's header was requested a tile ago; now request the next one's
+        n = hd_n; sn = hd_s;
+        const int64_t nx = tbase + TP + tid;
+        hd_n = 0u; hd_s = 0;
+        if (nx < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + nx, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + nx] : (int32_t)nx; }
+      } else {
+        const bool v = tid < tp;
+        n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+        sn = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+      }
       const uint32_t incl = seg_scan_incl<TP>(n);
       s_cnt[tid] = n;
       s_off[tid] = rd_base + (int64_t)(incl - n);
-      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+      s_snp[tid] = sn;
     }
     DMX_K2_SYNC();
     rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
@@ -1619,6 +1646,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
       const int32_t snp1 = on ? s_snp[ti1] : 0;
       const float* g0r = g + (size_t)snp1 * row_len;             // sample 0's row (alpha-0 lanes use it)
       const float gf0 = g0r[0], gf1 = g0r[1], gf2 = g0r[2];
@@ -1627,7 +1655,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
       for (int i = 0; i < 5; ++i) { q[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }   // :597
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
-        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
         const uint32_t bq = byte & 127u;
         const bool alt = (byte >> 7) != 0;
         const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
@@ -2173,12 +2201,13 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
       double pG[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) pG[i] = 1.0;
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
-        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
         const uint32_t bq = byte & 127u;
         const bool alt = (byte >> 7) != 0;
         const double pR = alt ? s_tab[128 + bq] : s_tab[bq];
@@ -2390,15 +2419,20 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
   const int ti1 = tid >> 1, n1 = tid & 1;
   double acc00 = 0.0;
 
+  uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
+  if (tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
     const int tp = (int)min((int64_t)TP, np - tbase);
     if (tid < TP) {
-      const bool v = tid < tp;
-      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t n = hd_n;                     // this tile's header was requested a tile ago; now request the next one's
+      const int32_t sn = hd_s;
+      const int64_t nx = tbase + TP + tid;
+      hd_n = 0u; hd_s = 0;
+      if (nx < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + nx, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + nx] : (int32_t)nx; }
       const uint32_t incl = seg_scan_incl<32>(n);
       s_cnt[tid] = n;
       s_off[tid] = rd_base + (int64_t)(incl - n);
-      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+      s_snp[tid] = sn;
     }
     DMX_WAVE_LDS_ORDER();
     rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
@@ -2413,13 +2447,14 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
       const int32_t snp1 = on ? s_snp[ti1] : 0;
       double qv[5], wA[5], wR[5];
 #pragma unroll
       for (int i = 0; i < 5; ++i) { qv[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }   // :597
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
-        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
         const uint32_t bq = byte & 127u;
         const bool alt = (byte >> 7) != 0;
         const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
@@ -3015,15 +3050,20 @@ __global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_wid
   bool ok = true;
   double acc = 0.0;                              // lanes 0..3: lower/upper bound of the (a,b) accumulator, of the (b,a) accumulator
   const int row_len = V * 3;
+  uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
+  if (tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
     const int tp = (int)min((int64_t)TP, np - tbase);
     if (tid < TP) {
-      const bool v = tid < tp;
-      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t n = hd_n;                     // this tile's header was requested a tile ago; now request the next one's
+      const int32_t sn = hd_s;
+      const int64_t nx = tbase + TP + tid;
+      hd_n = 0u; hd_s = 0;
+      if (nx < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + nx, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + nx] : (int32_t)nx; }
       const uint32_t incl = seg_scan_incl<32>(n);
       s_cnt[tid] = n;
       s_off[tid] = rd_base + (int64_t)(incl - n);
-      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+      s_snp[tid] = sn;
     }
     DMX_WAVE_LDS_ORDER();
     rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
@@ -3031,6 +3071,7 @@ __global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_wid
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
       const int32_t snp1 = on ? s_snp[ti1] : 0;
       const float* gr = g + (size_t)snp1 * row_len;
       const float fa0 = gr[ia * 3], fa1 = gr[ia * 3 + 1], fa2 = gr[ia * 3 + 2], fb0 = gr[ib * 3], fb1 = gr[ib * 3 + 1], fb2 = gr[ib * 3 + 2];
@@ -3039,7 +3080,7 @@ __global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_wid
       for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
-        const uint32_t byte = live ? pv.reads[off + r] : 0u;
+        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
         const uint32_t bq = byte & 127u;
         const bool alt = (byte >> 7) != 0;
         const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
