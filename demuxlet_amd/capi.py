@@ -19,6 +19,7 @@ DMX_MEM_HOST, DMX_MEM_DEVICE = 0, 1
 DMX_MODE_STRICT = 0
 DMX_MODE_FAST = 1
 DMX_CELL_NEAR_DOUBLET, DMX_CELL_NEAR_SINGLET, DMX_CELL_ORDER_CERTIFIED = 1, 2, 4
+DMX_ENGINE_NO_CERTIFY = 1
 
 # every symbol include/dmx.h declares (tests/test_abi.py checks the header against this list and the .so against both)
 SYMBOLS = [
@@ -48,7 +49,7 @@ class Pileup(C.Structure):
 
 class EngineConfig(C.Structure):
     _fields_ = [("n_samples", C.c_int32), ("n_alpha", C.c_int32), ("alpha", C.c_void_p), ("doublet_prior", C.c_double),
-                ("device", C.c_int32), ("mode", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("device", C.c_int32), ("mode", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class CellSummary(C.Structure):

@@ -3255,7 +3255,7 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTabTotal));
   HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabLogLo, dmx_log_table_lo_host, sizeof(double) * 128, hipMemcpyHostToDevice));
-  e->certify = !getenv("DMX_NO_CERTIFY") && dmx::libm_log_within_brackets();
+  e->certify = !(cfg->flags & DMX_ENGINE_NO_CERTIFY) && !getenv("DMX_NO_CERTIFY") && dmx::libm_log_within_brackets();
   HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
   HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
   double mat[256], err[256];
@@ -4048,6 +4048,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     dmx_engine_config cfg{};
     cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior;
     cfg.device = (job->device + (int)(i % (size_t)per_wave)) % ndev; cfg.mode = job->mode;
+    if (!job->arbiter) cfg.flags |= DMX_ENGINE_NO_CERTIFY;
     if (int rc = dmx_engine_create(&cfg, &eng[i])) return rc;
     if (int rc = dmx_engine_set_genotypes(eng[i], job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
   }

@@ -134,13 +134,13 @@ class Engine:
     """The likelihood engine on one MI355X."""
 
     def __init__(self, n_samples: int, alphas: Sequence[float] = (0.0, 0.5), doublet_prior: float = 0.5, device: int = 0,
-                 mode: int = capi.DMX_MODE_STRICT):
+                 mode: int = capi.DMX_MODE_STRICT, flags: int = 0):
         self._L = capi.load()
         self.V = int(n_samples)
         self.alphas = np.ascontiguousarray(alphas, dtype=np.float64)
         self.A = len(self.alphas)
         self.prior = float(doublet_prior)
-        cfg = capi.EngineConfig(self.V, self.A, self.alphas.ctypes.data, self.prior, device, mode)
+        cfg = capi.EngineConfig(self.V, self.A, self.alphas.ctypes.data, self.prior, device, mode, flags)
         h = C.c_void_p()
         check(self._L.dmx_engine_create(C.byref(cfg), C.byref(h)))
         self._h = h

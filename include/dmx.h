@@ -107,14 +107,19 @@ typedef struct {
   double  doublet_prior;       /* --doublet-prior */
   int32_t device;              /* HIP device ordinal */
   int32_t mode;                /* DMX_MODE_STRICT (0): reference operation order, no FMA contraction, IEEE division; or DMX_MODE_FAST */
-  int32_t reserved[4];
+  int32_t flags;               /* DMX_ENGINE_* */
+  int32_t reserved[3];
 } dmx_engine_config;
 enum { DMX_MODE_STRICT = 0,
-       /* Opt-in.  Same ownership and accumulation order; inside a doublet term the nine-term sum of cmd_cram_demuxlet.cpp:677-679
-        * is factored as g_j . (pG[n] g_k) with fused multiply-adds.  A term moves by a few ulp, a log-likelihood
-        * by <= ~1e-11 (tests bound it by 1e-9 against the reference); .best stays identical with the tie arbiter.  Affects the
-        * general (soft-field) A = 2 doublet kernel only; every other path is the STRICT one. */
+       /* Same ownership and accumulation order as STRICT.  Inside a doublet term the nine-term sum of cmd_cram_demuxlet.cpp:677-679
+        * is factored as g_j . (pG[n] g_k) with fused multiply-adds, and for the default grid {0, 0.5} only the
+        * entries demuxlet prints or decides on are evaluated: llksAB[j][0][0] and one of llksAB[j][k][1] / [k][j][1] (mirrored);
+        * llksAB[j][k != 0][0], read by the maxLLK scan (:713-721) only, is filled with llksAB[j][0][0].
+        * A printed log-likelihood moves by <= ~2e-11 (tests bound it by 1e-9 against the reference); .best stays identical.
+        * Other alpha grids and panels wider than 64 samples compute every entry, in the bilinear form. */
        DMX_MODE_FAST = 1 };
+enum { DMX_ENGINE_NO_CERTIFY = 1   /* skip the device-side tie-order certificate (K3b): for callers that do not need the
+                                      reference's DBL-a-b / DBL-b-a order (dmx_job.arbiter = 0 sets it) */ };
 
 /* per-cell result of the device-side reduction (K3) — what :713-734 and :746-770,:799-828 derive from one cell's grid */
 typedef struct {
