@@ -9,7 +9,7 @@ TAG=${1:-r02}; CFG=${2:-3}; EXTRA=${3:-}
 export TMPDIR=/tmp
 SFX=""; case "$EXTRA" in *--fast*) SFX="_fast";; esac
 OUT=$PWD/gpurun_out/prof_${TAG}_cfg${CFG}${SFX}; mkdir -p $OUT
-KRE="k_singlet|k_doublet_|k_reduce"
+KRE="k_singlet|k_doublet_|k_reduce|k_certify"
 STEPS=${STEPS:-5}; PSTEPS=${PSTEPS:-2}
 python bench.py --config $CFG $EXTRA --steps $STEPS --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
 ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$CFG$SFX -o kt -- python $OLDPWD/bench.py --config $CFG $EXTRA --steps $STEPS --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>/dev/null )
@@ -23,5 +23,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   ( cd /tmp && rocprofv3 --kernel-include-regex "$KRE" --output-format csv --pmc $set -d /tmp/pmc_${CFG}${SFX}_$i -o pmc -- python $OLDPWD/bench.py --config $CFG $EXTRA --steps $PSTEPS --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_$i.err )
   find /tmp/pmc_${CFG}${SFX}_$i -name "*counter_collection.csv" -exec cp {} $OUT/pmc_$i.csv \;
+  gzip -f $OUT/pmc_$i.csv            # gpurun copies at most 64 MiB back
 done
 ls -la $OUT

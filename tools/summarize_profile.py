@@ -11,6 +11,7 @@ v_cvt_f64_f32 is priced at 2 here (conservative: if it runs at the FP64 rate the
 gives that variant)."""
 import collections
 import csv
+import gzip
 import json
 import sys
 from pathlib import Path
@@ -31,8 +32,8 @@ with open(out / f"{tag}_cfg{cfg}{sfx}_kernel_stats.csv", "w") as f:
         w.writerow(r)
 summ = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
-for p in sorted(src.glob("pmc_*.csv")):
-    for r in csv.DictReader(open(p)):
+for p in sorted(list(src.glob("pmc_*.csv")) + list(src.glob("pmc_*.csv.gz"))):
+    for r in csv.DictReader(gzip.open(p, "rt") if p.suffix == ".gz" else open(p)):
         if "(anonymous namespace)::k_" not in r["Kernel_Name"]:
             continue
         k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
