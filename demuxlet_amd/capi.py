@@ -18,7 +18,7 @@ DMX_OK = 0
 DMX_MEM_HOST, DMX_MEM_DEVICE = 0, 1
 DMX_MODE_STRICT = 0
 DMX_MODE_FAST = 1
-DMX_CELL_NEAR_DOUBLET, DMX_CELL_NEAR_SINGLET, DMX_CELL_ORDER_CERTIFIED = 1, 2, 4
+DMX_CELL_NEAR_DOUBLET, DMX_CELL_NEAR_SINGLET, DMX_CELL_ORDER_CERTIFIED, DMX_CELL_ORDER_RESOLVABLE = 1, 2, 4, 8
 DMX_ENGINE_NO_CERTIFY = 1
 
 # every symbol include/dmx.h declares (tests/test_abi.py checks the header against this list and the .so against both)
@@ -31,6 +31,7 @@ SYMBOLS = [
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
     "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_write_doublet_summary", "dmx_debug_log_dd",
+    "dmx_resolve_tie_order",
 ]
 
 
@@ -59,13 +60,14 @@ class CellSummary(C.Structure):
                 ("llk00_0", C.c_double), ("llk00_best", C.c_double),
                 ("i_sing1", C.c_int32), ("i_sing2", C.c_int32), ("j_best", C.c_int32), ("k_best", C.c_int32),
                 ("n_best", C.c_int32), ("n_pairs", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32),
-                ("llk_ab", C.c_double), ("llk_ba", C.c_double)]
+                ("llk_ab", C.c_double), ("llk_ba", C.c_double), ("llk_ab_alt", C.c_double), ("llk_ba_alt", C.c_double),
+                ("ev_x_ab", C.c_double), ("ev_t_ab", C.c_double), ("ev_x_ba", C.c_double), ("ev_t_ba", C.c_double)]
 
 
 SUMMARY_DTYPE = np.dtype([(n, np.float64) for n in ("max_llk", "sum_single", "sum_double", "sing_llk1", "sing_llk2", "llk12",
                                                     "llk1", "llk2", "llk10", "llk20", "llk00_0", "llk00_best")] +
                          [(n, np.int32) for n in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best", "n_pairs", "flags", "reserved")] +
-                         [(n, np.float64) for n in ("llk_ab", "llk_ba")])
+                         [(n, np.float64) for n in ("llk_ab", "llk_ba", "llk_ab_alt", "llk_ba_alt", "ev_x_ab", "ev_t_ab", "ev_x_ba", "ev_t_ba")])
 assert SUMMARY_DTYPE.itemsize == C.sizeof(CellSummary)
 
 
@@ -142,6 +144,7 @@ def load() -> C.CDLL:
         "dmx_debug_device_div": [vp, vp, vp, C.c_int64, i32],
         "dmx_debug_log_rate": [i32, i32, i32, vp],
         "dmx_debug_log_dd": [vp, vp, vp, vp, vp, C.c_int64],
+        "dmx_resolve_tie_order": [vp, C.c_int64],
     }
     for name, args in sig.items():
         f = getattr(L, name)

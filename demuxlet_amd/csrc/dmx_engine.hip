@@ -2995,6 +2995,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
     r.llk10 = hasb ? G[(size_t)jb * V * A + nb] : kNaN; r.llk20 = hasb ? G[(size_t)kb * V * A + nb] : kNaN;    // :824-825
     r.llk00_0 = l00[(size_t)cell * A]; r.llk00_best = l00[(size_t)cell * A + nb];
     r.n_pairs = npairs; r.flags = flags; r.reserved = 0; r.llk_ab = 0.0; r.llk_ba = 0.0;
+    r.llk_ab_alt = 0.0; r.llk_ba_alt = 0.0; r.ev_x_ab = 0.0; r.ev_t_ab = 0.0; r.ev_x_ba = 0.0; r.ev_t_ba = 0.0;
     out[cell] = r;
   }
 }
@@ -3009,13 +3010,15 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
 // both operands).  When lower == upper for both, they ARE the reference's values and the order is decided here — for any such
 // libm; the host tie arbiter (which calls the host's log()) is left with the barcodes where a bracket stayed open, about one in
 // ten.  Requires A = 2 (phase 1 is k_doublet_a2's) and no other doublet entry within 1e-7 of the best (K3's flag).
-__global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_width, const float* __restrict__ g,
+__global__ __launch_bounds__(kThreads, 4) void k_certify(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                       const double* __restrict__ tabs, const double* __restrict__ alpha,
                                                       int32_t V, dmx_cell_summary* __restrict__ summ) {
   constexpr int TP = 32, T00 = TP + 2, TPC = 64, CPW = kThreads / TPC;
   __shared__ double s_tab[kTab];
   __shared__ double s_lo[128];
-  __shared__ __attribute__((aligned(16))) double s_t[CPW][4][T00];   // [ab_lo | ab_hi | ba_lo | ba_hi][pair]
+  __shared__ __attribute__((aligned(16))) double s_t[CPW][6][T00];   // [ab_lo | ab_hi | ba_lo | ba_hi | ab_x | ba_x][pair]
+  __shared__ double s_p[CPW][4][T00];                                // the four chains before each step of the tile (+ after the last)
+  __shared__ double s_ev[CPW][4];
   __shared__ int64_t s_offs[CPW][TP];
   __shared__ int32_t s_snps[CPW][TP];
   __shared__ uint32_t s_cnts[CPW][TP];
@@ -3027,9 +3030,11 @@ __global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_wid
   const int cw = t / TPC, tid = t % TPC;
   const int32_t cell = blockIdx.x * CPW + cw;
   if (cell >= pv.B) return;
-  const dmx_cell_summary sm = summ[cell];
-  if (sm.n_pairs <= 0 || sm.j_best < 0 || sm.k_best < 0 || sm.n_best != 1 || alpha[1] != 0.5 || (sm.flags & DMX_CELL_NEAR_DOUBLET)) return;
-  const int32_t ia = min(sm.j_best, sm.k_best), ib = max(sm.j_best, sm.k_best);
+  // only the five words the walk needs stay live (wave-uniform); the record itself is rewritten in place by lane 0
+  const int32_t sm_np = summ[cell].n_pairs, sm_j = __builtin_amdgcn_readfirstlane(summ[cell].j_best),
+                sm_k = __builtin_amdgcn_readfirstlane(summ[cell].k_best), sm_n = summ[cell].n_best, sm_fl = summ[cell].flags;
+  if (sm_np <= 0 || sm_j < 0 || sm_k < 0 || sm_n != 1 || alpha[1] != 0.5 || (sm_fl & DMX_CELL_NEAR_DOUBLET)) return;
+  const int32_t ia = min(sm_j, sm_k), ib = max(sm_j, sm_k);
   int64_t* s_off = s_offs[cw]; int32_t* s_snp = s_snps[cw]; uint32_t* s_cnt = s_cnts[cw];
   const int64_t p_beg = pv.cell_pair_off[cell];
   const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
@@ -3048,7 +3053,15 @@ __global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_wid
       }
   }
   bool ok = true;
-  double acc = 0.0;                              // lanes 0..3: lower/upper bound of the (a,b) accumulator, of the (b,a) accumulator
+  // Lanes 0..3 own the four chains: (a,b) low, (a,b) high, (b,a) low, (b,a) high = the accumulator had every ambiguous log() come
+  // out low / high.  While low == high an accumulator is known.  A step that splits them is an EVENT (its log() argument and
+  // lower candidate are kept); from there on each of the two paths has to stay unambiguous by itself (clean): then the
+  // reference's value is the low path if its libm returned the lower candidate at the event and the high path otherwise,
+  // whatever it returned elsewhere.  The chains are serial (one add per pair); the event / clean tests of a tile's 32 steps
+  // run lane-parallel on the chains' prefixes.
+  double acc = 0.0;
+  bool clean[2] = {true, true};
+  if (tid < 4) s_ev[cw][tid] = 0.0;               // [ab: log argument, lower candidate | ba: ...] of the open event
   const int row_len = V * 3;
   uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
   if (tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
@@ -3141,29 +3154,66 @@ __global__ __launch_bounds__(kThreads) void k_certify(PileupView pv, int nrd_wid
         ok &= __builtin_amdgcn_class(sx, 0x100);
         double lo1, hi1;
         dmx_log_bracket((uint32_t)__double2hiint(sx), (uint32_t)__double2loint(sx), s_log, s_lo, &lo1, &hi1);
-        s_t[cw][2 * n1][ti1] = lo1; s_t[cw][2 * n1 + 1][ti1] = hi1;
+        s_t[cw][2 * n1][ti1] = lo1; s_t[cw][2 * n1 + 1][ti1] = hi1; s_t[cw][4 + n1][ti1] = sx;
       }
     }
     DMX_WAVE_LDS_ORDER();
     if (tid < 4) {
       const double* row = &s_t[cw][tid][0];
-      for (int i = 0; i < tp; ++i) acc += row[i];                            // :683, in pair order
+      double* pre = &s_p[cw][tid][0];
+      double a = acc;
+      for (int i = 0; i < tp; ++i) { pre[i] = a; a += row[i]; }              // :683, in pair order
+      pre[tp] = a;
+      acc = a;
+    }
+    DMX_WAVE_LDS_ORDER();
+    {
+      const int i = tid & 31, w = tid >> 5;                                  // step i of accumulator w
+      bool ev = false, dirty = false;
+      if (i < tp) {
+        const double lo = s_p[cw][2 * w][i], hi = s_p[cw][2 * w + 1][i], ll = s_p[cw][2 * w][i + 1], hh = s_p[cw][2 * w + 1][i + 1];
+        const double tl = s_t[cw][2 * w][i], th = s_t[cw][2 * w + 1][i];
+        const double lh = lo + th, hl = hi + tl;
+        const bool closed = lo == hi;
+        ev = closed && (ll != lh);
+        dirty = !closed && !((ll == lh) && (hl == hh));
+      }
+      const uint64_t evm = __ballot(ev), dm = __ballot(dirty);
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2) {
+        const uint32_t e32 = (uint32_t)(evm >> (32 * w2)), d32 = (uint32_t)(dm >> (32 * w2));
+        if (e32) {
+          const int e = 31 - __clz((int)e32);                                // the tile's last event of this accumulator
+          if (tid == 0) { s_ev[cw][2 * w2] = s_t[cw][4 + w2][e]; s_ev[cw][2 * w2 + 1] = s_t[cw][2 * w2][e]; }
+          clean[w2] = (d32 & ~((2u << e) - 1u)) == 0u;                       // no dirty step after it
+        } else {
+          clean[w2] = clean[w2] && d32 == 0u;
+        }
+      }
     }
     DMX_WAVE_LDS_ORDER();
   }
   const bool all_ok = __all(ok ? 1 : 0) != 0;
   const double ab_lo = __shfl(acc, 0), ab_hi = __shfl(acc, 1), ba_lo = __shfl(acc, 2), ba_hi = __shfl(acc, 3);
+  if (tid == 0 && all_ok && !(ab_lo == ab_hi && ba_lo == ba_hi) && (ab_lo == ab_hi || clean[0]) && (ba_lo == ba_hi || clean[1])) {
+    dmx_cell_summary* r = summ + cell;
+    r->llk_ab = ab_lo; r->llk_ab_alt = ab_hi; r->llk_ba = ba_lo; r->llk_ba_alt = ba_hi;
+    r->ev_x_ab = s_ev[cw][0]; r->ev_t_ab = s_ev[cw][1]; r->ev_x_ba = s_ev[cw][2]; r->ev_t_ba = s_ev[cw][3];
+    r->flags = sm_fl | DMX_CELL_ORDER_RESOLVABLE;
+  }
   if (tid == 0 && all_ok && ab_lo == ab_hi && ba_lo == ba_hi) {
     // the reference's scan (:799-814, strict <) meets (a,b) before (b,a): it keeps (a,b) unless (b,a) is strictly larger
     const bool ba = ab_lo < ba_lo;
-    dmx_cell_summary r = sm;
+    dmx_cell_summary* r = summ + cell;
     const int32_t nj = ba ? ib : ia, nk = ba ? ia : ib;
-    if (nj != sm.j_best) { r.llk1 = sm.llk2; r.llk2 = sm.llk1; r.llk10 = sm.llk20; r.llk20 = sm.llk10; }
-    r.j_best = nj; r.k_best = nk;
-    r.llk12 = ba ? ba_lo : ab_lo;
-    r.llk_ab = ab_lo; r.llk_ba = ba_lo;
-    r.flags = sm.flags | DMX_CELL_ORDER_CERTIFIED;
-    summ[cell] = r;
+    if (nj != sm_j) {
+      const double l1 = r->llk1, l2 = r->llk2, l10 = r->llk10, l20 = r->llk20;
+      r->llk1 = l2; r->llk2 = l1; r->llk10 = l20; r->llk20 = l10;
+    }
+    r->j_best = nj; r->k_best = nk;
+    r->llk12 = ba ? ba_lo : ab_lo;
+    r->llk_ab = ab_lo; r->llk_ba = ba_lo; r->llk_ab_alt = ab_lo; r->llk_ba_alt = ba_lo;
+    r->flags = sm_fl | DMX_CELL_ORDER_CERTIFIED;
   }
 }
 

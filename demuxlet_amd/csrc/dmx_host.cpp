@@ -123,6 +123,43 @@ using dmx::set_error;
 
 extern "C" int dmx_abi_version(void) { return DMX_ABI_VERSION; }
 
+// DMX_CELL_ORDER_RESOLVABLE (K3b): each accumulator of the best alpha = 0.5 pair is one of two doubles the device computed, and
+// which one depends on what the reference's libm returns for one log().  The host's libm is that libm: ask it.  On success the
+// record reads like a certified one (order, llk12, llk_ab, llk_ba are the reference's); false = the libm's answer is neither
+// candidate (the tie arbiter decides).
+bool dmx::resolve_tie_order(dmx_cell_summary* r) {
+  double ab = r->llk_ab, ba = r->llk_ba;
+  if (r->llk_ab_alt != r->llk_ab) {
+    const double L = std::log(r->ev_x_ab);
+    if (L == r->ev_t_ab) ab = r->llk_ab;
+    else if (L == std::nextafter(r->ev_t_ab, HUGE_VAL)) ab = r->llk_ab_alt;
+    else return false;
+  }
+  if (r->llk_ba_alt != r->llk_ba) {
+    const double L = std::log(r->ev_x_ba);
+    if (L == r->ev_t_ba) ba = r->llk_ba;
+    else if (L == std::nextafter(r->ev_t_ba, HUGE_VAL)) ba = r->llk_ba_alt;
+    else return false;
+  }
+  const int32_t ia = std::min(r->j_best, r->k_best), ib = std::max(r->j_best, r->k_best);
+  const bool ba_wins = ab < ba;               // the reference's strict-< scan (:799-814) meets (a,b) first
+  const int32_t nj = ba_wins ? ib : ia, nk = ba_wins ? ia : ib;
+  if (nj != r->j_best) { std::swap(r->llk1, r->llk2); std::swap(r->llk10, r->llk20); }
+  r->j_best = nj; r->k_best = nk;
+  r->llk12 = ba_wins ? ba : ab;
+  r->llk_ab = ab; r->llk_ba = ba; r->llk_ab_alt = ab; r->llk_ba_alt = ba;
+  r->flags = (r->flags | DMX_CELL_ORDER_CERTIFIED) & ~DMX_CELL_ORDER_RESOLVABLE;
+  return true;
+}
+
+extern "C" int dmx_resolve_tie_order(dmx_cell_summary* summary, int64_t n) {
+  if (n < 0 || (n && !summary)) return set_error(DMX_ERR_ARG, "dmx_resolve_tie_order: bad arguments");
+  int left = 0;
+  for (int64_t i = 0; i < n; ++i)
+    if ((summary[i].flags & DMX_CELL_ORDER_RESOLVABLE) && !dmx::resolve_tie_order(&summary[i])) ++left;
+  return left;
+}
+
 bool dmx::libm_log_within_brackets() {
   static const bool ok = [] {
     uint64_t st = 0x243F6A8885A308D3ull;
@@ -914,12 +951,18 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
     double max_llk, sum_single, sum_double, sing1, sing2v, l12, l1, l2, l10, l20;
     int32_t i_sing1, i_sing2, jb, kb, nb;
     const double* sg = nullptr;                                            // singlet column when there is no grid
+    dmx_cell_summary resolved;
+    const dmx_cell_summary* smp = src.summary ? &src.summary[c] : nullptr;
+    if (arbiter && smp && (smp->flags & DMX_CELL_ORDER_RESOLVABLE)) {      // K3b left one log() per accumulator to the host's libm
+      resolved = *smp;
+      if (dmx::resolve_tie_order(&resolved)) smp = &resolved;
+    }
     if (grid) {
       constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
-      if (arbiter && src.summary && (src.summary[c].flags & DMX_CELL_ORDER_CERTIFIED) && !(src.summary[c].flags & kNear)) {
+      if (arbiter && smp && (smp->flags & DMX_CELL_ORDER_CERTIFIED) && !(smp->flags & kNear)) {
         // the device certified both accumulators of the best alpha = 0.5 pair (K3b) and K3 saw no other near-tie: the two
         // entries the arbiter would re-evaluate are known, bit for bit
-        const dmx_cell_summary& sm = src.summary[c];
+        const dmx_cell_summary& sm = *smp;
         const int32_t a = std::min(sm.j_best, sm.k_best), b = std::max(sm.j_best, sm.k_best);
         scratch.assign(grid, grid + ng);
         scratch[((size_t)a * V + b) * A + sm.n_best] = sm.llk_ab;
@@ -961,7 +1004,7 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
       l10 = grid[(size_t)jb * V * A + nb];                                 // :824 pairs with sample 0 (reference quirk)
       l20 = grid[(size_t)kb * V * A + nb];                                 // :825
     } else {
-      dmx_cell_summary sm = src.summary[c];
+      dmx_cell_summary sm = *smp;
       if (sm.i_sing1 < 0) sm.i_sing1 = 0;         // NaN likelihoods: see above
       if (sm.i_sing2 < 0) sm.i_sing2 = 0;
       if (sm.j_best < 0) { sm.j_best = 0; sm.k_best = 0; sm.n_best = 0; }

@@ -66,6 +66,7 @@ struct DoubletSource {
 };
 // true when the host libm's log() stays inside dmx_log_bracket()'s brackets on a fixed sample of arguments (checked once)
 bool libm_log_within_brackets();
+bool resolve_tie_order(dmx_cell_summary* r);   // DMX_CELL_ORDER_RESOLVABLE -> certified, by the host libm's log()
 int write_doublet_core(const dmx_final_input* in, const DoubletSource& src, const char* out_prefix, bool append, const char* who);
 
 // The writers behind dmx_write_single / dmx_write_doublet with an append mode: dmx_demuxlet_run streams contiguous ranges

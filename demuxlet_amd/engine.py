@@ -290,6 +290,13 @@ def write_doublet_summary(fa: FinalArgs, sing, l00, summary, out_prefix: str, ti
     check(capi.load().dmx_write_doublet_summary(C.byref(fin), sing.ctypes.data, summary.ctypes.data, out_prefix.encode()))
 
 
+def resolve_tie_order(summary: np.ndarray) -> int:
+    """dmx_resolve_tie_order: DMX_CELL_ORDER_RESOLVABLE records -> certified ones, in place (the host libm's log() decides).
+    Returns how many stayed unresolved."""
+    assert summary.dtype == capi.SUMMARY_DTYPE and summary.flags["C_CONTIGUOUS"]
+    return check(capi.load().dmx_resolve_tie_order(summary.ctypes.data, len(summary)))
+
+
 def demuxlet_run(store, g: np.ndarray, sample_ids: Sequence[str], alphas: Sequence[float], out_prefix: str,
                  doublet_prior: float = 0.5, min_total: int = 0, min_uniq: int = 0, min_snp: int = 0,
                  write_pair: bool = False, device: int = 0, arbiter: bool = True, n_gpus: int = 1, mode: int = capi.DMX_MODE_STRICT,

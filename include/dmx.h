@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 2
+#define DMX_ABI_VERSION 3
 
 typedef enum {
   DMX_OK = 0,
@@ -136,11 +136,18 @@ typedef struct {
   int32_t reserved;
   double  llk_ab, llk_ba;      /* with DMX_CELL_ORDER_CERTIFIED: llksAB[a][b][n_best] and llksAB[b][a][n_best], a = min(j_best, k_best),
                                   b = max, exactly as the reference computes them (what the host tie arbiter would re-evaluate) */
+  /* with DMX_CELL_ORDER_RESOLVABLE: each accumulator is one of two known doubles, and which one hangs on what the reference's
+   * libm returns for ONE log():  llksAB[a][b] = llk_ab if log(ev_x_ab) == ev_t_ab, llk_ab_alt if it is the next double above
+   * ev_t_ab (anything else: no statement); likewise (b,a).  An accumulator with llk_*_alt == llk_* is already certain. */
+  double  llk_ab_alt, llk_ba_alt;
+  double  ev_x_ab, ev_t_ab, ev_x_ba, ev_t_ba;
 } dmx_cell_summary;
 enum { DMX_CELL_NEAR_DOUBLET = 1,   /* another doublet entry (not the alpha = 0.5 mirror of the best one) within 1e-7 of the best */
        DMX_CELL_NEAR_SINGLET = 2,   /* the best two singlets within 1e-7 of each other, or a third within 1e-7 of the second */
-       DMX_CELL_ORDER_CERTIFIED = 4 /* the order (j_best, k_best) of an alpha = 0.5 best doublet and llk12 are the reference's, bit for
-                                       bit (device certificate, DESIGN.md "Ties"): the host tie arbiter has nothing left to decide */ };
+       DMX_CELL_ORDER_CERTIFIED = 4, /* the order (j_best, k_best) of an alpha = 0.5 best doublet and llk12 are the reference's, bit for
+                                       bit (device certificate, DESIGN.md "Ties"): the host tie arbiter has nothing left to decide */
+       DMX_CELL_ORDER_RESOLVABLE = 8 /* the certificate stayed open over a single log() per accumulator: one host log() call each
+                                       (dmx_write_doublet* do it) yields the reference's order and llk12 without the pileup */ };
 
 int dmx_engine_create(const dmx_engine_config*, dmx_engine** out);
 int dmx_engine_destroy(dmx_engine*);
@@ -211,6 +218,10 @@ int dmx_write_doublet(const dmx_final_input*, const char* out_prefix);          
  * in->llksAB is ignored; in->write_pair must be 0 (the .pair rows need the grid).  With in->tie_pileup the order of
  * the two samples of an alpha = 0.5 best doublet is arbitrated exactly. */
 int dmx_write_doublet_summary(const dmx_final_input*, const double* sing, const dmx_cell_summary* summary, const char* out_prefix);
+/* For consumers of the K3 records themselves: turn every DMX_CELL_ORDER_RESOLVABLE record among summary[0..n) into a certified one
+ * by asking this host's libm for the one or two log() values the device left open (the writers above do the same internally).
+ * Returns the number of records that stay unresolved (>= 0), or a negative dmx_status. */
+int dmx_resolve_tie_order(dmx_cell_summary* summary, int64_t n);
 
 /* Diagnostics: evaluate the device's log() replacement (dmx_log, csrc/dmx_log.hpp) on n host doubles. Used by the tests
  * to show the device function performs exactly the IEEE operation sequence whose accuracy is measured on the host. */

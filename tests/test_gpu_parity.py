@@ -682,14 +682,17 @@ def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_pat
     e.close()
     covered = summ["n_pairs"] > 0
     cert = (summ["flags"] & capi.DMX_CELL_ORDER_CERTIFIED) != 0
+    resv = (summ["flags"] & capi.DMX_CELL_ORDER_RESOLVABLE) != 0
+    assert not (cert & resv).any()
     frac = cert[covered].mean()
-    print(f"V={V} {field} {mode}: {cert.sum()} of {covered.sum()} covered barcodes carry the order certificate ({100 * frac:.1f} %)")
+    print(f"V={V} {field} {mode}: {cert.sum()} of {covered.sum()} covered barcodes carry the order certificate ({100 * frac:.1f} %), "
+          f"{resv.sum()} more hang on one host log() per accumulator ({100 * resv[covered].mean():.1f} %)")
     assert frac > 0.5
     fa = eng.FinalArgs([f"BC{i:05d}" for i in range(B)], [f"S{j}" for j in range(V)], (0.0, 0.5), 0.5, sp.rd_totl, sp.rd_pass, sp.rd_uniq,
                        pl.n_snp_per_cell)
     eng.write_doublet_summary(fa, sing, l00, summ, str(tmp_path / "cert"), tie_pileup=pl, tie_g=g)
     wiped = summ.copy()
-    wiped["flags"] &= ~np.int32(capi.DMX_CELL_ORDER_CERTIFIED)
+    wiped["flags"] &= ~np.int32(capi.DMX_CELL_ORDER_CERTIFIED | capi.DMX_CELL_ORDER_RESOLVABLE)
     eng.write_doublet_summary(fa, sing, l00, wiped, str(tmp_path / "host"), tie_pileup=pl, tie_g=g)
     for suf in ("sing2", "best"):
         assert (tmp_path / f"cert.{suf}").read_bytes() == (tmp_path / f"host.{suf}").read_bytes(), suf
@@ -703,3 +706,18 @@ def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_pat
         assert summ[c]["llk12"] == want["llk12"], c               # the reference's bits
         n_swapped += int(summ[c]["j_best"] > summ[c]["k_best"])
     print(f"   {n_swapped} certified barcodes name the doublet in descending sample order, as the reference does")
+    # the resolvable ones: the reference's accumulators are among the two candidates each, and the host's libm picks them
+    done = summ.copy()
+    left = eng.resolve_tie_order(done)
+    print(f"   {resv.sum() - left} of {resv.sum()} resolvable barcodes resolved by the host libm")
+    for c in np.flatnonzero(resv):
+        a, b = sorted((int(summ[c]["j_best"]), int(summ[c]["k_best"])))
+        assert ref.llksAB[c][a][b][1] in (summ[c]["llk_ab"], summ[c]["llk_ab_alt"]), c
+        assert ref.llksAB[c][b][a][1] in (summ[c]["llk_ba"], summ[c]["llk_ba_alt"]), c
+        if done[c]["flags"] & capi.DMX_CELL_ORDER_CERTIFIED:
+            want = summary_from_grid(ref.llksAB[c], ref.llks00[c], (0.0, 0.5), 0.5, int(summ[c]["n_pairs"]), summ.dtype)
+            assert (int(done[c]["j_best"]), int(done[c]["k_best"])) == (int(want["j_best"]), int(want["k_best"])), c
+            assert done[c]["llk12"] == want["llk12"] and done[c]["llk_ab"] == ref.llksAB[c][a][b][1] and done[c]["llk_ba"] == ref.llksAB[c][b][a][1], c
+            for f in ("llk1", "llk2", "llk10", "llk20"):
+                assert abs(done[c][f] - want[f]) < 1e-9, (c, f)
+    assert left <= max(1, resv.sum() // 20)
