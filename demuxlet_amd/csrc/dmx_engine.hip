@@ -20,6 +20,8 @@
 #include <mutex>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <new>
 #include <memory>
 #include <functional>
@@ -3233,14 +3235,19 @@ struct dmx_engine {
   float* d_rows = nullptr; uint8_t* d_ids = nullptr; uint32_t* d_idw = nullptr; uint32_t* d_idd = nullptr; int32_t nwd2 = 0; int32_t n_classes = 0;   // genotype classes (0 = not usable)
   // pileup
   PileupView pv{}; int32_t nrd_width = 1; int64_t P = 0, R = 0; bool have_pileup = false;
-  void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  int32_t* d_sched = nullptr;
+  void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // device copies of a host pileup (grow-only: a job's ranges reuse them)
+  size_t own_cap[5] = {0, 0, 0, 0, 0};
+  int32_t* d_sched = nullptr; size_t sched_cap = 0;
+  int32_t* d_bad = nullptr;                                          // set by k_check_snp_ids
+  bool have_gT = false;                                              // d_gT / d_g0T hold the current genotype matrix
+  // host -> device staging of the big pileup arrays: two pinned chunks filled by host threads while the other one is in flight
+  void* h_stage[2] = {nullptr, nullptr}; hipEvent_t ev_stage[2] = {nullptr, nullptr}; bool stage_busy[2] = {false, false}; int stage_cur = 0;
   // results
   double *d_llks = nullptr, *d_llk0s = nullptr, *d_grid = nullptr, *d_l00 = nullptr;
   dmx_cell_summary* d_sum = nullptr;
   uint8_t* d_flag = nullptr;
   double* d_sing = nullptr;
-  int32_t out_B = 0; bool have_grid = false, have_sing = false;
+  int32_t out_cap = 0, grid_cap = 0; bool have_grid = false, have_sing = false;   // cells the result buffers hold
   hipEvent_t ev[8] = {};
   bool timed[4] = {false, false, false, false};
 };
@@ -3248,10 +3255,21 @@ struct dmx_engine {
 namespace {
 
 int free_pileup(dmx_engine* e) {
-  for (void*& p : e->own) { if (p) (void)hipFree(p); p = nullptr; }
+  for (int i = 0; i < 5; ++i) { if (e->own[i]) (void)hipFree(e->own[i]); e->own[i] = nullptr; e->own_cap[i] = 0; }
   if (e->d_sched) (void)hipFree(e->d_sched);
-  e->d_sched = nullptr;
+  e->d_sched = nullptr; e->sched_cap = 0;
   e->have_pileup = false;
+  return DMX_OK;
+}
+// Device buffer of at least `bytes`, kept across calls.  hipFree waits for the whole device, so a job whose ranges alternate
+// between two engines must not free and allocate per range: buffers only grow (with some slack for the next, slightly larger range).
+int ensure_dev(void** p, size_t* cap, size_t bytes) {
+  bytes = std::max<size_t>(bytes, 16);
+  if (*p && *cap >= bytes) return DMX_OK;
+  if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+  const size_t want = bytes + bytes / 16;
+  HIP_TRY(hipMalloc(p, want));
+  *cap = want;
   return DMX_OK;
 }
 int free_results(dmx_engine* e) {
@@ -3264,7 +3282,7 @@ int free_results(dmx_engine* e) {
   if (e->d_sing) (void)hipFree(e->d_sing);
   e->d_flag = nullptr; e->d_sing = nullptr;
   e->d_llks = e->d_llk0s = e->d_grid = e->d_l00 = nullptr; e->d_sum = nullptr;
-  e->out_B = 0; e->have_grid = e->have_sing = false;
+  e->out_cap = 0; e->grid_cap = 0; e->have_grid = e->have_sing = false;
   return DMX_OK;
 }
 
@@ -3329,6 +3347,8 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_idd) (void)hipFree(e->d_idd);
   if (e->d_lut) (void)hipFree(e->d_lut);
   if (e->d_alpha) (void)hipFree(e->d_alpha);
+  if (e->d_bad) (void)hipFree(e->d_bad);
+  for (int i = 0; i < 2; ++i) { if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]); if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]); }
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -3366,6 +3386,7 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
   HIP_TRY(hipSetDevice(e->device));
   if (e->d_g_own) { (void)hipFree(e->d_g_own); e->d_g_own = nullptr; }
   if (e->d_gp0) { (void)hipFree(e->d_gp0); e->d_gp0 = nullptr; }
+  e->have_gT = false;
   const size_t n = (size_t)n_snps * e->V * 3;
   if (memory == DMX_MEM_DEVICE) {
     e->d_g = g;
@@ -3414,69 +3435,193 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
   return DMX_OK;
 }
 
+namespace {
+
+__global__ void k_check_snp_ids(const int32_t* __restrict__ snp, int64_t n, int32_t S, int32_t* __restrict__ bad) {
+  bool b = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) b |= (uint32_t)snp[i] >= (uint32_t)S;
+  if (b) atomicOr(bad, 1);
+}
+
+constexpr size_t kStageBytes = (size_t)16 << 20;
+
+void par_memcpy(uint8_t* dst, const uint8_t* src, size_t n) {
+  constexpr size_t kPart = (size_t)2 << 20;
+  if (n < 2 * kPart) { std::memcpy(dst, src, n); return; }
+  const int T = (int)std::min<size_t>(4, n / kPart);
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back([=] { std::memcpy(dst + n * t / T, src + n * t / T, n * (t + 1) / T - n * t / T); });
+  std::memcpy(dst, src, n / T);
+  for (std::thread& x : th) x.join();
+}
+
+// Streams host bytes into one device array through the engine's two pinned chunks: the host fills one while the copy engine
+// drains the other.  (hipMemcpy from pageable memory measured 4 GB/s on this platform; this path is bound by the host memcpy.)
+struct StageWriter {
+  dmx_engine* e;
+  uint8_t* dst;
+  size_t fill = 0;
+  int slot = 0;
+  StageWriter(dmx_engine* e_, void* dst_) : e(e_), dst((uint8_t*)dst_) {}
+  int put(const void* src_, size_t n) {
+    const uint8_t* src = (const uint8_t*)src_;
+    while (n) {
+      if (fill == 0) {
+        slot = e->stage_cur;
+        if (e->stage_busy[slot]) { HIP_TRY(hipEventSynchronize(e->ev_stage[slot])); e->stage_busy[slot] = false; }
+      }
+      const size_t m = std::min(n, kStageBytes - fill);
+      par_memcpy((uint8_t*)e->h_stage[slot] + fill, src, m);
+      fill += m; src += m; n -= m;
+      if (fill == kStageBytes) if (int rc = flush()) return rc;
+    }
+    return DMX_OK;
+  }
+  int flush() {
+    if (!fill) return DMX_OK;
+    HIP_TRY(hipMemcpyAsync(dst, e->h_stage[slot], fill, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipEventRecord(e->ev_stage[slot], e->stream));
+    e->stage_busy[slot] = true;
+    dst += fill; fill = 0; e->stage_cur ^= 1;
+    return DMX_OK;
+  }
+};
+
+// Cells cells[0..nb) of the host pileup `pl` (NULL = all of them, in order) become cells 0..nb-1 of the engine: the CSR is
+// re-based on the fly while it streams to the device, runs of consecutive cells move as one piece.
+int set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, int32_t nb, const char* who) {
+  const int32_t B = nb;
+  std::vector<int64_t> h_off((size_t)B + 1, 0), h_roff((size_t)B + 1, 0);
+  const bool dense = !pl->pair_snp && pl->n_pairs > 0;
+  for (int32_t k = 0; k < B; ++k) {
+    const int32_t c = cells ? cells[k] : k;
+    if (c < 0 || c >= pl->n_cells) return set_error(DMX_ERR_ARG, "%s: cell %d of %d", who, c, pl->n_cells);
+    const int64_t np = pl->cell_pair_off[c + 1] - pl->cell_pair_off[c], nr = pl->cell_read_off[c + 1] - pl->cell_read_off[c];
+    if (np < 0 || nr < 0) return set_error(DMX_ERR_ARG, "%s: cell_pair_off / cell_read_off not monotone at %d", who, c);
+    if (pl->cell_pair_off[c] < 0 || pl->cell_pair_off[c + 1] > pl->n_pairs || pl->cell_read_off[c] < 0 || pl->cell_read_off[c + 1] > pl->n_reads)
+      return set_error(DMX_ERR_ARG, "%s: offsets of cell %d leave the arrays", who, c);
+    if (dense && np != pl->n_snps) return set_error(DMX_ERR_ARG, "%s: dense layout needs n_snps pairs per cell (cell %d)", who, c);
+    h_off[(size_t)k + 1] = h_off[(size_t)k] + np;
+    h_roff[(size_t)k + 1] = h_roff[(size_t)k] + nr;
+  }
+  const int64_t P = h_off[(size_t)B], R = h_roff[(size_t)B];
+  const size_t w = (size_t)pl->nrd_width;
+  if (int rc = ensure_dev(&e->own[0], &e->own_cap[0], sizeof(int64_t) * ((size_t)B + 1))) return rc;
+  if (int rc = ensure_dev(&e->own[1], &e->own_cap[1], sizeof(int64_t) * ((size_t)B + 1))) return rc;
+  if (int rc = ensure_dev(&e->own[2], &e->own_cap[2], dense ? 16 : sizeof(int32_t) * (size_t)P)) return rc;
+  if (int rc = ensure_dev(&e->own[3], &e->own_cap[3], (size_t)P * w + 4)) return rc;
+  if (int rc = ensure_dev(&e->own[4], &e->own_cap[4], (size_t)R + 4)) return rc;
+  if (!e->h_stage[0]) {
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipHostMalloc(&e->h_stage[i], kStageBytes, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&e->ev_stage[i], hipEventDisableTiming));
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(e->own[0], h_off.data(), sizeof(int64_t) * ((size_t)B + 1), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->own[1], h_roff.data(), sizeof(int64_t) * ((size_t)B + 1), hipMemcpyHostToDevice, e->stream));
+  // the three big arrays, one after the other; a run of consecutive source cells is one contiguous piece of each
+  for (int arr = 0; arr < 3; ++arr) {
+    if (arr == 0 && dense) continue;
+    StageWriter sw(e, e->own[2 + arr]);
+    for (int32_t k = 0; k < B;) {
+      const int32_t c0 = cells ? cells[k] : k;
+      int32_t k1 = k + 1;
+      if (!cells) k1 = B; else while (k1 < B && cells[k1] == c0 + (k1 - k)) ++k1;
+      const int32_t c1 = c0 + (k1 - k);                                 // source cells [c0, c1)
+      const int64_t p0 = pl->cell_pair_off[c0], p1 = pl->cell_pair_off[c1], r0 = pl->cell_read_off[c0], r1 = pl->cell_read_off[c1];
+      int rc = DMX_OK;
+      if (arr == 0) rc = sw.put(pl->pair_snp + p0, sizeof(int32_t) * (size_t)(p1 - p0));
+      else if (arr == 1) rc = sw.put((const uint8_t*)pl->pair_nrd + (size_t)p0 * w, (size_t)(p1 - p0) * w);
+      else rc = sw.put(pl->reads + r0, (size_t)(r1 - r0));
+      if (rc) return rc;
+      k = k1;
+    }
+    if (int rc = sw.flush()) return rc;
+  }
+  e->pv.cell_pair_off = (const int64_t*)e->own[0]; e->pv.cell_read_off = (const int64_t*)e->own[1];
+  e->pv.pair_snp = (dense && P > 0) ? nullptr : (const int32_t*)e->own[2];   // a range without any pair is sparse with empty cells
+  e->pv.pair_nrd = (const uint8_t*)e->own[3]; e->pv.reads = (const uint8_t*)e->own[4];
+  if (!dense && P > 0) {                          // what the kernels will index the genotype matrix with
+    if (!e->d_bad) HIP_TRY(hipMalloc((void**)&e->d_bad, sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), e->stream));
+    hipLaunchKernelGGL(k_check_snp_ids, dim3(1024), dim3(256), 0, e->stream, e->pv.pair_snp, P, e->S, e->d_bad);
+    HIP_TRY(hipGetLastError());
+  }
+  e->pv.B = B; e->pv.S = e->S; e->pv.R = R; e->nrd_width = pl->nrd_width; e->P = P; e->R = R;
+  // launch order: longest cells first, so the tail of the grid is made of short cells and co-scheduled cells are alike
+  std::vector<int32_t> sched((size_t)B);
+  std::iota(sched.begin(), sched.end(), 0);
+  std::stable_sort(sched.begin(), sched.end(), [&](int32_t a, int32_t b) { return (h_off[a + 1] - h_off[a]) > (h_off[b + 1] - h_off[b]); });
+  if (int rc = ensure_dev((void**)&e->d_sched, &e->sched_cap, sizeof(int32_t) * (size_t)B)) return rc;
+  if (B) HIP_TRY(hipMemcpyAsync(e->d_sched, sched.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, e->stream));
+  int32_t bad = 0;
+  if (!dense && P > 0) HIP_TRY(hipMemcpyAsync(&bad, e->d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));       // h_off, h_roff, sched and the caller's arrays may go away after return
+  for (int i = 0; i < 2; ++i) e->stage_busy[i] = false;
+  if (bad) return set_error(DMX_ERR_ARG, "%s: a pair_snp entry is outside [0, %d)", who, e->S);
+  return DMX_OK;
+}
+
+}  // namespace
+
 extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
   if (!e || !pl) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: null argument");
-  if (pl->n_cells < 0 || pl->n_pairs < 0 || pl->n_reads < 0) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: negative size");
+  return dmx::engine_set_pileup_cells(e, pl, nullptr, pl->n_cells);
+}
+
+int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, int32_t nb) {
+  if (pl->n_cells < 0 || pl->n_pairs < 0 || pl->n_reads < 0 || nb < 0) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: negative size");
   if (pl->nrd_width != 1 && pl->nrd_width != 2 && pl->nrd_width != 4) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: nrd_width %d", pl->nrd_width);
   if (!pl->cell_pair_off || !pl->cell_read_off || (pl->n_pairs && !pl->pair_nrd) || (pl->n_reads && !pl->reads))
     return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: missing arrays");
   if (e->S == 0 && pl->n_pairs > 0) return set_error(DMX_ERR_STATE, "dmx_engine_set_pileup: call dmx_engine_set_genotypes first");
   if (pl->n_snps > e->S) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: pileup has %d SNPs, genotype matrix %d", pl->n_snps, e->S);
   HIP_TRY(hipSetDevice(e->device));
-  free_pileup(e);
-  const int32_t B = pl->n_cells;
-  std::vector<int64_t> h_off((size_t)B + 1);
+  e->have_pileup = false;
+  const int32_t B = nb;
   if (pl->memory == DMX_MEM_DEVICE) {
+    if (cells) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: a cell subset needs a host pileup");
+    std::vector<int64_t> h_off((size_t)B + 1);
     HIP_TRY(hipMemcpy(h_off.data(), pl->cell_pair_off, sizeof(int64_t) * ((size_t)B + 1), hipMemcpyDeviceToHost));
     e->pv.cell_pair_off = pl->cell_pair_off; e->pv.cell_read_off = pl->cell_read_off; e->pv.pair_snp = pl->pair_snp;
     e->pv.pair_nrd = pl->pair_nrd; e->pv.reads = pl->reads;
     if (!pl->pair_snp && pl->n_pairs == 0) {     // no pairs at all: never the dense layout (NULL would select it)
-      if (int rc = upload<int32_t>(e, nullptr, 0, &e->own[2], &e->pv.pair_snp)) return rc;
+      if (int rc = ensure_dev(&e->own[2], &e->own_cap[2], 16)) return rc;
+      e->pv.pair_snp = (const int32_t*)e->own[2];
     }
+    if (h_off[0] != 0 || h_off[(size_t)B] != pl->n_pairs) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off does not span n_pairs");
+    for (int32_t c = 0; c < B; ++c) {
+      if (h_off[c + 1] < h_off[c]) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off not monotone at %d", c);
+      if (!e->pv.pair_snp && h_off[c + 1] - h_off[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: dense layout needs n_snps pairs per cell (cell %d)", c);
+    }
+    e->pv.B = B; e->pv.S = e->S; e->pv.R = pl->n_reads; e->nrd_width = pl->nrd_width; e->P = pl->n_pairs; e->R = pl->n_reads;
+    std::vector<int32_t> sched((size_t)B);
+    std::iota(sched.begin(), sched.end(), 0);
+    std::stable_sort(sched.begin(), sched.end(), [&](int32_t a, int32_t b) { return (h_off[a + 1] - h_off[a]) > (h_off[b + 1] - h_off[b]); });
+    if (int rc = ensure_dev((void**)&e->d_sched, &e->sched_cap, sizeof(int32_t) * (size_t)B)) return rc;
+    if (B) HIP_TRY(hipMemcpyAsync(e->d_sched, sched.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
   } else {
-    std::memcpy(h_off.data(), pl->cell_pair_off, sizeof(int64_t) * ((size_t)B + 1));
-    if (pl->pair_snp) {   // host-side validation of what the kernels will index with
-      for (int64_t p = 0; p < pl->n_pairs; ++p)
-        if (pl->pair_snp[p] < 0 || pl->pair_snp[p] >= e->S) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: pair_snp[%lld]=%d out of range", (long long)p, pl->pair_snp[p]);
-    }
-    if (int rc = upload<int64_t>(e, pl->cell_pair_off, (size_t)B + 1, &e->own[0], &e->pv.cell_pair_off)) return rc;
-    if (int rc = upload<int64_t>(e, pl->cell_read_off, (size_t)B + 1, &e->own[1], &e->pv.cell_read_off)) return rc;
-    // NULL pair_snp = dense layout — but only when there are pairs: a pileup without any (no read overlaps a SNP, or a barcode
-    // range of uncovered cells) is a sparse pileup with empty cells, which the reference handles (.single rows only, :592)
-    if (pl->pair_snp || pl->n_pairs == 0) { if (int rc = upload<int32_t>(e, pl->pair_snp, (size_t)pl->n_pairs, &e->own[2], &e->pv.pair_snp)) return rc; }
-    else e->pv.pair_snp = nullptr;
-    const uint8_t* v = nullptr;
-    if (int rc = upload<uint8_t>(e, pl->pair_nrd, (size_t)pl->n_pairs * (size_t)pl->nrd_width, &e->own[3], &v)) return rc;
-    e->pv.pair_nrd = v;
-    if (int rc = upload<uint8_t>(e, pl->reads, (size_t)pl->n_reads, &e->own[4], &e->pv.reads)) return rc;
+    if (!cells && (pl->cell_pair_off[0] != 0 || pl->cell_pair_off[(size_t)B] != pl->n_pairs))
+      return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off does not span n_pairs");
+    if (int rc = set_pileup_cells(e, pl, cells, nb, "dmx_engine_set_pileup")) return rc;
   }
-  if (h_off[0] != 0 || h_off[(size_t)B] != pl->n_pairs) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off does not span n_pairs");
-  for (int32_t c = 0; c < B; ++c) {
-    if (h_off[c + 1] < h_off[c]) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off not monotone at %d", c);
-    if (!e->pv.pair_snp && h_off[c + 1] - h_off[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: dense layout needs n_snps pairs per cell (cell %d)", c);
-  }
-  // dense pileups: SNP-minor copies of the genotype probabilities for the singlet kernel
-  if (e->d_gT) { (void)hipFree(e->d_gT); e->d_gT = nullptr; }
-  if (e->d_g0T) { (void)hipFree(e->d_g0T); e->d_g0T = nullptr; }
-  if (!e->pv.pair_snp && e->S > 0) {
+  // dense pileups: SNP-minor copies of the genotype probabilities for the singlet kernel (once per genotype matrix)
+  if (!e->pv.pair_snp && e->S > 0 && !e->have_gT) {
+    if (e->d_gT) { (void)hipFree(e->d_gT); e->d_gT = nullptr; }
+    if (e->d_g0T) { (void)hipFree(e->d_g0T); e->d_g0T = nullptr; }
     HIP_TRY(hipMalloc((void**)&e->d_gT, (size_t)e->S * e->V * 3 * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&e->d_g0T, (size_t)e->S * 3 * sizeof(double)));
     hipLaunchKernelGGL(k_transpose_geno, dim3(2048), dim3(256), 0, e->stream, e->d_g, e->d_gp0, e->S, e->V, e->d_gT, e->d_g0T);
     HIP_TRY(hipGetLastError());
+    e->have_gT = true;
   }
-  e->pv.B = B; e->pv.S = e->S; e->pv.R = pl->n_reads; e->nrd_width = pl->nrd_width; e->P = pl->n_pairs; e->R = pl->n_reads;
-  // launch order: longest cells first, so the tail of the grid is made of short cells and co-scheduled cells are alike
-  std::vector<int32_t> sched((size_t)B);
-  std::iota(sched.begin(), sched.end(), 0);
-  std::stable_sort(sched.begin(), sched.end(), [&](int32_t a, int32_t b) { return (h_off[a + 1] - h_off[a]) > (h_off[b + 1] - h_off[b]); });
-  HIP_TRY(hipMalloc((void**)&e->d_sched, std::max<size_t>(sizeof(int32_t) * (size_t)B, 16)));
-  if (B) HIP_TRY(hipMemcpyAsync(e->d_sched, sched.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  if (e->out_B != B) {
+  if (e->out_cap < B || !e->d_llks) {
     free_results(e);
-    HIP_TRY(hipMalloc((void**)&e->d_llks, std::max<size_t>(sizeof(double) * (size_t)B * e->V, 16)));
-    HIP_TRY(hipMalloc((void**)&e->d_llk0s, std::max<size_t>(sizeof(double) * (size_t)B, 16)));
-    e->out_B = B;
+    const int32_t cap = B + B / 16 + 16;
+    HIP_TRY(hipMalloc((void**)&e->d_llks, sizeof(double) * (size_t)cap * e->V));
+    HIP_TRY(hipMalloc((void**)&e->d_llk0s, sizeof(double) * (size_t)cap));
+    e->out_cap = cap;
   }
   e->have_sing = e->have_grid = false;
   e->have_pileup = true;
@@ -3789,12 +3934,16 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   const int32_t B = e->pv.B;
   const size_t nAB = (size_t)e->V * e->V * e->A;
-  if (!e->d_grid) {
-    HIP_TRY(hipMalloc((void**)&e->d_grid, std::max<size_t>(sizeof(double) * nAB * (size_t)B, 16)));
-    HIP_TRY(hipMalloc((void**)&e->d_l00, std::max<size_t>(sizeof(double) * (size_t)e->A * (size_t)B, 16)));
-    HIP_TRY(hipMalloc((void**)&e->d_sum, std::max<size_t>(sizeof(dmx_cell_summary) * (size_t)B, 16)));
-    HIP_TRY(hipMalloc((void**)&e->d_flag, std::max<size_t>((size_t)B, 16)));
-    HIP_TRY(hipMalloc((void**)&e->d_sing, std::max<size_t>(sizeof(double) * (size_t)B * e->V, 16)));
+  if (!e->d_grid || e->grid_cap < B) {
+    if (e->d_grid) { (void)hipFree(e->d_grid); (void)hipFree(e->d_l00); (void)hipFree(e->d_sum); (void)hipFree(e->d_flag); (void)hipFree(e->d_sing); }
+    e->d_grid = e->d_l00 = e->d_sing = nullptr; e->d_sum = nullptr; e->d_flag = nullptr;
+    const size_t cap = (size_t)e->out_cap;       // the singlet buffers' capacity (>= B)
+    HIP_TRY(hipMalloc((void**)&e->d_grid, std::max<size_t>(sizeof(double) * nAB * cap, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_l00, std::max<size_t>(sizeof(double) * (size_t)e->A * cap, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_sum, std::max<size_t>(sizeof(dmx_cell_summary) * cap, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_flag, std::max<size_t>(cap, 16)));
+    HIP_TRY(hipMalloc((void**)&e->d_sing, std::max<size_t>(sizeof(double) * cap * e->V, 16)));
+    e->grid_cap = (int32_t)cap;
   }
   if (B == 0) { e->have_grid = true; return DMX_OK; }
   HIP_TRY(hipEventRecord(e->ev[4], e->stream));
@@ -4014,7 +4163,6 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   const int32_t B = pl.n_cells, V = job->n_samples, A = job->n_alpha;
   const size_t nAB = (size_t)V * V * A;
   const bool doublet_ok = V >= 2 && A >= 2;
-  const bool dense = pl.pair_snp == nullptr && pl.n_pairs > 0;
   std::vector<const char*> bcs((size_t)B);
   std::vector<int32_t> nsnp((size_t)B);
   for (int32_t c = 0; c < B; ++c) {
@@ -4045,7 +4193,13 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   const int by_mem = (int)std::min<double>((double)std::max(B, 1), std::ceil(grid_total / (double)budget));
   int by_overlap = 1;                                                // ranges per engine wanted for host/GPU overlap
   if (const char* env = getenv("DMX_RANGES_PER_GPU")) by_overlap = std::max(1, atoi(env));
-  else if (doublet_ok && work_total / ngpu > 3e10 && B / ngpu >= 8 * 1024) by_overlap = 4;   // >= ~50 ms of GPU work per engine
+  else {
+    // worth it when an engine has more than ~0.15 s of kernels ahead of it (at ~6e11 evaluations/s; FAST evaluates the printed
+    // entries only): the host then writes range r and stages r + 2 while the GPU computes r + 1
+    const bool sym = job->mode == DMX_MODE_FAST && A == 2 && job->alpha[0] == 0.0 && job->alpha[1] == 0.5 && V <= 64;
+    const double evals = (double)(V + 1) + (doublet_ok ? (sym ? (double)V + 0.5 * V * (V + 1) : (double)nAB) : 0.0);
+    if (doublet_ok && (double)pl.n_pairs * evals / ngpu > 0.15 * 6e11 && B / ngpu >= 8 * 1024) by_overlap = 4;
+  }
   int R = std::max(ngpu * by_overlap, by_mem);
   R = ((R + ngpu - 1) / ngpu) * ngpu;                                 // whole waves
   R = std::max(1, std::min(R, std::max(B, 1)));
@@ -4072,15 +4226,12 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   tm.n_ranges = R;
 
   struct Range {
-    std::vector<int64_t> pair_off, read_off;
-    std::vector<int32_t> snp, totl, pass, uniq, ns;
-    std::vector<uint8_t> nrd, reads;
+    std::vector<int32_t> totl, pass, uniq, ns;
     std::vector<const char*> bc;
     std::vector<double> llks, llk0s, grid, l00, sing;
     std::vector<dmx_cell_summary> summ;
     std::vector<std::vector<double>> flagged_grid;
     std::vector<const double*> cell_grid;
-    dmx_pileup pl{};
     int32_t lo = 0, hi = 0;
     void release() { *this = Range(); }
   };
@@ -4094,13 +4245,22 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   std::vector<dmx_engine*> eng((size_t)per_wave * nset, nullptr);
   tm.n_engines = (int32_t)eng.size();
   struct Guard { std::vector<dmx_engine*>* e; ~Guard() { for (dmx_engine* x : *e) if (x) dmx_engine_destroy(x); } } guard{&eng};
-  for (size_t i = 0; i < eng.size(); ++i) {
-    dmx_engine_config cfg{};
-    cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior;
-    cfg.device = (job->device + (int)(i % (size_t)per_wave)) % ndev; cfg.mode = job->mode;
-    if (!job->arbiter) cfg.flags |= DMX_ENGINE_NO_CERTIFY;
-    if (int rc = dmx_engine_create(&cfg, &eng[i])) return rc;
-    if (int rc = dmx_engine_set_genotypes(eng[i], job->g, pl.n_snps, DMX_MEM_HOST)) return rc;
+  {
+    auto make = [&](size_t i) -> int {
+      dmx_engine_config cfg{};
+      cfg.n_samples = V; cfg.n_alpha = A; cfg.alpha = job->alpha; cfg.doublet_prior = job->doublet_prior;
+      cfg.device = (job->device + (int)(i % (size_t)per_wave)) % ndev; cfg.mode = job->mode;
+      if (!job->arbiter) cfg.flags |= DMX_ENGINE_NO_CERTIFY;
+      if (int rc = dmx_engine_create(&cfg, &eng[i])) return rc;
+      return dmx_engine_set_genotypes(eng[i], job->g, pl.n_snps, DMX_MEM_HOST);
+    };
+    if (int rc = make(0)) return rc;              // the first one builds the host-side seed tables the others reuse
+    std::vector<int> rcs(eng.size(), DMX_OK);
+    std::vector<std::string> msgs(eng.size());
+    std::vector<std::thread> th;
+    for (size_t i = 1; i < eng.size(); ++i) th.emplace_back([&, i] { rcs[i] = make(i); if (rcs[i]) msgs[i] = dmx_last_error(); });
+    for (std::thread& t : th) t.join();
+    for (size_t i = 1; i < eng.size(); ++i) if (rcs[i]) return set_error(rcs[i], "%s", msgs[i].c_str());
   }
   tm.setup_s = secs(t_setup, clk::now());
   std::mutex tm_mu;
@@ -4113,42 +4273,17 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     Range& x = rg[(size_t)r];
     x.lo = cut[(size_t)r]; x.hi = cut[(size_t)r + 1];
     const int32_t nb = x.hi - x.lo;
-    const dmx_pileup* use = &pl;
-    if (sliced) {                                // slice the CSR: cells order[lo..hi) become cells 0..nb-1 of the range
-      x.pair_off.assign((size_t)nb + 1, 0); x.read_off.assign((size_t)nb + 1, 0);
-      const size_t nb1 = (size_t)std::max(nb, 1);                      // an empty range still hands non-null arrays to the writers
+    if (sliced) {                                // cells order[lo..hi) become cells 0..nb-1 of the range: the small per-cell arrays
+      const size_t nb1 = (size_t)std::max(nb, 1);                      // here, the CSR itself while it streams to the device
       x.totl.resize(nb1); x.pass.resize(nb1); x.uniq.resize(nb1); x.ns.resize(nb1); x.bc.resize(nb1);
       for (int32_t k = 0; k < nb; ++k) {
         const int32_t c = order[(size_t)x.lo + k];
-        x.pair_off[(size_t)k + 1] = x.pair_off[(size_t)k] + (pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]);
-        x.read_off[(size_t)k + 1] = x.read_off[(size_t)k] + (pl.cell_read_off[c + 1] - pl.cell_read_off[c]);
         x.totl[(size_t)k] = pl.rd_totl[c]; x.pass[(size_t)k] = pl.rd_pass[c]; x.uniq[(size_t)k] = pl.rd_uniq[c];
         x.ns[(size_t)k] = nsnp[(size_t)c]; x.bc[(size_t)k] = bcs[(size_t)c];
       }
-      if (!dense) x.snp.resize((size_t)x.pair_off[(size_t)nb] + 1);
-      x.nrd.resize((size_t)x.pair_off[(size_t)nb] * (size_t)pl.nrd_width + 4);
-      x.reads.resize((size_t)x.read_off[(size_t)nb] + 4);
-      for (int32_t k = 0; k < nb; ++k) {
-        const int32_t c = order[(size_t)x.lo + k];
-        const int64_t np = pl.cell_pair_off[c + 1] - pl.cell_pair_off[c], nr = pl.cell_read_off[c + 1] - pl.cell_read_off[c];
-        if (np) {
-          if (!dense) std::memcpy(&x.snp[(size_t)x.pair_off[(size_t)k]], pl.pair_snp + pl.cell_pair_off[c], sizeof(int32_t) * (size_t)np);
-          std::memcpy(&x.nrd[(size_t)x.pair_off[(size_t)k] * (size_t)pl.nrd_width],
-                      (const uint8_t*)pl.pair_nrd + (size_t)pl.cell_pair_off[c] * (size_t)pl.nrd_width, (size_t)np * (size_t)pl.nrd_width);
-        }
-        if (nr) std::memcpy(&x.reads[(size_t)x.read_off[(size_t)k]], pl.reads + pl.cell_read_off[c], (size_t)nr);
-      }
-      x.pl = pl;
-      x.pl.n_cells = nb; x.pl.n_pairs = x.pair_off[(size_t)nb]; x.pl.n_reads = x.read_off[(size_t)nb];
-      x.pl.cell_pair_off = x.pair_off.data(); x.pl.cell_read_off = x.read_off.data();
-      x.pl.pair_snp = (dense && x.pl.n_pairs > 0) ? nullptr : x.snp.data();      // a dense job stays dense; an all-empty range is sparse
-      if (!x.pl.pair_snp && x.pl.n_pairs == 0) { x.snp.resize(1); x.pl.pair_snp = x.snp.data(); }
-      x.pl.pair_nrd = x.nrd.data(); x.pl.reads = x.reads.data();
-      x.pl.rd_totl = x.totl.data(); x.pl.rd_pass = x.pass.data(); x.pl.rd_uniq = x.uniq.data();
-      use = &x.pl;
     }
     dmx_engine* e = eng_of(r);
-    if (int rc = dmx_engine_set_pileup(e, use)) return rc;
+    if (int rc = dmx::engine_set_pileup_cells(e, &pl, sliced ? order.data() + x.lo : nullptr, nb)) return rc;
     if (int rc = dmx_engine_run_singlet(e)) return rc;
     if (doublet_ok) if (int rc = dmx_engine_run_doublet(e)) return rc;
     { std::lock_guard<std::mutex> lk(tm_mu); stage_s += secs(t0, clk::now()); }
@@ -4205,8 +4340,9 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     if (int rc = dmx::write_single_impl(&fin, (pre + ".single").c_str(), r > 0)) return rc;
     if (doublet_ok) {
       fin.llks00 = x.l00.data();
-      if (job->arbiter) { fin.tie_pileup = sliced ? &x.pl : &pl; fin.tie_g = job->g; }
+      if (job->arbiter) { fin.tie_pileup = &pl; fin.tie_g = job->g; }
       dmx::DoubletSource src{};
+      if (sliced) src.tie_cell = order.data() + x.lo;
       if (job->write_pair) { fin.llksAB = x.grid.data(); src.grid_all = x.grid.data(); src.summary = x.summ.data(); }
       else { src.sing = x.sing.data(); src.summary = x.summ.data(); src.cell_grid = x.cell_grid.data(); }
       if (int rc = dmx::write_doublet_core(&fin, src, job->out_prefix, r > 0, "dmx_demuxlet_run")) return rc;
@@ -4230,12 +4366,36 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     return DMX_OK;
   };
   auto wave_lo = [&](int w) { return std::min(R, w * per_wave); };
+  // The rows of a fetched wave are arbitrated, formatted and appended by a writer thread, in range order, while this thread
+  // stages and fetches the next waves; at most one wave waits for the writer when another is fetched (host memory: the results
+  // of two waves, as the byte budget assumes).
+  struct Writer {
+    std::mutex mu; std::condition_variable cv; std::deque<int> q; bool closing = false; int pending = 0; int rc = DMX_OK; std::string msg; std::thread th;
+    void close() { { std::lock_guard<std::mutex> lk(mu); closing = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+    ~Writer() { close(); }
+  } wr;
+  wr.th = std::thread([&] {
+    for (;;) {
+      int r;
+      { std::unique_lock<std::mutex> lk(wr.mu); wr.cv.wait(lk, [&] { return !wr.q.empty() || wr.closing; }); if (wr.q.empty()) return; r = wr.q.front(); wr.q.pop_front(); }
+      int rc = DMX_OK;
+      { std::lock_guard<std::mutex> lk(wr.mu); rc = wr.rc; }
+      if (rc == DMX_OK) { rc = write(r); if (rc) { std::lock_guard<std::mutex> lk(wr.mu); wr.rc = rc; wr.msg = dmx_last_error(); } }
+      else rg[(size_t)r].release();
+      { std::lock_guard<std::mutex> lk(wr.mu); --wr.pending; }
+      wr.cv.notify_all();
+    }
+  });
   for (int w = 0; w < std::min(waves, nset); ++w) if (int rc = for_ranges(wave_lo(w), wave_lo(w + 1), launch)) return rc;
   for (int w = 0; w < waves; ++w) {
+    { std::unique_lock<std::mutex> lk(wr.mu); wr.cv.wait(lk, [&] { return wr.pending <= per_wave; }); if (wr.rc) break; }
     if (int rc = for_ranges(wave_lo(w), wave_lo(w + 1), fetch)) return rc;
-    if (w + nset < waves) if (int rc = for_ranges(wave_lo(w + nset), wave_lo(w + nset + 1), launch)) return rc;   // the freed engines stage wave w + nset ...
-    for (int r = wave_lo(w); r < wave_lo(w + 1); ++r) if (int rc = write(r)) return rc;           // ... while the host writes wave w and the GPUs run w + 1
+    { std::lock_guard<std::mutex> lk(wr.mu); for (int r = wave_lo(w); r < wave_lo(w + 1); ++r) { wr.q.push_back(r); ++wr.pending; } }
+    wr.cv.notify_all();
+    if (w + nset < waves) if (int rc = for_ranges(wave_lo(w + nset), wave_lo(w + nset + 1), launch)) return rc;   // the freed engines stage wave w + nset
   }
+  wr.close();
+  if (wr.rc) return set_error(wr.rc, "%s", wr.msg.c_str());
   tm.stage_s = stage_s; tm.wait_s = wait_s; tm.write_s = write_s; tm.kernel_ms = kernel_ms; tm.n_cells_grid_fetched = n_fetched;
   tm.total_s = secs(t_begin, clk::now());
   if (job->timing) *job->timing = tm;

@@ -984,7 +984,7 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
           if (grid[((size_t)j * V + k) * A + a] >= mab - tol) reqs.push_back({j, k, a, 0.0});
         if (reqs.size() - nd0 == 1) reqs.pop_back();
         if (!reqs.empty()) {
-          dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), c, reqs);
+          dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), src.tie_cell ? src.tie_cell[c] : c, reqs);
           scratch.assign(grid, grid + ng);
           for (const dmx::GridReq& r : reqs) scratch[((size_t)r.j * V + r.k) * A + r.n] = r.value;
           grid = scratch.data();
@@ -1018,7 +1018,7 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
         // reference's operation order and let its strict-< scan decide, which visits the smaller first index first.
         const int32_t a = std::min(jb, kb), b = std::max(jb, kb);
         reqs.assign({{a, b, nb, 0.0}, {b, a, nb, 0.0}});
-        dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), c, reqs);
+        dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), src.tie_cell ? src.tie_cell[c] : c, reqs);
         const bool swap_to_ba = reqs[0].value < reqs[1].value;
         const int32_t nj = swap_to_ba ? b : a, nk = swap_to_ba ? a : b;
         if (nj != jb) { std::swap(l1, l2); std::swap(l10, l20); }
