@@ -1462,8 +1462,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             const double s0 = __builtin_fma(a2, x[2], __builtin_fma(a1, x[1], a0 * x[0]));
             const double s1 = __builtin_fma(a2, y[2], __builtin_fma(a1, y[1], a0 * y[0]));
             ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-            acc[kk][0] += dmx_log_fast(s0, s_log);
-            acc[kk][1] += dmx_log_fast(s1, s_log);
+            acc[kk][0] += dmx_log_lite(s0, s_log);
+            acc[kk][1] += dmx_log_lite(s1, s_log);
           }
         }
       }
@@ -1500,8 +1500,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             const double s0 = __builtin_fma(a2, x2, __builtin_fma(a1, x01.y, a0 * x01.x));
             const double s1 = __builtin_fma(a2, y2, __builtin_fma(a1, y01.y, a0 * y01.x));
             ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-            acc[kk][0] += dmx_log_fast(s0, s_log);
-            acc[kk][1] += dmx_log_fast(s1, s_log);
+            acc[kk][0] += dmx_log_lite(s0, s_log);
+            acc[kk][1] += dmx_log_lite(s1, s_log);
           }
         }
       }
@@ -1785,7 +1785,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
             const double x0 = up[ek[i]], x1 = up[VUS + ek[i]], x2 = up[2 * VUS + ek[i]];
             const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
             ok &= __builtin_amdgcn_class(sj, 0x100);
-            acc[i] += dmx_log_fast(sj, s_log);
+            acc[i] += dmx_log_lite(sj, s_log);
           }
         }
       }
