@@ -631,8 +631,8 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
 // Same walk and ownership as k_singlet; per pair the lane evaluates log(GL . row_d) once per class d plus the llk0 term,
 // and stores those five terms and the SNP's packed class ids; chain lane (cell, k) then adds term[id[snp][k]] for the
 // tile's pairs in ascending order — the very doubles k_singlet would have formed for sample k, in the same order.
-template <int CW>
-__global__ __launch_bounds__(kThreads, 4) void k_singlet_clsw(PileupView pv, int nrd_width, const float* __restrict__ rows,
+template <int CW, int MINW = 4>
+__global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                              const uint32_t* __restrict__ idw, const double* __restrict__ gp0,
                                                              const double* __restrict__ tabs,
                                                              const int32_t* __restrict__ sched, int32_t V,
@@ -2111,8 +2111,8 @@ __global__ void k_build_classes(const float* __restrict__ g, int32_t S, int32_t 
 //   phase 1b the class table T[pair][cj][ck][n] = log(sum_lm row_cj[l] row_ck[m] pG[n][l][m]) — the very expression of
 //            :553,:677-683 on the very operands, once per distinct (cj, ck)
 //   phase 2  thread (j, k-block): acc[j][k][n] += T[pair][id_j][id_k][n], pairs in ascending SNP order
-template <int TPC, int NK>
-__global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
+template <int TPC, int NK, int MINW = 1>
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                           const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
                                                           const double* __restrict__ tabs, const double* __restrict__ alpha,
                                                           const int32_t* __restrict__ sched, int32_t V, int32_t VS,
@@ -2125,9 +2125,16 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab];
+  __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha (see k_doublet_a2): registers only while phase 1 runs
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
   for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  if (t < 18) {
+    const int n = t / 9, l = (t % 9) / 3, m = t % 3;
+    const double p = 0.5 * l + (m - l) * 0.5 * alpha[n];
+    s_w[n][t % 9] = p;
+    s_w[n][9 + t % 9] = 1.0 - p;
+  }
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;
@@ -2160,18 +2167,6 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
   for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
   bool ok = true;
   const int ti1 = tid >> 1, n1 = tid & 1;
-  double wA[9], wR[9];
-  {
-    const double al = alpha[n1];
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const double p = 0.5 * l + (m - l) * 0.5 * al;
-        wA[l * 3 + m] = p;
-        wR[l * 3 + m] = 1.0 - p;
-      }
-  }
   double acc00 = 0.0;
 
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
@@ -2204,9 +2199,9 @@ __global__ __launch_bounds__(kThreads) void k_doublet_cls(PileupView pv, int nrd
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
       const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
-      double pG[9];
+      double pG[9], wA[9], wR[9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) pG[i] = 1.0;
+      for (int i = 0; i < 9; ++i) { pG[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][9 + i]; }
       for (uint32_t r = 0; __any(r < cnt); ++r) {
         const bool live = r < cnt;
         const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
@@ -3643,6 +3638,11 @@ int launch_singlet(dmx_engine* e) {
       const size_t dynw = (size_t)(kThreads / 64) * 64 * ((V + 15) / 16) * sizeof(uint32_t);
       const dim3 blkw(kThreads), grdw((unsigned)((B + (kThreads / 64) - 1) / (kThreads / 64)), (unsigned)((V + 1 + 255) / 256));
       if (dynw > 30 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_singlet_clsw<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynw));
+      if (getenv("DMX_K1W_MINW3")) {              // kernel experiments only
+        hipLaunchKernelGGL((k_singlet_clsw<1, 3>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,
+                           e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s);
+        return DMX_OK;
+      }
       hipLaunchKernelGGL((k_singlet_clsw<1>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,
                          e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s);
       return DMX_OK;
@@ -3812,13 +3812,15 @@ int launch_doublet(dmx_engine* e) {
     cb = (cb + 15) & ~(size_t)15;
     HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
     const dim3 blk(kThreads);
-#define DMX_K2C(TPC, NK)                                                                                             \
-  hipLaunchKernelGGL((k_doublet_cls<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), blk,   \
+#define DMX_K2C(TPC, NK, ...)                                                                                        \
+  hipLaunchKernelGGL((k_doublet_cls<TPC, NK, ##__VA_ARGS__>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), blk,   \
                      cb * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0, e->d_lut,   \
                      e->d_alpha, e->d_sched, V, VS, e->d_grid, e->d_l00, e->d_flag)
     if (V <= 8) DMX_K2C(64, 1);
     else if (V <= 16) DMX_K2C(64, 4);
     else if (V <= 32) DMX_K2C(256, 4);
+    else if (getenv("DMX_CLS_MINW3")) DMX_K2C(256, 16, 3);    // kernel experiments only (36 spills: slower)
+    else if (getenv("DMX_CLS_NK8")) { if (atoi(getenv("DMX_CLS_NK8")) == 3) DMX_K2C(256, 8, 3); else DMX_K2C(256, 8); }
     else DMX_K2C(256, 16);
 #undef DMX_K2C
     HIP_TRY(hipGetLastError());
