@@ -278,3 +278,40 @@ def test_geno_transforms_hand_vectors(eng, oracle):
     # the oracle restatement agrees on all of the above (it is what the GPU tests check the product against)
     for a, e in ((np.array([[0, -1]]), 0.01), (np.array([[0, 0], [0, 0], [0, 1], [-1, -1]]), 0.01)):
         assert np.array_equal(eng.geno_from_gt(a, e), oracle.geno_from_gt(a, e))
+
+
+def test_resolve_tie_order_asks_the_host_libm(eng):
+    """dmx_resolve_tie_order (K3b's RESOLVABLE records, DESIGN.md "Ties"): the accumulator is the lower candidate when the host
+    libm's log() of the recorded argument equals the recorded lower log value, the upper one when it is the next double, and
+    the record stays unresolved otherwise.  The order then follows the reference's strict-< scan (:799-814)."""
+    import math
+    from demuxlet_amd import capi
+    x = 0.37251
+    L = math.log(x)
+    up = np.nextafter(L, np.inf)
+    dn = np.nextafter(L, -np.inf)
+    s = np.zeros(4, dtype=capi.SUMMARY_DTYPE)
+    s["n_pairs"] = 10; s["n_best"] = 1
+    s["j_best"] = 3; s["k_best"] = 7
+    s["llk1"] = -1.0; s["llk2"] = -2.0; s["llk10"] = -10.0; s["llk20"] = -20.0
+    s["flags"] = capi.DMX_CELL_ORDER_RESOLVABLE
+    # 0: (a,b) open, libm returns the lower candidate -> llk_ab; (b,a) certain and smaller -> order stays (3, 7)
+    s[0]["llk_ab"], s[0]["llk_ab_alt"], s[0]["ev_x_ab"], s[0]["ev_t_ab"] = -100.0, -99.5, x, L
+    s[0]["llk_ba"] = s[0]["llk_ba_alt"] = -100.25
+    # 1: (a,b) open, libm returns the upper candidate -> llk_ab_alt = -100.5 < (b,a) = -100.25 -> (b,a) wins: order (7, 3)
+    s[1]["llk_ab"], s[1]["llk_ab_alt"], s[1]["ev_x_ab"], s[1]["ev_t_ab"] = -101.0, -100.5, x, dn
+    s[1]["llk_ba"] = s[1]["llk_ba_alt"] = -100.25
+    # 2: both open
+    s[2]["llk_ab"], s[2]["llk_ab_alt"], s[2]["ev_x_ab"], s[2]["ev_t_ab"] = -50.0, -49.0, x, L
+    s[2]["llk_ba"], s[2]["llk_ba_alt"], s[2]["ev_x_ba"], s[2]["ev_t_ba"] = -50.0, -49.0, x, dn
+    # 3: the libm's answer is neither candidate -> stays unresolved
+    s[3]["llk_ab"], s[3]["llk_ab_alt"], s[3]["ev_x_ab"], s[3]["ev_t_ab"] = -5.0, -4.0, x, up
+    s[3]["llk_ba"] = s[3]["llk_ba_alt"] = -6.0
+    left = eng.resolve_tie_order(s)
+    assert left == 1
+    C, R = capi.DMX_CELL_ORDER_CERTIFIED, capi.DMX_CELL_ORDER_RESOLVABLE
+    assert [int(f) for f in s["flags"]] == [C, C, C, R]
+    assert (s[0]["j_best"], s[0]["k_best"], s[0]["llk12"], s[0]["llk1"], s[0]["llk10"]) == (3, 7, -100.0, -1.0, -10.0)
+    assert (s[1]["j_best"], s[1]["k_best"], s[1]["llk12"], s[1]["llk1"], s[1]["llk2"], s[1]["llk10"], s[1]["llk20"]) == (7, 3, -100.25, -2.0, -1.0, -20.0, -10.0)
+    assert (s[2]["llk_ab"], s[2]["llk_ba"]) == (-50.0, -49.0) and (s[2]["j_best"], s[2]["k_best"], s[2]["llk12"]) == (7, 3, -49.0)
+    assert (s[3]["j_best"], s[3]["k_best"]) == (3, 7)
