@@ -1541,7 +1541,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 // Entry e = tid + TPC*i of a lane: e < V*D (D = V/2 + 1): j = e % V, k = (j + e / V) % V at alpha 0.5 (the rotation makes the
 // lanes of a wavefront read consecutive u_k: conflict-free LDS); V*D <= e < V*D + V: the singlet entry [j][0][0], j = e - V*D.
 // For even V the offset d = V/2 is computed from both sides; only the j < k copy is stored.
-template <int TPC, int VMAX, int SUB, bool FIXJ, int MINW = 3>
+// Panels wider than 64 samples cut the entry list into slabs of NEP entries per lane, one workgroup (blockIdx.y) per slab: each slab
+// repeats the per-tile phases (cheap next to 256 * NEP evaluations per pair) and owns its entries' accumulators.
+template <int TPC, int VMAX, int SUB, bool FIXJ, int MINW = 3, int NEP = 0>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                           const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                           const int32_t* __restrict__ sched, int32_t V,
@@ -1555,7 +1557,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   static_assert(SUB <= TP && TP % 8 == 0, "sub-tile");
   constexpr int CPW = kThreads / TPC;            // cells per workgroup
   constexpr int T00 = TP + 2;
-  constexpr int NE = (VMAX * (VMAX / 2 + 1) + VMAX + TPC - 1) / TPC;   // entries per lane
+  constexpr int NE = NEP ? NEP : (VMAX * (VMAX / 2 + 1) + VMAX + TPC - 1) / TPC;   // entries per lane (and slab)
+  const int e_base = NEP ? (int)blockIdx.y * NEP * TPC : 0;         // first entry of this slab
   constexpr int VUS = (VMAX + 2) & ~1;           // u row stride (V alpha-0.5 rows + the alpha-0 row of sample 0), even
   constexpr int GSS = (3 * VMAX + 3) & ~3;       // genotype row stride (floats)
 #define DMX_K2_SYNC() do { if (TPC <= 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
@@ -1601,7 +1604,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   int ek[NE], ej[NE];                            // u row (k, or V = the alpha-0 row) and sample j of each entry
 #pragma unroll
   for (int i = 0; i < NE; ++i) {
-    const int e = tid + TPC * i;
+    const int e = e_base + tid + TPC * i;
     if (e < VD) { const int j = e % V; int k = j + e / V; k = k >= V ? k - V : k; ej[i] = j; ek[i] = k; }
     else if (e < VD + V) { ej[i] = e - VD; ek[i] = V; }
     else { ej[i] = 0; ek[i] = V; }               // idle slot: computes the first singlet term, never stored
@@ -1796,7 +1799,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
     double* G = grid + (size_t)cell * V * V * A;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-      const int e = tid + TPC * i;
+      const int e = e_base + tid + TPC * i;
       if (e < VD) {
         const int j = ej[i], k = ek[i], d = e / V;
         if (!(2 * d == V && j > k)) {              // d = V/2 is reached from both sides: the j < k lane stores
@@ -1808,7 +1811,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
         for (int k = 0; k < V; ++k) G[((size_t)j * V + k) * A] = acc[i];
       }
     }
-    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (tid < 2 && e_base == 0) l00[(size_t)cell * A + tid] = acc00;
     if (!ok) flagged[cell] = 1;
   }
 #undef DMX_K2_SYNC
@@ -3834,7 +3837,7 @@ int launch_doublet(dmx_engine* e) {
   hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
                      e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag)
-  if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 64 && !getenv("DMX_NO_SYM")) {
+  if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 128 && !getenv("DMX_NO_SYM")) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do {                                                                                                                \
@@ -3873,7 +3876,22 @@ int launch_doublet(dmx_engine* e) {
       } else DMX_K2S(64, 32, 4, false);
     }
     else if (V <= 48) DMX_K2S(256, 48, 8, false);
-    else { if (V == 64) DMX_K2S(256, 64, 8, true); else DMX_K2S(256, 64, 8, false); }
+    else if (V <= 64) { if (V == 64) DMX_K2S(256, 64, 8, true); else DMX_K2S(256, 64, 8, false); }
+    else {
+      // 64 < V <= 128: the entry list (V (V/2 + 1) + V, up to 8 448) in slabs of 9 entries per lane
+      const unsigned ns = (unsigned)((V * (V / 2 + 1) + V + 256 * 9 - 1) / (256 * 9));
+#define DMX_K2SS(VMAX, FIX)                                                                                            \
+  do {                                                                                                                \
+    constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1;                                                  \
+    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)8 * GSS_ * 4 + (size_t)8 * 3 * VUS_ * 8; \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, 8, FIX, 3, 9>),                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
+    hipLaunchKernelGGL((k_doublet_sym<256, VMAX, 8, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv,   \
+                       e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V, e->d_grid, e->d_l00, e->d_flag);        \
+  } while (0)
+      if (V <= 96) DMX_K2SS(96, false); else if (V == 128) DMX_K2SS(128, true); else DMX_K2SS(128, false);
+#undef DMX_K2SS
+    }
 #undef DMX_K2SV
 #undef DMX_K2S
     HIP_TRY(hipGetLastError());
@@ -4198,7 +4216,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   else {
     // worth it when an engine has more than ~0.15 s of kernels ahead of it (at ~6e11 evaluations/s; FAST evaluates the printed
     // entries only): the host then writes range r and stages r + 2 while the GPU computes r + 1
-    const bool sym = job->mode == DMX_MODE_FAST && A == 2 && job->alpha[0] == 0.0 && job->alpha[1] == 0.5 && V <= 64;
+    const bool sym = job->mode == DMX_MODE_FAST && A == 2 && job->alpha[0] == 0.0 && job->alpha[1] == 0.5 && V <= 128;
     const double evals = (double)(V + 1) + (doublet_ok ? (sym ? (double)V + 0.5 * V * (V + 1) : (double)nAB) : 0.0);
     if (doublet_ok && (double)pl.n_pairs * evals / ngpu > 0.15 * 6e11 && B / ngpu >= 8 * 1024) by_overlap = 4;
   }
