@@ -3804,7 +3804,8 @@ int launch_doublet(dmx_engine* e) {
                      e->nrd_width, e->d_rows, e->d_idd, e->nwd2, e->d_gp0, e->d_lut, e->d_sched, V, e->d_grid, e->d_l00, e->d_flag)
     if (need <= 1) DMX_K2CS(1, 4); else if (need <= 2) DMX_K2CS(2, 4); else if (need <= 3) DMX_K2CS(3, 4); else if (need <= 5) DMX_K2CS(5, 4);
     else if (need <= 7) DMX_K2CS(7, 3); else if (need <= 9) DMX_K2CS(9, 3); else if (need <= 11) DMX_K2CS(11, 3);
-    else if (need <= 13) DMX_K2CS(13, 3); else if (need <= 15) DMX_K2CS(15, 3); else DMX_K2CS(17, 3);
+    else if (need <= 13) DMX_K2CS(13, 3); else if (need <= 15) DMX_K2CS(15, 3); else if (need <= 17) DMX_K2CS(17, 3);
+    else DMX_K2CS(33, 2);                         // DMX_CLSYM_NED=33 (kernel experiments): one slab, 2 wavefronts per SIMD
 #undef DMX_K2CS
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
