@@ -3794,6 +3794,10 @@ int launch_doublet(dmx_engine* e) {
     // offsets per lane NED and slabs NS with Q * NED * NS >= D: as few slabs as 17 accumulators per lane allow (more do not fit
     // the register file beside the kernel's invariants at 3 wavefronts per SIMD), then the smallest NED
     int NS = (D + Q * 17 - 1) / (Q * 17);
+    // ... except that a panel that would need two slabs of 17 runs as ONE slab of up to 33 at 2 wavefronts per SIMD (212
+    // registers, no spills): every slab repeats phase 1 and the class table, which is two thirds of a 17-offset slab's time
+    // (cfg4, 6 144 barcodes: 267 ms against 302 ms)
+    if (NS == 2 && (D + Q - 1) / Q <= 33) NS = 1;
     if (const char* env = getenv("DMX_CLSYM_NED")) NS = (D + Q * atoi(env) - 1) / (Q * atoi(env));   // kernel experiments only
     const int need = (D + Q * NS - 1) / (Q * NS);
     HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
@@ -3805,7 +3809,7 @@ int launch_doublet(dmx_engine* e) {
     if (need <= 1) DMX_K2CS(1, 4); else if (need <= 2) DMX_K2CS(2, 4); else if (need <= 3) DMX_K2CS(3, 4); else if (need <= 5) DMX_K2CS(5, 4);
     else if (need <= 7) DMX_K2CS(7, 3); else if (need <= 9) DMX_K2CS(9, 3); else if (need <= 11) DMX_K2CS(11, 3);
     else if (need <= 13) DMX_K2CS(13, 3); else if (need <= 15) DMX_K2CS(15, 3); else if (need <= 17) DMX_K2CS(17, 3);
-    else DMX_K2CS(33, 2);                         // DMX_CLSYM_NED=33 (kernel experiments): one slab, 2 wavefronts per SIMD
+    else if (need <= 25) DMX_K2CS(25, 2); else DMX_K2CS(33, 2);   // one slab, 2 wavefronts per SIMD
 #undef DMX_K2CS
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);

@@ -116,7 +116,7 @@ enum { DMX_MODE_STRICT = 0,
         * entries demuxlet prints or decides on are evaluated: llksAB[j][0][0] and one of llksAB[j][k][1] / [k][j][1] (mirrored);
         * llksAB[j][k != 0][0], read by the maxLLK scan (:713-721) only, is filled with llksAB[j][0][0].
         * A printed log-likelihood moves by <= ~2e-11 (tests bound it by 1e-9 against the reference); .best stays identical.
-        * Other alpha grids and panels wider than 128 samples compute every entry, in the bilinear form. */
+        * Other alpha grids compute every entry, in the bilinear form; panels wider than 128 samples (GT inputs: 64) run the STRICT kernels. */
        DMX_MODE_FAST = 1 };
 enum { DMX_ENGINE_NO_CERTIFY = 1   /* skip the device-side tie-order certificate (K3b): for callers that do not need the
                                       reference's DBL-a-b / DBL-b-a order (dmx_job.arbiter = 0 sets it) */ };
