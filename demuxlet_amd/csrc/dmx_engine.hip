@@ -2419,10 +2419,62 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
   const int ti1 = tid >> 1, n1 = tid & 1;
   double acc00 = 0.0;
 
-  uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
-  if (tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
+  // The two-wavefront-per-SIMD forms (one slab of up to 33 offsets) have registers to spare and little else to hide memory
+  // latency with: they run a two-deep pipeline like K1's.  While tile t computes, the header of tile t + 2 and everything tile
+  // t + 1 reads from global memory (class rows, id streams, leading read bytes, gp0) are in flight into registers.
+  constexpr bool PF = MINW <= 2;
+  constexpr int NR_ROWS = TP * 12 / TPC, NR_PK = TP * NW / TPC;   // per-lane registers of a tile's rows (6) and id words (5)
+  uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile (PF: tile + 2)
+  uint32_t pn = 0u; int32_t psn = 0; int64_t poff = 0;             // PF: prepared header of the tile whose data is in flight
+  float d_rows[NR_ROWS]; uint32_t d_pk[NR_PK]; uint32_t d_rd4 = 0u; double d_g0[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NR_ROWS; ++i) d_rows[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NR_PK; ++i) d_pk[i] = 0u;
+  auto load_hdr = [&](int64_t first) {           // header loads of the tile that starts at pair `first`
+    hd_n = 0u; hd_s = 0;
+    const int64_t nx = first + tid;
+    if (tid < TP && nx < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + nx, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + nx] : (int32_t)nx; }
+  };
+  auto prepare = [&]() {                         // PF: hd_* (arrived) -> pn/psn/poff, then request that tile's data
+    pn = hd_n; psn = hd_s;
+    const uint32_t incl = seg_scan_incl<32>(pn);
+    poff = rd_base + (int64_t)(incl - pn);
+    rd_base += (int64_t)__shfl(incl, 31);        // lanes >= 32 carry zeros: lane 31 holds the tile's read count
+#pragma unroll
+    for (int i = 0; i < NR_ROWS; ++i) {
+      const int e = tid + TPC * i;
+      d_rows[i] = rows[(size_t)__shfl(psn, e / 12) * 12 + (e % 12)];
+    }
+#pragma unroll
+    for (int i = 0; i < NR_PK; ++i) {
+      const int e = tid + TPC * i, w = e % NW;
+      const int32_t sn_e = __shfl(psn, e / NW);
+      d_pk[i] = w < nwd2 ? idd[(size_t)sn_e * nwd2 + w] : 0u;
+    }
+    const uint32_t cnt1 = __shfl(pn, ti1);
+    const int64_t off1 = ((int64_t)__shfl((int)(poff >> 32), ti1) << 32) | (uint32_t)__shfl((int)(uint32_t)poff, ti1);
+    d_rd4 = load_rd4(pv, off1, cnt1);
+    const double* g0 = gp0 + (size_t)__shfl(psn, ti1) * 3;
+    d_g0[0] = g0[0]; d_g0[1] = g0[1]; d_g0[2] = g0[2];
+  };
+  load_hdr(0);
+  if (PF) { prepare(); load_hdr(TP); }
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
     const int tp = (int)min((int64_t)TP, np - tbase);
+    uint32_t rd4_cur = 0u; double g0_cur[3] = {0.0, 0.0, 0.0};
+    if (PF) {
+      // this tile's data (requested a tile ago) -> LDS; then prepare the next tile and request the one after's header
+      if (tid < TP) { s_cnt[tid] = pn; s_off[tid] = poff; s_snp[tid] = psn; }
+#pragma unroll
+      for (int i = 0; i < NR_ROWS; ++i) s_rows[tid + TPC * i] = d_rows[i];
+#pragma unroll
+      for (int i = 0; i < NR_PK; ++i) s_pk[tid + TPC * i] = d_pk[i];
+      rd4_cur = d_rd4; g0_cur[0] = d_g0[0]; g0_cur[1] = d_g0[1]; g0_cur[2] = d_g0[2];
+      prepare();
+      load_hdr(tbase + 2 * TP);
+      DMX_WAVE_LDS_ORDER();
+    } else {
     if (tid < TP) {
       const uint32_t n = hd_n;                     // this tile's header was requested a tile ago; now request the next one's
       const int32_t sn = hd_s;
@@ -2442,12 +2494,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
       const int ti = e / NW, w = e % NW;
       s_pk[e] = w < nwd2 ? idd[(size_t)s_snp[ti] * nwd2 + w] : 0u;
     }
+    }
     // ---- phase 1 (k_doublet_sym's: five distinct values per alpha lane)
     {
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
-      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
+      const uint32_t rd4 = PF ? rd4_cur : load_rd4(pv, off, cnt);   // the first four read bytes in one load (one dependent latency instead of four)
       const int32_t snp1 = on ? s_snp[ti1] : 0;
       double qv[5], wA[5], wR[5];
 #pragma unroll
@@ -2497,7 +2550,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
 #pragma unroll
         for (int i = 0; i < 5; ++i) qv[i] = div_by(qv[i], mx, y);            // :656-663
         const double* g0 = gp0 + (size_t)snp1 * 3;
-        const double qq[3] = {g0[0], g0[1], g0[2]};
+        const double qq[3] = {PF ? g0_cur[0] : g0[0], PF ? g0_cur[1] : g0[1], PF ? g0_cur[2] : g0[2]};
         double sum = 0.0;
 #pragma unroll
         for (int l = 0; l < 3; ++l)
