@@ -2141,7 +2141,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;
-  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * NT * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)TP * 12 * 4 + (size_t)TP * VS;
+  // The V > 32 form (NK = 16: 208 registers, 2 wavefronts per SIMD either way) runs a two-deep pipeline: while tile t computes,
+  // the header of tile t + 2 and the class rows, ids, leading read bytes and gp0 of tile t + 1 are in flight into registers.
+  // (panels of up to 64 samples: a tile's id words fit two registers per thread)
+  constexpr bool PF_T = NK >= 16 && TPC == 256;
+  const bool PF = PF_T && VS <= 64;
+  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * NT * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)TP * 12 * 4 + (size_t)TP * VS +
+                            (PF_T ? (size_t)TP * 16 : 0);
   unsigned char* base = s_raw + (size_t)cw * ((cell_bytes + 15) & ~(size_t)15);
   double* s_pG = (double*)base;                                  // [TP][2][9]
   double* s_T = s_pG + TP * 18;                                  // [TP][4][4][2]
@@ -2151,6 +2157,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
   uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
   float* s_rows = (float*)(s_cnt + TP);                          // [TP][4][3]
   uint8_t* s_ids = (uint8_t*)(s_rows + TP * 12);                 // [TP][VS]
+  int64_t* s_off2 = (int64_t*)(s_ids + (size_t)TP * VS);         // PF: [TP] header of the NEXT tile (VS is a multiple of 4, TP * VS of 128)
+  int32_t* s_snp2 = (int32_t*)(s_off2 + TP);
+  uint32_t* s_cnt2 = (uint32_t*)(s_snp2 + TP);
 
   const int slot = blockIdx.x * CPW + cw;
   if (TPC == 64 && slot >= pv.B) return;
@@ -2172,8 +2181,75 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
   const int ti1 = tid >> 1, n1 = tid & 1;
   double acc00 = 0.0;
 
+  constexpr int NRR = (TP * 12 + TPC - 1) / TPC, NRI = (TP * 16 + TPC - 1) / TPC;   // per-thread registers of a tile's rows / id words
+  const int wpr = VS / 4;                        // id words per pair
+  uint32_t hd_n = 0u; int32_t hd_s = 0;          // PF: header loads in flight (lanes < TP of the first wavefront)
+  uint32_t pn = 0u; int32_t psn = 0; int64_t poff = 0;
+  float d_rows[NRR]; uint32_t d_ids[NRI]; uint32_t d_rd4 = 0u; double d_g0[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NRR; ++i) d_rows[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NRI; ++i) d_ids[i] = 0u;
+  auto load_hdr = [&](int64_t first) {
+    hd_n = 0u; hd_s = 0;
+    const int64_t nx = first + tid;
+    if (tid < TP && nx < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + nx, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + nx] : (int32_t)nx; }
+  };
+  auto publish_next = [&]() {                    // first wavefront: hd_* (arrived) -> prepared header of the next tile, into LDS
+    if (tid < 64) {
+      pn = hd_n; psn = hd_s;
+      const uint32_t incl = seg_scan_incl<32>(pn);
+      poff = rd_base + (int64_t)(incl - pn);
+      rd_base += (int64_t)__shfl(incl, 31);
+      if (tid < TP) { s_cnt2[tid] = pn; s_off2[tid] = poff; s_snp2[tid] = psn; }
+    }
+  };
+  auto request_next = [&]() {                    // everybody: the published tile's rows / ids (and read bytes, gp0) -> registers
+#pragma unroll
+    for (int i = 0; i < NRR; ++i) {
+      const int e = tid + TPC * i;
+      if (e < TP * 12) d_rows[i] = rows[(size_t)s_snp2[e / 12] * 12 + (e % 12)];
+    }
+#pragma unroll
+    for (int i = 0; i < NRI; ++i) {
+      const int e = tid + TPC * i;
+      if (e < TP * wpr) {
+        const int ti = e / wpr, wq = e % wpr;
+        const uint8_t* src = ids + (size_t)s_snp2[ti] * V + wq * 4;
+        uint32_t wv = 0;
+        for (int b = 0; b < 4; ++b) if (wq * 4 + b < V) wv |= (uint32_t)src[b] << (8 * b);
+        d_ids[i] = wv;
+      }
+    }
+    if (tid < 64) {
+      d_rd4 = load_rd4(pv, s_off2[ti1], s_cnt2[ti1]);
+      const double* g0 = gp0 + (size_t)s_snp2[ti1] * 3;
+      d_g0[0] = g0[0]; d_g0[1] = g0[1]; d_g0[2] = g0[2];
+    }
+  };
+  if (PF) {
+    load_hdr(0);
+    publish_next();
+    load_hdr(TP);
+    __syncthreads();
+    request_next();
+    __syncthreads();                             // the next tile's header may be overwritten from here on
+  }
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
     const int tp = (int)min((int64_t)TP, np - tbase);
+    uint32_t rd4_cur = 0u; double g0_cur[3] = {0.0, 0.0, 0.0};
+    if (PF) {
+      if (tid < TP) { s_cnt[tid] = pn; s_off[tid] = poff; s_snp[tid] = psn; }
+#pragma unroll
+      for (int i = 0; i < NRR; ++i) { const int e = tid + TPC * i; if (e < TP * 12) s_rows[e] = d_rows[i]; }
+#pragma unroll
+      for (int i = 0; i < NRI; ++i) { const int e = tid + TPC * i; if (e < TP * wpr) reinterpret_cast<uint32_t*>(s_ids)[e] = d_ids[i]; }
+      rd4_cur = d_rd4; g0_cur[0] = d_g0[0]; g0_cur[1] = d_g0[1]; g0_cur[2] = d_g0[2];
+      publish_next();
+      load_hdr(tbase + 2 * TP);
+      DMX_K2_SYNC();
+      request_next();
+    } else {
     if (tid < TP) {
       const bool v = tid < tp;
       const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
@@ -2187,7 +2263,6 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
     // ---- class rows and ids -> LDS
     for (int e = tid; e < tp * 12; e += TPC) s_rows[e] = rows[(size_t)s_snp[e / 12] * 12 + (e % 12)];
     {
-      const int wpr = VS / 4;                    // id words per pair
       for (int e = tid; e < tp * wpr; e += TPC) {
         const int ti = e / wpr, wq = e % wpr;
         const uint8_t* src = ids + (size_t)s_snp[ti] * V + wq * 4;
@@ -2196,12 +2271,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
         reinterpret_cast<uint32_t*>(s_ids)[ti * wpr + wq] = wv;
       }
     }
+    }
     // ---- phase 1 (identical to k_doublet_a2)
     if (tid < 64) {
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
-      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
+      const uint32_t rd4 = PF ? rd4_cur : load_rd4(pv, off, cnt);   // the first four read bytes in one load (one dependent latency instead of four)
       double pG[9], wA[9], wR[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) { pG[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][9 + i]; }
@@ -2248,7 +2324,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
       if (on) {
         const double y = rcp_refined(mx);
         const double* g0 = gp0 + (size_t)s_snp[ti1] * 3;
-        const double qq[3] = {g0[0], g0[1], g0[2]};
+        const double qq[3] = {PF ? g0_cur[0] : g0[0], PF ? g0_cur[1] : g0[1], PF ? g0_cur[2] : g0[2]};
         double sum = 0.0;
 #pragma unroll
         for (int l = 0; l < 3; ++l)
@@ -3870,6 +3946,7 @@ int launch_doublet(dmx_engine* e) {
   if (use_cls) {
     const int VS = (V <= 32) ? ((V + 3) & ~3) : ((V + 15) & ~15);   // id row stride: a whole number of k-blocks
     size_t cb = (size_t)32 * 18 * 8 + (size_t)32 * 32 * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8) + (size_t)32 * 12 * 4 + (size_t)32 * VS;
+    if (V > 32) cb += 32 * 16;                      // the pipelined form's second header buffer
     cb = (cb + 15) & ~(size_t)15;
     HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
     const dim3 blk(kThreads);
