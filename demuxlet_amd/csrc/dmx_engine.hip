@@ -26,6 +26,7 @@
 #include <memory>
 #include <functional>
 #include <thread>
+#include <type_traits>
 #include <string>
 #include <numeric>
 #include <vector>
@@ -1044,7 +1045,9 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 //           :553), the nine-term l-major sums for both alphas (:677-679), log, add (:683).
 // log() arguments outside the normal positive range cannot occur for genuine likelihoods; if one does, the cell is
 // flagged and recomputed by k_doublet_generic<FIXUP> with ocml's log().
-template <int TPC, int NK, int MINW = 1>
+// GD: the genotype rows are widened to binary64 once, when they are staged (a conversion per element and tile instead of one per
+// use in phase 2); the LDS holds them as doubles.
+template <int TPC, int NK, int MINW = 1, bool GD = false>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                          const double* __restrict__ alpha,
@@ -1072,11 +1075,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
 
   const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
   // per-cell LDS regions
-  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * GS * 4 + 2 * T00 * 8 + TP * (4 + 4 + 8);
+  using g_t = typename std::conditional<GD, double, float>::type;
+  const size_t cell_bytes = (size_t)TP * 18 * 8 + (size_t)TP * GS * sizeof(g_t) + 2 * T00 * 8 + TP * (4 + 4 + 8);
   unsigned char* base = s_raw + (size_t)cw * cell_bytes;
   double* s_pG = (double*)base;                                  // [TP][2][9]
-  float* s_g = (float*)(base + (size_t)TP * 18 * 8);             // [TP][GS]   genotype rows of the tile's SNPs
-  double* s_t00 = (double*)((unsigned char*)s_g + (size_t)TP * GS * 4);   // [2][T00]   llks00 terms
+  g_t* s_g = (g_t*)(base + (size_t)TP * 18 * 8);                 // [TP][GS]   genotype rows of the tile's SNPs
+  double* s_t00 = (double*)((unsigned char*)s_g + (size_t)TP * GS * sizeof(g_t));   // [2][T00]   llks00 terms
   int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                  // [TP]
   int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
   uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
@@ -1123,7 +1127,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
       int r = tid % row_len, ti = tid / row_len;
       const int dr = TPC % row_len, dt = TPC / row_len;
       while (ti < tp) {
-        s_g[ti * GS + r] = g[(size_t)s_snp[ti] * row_len + r];
+        s_g[ti * GS + r] = (g_t)g[(size_t)s_snp[ti] * row_len + r];
         r += dr; ti += dt;
         if (r >= row_len) { r -= row_len; ++ti; }
       }
@@ -1216,7 +1220,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
         double P0[9], P1[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) { P0[i] = P[i]; P1[i] = P[9 + i]; }
-        const float* gr = &s_g[ti * GS];
+        const g_t* gr = &s_g[ti * GS];
         const double a0 = (double)gr[j * 3], a1 = (double)gr[j * 3 + 1], a2 = (double)gr[j * 3 + 2];
         const double aj[3] = {a0, a1, a2};
 #pragma unroll
@@ -4056,7 +4060,11 @@ int launch_doublet(dmx_engine* e) {
   else if (V <= 16) DMX_K2A(64, 4);
   else if (V <= 32) {
     // 4 wavefronts per SIMD (128 VGPRs, a few spills outside the hot loop) measured 2.8 % faster than 3 (158 VGPRs) on cfg3
-    if (!getenv("DMX_A2_MINW1"))
+    if (!getenv("DMX_A2_NO_GD") && !getenv("DMX_A2_MINW1")) {   // rows widened to binary64 at staging: 1-2.5 % (cfg3, 5 000 barcodes: 741-753 vs 760 ms)
+      const size_t cbd = (size_t)32 * 18 * 8 + (size_t)32 * GS * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
+      hipLaunchKernelGGL((k_doublet_a2<256, 4, 4, true>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
+                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
+    } else if (!getenv("DMX_A2_MINW1"))
       hipLaunchKernelGGL((k_doublet_a2<256, 4, 4>), dim3((unsigned)B, slabs_of(256, 4)), block, cell_bytes, e->stream, e->pv, e->nrd_width, e->d_g,
                          e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
     else DMX_K2A(256, 4);
