@@ -1550,9 +1550,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 template <int TPC, int VMAX, int SUB, bool FIXJ, int MINW = 3, int NEP = 0>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                           const double* __restrict__ gp0, const double* __restrict__ tabs,
-                                                          const int32_t* __restrict__ sched, int32_t V,
+                                                          const int32_t* __restrict__ sched, int32_t V_and_flags,
                                                           double* __restrict__ grid, double* __restrict__ l00,
                                                           uint8_t* __restrict__ flagged) {
+  const int32_t V = V_and_flags & 0xFFFF;
+  const bool no_dma = (V_and_flags >> 16) & 1;   // kernel experiments (DMX_SYM_NO_DMA)
   // Narrow panels put SEVERAL barcodes in one wavefront (TPC = 32: two, TPC = 16: four): their entries fill the lanes (V = 16: 160
   // entries = 5 per lane of 32; V = 8: 48 = 3 per lane of 16) and the per-tile phases 0-1 are shared instruction-wise.  The tile is
   // what one pass of phase 1 covers: two lanes per pair.
@@ -1584,7 +1586,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
-  constexpr size_t cell_bytes = (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)SUB * GSS * 4 + (size_t)SUB * 3 * VUS * 8;
+  // One barcode per wavefront or more wavefronts per barcode (TPC >= 64): the genotype rows of a sub-tile go from global memory
+  // straight into the LDS (global_load_lds: no registers, uniform source base per row), one sub-tile ahead of their use, into the
+  // other half of a double buffer — the first sub-tile's while phase 1 runs.  cfg3 FAST: 394 -> 349 ms on one box.
+  constexpr bool DMA_T = TPC >= 64;
+  constexpr size_t cell_bytes = (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)(DMA_T ? 2 : 1) * SUB * GSS * 4 + (size_t)SUB * 3 * VUS * 8;
   unsigned char* base = s_raw + (size_t)cw * cell_bytes;
   double* s_q1 = (double*)base;                                  // [TP][6]    pG of alpha 0.5: q[l+m], five distinct values
   double* s_u0 = s_q1 + TP * 6;                                  // [TP][4]    u of (alpha 0, sample 0)
@@ -1592,8 +1598,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                  // [TP]
   int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
   uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
-  float* s_g = (float*)(s_cnt + TP);                             // [SUB][GSS] genotype rows of the sub-tile's SNPs
-  double* s_u = (double*)(s_g + SUB * GSS);                      // [SUB][3][VUS]
+  float* s_g0 = (float*)(s_cnt + TP);                            // [SUB][GSS] genotype rows of the sub-tile's SNPs (DMA: x 2)
+  double* s_u = (double*)(s_g0 + (DMA_T ? 2 : 1) * SUB * GSS);   // [SUB][3][VUS]
 
   const int slot = blockIdx.x * CPW + cw;
   if (TPC == 64 && slot >= pv.B) return;         // whole wavefront idle (no workgroup barriers below in this mode)
@@ -1627,6 +1633,21 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   constexpr bool PREFETCH = TPC < 64;
   uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
   if (PREFETCH && tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
+  const bool dma = DMA_T && !no_dma;
+  auto request_rows = [&](int sub, int buf) {    // rows of the pairs sub .. sub+SUB-1 of the current tile -> s_g0[buf], asynchronously
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+    const int wv = tid & ~63;                      // first lane of this wavefront inside the cell
+#pragma unroll
+    for (int pi = 0; pi < SUB; ++pi) {             // a row at a time: uniform source base, lane r reads element r
+      const float* src = g + (size_t)__builtin_amdgcn_readfirstlane(s_snp[sub + pi]) * row_len;
+#pragma unroll
+      for (int h = 0; h < (GSS + TPC - 1) / TPC; ++h) {
+        const int r = tid + TPC * h;
+        if (r < row_len) __builtin_amdgcn_global_load_lds((gptr)(src + r), (lptr)(s_g0 + (buf * SUB + pi) * GSS + wv + TPC * h), 4, 0, 0);
+      }
+    }
+  };
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
     const int tp = (int)min((int64_t)TP, np - tbase);
     // ---- headers of the tile's pairs (first 32 lanes of the cell)
@@ -1649,6 +1670,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
     }
     DMX_K2_SYNC();
     rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    if (dma) request_rows(0, 0);                   // sub-tile 0's rows travel while phase 1 runs
     // ---- phase 1: pG[n][3][3] of the pair (:600-663), exactly as k_doublet_a2; kept: alpha 0.5's nine values, and for
     //      alpha 0 the three u values of sample 0 (the only k the singlet column [j][0][0] needs)
     if (tid < 2 * TP) {
@@ -1750,8 +1772,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #pragma unroll 1
     for (int sub = 0; sub < tp; sub += SUB) {
       const int ns = min(SUB, tp - sub);
+      const int buf = dma ? (sub / SUB) & 1 : 0;
+      float* s_g = s_g0 + buf * SUB * GSS;
+      if (dma) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this sub-tile's rows have landed ...
+        if (sub + SUB < tp) request_rows(sub + SUB, buf ^ 1);   // ... the next one's take off (its buffer was last read two syncs ago)
+      } else {
       // genotype rows of the sub-tile -> LDS (coalesced along the row)
-      {
         int r = tid % row_len, pi = tid / row_len;
         const int dr = TPC % row_len, dt = TPC / row_len;
         while (pi < ns) {
@@ -3981,25 +4008,26 @@ int launch_doublet(dmx_engine* e) {
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do {                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
-    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 64 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
     hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
-                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V,           \
+                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
 #define DMX_K2SV(TPC, VMAX, SUB, FIX, MINW)                                                                            \
   do {                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
-    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 64 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
     hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
-                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V,           \
+                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
+    const int32_t sym_flags = getenv("DMX_SYM_NO_DMA") ? (1 << 16) : 0;       // kernel experiments only
     const bool wide_cells = getenv("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
     if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
     else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
@@ -4022,11 +4050,11 @@ int launch_doublet(dmx_engine* e) {
 #define DMX_K2SS(VMAX, FIX)                                                                                            \
   do {                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1;                                                  \
-    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)8 * GSS_ * 4 + (size_t)8 * 3 * VUS_ * 8; \
+    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)2 * 8 * GSS_ * 4 + (size_t)8 * 3 * VUS_ * 8; \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, 8, FIX, 3, 9>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
     hipLaunchKernelGGL((k_doublet_sym<256, VMAX, 8, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv,   \
-                       e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V, e->d_grid, e->d_l00, e->d_flag);        \
+                       e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);        \
   } while (0)
       if (V <= 96) DMX_K2SS(96, false); else if (V == 128) DMX_K2SS(128, true); else DMX_K2SS(128, false);
 #undef DMX_K2SS
