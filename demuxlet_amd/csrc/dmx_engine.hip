@@ -3160,6 +3160,65 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
   }
 }
 
+// Phase 1 of k_certify for one (pair, alpha) lane: the pG values of :597-663 with the one-max-across-both-alphas renormalisation
+// after every read, finished (:656-663) and handed from the alpha = 0.5 lane to its alpha = 0 neighbour.  NV = 9: the nine
+// values pG[l][m]; NV = 5 (alpha[0] == 0): the five distinct values of alpha 0.5 (weight p = (l + m) / 4, index l + m) beside the
+// three of alpha 0 (p = l / 2) — entries with equal weights go through identical operations, so the values are bit-identical.
+template <int NV>
+__device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32_t cnt, int64_t off, uint32_t rd4, const double* s_tab,
+                                                    const double (&wA)[NV], const double (&wR)[NV], int n1, double (&v)[NV]) {
+  double pG[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) pG[i] = 1.0;                               // :597
+  for (uint32_t r = 0; __any(r < cnt); ++r) {
+    const bool live = r < cnt;
+    const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
+    const uint32_t bq = byte & 127u;
+    const bool alt = (byte >> 7) != 0;
+    const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+    const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+    double mx = 0.0;
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+        mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+      }
+    }
+    {
+      const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+      mx = (mx < o) ? o : mx;
+    }
+    if (live) {
+      if (cnt <= kSafeReads) {
+        const double y = rcp_refined(mx);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) pG[i] = div_by(pG[i], mx, y);      // :632-639
+      } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) pG[i] = div_slow(pG[i], mx);
+      }
+    }
+  }
+  double mx = 0.0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    pG[i] += 1e-6;                                                       // :649
+    mx = (mx < pG[i]) ? pG[i] : mx;
+  }
+  {
+    const double o = __shfl_xor(mx, 1);
+    mx = (mx < o) ? o : mx;
+  }
+  // the alpha = 0.5 lane finishes its values (:656-663) and hands a copy to its alpha = 0 neighbour (which only had to contribute
+  // to the shared maxima): the two lanes of a pair then take one accumulator each
+  const double y = rcp_refined(mx);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = div_by(pG[i], mx, y);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { const double o = __shfl_xor(v[i], 1); v[i] = n1 ? v[i] : o; }
+}
+
 // K3b — the tie-order certificate (DESIGN.md "Ties").  At alpha = 0.5 the reference's llksAB[j][k] and llksAB[k][j] are one number
 // mathematically and differ by the rounding noise of its own evaluation order; its strict-< scan then names the doublet
 // "a-b" or "b-a" by that noise.  To print the same order one has to know BOTH accumulators as the reference computes them, bit for
@@ -3200,17 +3259,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_certify(PileupView pv, int nrd_
   const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
   int64_t rd_base = pv.cell_read_off[cell];
   const int ti1 = tid >> 1, n1 = tid & 1;
-  double wA[9], wR[9];
+  const bool five = alpha[0] == 0.0;             // the default grid {0, 0.5}: five distinct values per lane instead of nine
+  double wA5[5], wR5[5];
   {
-    const double al = alpha[n1];
 #pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        const double p = 0.5 * l + (m - l) * 0.5 * al;
-        wA[l * 3 + m] = p;
-        wR[l * 3 + m] = 1.0 - p;
-      }
+    for (int q = 0; q < 5; ++q) {                  // alpha 0.5: p = 0.25 (l + m), slot l + m; alpha 0: p = 0.5 l, slots 0..2 (3, 4 repeat 2)
+      const int l = n1 ? (q > 2 ? 2 : q) : min(q, 2), m = n1 ? q - l : 0;
+      const double p = 0.5 * l + (m - l) * 0.5 * (n1 ? 0.5 : 0.0);
+      wA5[q] = p;
+      wR5[q] = 1.0 - p;
+    }
   }
   bool ok = true;
   // Lanes 0..3 own the four chains: (a,b) low, (a,b) high, (b,a) low, (b,a) high = the accumulator had every ambiguous log() come
@@ -3248,58 +3306,26 @@ __global__ __launch_bounds__(kThreads, 4) void k_certify(PileupView pv, int nrd_
       const int32_t snp1 = on ? s_snp[ti1] : 0;
       const float* gr = g + (size_t)snp1 * row_len;
       const float fa0 = gr[ia * 3], fa1 = gr[ia * 3 + 1], fa2 = gr[ia * 3 + 2], fb0 = gr[ib * 3], fb1 = gr[ib * 3 + 1], fb2 = gr[ib * 3 + 2];
-      double pG[9];
+      double v[9];                                 // pG[1][l][m] of the pair (five: v[l + m])
+      if (five) {
+        double v5[5];
+        certify_pair_values<5>(pv, cnt, off, rd4, s_tab, wA5, wR5, n1, v5);
 #pragma unroll
-      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
-      for (uint32_t r = 0; __any(r < cnt); ++r) {
-        const bool live = r < cnt;
-        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
-        const uint32_t bq = byte & 127u;
-        const bool alt = (byte >> 7) != 0;
-        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
-        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
-        double mx = 0.0;
-        if (live) {
+        for (int l = 0; l < 3; ++l)
 #pragma unroll
-          for (int i = 0; i < 9; ++i) {
-            pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
-            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+          for (int m = 0; m < 3; ++m) v[l * 3 + m] = v5[l + m];
+      } else {                                     // other alpha[0]: the nine-value form, weights formed here (:613)
+        double wA[9], wR[9];
+        const double al = alpha[n1];
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double p = 0.5 * l + (m - l) * 0.5 * al;
+            wA[l * 3 + m] = p;
+            wR[l * 3 + m] = 1.0 - p;
           }
-        }
-        {
-          const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
-          mx = (mx < o) ? o : mx;
-        }
-        if (live) {
-          if (cnt <= kSafeReads) {
-            const double y = rcp_refined(mx);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);       // :632-639
-          } else {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) pG[i] = div_slow(pG[i], mx);
-          }
-        }
-      }
-      double mx = 0.0;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) {
-        pG[i] += 1e-6;                                                       // :649
-        mx = (mx < pG[i]) ? pG[i] : mx;
-      }
-      {
-        const double o = __shfl_xor(mx, 1);
-        mx = (mx < o) ? o : mx;
-      }
-      // the alpha = 0.5 lane finishes its nine values (:656-663) and hands a copy to its alpha = 0 neighbour (which only had to
-      // contribute to the shared maxima): the two lanes of a pair then take one accumulator each
-      double v[9];
-      {
-        const double y = rcp_refined(mx);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) v[i] = div_by(pG[i], mx, y);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { const double o = __shfl_xor(v[i], 1); v[i] = n1 ? v[i] : o; }
+        certify_pair_values<9>(pv, cnt, off, rd4, s_tab, wA, wR, n1, v);
       }
       if (on) {
         const double aj[3] = {(double)fa0, (double)fa1, (double)fa2}, bk[3] = {(double)fb0, (double)fb1, (double)fb2};

@@ -658,15 +658,17 @@ def test_engines_on_distinct_devices_when_there_are_several(eng, oracle, tmp_pat
         assert (tmp_path / f"o.{suf}").read_bytes() == ref, suf
 
 
-@pytest.mark.parametrize("V,field,S,B,mode", [(8, "GT", 1500, 300, "strict"), (16, "GP", 800, 200, "fast"), (32, "GT", 600, 120, "fast"),
-                                              (5, "PL", 3000, 200, "strict"), (64, "GT", 300, 60, "fast")])
-def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_path, V, field, S, B, mode):
+@pytest.mark.parametrize("V,field,S,B,mode,a0", [(8, "GT", 1500, 300, "strict", 0.0), (16, "GP", 800, 200, "fast", 0.0), (32, "GT", 600, 120, "fast", 0.0),
+                                                 (5, "PL", 3000, 200, "strict", 0.0), (64, "GT", 300, 60, "fast", 0.0),
+                                                 (12, "GP", 900, 150, "strict", 0.2)])     # alpha[0] != 0: K3b's nine-value phase 1
+def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_path, V, field, S, B, mode, a0):
     """K3b (k_certify) decides on the device, for most barcodes, in which order the reference names the two samples of an
     alpha = 0.5 best doublet — by bracketing the reference's two accumulators bit for bit (DESIGN.md "Ties").  The host tie
     arbiter re-evaluates both accumulators with the host's log().  Wherever the device claims a certificate the two must agree on
     the order AND on LLK12's bits: writing .sing2/.best from the records as certified must give the same bytes as writing them
     with every certificate wiped (= the arbiter decides every barcode)."""
     from demuxlet_amd import synth, capi
+    alphas = (a0, 0.5)
     rng = np.random.default_rng(900 + V)
     raw = synth.make_raw_genotypes(rng, S, V)
     if field == "GT":
@@ -677,7 +679,7 @@ def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_pat
         g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, raw.alleles)])
     sp = synth.make_pileup(rng, raw.alleles, B, 0.5, 1.6, dense_layout=False, doublet_rate=0.5)
     pl = host_pileup(eng, sp)
-    e = eng.Engine(V, (0.0, 0.5), 0.5, mode=capi.DMX_MODE_FAST if mode == "fast" else capi.DMX_MODE_STRICT)
+    e = eng.Engine(V, alphas, 0.5, mode=capi.DMX_MODE_FAST if mode == "fast" else capi.DMX_MODE_STRICT)
     e.set_genotypes(g); e.set_pileup(pl)
     e.run_singlet(); e.run_doublet()
     _, l00, summ = e.get_doublet(want_grid=False)
@@ -691,7 +693,7 @@ def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_pat
     print(f"V={V} {field} {mode}: {cert.sum()} of {covered.sum()} covered barcodes carry the order certificate ({100 * frac:.1f} %), "
           f"{resv.sum()} more hang on one host log() per accumulator ({100 * resv[covered].mean():.1f} %)")
     assert frac > 0.5
-    fa = eng.FinalArgs([f"BC{i:05d}" for i in range(B)], [f"S{j}" for j in range(V)], (0.0, 0.5), 0.5, sp.rd_totl, sp.rd_pass, sp.rd_uniq,
+    fa = eng.FinalArgs([f"BC{i:05d}" for i in range(B)], [f"S{j}" for j in range(V)], alphas, 0.5, sp.rd_totl, sp.rd_pass, sp.rd_uniq,
                        pl.n_snp_per_cell)
     eng.write_doublet_summary(fa, sing, l00, summ, str(tmp_path / "cert"), tie_pileup=pl, tie_g=g)
     wiped = summ.copy()
@@ -700,11 +702,11 @@ def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_pat
     for suf in ("sing2", "best"):
         assert (tmp_path / f"cert.{suf}").read_bytes() == (tmp_path / f"host.{suf}").read_bytes(), suf
     # and both are the oracle's files (the arbiter path is what the golden tests pin)
-    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    ref = oracle_from_pileup(oracle, sp, g, alphas, 0.5)
     from golden_util import summary_from_grid
     n_swapped = 0
     for c in np.flatnonzero(cert):
-        want = summary_from_grid(ref.llksAB[c], ref.llks00[c], (0.0, 0.5), 0.5, int(summ[c]["n_pairs"]), summ.dtype)
+        want = summary_from_grid(ref.llksAB[c], ref.llks00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)
         assert (int(summ[c]["j_best"]), int(summ[c]["k_best"])) == (int(want["j_best"]), int(want["k_best"])), c
         assert summ[c]["llk12"] == want["llk12"], c               # the reference's bits
         n_swapped += int(summ[c]["j_best"] > summ[c]["k_best"])
@@ -718,7 +720,7 @@ def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_pat
         assert ref.llksAB[c][a][b][1] in (summ[c]["llk_ab"], summ[c]["llk_ab_alt"]), c
         assert ref.llksAB[c][b][a][1] in (summ[c]["llk_ba"], summ[c]["llk_ba_alt"]), c
         if done[c]["flags"] & capi.DMX_CELL_ORDER_CERTIFIED:
-            want = summary_from_grid(ref.llksAB[c], ref.llks00[c], (0.0, 0.5), 0.5, int(summ[c]["n_pairs"]), summ.dtype)
+            want = summary_from_grid(ref.llksAB[c], ref.llks00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)
             assert (int(done[c]["j_best"]), int(done[c]["k_best"])) == (int(want["j_best"]), int(want["k_best"])), c
             assert done[c]["llk12"] == want["llk12"] and done[c]["llk_ab"] == ref.llksAB[c][a][b][1] and done[c]["llk_ba"] == ref.llksAB[c][b][a][1], c
             for f in ("llk1", "llk2", "llk10", "llk20"):
