@@ -174,6 +174,10 @@ def main():
                   write_pair=True, doublet_prior=0.2),
         make_case("gt_v24_a2_deep", 109, B=10, S=200, V=24, alphas=(0.0, 0.5), field="GT", delta=0.5, rbar=6.0, write_pair=True,
                   missing_rate=0.1),
+        # the headline shape in small: soft field, 32 samples, default grid, dense layout (the A = 2 kernels of 17..32 samples and,
+        # in FAST mode, the printed-entries kernel with its LDS-direct row loads); and a 100-sample soft-field panel (entry slabs)
+        make_case("gp_v32_a2_dense", 110, B=12, S=160, V=32, alphas=(0.0, 0.5), field="GP", delta=1.0, rbar=1.25, write_pair=True),
+        make_case("pl_v100_a2", 111, B=5, S=220, V=100, alphas=(0.0, 0.5), field="PL", delta=0.35, rbar=1.5),
     ]
     only = set(sys.argv[1:])                 # python make_golden.py [case ...]: regenerate just these
     if only:

@@ -5,7 +5,7 @@ import numpy as np
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 CASES = ["kat_micro", "gt_v4_a2_pair", "gp_v8_a2_minsnp", "pl_v32_a3", "gt_v64_a2", "gt_v3_alpha_quirk", "gt_v5_dense",
-         "gp_v70_a5", "pl_v12_a6_pair", "gt_v24_a2_deep"]
+         "gp_v70_a5", "pl_v12_a6_pair", "gt_v24_a2_deep", "gp_v32_a2_dense", "pl_v100_a2"]
 
 
 class Golden:
