@@ -67,6 +67,39 @@ def test_golden_raw_arrays(eng, oracle, name):
     print(f"{name}: max|d| llks={d1:.2e} llk0s={d0:.2e} grid={dg:.2e} llks00={d00:.2e}")
     assert max(d1, d0, dg, d00) < TOL
 
+@pytest.mark.parametrize("name", CASES)
+def test_golden_files_end_to_end_fast_mode(eng, oracle, name, tmp_path):
+    """The same twelve jobs in DMX_MODE_FAST (what the demuxlet binary runs by default), against the REFERENCE's files: every string
+    field identical (barcodes, sample ids, BEST calls, the order of the two samples of a doublet), every printed number equal
+    or different in its last printed digit only (FAST moves a log-likelihood by ~1e-11; on these fixtures no digit flips)."""
+    from demuxlet_amd import capi
+    gd = Golden(name)
+    pb = gd.problem(oracle)
+    st = build_store(eng, pb)
+    eng.demuxlet_run(st, gd.g, gd.sample_ids, gd.alphas, str(tmp_path / "o"), gd.doublet_prior, gd.min_total, gd.min_uniq,
+                     gd.min_snp, gd.write_pair, arbiter=True, n_gpus=2, mode=capi.DMX_MODE_FAST)
+    n_text_diff = 0
+    for suf, ref in gd.files.items():
+        got = (tmp_path / f"o.{suf}").read_text().splitlines()
+        want = ref.decode().splitlines()
+        assert len(got) == len(want), suf
+        assert got[0] == want[0]
+        for a, b in zip(got[1:], want[1:]):
+            fa, fb = a.split("\t"), b.split("\t")
+            assert len(fa) == len(fb)
+            for x, y in zip(fa, fb):
+                try:
+                    fx, fy = float(x), float(y)
+                except ValueError:
+                    assert x == y, (suf, a, b)
+                    continue
+                if x != y:
+                    n_text_diff += 1
+                    assert abs(fx - fy) <= 1e-3 * max(1e-3, abs(fy)) + 1.01e-4, (suf, a, b)
+    print(f"{name}: FAST end to end, {n_text_diff} printed numbers differ in the last digit")
+    assert n_text_diff <= 2
+
+
 
 @pytest.mark.parametrize("n_gpus,range_bytes", [(1, 0), (3, 0), (1, 3000), (2, 20000)])
 @pytest.mark.parametrize("name", CASES)
