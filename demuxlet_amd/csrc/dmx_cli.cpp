@@ -488,18 +488,25 @@ struct VcfReader {
     if (!in.open(path)) fatal("[E:%s] Cannot open VCF file %s", __func__, path.c_str());
     std::string line;
     bool have_header = false;
-    while (in.getline(line)) {
-      if (line.rfind("##contig=<ID=", 0) == 0) {
-        size_t b = 13, e = line.find_first_of(",>", b);
-        const std::string id = line.substr(b, e - b);
-        if (!contig_rid.count(id)) { int r = (int)contig_rid.size(); contig_rid[id] = r; }
-      } else if (line.rfind("#CHROM", 0) == 0) {
-        auto f = split(line, '\t');
-        for (size_t i = 9; i < f.size(); ++i) samples.push_back(f[i]);
-        have_header = true;
-        break;
-      } else if (line.rfind("##", 0) != 0) {
-        fatal("[E:%s] %s does not look like a VCF file (BCF/CRAM need htslib, which this build does not use)", __func__, path.c_str());
+    dict.assign(1, "PASS");                      // the implicit first dictionary entry
+    in.fill();
+    is_bcf = in.cur.size() >= 5 && memcmp(in.cur.data(), "BCF\2\2", 5) == 0;
+    if (is_bcf) {                                // BCF2: magic, l_text, the VCF header as text (NUL-terminated), then binary records
+      uint8_t magic[5]; uint32_t l_text = 0;
+      if (!in.read(magic, 5) || !in.read(&l_text, 4) || l_text > (1u << 30)) fatal("[E:%s] %s: truncated BCF header", __func__, path.c_str());
+      std::string text((size_t)l_text, '\0');
+      if (!in.read(&text[0], l_text)) fatal("[E:%s] %s: truncated BCF header", __func__, path.c_str());
+      while (!text.empty() && text.back() == '\0') text.pop_back();
+      for (std::string ln : split(text, '\n')) {
+        if (!ln.empty() && ln.back() == '\r') ln.pop_back();
+        parse_header_line(ln, have_header);
+      }
+    } else {
+      while (in.getline(line)) {
+        if (line.rfind("##", 0) != 0 && line.rfind("#CHROM", 0) != 0)
+          fatal("[E:%s] %s does not look like a VCF or BCF file (CRAM and indexed access need htslib, which this build does not use)", __func__, path.c_str());
+        parse_header_line(line, have_header);
+        if (have_header) break;
       }
     }
     if (!have_header) fatal("[E:%s] No #CHROM header line in %s", __func__, path.c_str());
@@ -518,75 +525,264 @@ struct VcfReader {
   int nsamples() const { return (int)sm_icols.size(); }
   const char* sample_id(int i) const { return samples[sm_icols[i]].c_str(); }
 
+  // One record, decoded from VCF text or from BCF2 into the same shape; the filter and the a3 transforms see no difference.
+  struct Rec {
+    std::string chrom, ref; std::vector<std::string> alts;
+    int64_t pos = 0;                             // 0-based
+    bool has_gt = false, has_fld = false;
+    std::vector<int32_t> alleles;                // [nv*2], -1 = missing
+    std::vector<int32_t> pl;                     // [nv*3], INT32_MIN = missing   (field PL)
+    std::vector<float> gp;                       // [nv*3], NaN = missing         (field GP)
+  };
+
+  // ---- BCF2 (the binary VCF; bgzip'd).  Typed values: descriptor byte = (length << 4) | type, length 15 = "a typed integer
+  //      follows"; types 1/2/3 = int8/16/32, 5 = float, 7 = char.  Strings of FILTER/INFO/FORMAT keys and contig names are
+  //      indices into dictionaries built from the header lines (implicit PASS = 0; IDX= overrides the running index).
+  bool is_bcf = false;
+  std::vector<std::string> dict, ctg_names;
+  std::vector<uint8_t> rbuf;
+
+  static int64_t typed_int(const uint8_t*& p, const uint8_t* end, int type) {
+    if (type == 1) { if (p + 1 > end) return INT64_MIN; const int8_t x = (int8_t)*p; p += 1; return x; }
+    if (type == 2) { if (p + 2 > end) return INT64_MIN; int16_t x; memcpy(&x, p, 2); p += 2; return x; }
+    if (type == 3) { if (p + 4 > end) return INT64_MIN; int32_t x; memcpy(&x, p, 4); p += 4; return x; }
+    return INT64_MIN;
+  }
+  // descriptor -> (type, length); false on truncation
+  static bool typed_desc(const uint8_t*& p, const uint8_t* end, int& type, int64_t& len) {
+    if (p >= end) return false;
+    const uint8_t d = *p++;
+    type = d & 15; len = d >> 4;
+    if (len == 15) {
+      if (p >= end) return false;
+      const int t2 = *p++ & 15;
+      len = typed_int(p, end, t2);
+      if (len < 0) return false;
+    }
+    return true;
+  }
+  static int type_size(int type) { return type == 1 ? 1 : type == 2 ? 2 : type == 3 ? 4 : type == 5 ? 4 : type == 7 ? 1 : 0; }
+  static bool typed_string(const uint8_t*& p, const uint8_t* end, std::string& out) {
+    int type; int64_t len;
+    if (!typed_desc(p, end, type, len)) return false;
+    if (type == 0 && len == 0) { out.clear(); return true; }          // missing
+    if (type != 7 || p + len > end) return false;
+    out.assign((const char*)p, (size_t)len); p += len;
+    return true;
+  }
+  static bool typed_skip(const uint8_t*& p, const uint8_t* end) {
+    int type; int64_t len;
+    if (!typed_desc(p, end, type, len)) return false;
+    const int64_t n = len * type_size(type);
+    if (p + n > end) return false;
+    p += n;
+    return true;
+  }
+
+  void parse_header_line(const std::string& line, bool& have_header) {
+    auto attr = [&](const char* key) -> std::string {                // value of key= inside <...>
+      const std::string k = std::string(key) + "=";
+      size_t b = line.find("<" + k);
+      if (b == std::string::npos) b = line.find("," + k);
+      if (b == std::string::npos) return "";
+      b += 1 + k.size();
+      const size_t e = line.find_first_of(",>", b);
+      return line.substr(b, e == std::string::npos ? std::string::npos : e - b);
+    };
+    if (line.rfind("##contig=<", 0) == 0) {
+      const std::string id = attr("ID");
+      if (!contig_rid.count(id)) { int r = (int)contig_rid.size(); contig_rid[id] = r; }
+      const std::string idx = attr("IDX");
+      const size_t at = idx.empty() ? ctg_names.size() : (size_t)atoll(idx.c_str());
+      if (ctg_names.size() <= at) ctg_names.resize(at + 1);
+      ctg_names[at] = id;
+    } else if (line.rfind("##FILTER=<", 0) == 0 || line.rfind("##INFO=<", 0) == 0 || line.rfind("##FORMAT=<", 0) == 0) {
+      const std::string id = attr("ID");
+      if (std::find(dict.begin(), dict.end(), id) != dict.end()) return;
+      const std::string idx = attr("IDX");
+      const size_t at = idx.empty() ? dict.size() : (size_t)atoll(idx.c_str());
+      if (dict.size() <= at) dict.resize(at + 1);
+      dict[at] = id;
+    } else if (line.rfind("#CHROM", 0) == 0) {
+      auto f = split(line, '\t');
+      for (size_t i = 9; i < f.size(); ++i) samples.push_back(f[i]);
+      have_header = true;
+    }
+  }
+
+  template <typename T> static T rd(const uint8_t* p) { T x; memcpy(&x, p, sizeof x); return x; }
+
+  bool read_bcf(Rec& r) {
+    uint32_t len[2];
+    if (!in.read(len, 8)) return false;
+    const size_t l_shared = len[0], l_indiv = len[1];
+    if (l_shared < 24 || l_shared + l_indiv > ((size_t)1 << 31)) fatal("[E:%s] %s: corrupt BCF record (lengths %u, %u)", __func__, in.path.c_str(), len[0], len[1]);
+    rbuf.resize(l_shared + l_indiv);
+    if (!in.read(rbuf.data(), rbuf.size())) fatal("[E:%s] %s: truncated BCF record", __func__, in.path.c_str());
+    const uint8_t* p = rbuf.data();
+    const uint8_t* se = p + l_shared;
+    const int32_t chrom = rd<int32_t>(p), pos = rd<int32_t>(p + 4);
+    const uint32_t n_allele_info = rd<uint32_t>(p + 16), n_fmt_sample = rd<uint32_t>(p + 20);
+    const int n_allele = (int)(n_allele_info >> 16), n_fmt = (int)(n_fmt_sample >> 24);
+    const size_t n_sample = n_fmt_sample & 0xFFFFFFu;
+    p += 24;
+    if (chrom < 0 || (size_t)chrom >= ctg_names.size()) fatal("[E:%s] %s: BCF record names contig %d, the header has %u", __func__, in.path.c_str(), chrom, (unsigned)ctg_names.size());
+    if (n_sample != samples.size()) fatal("[E:%s] %s: BCF record with %u samples, header with %u", __func__, in.path.c_str(), (unsigned)n_sample, (unsigned)samples.size());
+    r.chrom = ctg_names[(size_t)chrom];
+    r.pos = pos;
+    std::string id;
+    if (!typed_string(p, se, id)) fatal("[E:%s] %s: corrupt BCF record (ID)", __func__, in.path.c_str());
+    r.alts.clear(); r.ref.clear();
+    for (int a = 0; a < n_allele; ++a) {
+      std::string al;
+      if (!typed_string(p, se, al)) fatal("[E:%s] %s: corrupt BCF record (alleles)", __func__, in.path.c_str());
+      if (a == 0) r.ref = al; else r.alts.push_back(al);
+    }
+    // FILTER and INFO are not used by the scan
+    const int nv = nsamples();
+    r.has_gt = r.has_fld = false;
+    r.alleles.assign((size_t)nv * 2, -1);
+    if (field == "PL") r.pl.assign((size_t)nv * 3, INT32_MIN);
+    if (field == "GP") r.gp.assign((size_t)nv * 3, NAN);
+    p = se;
+    const uint8_t* ie = se + l_indiv;
+    for (int k = 0; k < n_fmt; ++k) {
+      int kt; int64_t kl;
+      if (!typed_desc(p, ie, kt, kl) || kl != 1) fatal("[E:%s] %s: corrupt BCF record (FORMAT key)", __func__, in.path.c_str());
+      const int64_t key = typed_int(p, ie, kt);
+      int type; int64_t n;
+      if (!typed_desc(p, ie, type, n)) fatal("[E:%s] %s: corrupt BCF record (FORMAT type)", __func__, in.path.c_str());
+      const size_t esz = (size_t)type_size(type), stride = (size_t)n * esz;
+      if (p + stride * n_sample > ie) fatal("[E:%s] %s: corrupt BCF record (FORMAT data)", __func__, in.path.c_str());
+      const std::string& name = (key >= 0 && (size_t)key < dict.size()) ? dict[(size_t)key] : std::string();
+      auto ival = [&](const uint8_t* q, bool& missing, bool& end_) -> int32_t {      // one integer element of this field
+        missing = end_ = false;
+        if (type == 1) { const int8_t x = (int8_t)*q; missing = x == INT8_MIN; end_ = x == INT8_MIN + 1; return x; }
+        if (type == 2) { const int16_t x = rd<int16_t>(q); missing = x == INT16_MIN; end_ = x == INT16_MIN + 1; return x; }
+        const int32_t x = rd<int32_t>(q); missing = x == INT32_MIN; end_ = x == INT32_MIN + 1; return x;
+      };
+      if (name == "GT" && type >= 1 && type <= 3) {
+        r.has_gt = true;
+        for (int i = 0; i < nv; ++i) {
+          const uint8_t* q = p + stride * (size_t)sm_icols[i];
+          for (int h = 0; h < 2 && h < n; ++h) {
+            bool ms, en;
+            const int32_t x = ival(q + esz * (size_t)h, ms, en);
+            r.alleles[(size_t)2 * i + h] = (ms || en) ? -1 : (x >> 1) - 1;              // bcf_gt_allele
+          }
+        }
+        if (field == "GT") r.has_fld = true;
+      }
+      if (name == field && field == "PL" && type >= 1 && type <= 3) {
+        r.has_fld = true;
+        for (int i = 0; i < nv; ++i) {
+          const uint8_t* q = p + stride * (size_t)sm_icols[i];
+          for (int g = 0; g < 3 && g < n; ++g) {
+            bool ms, en;
+            const int32_t x = ival(q + esz * (size_t)g, ms, en);
+            if (en) break;
+            r.pl[(size_t)i * 3 + g] = ms ? INT32_MIN : x;
+          }
+        }
+      }
+      if (name == field && field == "GP" && type == 5) {
+        r.has_fld = true;
+        for (int i = 0; i < nv; ++i) {
+          const uint8_t* q = p + stride * (size_t)sm_icols[i];
+          for (int g = 0; g < 3 && g < n; ++g) {
+            const uint32_t bits = rd<uint32_t>(q + 4 * (size_t)g);
+            if (bits == 0x7F800002u) break;                                          // end of vector
+            r.gp[(size_t)i * 3 + g] = bits == 0x7F800001u ? NAN : rd<float>(q + 4 * (size_t)g);
+          }
+        }
+      }
+      p += stride * n_sample;
+    }
+    return true;
+  }
+
+  bool read_text(Rec& r) {
+    std::string line;
+    for (;;) {
+      if (!in.getline(line)) return false;
+      if (!line.empty() && line[0] != '#') break;
+    }
+    auto f = split(line, '\t');
+    if (f.size() < 10) fatal("[E:%s] VCF record with %u columns at line starting %.40s", __func__, (unsigned)f.size(), line.c_str());
+    r.chrom = f[0];
+    r.pos = atoll(f[1].c_str()) - 1;
+    r.ref = f[3];
+    r.alts.clear();
+    if (f[4] != ".") r.alts = split(f[4], ',');
+    const auto keys = split(f[8], ':');
+    int i_gt = -1, i_fld = -1;
+    for (size_t k = 0; k < keys.size(); ++k) { if (keys[k] == "GT") i_gt = (int)k; if (keys[k] == field) i_fld = (int)k; }
+    r.has_gt = i_gt >= 0; r.has_fld = i_fld >= 0;
+    const int nv = nsamples();
+    r.alleles.assign((size_t)nv * 2, -1);
+    if (field == "PL") r.pl.assign((size_t)nv * 3, INT32_MIN);
+    if (field == "GP") r.gp.assign((size_t)nv * 3, NAN);
+    for (int i = 0; i < nv; ++i) {
+      const auto sf = split(f[9 + sm_icols[i]], ':');
+      static const std::string kMissingGt = ".";
+      const std::string& gt = (i_gt >= 0 && i_gt < (int)sf.size()) ? sf[i_gt] : kMissingGt;
+      // diploid GT "a/b" or "a|b"; '.' = missing allele (bcf_gt_allele < 0); haploid "a" leaves the second allele missing
+      size_t sep = gt.find_first_of("/|");
+      const std::string a1 = gt.substr(0, sep), a2 = sep == std::string::npos ? "." : gt.substr(sep + 1);
+      auto al = [](const std::string& s) { return (s.empty() || s == ".") ? -1 : atoi(s.c_str()); };
+      r.alleles[2 * i] = al(a1); r.alleles[2 * i + 1] = al(a2);
+      if (i_fld >= 0 && i_fld < (int)sf.size() && field != "GT") {
+        const auto pv = split(sf[i_fld], ',');
+        for (int g = 0; g < 3 && g < (int)pv.size(); ++g) {
+          if (field == "PL") r.pl[(size_t)i * 3 + g] = (pv[g] == "." ? INT32_MIN : atoi(pv[g].c_str()));
+          else r.gp[(size_t)i * 3 + g] = (pv[g] == "." ? NAN : (float)atof(pv[g].c_str()));
+        }
+      }
+    }
+    return true;
+  }
+
   // next variant that passes the filter (bcf_filtered_reader.cpp:751-764 + passed_vfilter :498-574); false at EOF
   bool read(Variant& v) {
-    std::string line;
-    while (in.getline(line)) {
-      if (line.empty() || line[0] == '#') continue;
+    Rec r;
+    while (is_bcf ? read_bcf(r) : read_text(r)) {
       ++n_read;
-      auto f = split(line, '\t');
-      if (f.size() < 10) fatal("[E:%s] VCF record with %u columns at line starting %.40s", __func__, (unsigned)f.size(), line.c_str());
-      if (verbose > 0 && n_read % verbose == 0) notice("Reading %lld variants at %s:%s, Skipping %lld, Missing 0.", (long long)n_read, f[0].c_str(), f[1].c_str(), (long long)n_skip);
-      if (!contig_rid.count(f[0])) { int r = (int)contig_rid.size(); contig_rid[f[0]] = r; }     // headers without ##contig lines
-      v.rid = contig_rid[f[0]];
-      v.pos = atoll(f[1].c_str()) - 1;
-      v.ref = f[3]; v.alt = f[4];
+      if (verbose > 0 && n_read % verbose == 0) notice("Reading %lld variants at %s:%lld, Skipping %lld, Missing 0.", (long long)n_read, r.chrom.c_str(), (long long)r.pos + 1, (long long)n_skip);
+      if (!contig_rid.count(r.chrom)) { int rr = (int)contig_rid.size(); contig_rid[r.chrom] = rr; }     // headers without ##contig lines
+      v.rid = contig_rid[r.chrom];
+      v.pos = r.pos;
+      v.ref = r.ref;
+      v.alt.clear();
+      for (size_t a = 0; a < r.alts.size(); ++a) { if (a) v.alt.push_back(','); v.alt += r.alts[a]; }
+      if (r.alts.empty()) v.alt = ".";
       v.rlen = (int)v.ref.size();
-      const auto alts = split(f[4], ',');
-      v.n_allele = (f[4] == "." ? 1 : 1 + (int)alts.size());
+      v.n_allele = 1 + (int)r.alts.size();
       v.ref0 = v.ref.empty() ? 'N' : v.ref[0];
-      v.alt0 = (v.n_allele > 1 && !alts[0].empty()) ? alts[0][0] : '.';
+      v.alt0 = (v.n_allele > 1 && !r.alts[0].empty()) ? r.alts[0][0] : '.';
       // passed_vfilter returns true before ANY check when neither --min-mac nor --min-callrate asks for genotypes
       // (require_GT = false, bcf_filtered_reader.cpp:507; cmd_cram_demuxlet.cpp:104-105 sets it from those two options)
       const bool require_gt = (min_mac > 0) || (min_callrate > 0);
       // (multi-allelic records stay skipped in that case too: the reference lets them through and then reads its 6-genotype
       //  layout as if it had 3 per sample, cmd_cram_demuxlet.cpp:227-231 — garbage this build does not reproduce)
       if (v.n_allele > max_alleles) { ++n_skip; continue; }                                    // :534
-      // FORMAT keys
-      const auto keys = split(f[8], ':');
-      int i_gt = -1, i_fld = -1;
-      for (size_t k = 0; k < keys.size(); ++k) { if (keys[k] == "GT") i_gt = (int)k; if (keys[k] == field) i_fld = (int)k; }
-      if (i_gt < 0 && (require_gt || field == "GT")) fatal("[E:%s] Cannot find the field GT from the VCF file at position %s:%lld", __func__, f[0].c_str(), (long long)v.pos + 1);   // :548-549
+      if (!r.has_gt && (require_gt || field == "GT")) fatal("[E:%s] Cannot find the field GT from the VCF file at position %s:%lld", __func__, r.chrom.c_str(), (long long)v.pos + 1);   // :548-549
       const int nv = nsamples();
-      std::vector<int32_t> alleles((size_t)nv * 2, -1);
-      std::vector<std::vector<std::string>> sf((size_t)nv);
       int an = 0; std::vector<int> acs((size_t)std::max(v.n_allele, 2), 0);
-      for (int i = 0; i < nv; ++i) {
-        sf[i] = split(f[9 + sm_icols[i]], ':');
-        static const std::string kMissingGt = ".";
-        const std::string& gt = (i_gt >= 0 && i_gt < (int)sf[i].size()) ? sf[i][i_gt] : kMissingGt;
-        // diploid GT "a/b" or "a|b"; '.' = missing allele (bcf_gt_allele < 0); haploid "a" leaves the second allele missing
-        size_t sep = gt.find_first_of("/|");
-        const std::string a1 = gt.substr(0, sep), a2 = sep == std::string::npos ? "." : gt.substr(sep + 1);
-        auto al = [](const std::string& s) { return (s.empty() || s == ".") ? -1 : atoi(s.c_str()); };
-        alleles[2 * i] = al(a1); alleles[2 * i + 1] = al(a2);
-        for (int h = 0; h < 2; ++h) { const int x = alleles[2 * i + h]; if (x >= 0 && x < (int)acs.size()) { ++an; ++acs[x]; } }   // :230-240
-      }
+      for (int i = 0; i < nv; ++i)
+        for (int h = 0; h < 2; ++h) { const int x = r.alleles[2 * i + h]; if (x >= 0 && x < (int)acs.size()) { ++an; ++acs[x]; } }   // :230-240
       if (require_gt && min_callrate > (double)an / (2.0 * (double)nv)) { ++n_skip; continue; }   // :554
       const int ac = an - acs[0];
       if (require_gt && ((ac < min_mac) || (an - ac < min_mac))) { ++n_skip; continue; }       // :565
       // parse_posteriors (:360-454) through the library's a3 transforms
       v.gps.assign((size_t)nv * 3, 0.f);
       if (field == "GT") {
-        if (dmx_geno_from_gt(alleles.data(), nv, gt_error, v.gps.data()) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
+        if (dmx_geno_from_gt(r.alleles.data(), nv, gt_error, v.gps.data()) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
       } else {
-        if (i_fld < 0) fatal("[E:%s] Cannot parse posterior probability at %s:%lld", __func__, f[0].c_str(), (long long)v.pos + 1);   // :154, :212
+        if (!r.has_fld) fatal("[E:%s] Cannot parse posterior probability at %s:%lld", __func__, r.chrom.c_str(), (long long)v.pos + 1);   // :154, :212
         if (field == "PL") {
-          std::vector<int32_t> pl((size_t)nv * 3, INT32_MIN);
-          for (int i = 0; i < nv; ++i) {
-            if (i_fld >= (int)sf[i].size()) continue;
-            const auto p = split(sf[i][i_fld], ',');
-            for (int g = 0; g < 3 && g < (int)p.size(); ++g) pl[(size_t)i * 3 + g] = (p[g] == "." ? INT32_MIN : atoi(p[g].c_str()));
-          }
-          if (dmx_geno_from_pl(pl.data(), nv, v.gps.data()) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
+          if (dmx_geno_from_pl(r.pl.data(), nv, v.gps.data()) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
         } else {
-          std::vector<float> gp((size_t)nv * 3, NAN);
-          for (int i = 0; i < nv; ++i) {
-            if (i_fld >= (int)sf[i].size()) continue;
-            const auto p = split(sf[i][i_fld], ',');
-            for (int g = 0; g < 3 && g < (int)p.size(); ++g) gp[(size_t)i * 3 + g] = (p[g] == "." ? NAN : (float)atof(p[g].c_str()));
-          }
-          if (dmx_geno_from_gp(gp.data(), nv, gt_error, v.gps.data()) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
+          if (dmx_geno_from_gp(r.gp.data(), nv, gt_error, v.gps.data()) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
         }
       }
       return true;

@@ -262,3 +262,101 @@ def scan(reads, recs, contigs, samples, sm_ids=None, min_mq=20, excl_flag=0x0f04
         if first:
             events.append((cb, -1, ".", 0, 0, 1))
     return snps, events, gts, sm_cols
+
+
+def vcf_text_to_bcf(vcf_text: str, path, block: int = 0xff00, int_type: int = 2, idx_attrs: bool = False):
+    """Writes VCF text as BCF2.2 (VCF spec 6.3: 'BCF\\2\\2', l_text, header text, then per record l_shared | l_indiv | shared block |
+    per-sample block; typed values; GT as (allele + 1) << 1 | phased with 0 = missing allele and the end-of-vector code padding
+    haploid calls) inside BGZF — what `bcftools view -Ob` writes.  Test helper for the binary's BCF reader: FILTER is written,
+    INFO dropped (the scan reads neither), integer FORMAT vectors use int8 (GT) and `int_type` (1/2/3) for the rest."""
+    lines = vcf_text.split("\n")
+    header = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if l and not l.startswith("#")]
+    dict_ids, contigs = ["PASS"], []
+    out_header = []
+    fmt_type = {}
+    for l in header:
+        if l.startswith("##FORMAT=<"):
+            fmt_type[l.split("ID=")[1].split(",")[0].rstrip(">")] = l.split("Type=")[1].split(",")[0].rstrip(">")
+        if l.startswith("##contig=<"):
+            cid = l.split("ID=")[1].split(",")[0].rstrip(">")
+            if idx_attrs:
+                l = l[:-1] + f",IDX={len(contigs)}>"
+            contigs.append(cid)
+        elif l.startswith(("##FILTER=<", "##INFO=<", "##FORMAT=<")):
+            fid = l.split("ID=")[1].split(",")[0].rstrip(">")
+            if fid not in dict_ids:
+                if idx_attrs:
+                    l = l[:-1] + f",IDX={len(dict_ids)}>"
+                dict_ids.append(fid)
+        out_header.append(l)
+    text = ("\n".join(out_header) + "\n").encode() + b"\0"
+    n_sample = len(header[-1].split("\t")) - 9
+    INT_FMT = {1: ("<b", -128, -127), 2: ("<h", -32768, -32767), 3: ("<i", -2147483648, -2147483647)}
+
+    def desc(n, t):
+        return bytes([(n << 4) | t]) if n < 15 else bytes([0xF0 | t, 0x11, n]) if n < 128 else bytes([0xF0 | t, 0x12]) + struct.pack("<h", n)
+
+    def tstr(sv):
+        b = sv.encode()
+        return desc(len(b), 7) + b
+
+    raw = bytearray(b"BCF\x02\x02" + struct.pack("<I", len(text)) + text)
+    for l in body:
+        f = l.split("\t")
+        alts = [] if f[4] == "." else f[4].split(",")
+        keys = f[8].split(":")
+        shared = struct.pack("<iii", contigs.index(f[0]), int(f[1]) - 1, len(f[3]))
+        shared += struct.pack("<I", 0x7F800001) if f[5] == "." else struct.pack("<f", float(f[5]))
+        shared += struct.pack("<II", ((1 + len(alts)) << 16) | 0, (len(keys) << 24) | n_sample)
+        shared += (b"\x07" if f[2] == "." else tstr(f[2])) + tstr(f[3]) + b"".join(tstr(a) for a in alts)
+        shared += b"\x00" if f[6] == "." else b"\x11" + bytes([dict_ids.index(f[6])])
+        indiv = bytearray()
+        sf = [x.split(":") for x in f[9:]]
+        for ki, key in enumerate(keys):
+            vals = [s[ki] if ki < len(s) else "." for s in sf]
+            indiv += b"\x11" + bytes([dict_ids.index(key)])
+            if key == "GT":
+                rows = []
+                for v in vals:
+                    parts = v.replace("|", "/").split("/")
+                    phased = "|" in v
+                    row = [0 if a in (".", "") else ((int(a) + 1) << 1) | (1 if phased and h > 0 else 0) for h, a in enumerate(parts)]
+                    rows.append(row)
+                n = max(2, max(len(r) for r in rows))
+                indiv += desc(n, 1)
+                for r in rows:
+                    indiv += bytes([x & 0xFF for x in r] + [0x81] * (n - len(r)))
+            elif fmt_type.get(key) in ("String", "Character"):
+                bs = [b"." if v == "" else v.encode() for v in vals]
+                n = max(len(b) for b in bs)
+                indiv += desc(n, 7)
+                for b in bs:
+                    indiv += b + b"\0" * (n - len(b))
+            elif key == "GP" or fmt_type.get(key) == "Float":
+                rows = [[] if v == "." else v.split(",") for v in vals]
+                n = max(1, max(len(r) for r in rows))
+                indiv += desc(n, 5)
+                for r in rows:
+                    if not r:
+                        indiv += struct.pack("<I", 0x7F800001) + struct.pack("<I", 0x7F800002) * (n - 1)
+                        continue
+                    for x in r:
+                        indiv += struct.pack("<I", 0x7F800001) if x == "." else struct.pack("<f", float(x))
+                    indiv += struct.pack("<I", 0x7F800002) * (n - len(r))
+            else:                        # integer vectors (PL, ...)
+                rows = [[] if v == "." else v.split(",") for v in vals]
+                big = max([abs(int(x)) for r in rows for x in r if x != "."] + [0])
+                it = max(int_type, 1 if big <= 120 else 2 if big <= 32000 else 3)      # like bcftools: the smallest type that fits
+                fmt, miss, end = INT_FMT[it]
+                n = max(1, max(len(r) for r in rows))
+                indiv += desc(n, it)
+                for r in rows:
+                    if not r:
+                        indiv += struct.pack(fmt, miss) + struct.pack(fmt, end) * (n - 1)
+                        continue
+                    for x in r:
+                        indiv += struct.pack(fmt, miss if x == "." else int(x))
+                    indiv += struct.pack(fmt, end) * (n - len(r))
+        raw += struct.pack("<II", len(shared), len(indiv)) + shared + indiv
+    open(path, "wb").write(bgzf_compress(bytes(raw), block=block))

@@ -119,6 +119,42 @@ def test_sam_and_bam_give_the_same_pileup(cli, tmp_path):
         assert outs[i] == outs[0], runs[i]
 
 
+@pytest.mark.parametrize("field", ["GT", "PL", "GP"])
+def test_bcf_and_vcf_give_the_same_pileup(cli, tmp_path, field):
+    """--vcf accepts BCF2 (bgzip'd binary VCF, read without htslib): the same records as VCF text and as BCF — integer vectors as
+    int8, int16 or int32, records straddling BGZF blocks, explicit IDX= dictionary indices — give the same pileup, byte for byte,
+    including the records the variant filter drops (missing calls, half-missing and haploid genotypes, multi-allelic sites)."""
+    import gzip
+    rng = np.random.default_rng(77)
+    recs = sv.make_vcf(rng, CONTIGS, 90, SAMPLES, tmp_path / "v.vcf")
+    reads = sv.make_reads(rng, CONTIGS, recs, 1500, ["A-1", "C-1", "G-1", "T-1"], tmp_path / "r.sam")
+    text = (tmp_path / "v.vcf").read_text()
+    # a few haploid and all-missing calls beside what make_vcf already draws
+    lines = text.split("\n")
+    k = 0
+    for i, l in enumerate(lines):
+        if l and not l.startswith("#"):
+            f = l.split("\t")
+            if k % 7 == 0: f[9] = "1:" + f[9].split(":", 1)[1] if ":" in f[9] else "1"
+            if k % 11 == 0: f[10] = "."
+            lines[i] = "\t".join(f)
+            k += 1
+    text = "\n".join(lines)
+    (tmp_path / "v2.vcf").write_text(text)
+    sv.vcf_text_to_bcf(text, tmp_path / "a.bcf", int_type=2)
+    sv.vcf_text_to_bcf(text, tmp_path / "b.bcf", block=333, int_type=1 if field != "PL" else 3, idx_attrs=True)
+    outs = []
+    for v in ("v2.vcf", "a.bcf", "b.bcf"):
+        o = tmp_path / ("o_" + v.split(".")[0])
+        subprocess.run([cli, "--sam", str(tmp_path / "r.sam"), "--vcf", str(tmp_path / v), "--field", field, "--out", str(o), "--pileup-only"],
+                       check=True, stderr=subprocess.DEVNULL)
+        outs.append((str(o) + ".pileup.txt"))
+    ref = open(outs[0], "rb").read()
+    assert len(ref) > 1000
+    for o in outs[1:]:
+        assert open(o, "rb").read() == ref, o
+
+
 def test_corrupt_bgzf_is_fatal(cli, tmp_path):
     """A flipped byte inside a BGZF block (CRC mismatch) and a truncated file stop the run with a message, as htslib would."""
     rng = np.random.default_rng(6)
@@ -187,6 +223,11 @@ def test_tutorial_vcf_plumbing(cli, oracle, tmp_path):
     assert len(dump["snps"]) == len(snps) and len(snps) > 500
     assert sum(len(c["pairs"]) for c in dump["cells"]) > 500
     check_dump_against_scan(oracle, dump, snps, events, gts, recs, sm_cols, "GT")
+    # the same file as BCF2 (a real-world header: INFO / FILTER / FORMAT dictionaries, many contigs): the same pileup
+    sv.vcf_text_to_bcf(gzip.open(vcf, "rt").read(), tmp_path / "t.bcf")
+    subprocess.run([cli, "--sam", str(tmp_path / "r.sam"), "--vcf", str(tmp_path / "t.bcf"), "--field", "GT", "--out", str(tmp_path / "ob"), "--pileup-only"],
+                   check=True, stderr=subprocess.DEVNULL)
+    assert (tmp_path / "ob.pileup.txt").read_bytes() == (tmp_path / "o.pileup.txt").read_bytes()
 
 
 HELP_HEAD = """
