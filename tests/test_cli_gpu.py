@@ -128,3 +128,10 @@ def test_cfg1_tutorial_vcf_through_the_binary_on_the_gpu(oracle, tmp_path):
     assert [r[:5] for r in got] == [r[:5] for r in want]                            # barcodes and read/SNP counters
     calls = {r[5][:3] for r in got[1:]}
     assert "SNG" in calls                                                          # the job is not degenerate
+    # the same genotypes as BCF2: the same three files, byte for byte
+    sv.vcf_text_to_bcf(gzip.open(vcf, "rt").read(), tmp_path / "t.bcf")
+    outb = tmp_path / "ob"
+    subprocess.run([str(CLI), "--sam", str(tmp_path / "r.bam"), "--vcf", str(tmp_path / "t.bcf"), "--field", "GT", "--alpha", "0", "--alpha", "0.5",
+                    "--out", str(outb)], check=True, stderr=subprocess.DEVNULL)
+    for suf in ("single", "sing2", "best"):
+        assert Path(f"{outb}.{suf}").read_bytes() == Path(f"{out}.{suf}").read_bytes(), suf
