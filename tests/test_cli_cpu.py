@@ -155,6 +155,35 @@ def test_bcf_and_vcf_give_the_same_pileup(cli, tmp_path, field):
         assert open(o, "rb").read() == ref, o
 
 
+def test_corrupt_bcf_records_never_crash_the_reader(cli, tmp_path):
+    """Random byte damage inside a BCF (valid BGZF around it): the binary either reads through or stops with a fatal message
+    (exit 1) — never a signal.  (An AddressSanitizer/UBSan build of the same source ran 300 such mutations clean.)"""
+    import struct
+    import zlib
+    rng = np.random.default_rng(123)
+    recs = sv.make_vcf(rng, CONTIGS, 40, SAMPLES, tmp_path / "v.vcf")
+    sv.make_reads(rng, CONTIGS, recs, 300, ["A-1", "C-1"], tmp_path / "r.sam")
+    sv.vcf_text_to_bcf((tmp_path / "v.vcf").read_text(), tmp_path / "a.bcf")
+    bg = (tmp_path / "a.bcf").read_bytes()
+    data, o = bytearray(), 0
+    while o < len(bg):
+        bsize = struct.unpack_from("<H", bg, o + 16)[0] + 1
+        data += zlib.decompress(bg[o + 18:o + bsize - 8], -15)
+        o += bsize
+    hdr_len = 9 + struct.unpack_from("<I", data, 5)[0]
+    codes = set()
+    for it in range(60):
+        d = bytearray(data)
+        for _ in range(int(rng.integers(1, 5))):
+            d[int(rng.integers(hdr_len, len(d)))] = int(rng.integers(0, 256))
+        (tmp_path / "m.bcf").write_bytes(sv.bgzf_compress(bytes(d)))
+        r = subprocess.run([cli, "--sam", str(tmp_path / "r.sam"), "--vcf", str(tmp_path / "m.bcf"), "--field", ["GT", "PL", "GP"][it % 3],
+                            "--out", str(tmp_path / "o"), "--pileup-only"], capture_output=True)
+        assert r.returncode in (0, 1), (it, r.returncode, r.stderr[-300:])
+        codes.add(r.returncode)
+    assert codes == {0, 1}                      # some damage is harmless, some is detected
+
+
 def test_corrupt_bgzf_is_fatal(cli, tmp_path):
     """A flipped byte inside a BGZF block (CRC mismatch) and a truncated file stop the run with a message, as htslib would."""
     rng = np.random.default_rng(6)
