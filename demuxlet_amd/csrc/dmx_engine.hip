@@ -1586,10 +1586,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
-  // One barcode per wavefront or more wavefronts per barcode (TPC >= 64): the genotype rows of a sub-tile go from global memory
+  // Up to two barcodes per wavefront (TPC >= 32): the genotype rows of a sub-tile go from global memory
   // straight into the LDS (global_load_lds: no registers, uniform source base per row), one sub-tile ahead of their use, into the
   // other half of a double buffer — the first sub-tile's while phase 1 runs.  cfg3 FAST: 394 -> 349 ms on one box.
-  constexpr bool DMA_T = TPC >= 64;
+  constexpr bool DMA_T = TPC >= 32;              // (four barcodes per wavefront, TPC = 16: too many small masked loads, measured +17 %)
   constexpr size_t cell_bytes = (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)(DMA_T ? 2 : 1) * SUB * GSS * 4 + (size_t)SUB * 3 * VUS * 8;
   unsigned char* base = s_raw + (size_t)cw * cell_bytes;
   double* s_q1 = (double*)base;                                  // [TP][6]    pG of alpha 0.5: q[l+m], five distinct values
@@ -1638,13 +1638,22 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
     using gptr = const __attribute__((address_space(1))) void*;
     using lptr = __attribute__((address_space(3))) void*;
     const int wv = tid & ~63;                      // first lane of this wavefront inside the cell
+    constexpr int SPW = TPC >= 64 ? 1 : 64 / TPC;
+    const int slot = SPW == 1 ? 0 : (threadIdx.x & 63) / TPC;
+    // (a ROLLED loop over the slots: with the slots as separate branches the compiler merges their identical tails into one
+    //  instruction that serves lanes of two barcodes with one LDS base — it takes the base operand for uniform)
+#pragma unroll 1
+    for (int c = 0; c < SPW; ++c) {
+      if (SPW == 1 || slot == c) {
 #pragma unroll
     for (int pi = 0; pi < SUB; ++pi) {             // a row at a time: uniform source base, lane r reads element r
       const float* src = g + (size_t)__builtin_amdgcn_readfirstlane(s_snp[sub + pi]) * row_len;
 #pragma unroll
       for (int h = 0; h < (GSS + TPC - 1) / TPC; ++h) {
         const int r = tid + TPC * h;
-        if (r < row_len) __builtin_amdgcn_global_load_lds((gptr)(src + r), (lptr)(s_g0 + (buf * SUB + pi) * GSS + wv + TPC * h), 4, 0, 0);
+        if (r < row_len) __builtin_amdgcn_global_load_lds((gptr)(src + r), (lptr)(s_g0 + (buf * SUB + pi) * GSS + wv + TPC * h - c * TPC), 4, 0, 0);
+      }
+    }
       }
     }
   };
@@ -4034,7 +4043,7 @@ int launch_doublet(dmx_engine* e) {
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do {                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
-    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 64 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 32 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
@@ -4045,7 +4054,7 @@ int launch_doublet(dmx_engine* e) {
 #define DMX_K2SV(TPC, VMAX, SUB, FIX, MINW)                                                                            \
   do {                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
-    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 64 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 32 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
