@@ -2,4 +2,4 @@
 // operations the device performs (fma via libm's correctly-rounded fma()).
 #include "dmx_log.hpp"
 extern "C" void dmx_log_emul_n(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = dmx_log_host_emul(x[i]); }
-extern "C" void dmx_log_lite_emul_n(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = dmx_log_lite_host_emul(x[i]); }
+extern "C" void dmx_log_lite_emul_n(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = dmx_log_comp_host_emul(x[i]); }   // the compensated form kept for the record
