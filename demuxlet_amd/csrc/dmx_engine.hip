@@ -236,6 +236,15 @@ __device__ __forceinline__ uint32_t load_rd4(const PileupView& pv, int64_t off, 
   return rd4;
 }
 
+// The value of the neighbouring lane (lane ^ 1: the other alpha of the same pair in phase 1) by DPP quad permutation [1,0,3,2] —
+// two VALU moves instead of the two LDS-crossbar operations (ds_bpermute) that __shfl_xor becomes, in the middle of phase 1's
+// dependent chain (products -> maximum -> neighbour's maximum -> reciprocal -> quotients).
+__device__ __forceinline__ double shfl_xor1(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ uint32_t load_nrd(const void* __restrict__ base, int64_t p, int width) {
   if (width == 1) return ((const uint8_t*)base)[p];
   if (width == 2) return ((const uint16_t*)base)[p];
@@ -1157,7 +1166,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
           }
         }
         {
-          const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+          const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
           mx = (mx < o) ? o : mx;
         }
         if (live) {
@@ -1178,7 +1187,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
         mx = (mx < pG[i]) ? pG[i] : mx;
       }
       {
-        const double o = __shfl_xor(mx, 1);
+        const double o = shfl_xor1(mx);
         mx = (mx < o) ? o : mx;
       }
       if (on) {
@@ -1384,7 +1393,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
           }
         }
         {
-          const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+          const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
           mx = (mx < o) ? o : mx;
         }
         if (live) {
@@ -1405,7 +1414,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
         mx = (mx < pG[i]) ? pG[i] : mx;
       }
       {
-        const double o = __shfl_xor(mx, 1);
+        const double o = shfl_xor1(mx);
         mx = (mx < o) ? o : mx;
       }
       if (on) {
@@ -1709,7 +1718,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
           }
         }
         {
-          const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+          const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
           mx = (mx < o) ? o : mx;
         }
         if (live) {
@@ -1730,7 +1739,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
         mx = (mx < q[i]) ? q[i] : mx;
       }
       {
-        const double o = __shfl_xor(mx, 1);
+        const double o = shfl_xor1(mx);
         mx = (mx < o) ? o : mx;
       }
       if (on) {
@@ -2337,7 +2346,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
           }
         }
         {
-          const double o = __shfl_xor(mx, 1);
+          const double o = shfl_xor1(mx);
           mx = (mx < o) ? o : mx;
         }
         if (live) {
@@ -2358,7 +2367,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
         mx = (mx < pG[i]) ? pG[i] : mx;
       }
       {
-        const double o = __shfl_xor(mx, 1);
+        const double o = shfl_xor1(mx);
         mx = (mx < o) ? o : mx;
       }
       if (on) {
@@ -2637,7 +2646,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
           }
         }
         {
-          const double o = __shfl_xor(mx, 1);
+          const double o = shfl_xor1(mx);
           mx = (mx < o) ? o : mx;
         }
         if (live) {
@@ -2658,7 +2667,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
         mx = (mx < qv[i]) ? qv[i] : mx;
       }
       {
-        const double o = __shfl_xor(mx, 1);
+        const double o = shfl_xor1(mx);
         mx = (mx < o) ? o : mx;
       }
       if (on) {
@@ -3195,7 +3204,7 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
       }
     }
     {
-      const double o = __shfl_xor(mx, 1);                               // one max across both alphas of the pair
+      const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
       mx = (mx < o) ? o : mx;
     }
     if (live) {
@@ -3216,7 +3225,7 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
     mx = (mx < pG[i]) ? pG[i] : mx;
   }
   {
-    const double o = __shfl_xor(mx, 1);
+    const double o = shfl_xor1(mx);
     mx = (mx < o) ? o : mx;
   }
   // the alpha = 0.5 lane finishes its values (:656-663) and hands a copy to its alpha = 0 neighbour (which only had to contribute
@@ -3225,7 +3234,7 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = div_by(pG[i], mx, y);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { const double o = __shfl_xor(v[i], 1); v[i] = n1 ? v[i] : o; }
+  for (int i = 0; i < NV; ++i) { const double o = shfl_xor1(v[i]); v[i] = n1 ? v[i] : o; }
 }
 
 // K3b — the tie-order certificate (DESIGN.md "Ties").  At alpha = 0.5 the reference's llksAB[j][k] and llksAB[k][j] are one number
