@@ -964,12 +964,12 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 #pragma unroll
           for (int i = 0; i < 9; ++i) {
             pG[i] *= (pR * wR[i] + pA * wA[i]);                            // :625
-            mx = (mx < pG[i]) ? pG[i] : mx;                                // :626-627
+            mx = fmax(mx, pG[i]);                                // :626-627
           }
         }
         for (int d = 1; d < A_pad; d <<= 1) {                              // one max across ALL alphas of the pair
           const double o = __shfl_xor(mx, d);
-          mx = (mx < o) ? o : mx;
+          mx = fmax(mx, o);
         }
         if (live) {
           if (cnt <= kSafeReads) {
@@ -987,12 +987,12 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
           pG[i] += 1e-6;                                                    // :649
-          mx = (mx < pG[i]) ? pG[i] : mx;
+          mx = fmax(mx, pG[i]);
         }
       }
       for (int d = 1; d < A_pad; d <<= 1) {
         const double o = __shfl_xor(mx, d);
-        mx = (mx < o) ? o : mx;
+        mx = fmax(mx, o);
       }
       if (on) {
         const double y = rcp_refined(mx);                                   // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
@@ -1162,12 +1162,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
 #pragma unroll
           for (int i = 0; i < 9; ++i) {
             pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
-            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+            mx = fmax(mx, pG[i]);                                 // :626-627
           }
         }
         {
           const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
-          mx = (mx < o) ? o : mx;
+          mx = fmax(mx, o);
         }
         if (live) {
           if (cnt <= kSafeReads) {
@@ -1184,11 +1184,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         pG[i] += 1e-6;                                                       // :649
-        mx = (mx < pG[i]) ? pG[i] : mx;
+        mx = fmax(mx, pG[i]);
       }
       {
         const double o = shfl_xor1(mx);
-        mx = (mx < o) ? o : mx;
+        mx = fmax(mx, o);
       }
       if (on) {
         const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
@@ -1389,12 +1389,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 #pragma unroll
           for (int i = 0; i < 9; ++i) {
             pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
-            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+            mx = fmax(mx, pG[i]);                                 // :626-627
           }
         }
         {
           const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
-          mx = (mx < o) ? o : mx;
+          mx = fmax(mx, o);
         }
         if (live) {
           if (cnt <= kSafeReads) {
@@ -1411,11 +1411,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         pG[i] += 1e-6;                                                       // :649
-        mx = (mx < pG[i]) ? pG[i] : mx;
+        mx = fmax(mx, pG[i]);
       }
       {
         const double o = shfl_xor1(mx);
-        mx = (mx < o) ? o : mx;
+        mx = fmax(mx, o);
       }
       if (on) {
         const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
@@ -1714,12 +1714,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #pragma unroll
           for (int i = 0; i < 5; ++i) {
             q[i] *= (pR * wR[i] + pA * wA[i]);                              // :625
-            mx = (mx < q[i]) ? q[i] : mx;                                   // :626-627
+            mx = fmax(mx, q[i]);                                   // :626-627
           }
         }
         {
           const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
-          mx = (mx < o) ? o : mx;
+          mx = fmax(mx, o);
         }
         if (live) {
           if (cnt <= kSafeReads) {
@@ -1736,11 +1736,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         q[i] += 1e-6;                                                        // :649
-        mx = (mx < q[i]) ? q[i] : mx;
+        mx = fmax(mx, q[i]);
       }
       {
         const double o = shfl_xor1(mx);
-        mx = (mx < o) ? o : mx;
+        mx = fmax(mx, o);
       }
       if (on) {
         const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
@@ -1983,13 +1983,13 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
 #pragma unroll
           for (int i = 0; i < 9; ++i) {
             pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
-            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+            mx = fmax(mx, pG[i]);                                 // :626-627
           }
         }
 #pragma unroll
         for (int d = 1; d < AP; d <<= 1) {                                  // one max across ALL alphas of the pair
           const double o = __shfl_xor(mx, d);
-          mx = (mx < o) ? o : mx;
+          mx = fmax(mx, o);
         }
         if (live) {
           if (cnt <= kSafeReads) {
@@ -2007,13 +2007,13 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
           pG[i] += 1e-6;                                                     // :649
-          mx = (mx < pG[i]) ? pG[i] : mx;
+          mx = fmax(mx, pG[i]);
         }
       }
 #pragma unroll
       for (int d = 1; d < AP; d <<= 1) {
         const double o = __shfl_xor(mx, d);
-        mx = (mx < o) ? o : mx;
+        mx = fmax(mx, o);
       }
       if (on) {
         const double y = rcp_refined(mx);
@@ -2342,12 +2342,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
 #pragma unroll
           for (int i = 0; i < 9; ++i) {
             pG[i] *= (pR * wR[i] + pA * wA[i]);
-            mx = (mx < pG[i]) ? pG[i] : mx;
+            mx = fmax(mx, pG[i]);
           }
         }
         {
           const double o = shfl_xor1(mx);
-          mx = (mx < o) ? o : mx;
+          mx = fmax(mx, o);
         }
         if (live) {
           if (cnt <= kSafeReads) {
@@ -2364,11 +2364,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         pG[i] += 1e-6;
-        mx = (mx < pG[i]) ? pG[i] : mx;
+        mx = fmax(mx, pG[i]);
       }
       {
         const double o = shfl_xor1(mx);
-        mx = (mx < o) ? o : mx;
+        mx = fmax(mx, o);
       }
       if (on) {
         const double y = rcp_refined(mx);
@@ -2642,12 +2642,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
 #pragma unroll
           for (int i = 0; i < 5; ++i) {
             qv[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
-            mx = (mx < qv[i]) ? qv[i] : mx;                                 // :626-627
+            mx = fmax(mx, qv[i]);                                 // :626-627
           }
         }
         {
           const double o = shfl_xor1(mx);
-          mx = (mx < o) ? o : mx;
+          mx = fmax(mx, o);
         }
         if (live) {
           if (cnt <= kSafeReads) {
@@ -2664,11 +2664,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         qv[i] += 1e-6;                                                       // :649
-        mx = (mx < qv[i]) ? qv[i] : mx;
+        mx = fmax(mx, qv[i]);
       }
       {
         const double o = shfl_xor1(mx);
-        mx = (mx < o) ? o : mx;
+        mx = fmax(mx, o);
       }
       if (on) {
         const double y = rcp_refined(mx);
@@ -2925,13 +2925,13 @@ __global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nr
 #pragma unroll
           for (int i = 0; i < 9; ++i) {
             pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
-            mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+            mx = fmax(mx, pG[i]);                                 // :626-627
           }
         }
 #pragma unroll
         for (int d = 1; d < AP; d <<= 1) {                                  // one max across ALL alphas of the pair
           const double o = __shfl_xor(mx, d);
-          mx = (mx < o) ? o : mx;
+          mx = fmax(mx, o);
         }
         if (live) {
           if (cnt <= kSafeReads) {
@@ -2949,13 +2949,13 @@ __global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nr
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
           pG[i] += 1e-6;                                                     // :649
-          mx = (mx < pG[i]) ? pG[i] : mx;
+          mx = fmax(mx, pG[i]);
         }
       }
 #pragma unroll
       for (int d = 1; d < AP; d <<= 1) {
         const double o = __shfl_xor(mx, d);
-        mx = (mx < o) ? o : mx;
+        mx = fmax(mx, o);
       }
       if (on) {
         const double y = rcp_refined(mx);
@@ -3062,7 +3062,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
   for (int32_t jj = t; jj < V; jj += kThreads) sing[(size_t)cell * V + jj] = G[(size_t)jj * V * A];   // llksAB[j][0][0]
   // (1) max over the whole grid (:713-721)
   double mx = -1e300;
-  for (int32_t q = t; q < nAB; q += kThreads) mx = (mx < G[q]) ? G[q] : mx;
+  for (int32_t q = t; q < nAB; q += kThreads) mx = fmax(mx, G[q]);
   s_d[t] = mx;
   __syncthreads();
   for (int s = kThreads / 2; s > 0; s >>= 1) {
@@ -3200,12 +3200,12 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
-        mx = (mx < pG[i]) ? pG[i] : mx;                                 // :626-627
+        mx = fmax(mx, pG[i]);                                 // :626-627
       }
     }
     {
       const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
-      mx = (mx < o) ? o : mx;
+      mx = fmax(mx, o);
     }
     if (live) {
       if (cnt <= kSafeReads) {
@@ -3222,11 +3222,11 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     pG[i] += 1e-6;                                                       // :649
-    mx = (mx < pG[i]) ? pG[i] : mx;
+    mx = fmax(mx, pG[i]);
   }
   {
     const double o = shfl_xor1(mx);
-    mx = (mx < o) ? o : mx;
+    mx = fmax(mx, o);
   }
   // the alpha = 0.5 lane finishes its values (:656-663) and hands a copy to its alpha = 0 neighbour (which only had to contribute
   // to the shared maxima): the two lanes of a pair then take one accumulator each
