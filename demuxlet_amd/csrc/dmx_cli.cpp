@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
@@ -77,8 +78,8 @@ struct Options {
   int gpu = 0, gpus = 1;
   bool pileup_only = false;      // stop after the scan and write <out>.pileup.txt (no GPU needed)
   bool no_arbiter = false;
-  bool fast = false;       // accepted for compatibility with round-1 command lines: FAST is the default now
-  bool strict = false;
+  bool fast = false;       // opt-in: DMX_MODE_FAST (printed entries only; a printed number may differ from the reference in its last digit)
+  bool strict = false;     // the default, spelled out (kept for round-2 command lines)
 };
 
 enum OptType { O_BOOL, O_INT, O_DOUBLE, O_STRING, O_MULTI_DOUBLE, O_MULTI_STRING };
@@ -226,8 +227,8 @@ void parse_options(int argc, char** argv, Options& o) {
       {"gpus", O_INT, &o.gpus, "[MI355X build] number of GPUs to shard the barcodes over (starting at --gpu)", "MI355X build"},
       {"pileup-only", O_BOOL, &o.pileup_only, "[MI355X build] stop after the BAM x VCF scan and write <out>.pileup.txt", "MI355X build"},
       {"no-arbiter", O_BOOL, &o.no_arbiter, "[MI355X build] skip the host tie arbiter (DESIGN.md, Ties)", "MI355X build"},
-      {"strict", O_BOOL, &o.strict, "[MI355X build] DMX_MODE_STRICT: every grid entry in the reference's operation order (default: DMX_MODE_FAST, the printed entries only, log-likelihoods within 1e-9, same calls)", "MI355X build"},
-      {"fast", O_BOOL, &o.fast, "[MI355X build] DMX_MODE_FAST (the default; kept for older command lines)", "MI355X build"},
+      {"strict", O_BOOL, &o.strict, "[MI355X build] DMX_MODE_STRICT (the default): every grid entry in the reference's operation order", "MI355X build"},
+      {"fast", O_BOOL, &o.fast, "[MI355X build] DMX_MODE_FAST: only the entries demuxlet prints or decides on, 2-4x faster; same calls, log-likelihoods within 1e-9 of the reference (a printed number may differ in its last digit)", "MI355X build"},
   };
   std::set<std::string> touched;
   std::string errors;
@@ -446,6 +447,18 @@ struct GzIn {
     }
     return true;
   }
+  // a record's length prefix: 1 = read, 0 = clean end of file (not one byte left), -1 = the file ends inside the prefix
+  int read_prefix(void* dst, size_t n) {
+    uint8_t* d = (uint8_t*)dst;
+    size_t got = 0;
+    while (got < n) {
+      if (pos >= cur.size() && !fill()) return got ? -1 : 0;
+      const size_t k = std::min(n - got, cur.size() - pos);
+      memcpy(d + got, cur.data() + pos, k);
+      got += k; pos += k;
+    }
+    return 1;
+  }
   void unread_all_to(size_t p) { pos = p; }      // rewind inside the first chunk (SAM text sniffing)
 };
 
@@ -579,6 +592,15 @@ struct VcfReader {
     return true;
   }
 
+  // IDX= of a BCF header dictionary line: a position in the string / contig dictionary.  A damaged header must not become an
+  // allocation request: anything but a plain number below 2^24 is fatal.
+  static size_t parse_idx(const std::string& idx, const std::string& line) {
+    char* end = nullptr;
+    errno = 0;
+    const long long v = strtoll(idx.c_str(), &end, 10);
+    if (errno || end == idx.c_str() || *end || v < 0 || v >= (1ll << 24)) fatal("[E:%s] bad IDX=%s in header line %.120s", __func__, idx.c_str(), line.c_str());
+    return (size_t)v;
+  }
   void parse_header_line(const std::string& line, bool& have_header) {
     auto attr = [&](const char* key) -> std::string {                // value of key= inside <...>
       const std::string k = std::string(key) + "=";
@@ -593,14 +615,14 @@ struct VcfReader {
       const std::string id = attr("ID");
       if (!contig_rid.count(id)) { int r = (int)contig_rid.size(); contig_rid[id] = r; }
       const std::string idx = attr("IDX");
-      const size_t at = idx.empty() ? ctg_names.size() : (size_t)atoll(idx.c_str());
+      const size_t at = idx.empty() ? ctg_names.size() : parse_idx(idx, line);
       if (ctg_names.size() <= at) ctg_names.resize(at + 1);
       ctg_names[at] = id;
     } else if (line.rfind("##FILTER=<", 0) == 0 || line.rfind("##INFO=<", 0) == 0 || line.rfind("##FORMAT=<", 0) == 0) {
       const std::string id = attr("ID");
       if (std::find(dict.begin(), dict.end(), id) != dict.end()) return;
       const std::string idx = attr("IDX");
-      const size_t at = idx.empty() ? dict.size() : (size_t)atoll(idx.c_str());
+      const size_t at = idx.empty() ? dict.size() : parse_idx(idx, line);
       if (dict.size() <= at) dict.resize(at + 1);
       dict[at] = id;
     } else if (line.rfind("#CHROM", 0) == 0) {
@@ -614,7 +636,9 @@ struct VcfReader {
 
   bool read_bcf(Rec& r) {
     uint32_t len[2];
-    if (!in.read(len, 8)) return false;
+    const int got = in.read_prefix(len, 8);
+    if (got == 0) return false;
+    if (got < 0) fatal("[E:%s] %s: truncated BCF record (the file ends inside a record's length prefix)", __func__, in.path.c_str());
     const size_t l_shared = len[0], l_indiv = len[1];
     if (l_shared < 24 || l_shared + l_indiv > ((size_t)1 << 31)) fatal("[E:%s] %s: corrupt BCF record (lengths %u, %u)", __func__, in.path.c_str(), len[0], len[1]);
     rbuf.resize(l_shared + l_indiv);
@@ -924,7 +948,9 @@ struct SamReader {
 
   bool parse_bam_record(Read& r) {
     int32_t block = 0;
-    if (!in.read(&block, 4)) return false;
+    const int got = in.read_prefix(&block, 4);
+    if (got == 0) return false;
+    if (got < 0) fatal("[E:%s] truncated BAM record (the file ends inside a record's block size)", __func__);
     if (block < 32) fatal("[E:%s] corrupt BAM record (block size %d)", __func__, block);
     std::vector<uint8_t>& b = rec_buf;
     b.resize((size_t)block);
@@ -1256,7 +1282,7 @@ int main(int argc, char** argv) {
   job.store = scl; job.g = G.data(); job.n_samples = nv; job.sample_ids = sm.data();
   job.n_alpha = (int32_t)o.alpha.size(); job.alpha = o.alpha.data(); job.doublet_prior = o.doublet_prior;
   job.min_total = o.min_total; job.min_uniq = o.min_uniq; job.min_snp = o.min_snp; job.write_pair = o.write_pair;
-  job.out_prefix = o.out.c_str(); job.device = o.gpu; job.arbiter = o.no_arbiter ? 0 : 1; job.n_gpus = o.gpus; job.mode = o.strict ? DMX_MODE_STRICT : DMX_MODE_FAST;
+  job.out_prefix = o.out.c_str(); job.device = o.gpu; job.arbiter = o.no_arbiter ? 0 : 1; job.n_gpus = o.gpus; job.mode = (o.fast && !o.strict) ? DMX_MODE_FAST : DMX_MODE_STRICT;
   if (dmx_demuxlet_run(&job) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
   notice("Finished writing output files");                                                                 // :876
   dmx_store_free(scl);

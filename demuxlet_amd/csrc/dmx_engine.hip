@@ -251,6 +251,12 @@ __device__ __forceinline__ uint32_t load_nrd(const void* __restrict__ base, int6
   return ((const uint32_t*)base)[p];
 }
 
+// Cells whose fast kernels met a log() argument outside the normal positive range: one byte per cell, and in front of the array
+// (kFlagHead bytes) a word that says whether ANY cell of the launch was flagged — what the fix-up pass looks at first.
+constexpr int kFlagHead = 16;
+__device__ __forceinline__ void flag_cell(uint8_t* __restrict__ flagged, int32_t cell) { flagged[cell] = 1; *(flagged - kFlagHead) = 1; }
+__device__ __forceinline__ bool flags_any(const uint8_t* __restrict__ flagged) { return *(const volatile uint8_t*)(flagged - kFlagHead) != 0; }
+
 // K1.  Wavefronts are independent (no workgroup barrier in the loop).  A wavefront owns CW cells for their whole SNP
 // range and walks them tile by tile, T = 64/CW SNP-pairs per cell per tile:
 //   compute  lane (cell c = lane/T, pair ti = lane%T): GL of its pair once per tile, then per chunk of KC samples the KC
@@ -866,9 +872,12 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
                                                               int32_t A_pad, int32_t TP, double* __restrict__ grid,
                                                               double* __restrict__ l00,
                                                               uint8_t* __restrict__ flagged) {
-  // FIXUP: second pass behind k_doublet_a2 — only cells in which that kernel met a log() argument outside the normal
-  // positive range (flagged[cell] != 0) are recomputed, with ocml's log() for exact log(0) / log(nan) semantics.
-  if (FIXUP && !flagged[sched[blockIdx.x]]) return;
+  // FIXUP: second pass behind the fast kernels — only cells in which one of them met a log() argument outside the normal
+  // positive range (flagged[cell] != 0) are recomputed, with ocml's log() for exact log(0) / log(nan) semantics.  The pass is
+  // launched with a small fixed grid whose workgroups stride over the cells, and it ends at once when no cell of the launch was
+  // flagged at all (flag_cell also raises the launch-wide word in front of the array): nothing to fix costs ~2 us instead of a
+  // dispatch of B workgroups.  The first pass (FIXUP = false) is launched with one workgroup per cell: one trip through the loop.
+  if (FIXUP && !flags_any(flagged)) return;
   __shared__ double s_lut[kTab];
   __shared__ double s_pG[kThreads * 9];
   __shared__ int32_t s_snp[32];
@@ -878,7 +887,9 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
   const int t = threadIdx.x;
   for (int i = t; i < kTab; i += kThreads) s_lut[i] = lut[i];
   const double* s_log = s_lut + kLut;
-  const int32_t cell = sched[blockIdx.x];
+  for (int32_t bx = (int32_t)blockIdx.x; bx < pv.B; bx += (int32_t)gridDim.x) {
+  if (FIXUP && !flagged[sched[bx]]) continue;
+  const int32_t cell = sched[bx];
   const int64_t p_beg = pv.cell_pair_off[cell];
   const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
   int64_t rd_base = pv.cell_read_off[cell];
@@ -1038,7 +1049,9 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
     if (q < nAB) grid[(size_t)cell * nAB + q] = acc[i];
     else if (q < nacc) l00[(size_t)cell * A + (q - nAB)] = acc[i];
   }
-  if (!FIXUP && !ok) flagged[cell] = 1;   // recomputed with ocml's log() by the FIXUP pass
+  if (!FIXUP && !ok) flag_cell(flagged, cell);   // recomputed with ocml's log() by the FIXUP pass
+  __syncthreads();                               // the next cell of this workgroup reuses the shared arrays
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1269,7 +1282,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
       }
     }
     if (tid < 2 && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
-    if (!ok) flagged[cell] = 1;
+    if (!ok) flag_cell(flagged, cell);
   }
 #undef DMX_K2_SYNC
 }
@@ -1534,7 +1547,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
       }
     }
     if (tid < 2 && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
-    if (!ok) flagged[cell] = 1;
+    if (!ok) flag_cell(flagged, cell);
   }
 #undef DMX_K2_SYNC
 }
@@ -1861,7 +1874,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
       }
     }
     if (tid < 2 && e_base == 0) l00[(size_t)cell * A + tid] = acc00;
-    if (!ok) flagged[cell] = 1;
+    if (!ok) flag_cell(flagged, cell);
   }
 #undef DMX_K2_SYNC
 }
@@ -2102,7 +2115,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
       }
     }
     if (tid < A && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
-    if (!ok) flagged[cell] = 1;
+    if (!ok) flag_cell(flagged, cell);
   }
 #undef DMX_K2_SYNC
 }
@@ -2460,7 +2473,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
       }
     }
     if (tid < 2 && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
-    if (!ok) flagged[cell] = 1;
+    if (!ok) flag_cell(flagged, cell);
   }
 #undef DMX_K2_SYNC
 }
@@ -2802,7 +2815,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
       if (sing_owner) for (int k = 0; k < V; ++k) G[((size_t)j * V + k) * A] = accS;
     }
     if (tid < 2 && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
-    if (!ok) flagged[cell] = 1;
+    if (!ok) flag_cell(flagged, cell);
   }
 }
 
@@ -3033,7 +3046,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nr
       }
     }
     if (tid < A && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
-    if (!ok) flagged[cell] = 1;
+    if (!ok) flag_cell(flagged, cell);
   }
 #undef DMX_K2_SYNC
 }
@@ -3451,6 +3464,10 @@ struct dmx_engine {
   double* d_sing = nullptr;
   int32_t out_cap = 0, grid_cap = 0; bool have_grid = false, have_sing = false;   // cells the result buffers hold
   hipEvent_t ev[8] = {};
+  // the last kRing launches of K1 and of K2 / K3 / K3b, bracketed by events on the engine's stream (dmx_engine_mean_kernel_times)
+  static constexpr int kRing = 16;
+  hipEvent_t ring_s[kRing][2] = {}, ring_d[kRing][4] = {};
+  int64_t n_ring_s = 0, n_ring_d = 0; bool ring_certified[kRing] = {};
   bool timed[4] = {false, false, false, false};
 };
 
@@ -3480,7 +3497,7 @@ int free_results(dmx_engine* e) {
   if (e->d_grid) (void)hipFree(e->d_grid);
   if (e->d_l00) (void)hipFree(e->d_l00);
   if (e->d_sum) (void)hipFree(e->d_sum);
-  if (e->d_flag) (void)hipFree(e->d_flag);
+  if (e->d_flag) (void)hipFree(e->d_flag - kFlagHead);
   if (e->d_sing) (void)hipFree(e->d_sing);
   e->d_flag = nullptr; e->d_sing = nullptr;
   e->d_llks = e->d_llk0s = e->d_grid = e->d_l00 = nullptr; e->d_sum = nullptr;
@@ -3522,6 +3539,8 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
   for (hipEvent_t& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+  for (auto& r : e->ring_s) for (hipEvent_t& ev : r) HIP_TRY(hipEventCreate(&ev));
+  for (auto& r : e->ring_d) for (hipEvent_t& ev : r) HIP_TRY(hipEventCreate(&ev));
   HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTabTotal));
   HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabLogLo, dmx_log_table_lo_host, sizeof(double) * 128, hipMemcpyHostToDevice));
@@ -3552,6 +3571,8 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_bad) (void)hipFree(e->d_bad);
   for (int i = 0; i < 2; ++i) { if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]); if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]); }
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& r : e->ring_s) for (hipEvent_t& ev : r) if (ev) (void)hipEventDestroy(ev);
+  for (auto& r : e->ring_d) for (hipEvent_t& ev : r) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
   return DMX_OK;
@@ -3902,7 +3923,8 @@ int launch_doublet_generic(dmx_engine* e) {
   const int slab_acc = 33;                        // accumulators per thread when the grid is cut into slabs
   const unsigned slabs = per <= 65 ? 1u : (unsigned)((nacc + (int64_t)slab_acc * kThreads - 1) / ((int64_t)slab_acc * kThreads));
   if (slabs > 65535u) return set_error(DMX_ERR_ARG, "run_doublet: V*V*A = %lld accumulators per cell exceed this build's limit (5.5e8)", (long long)nacc);
-  const dim3 grid((unsigned)B, slabs), block(kThreads);
+  // the fix-up pass strides a fixed grid over the cells (see the kernel); the first pass has one workgroup per cell
+  const dim3 grid(FIXUP ? (unsigned)std::min(B, 256) : (unsigned)B, slabs), block(kThreads);
 #define DMX_K2(NN)                                                                                                   \
   hipLaunchKernelGGL((k_doublet_generic<NRD, NN, FIXUP>), grid, block, 0, e->stream, e->pv, e->d_g, e->d_gp0, e->d_lut, \
                      e->d_alpha, e->d_sched, V, A, A_pad, TP, e->d_grid, e->d_l00, e->d_flag)
@@ -3936,7 +3958,7 @@ int launch_doublet(dmx_engine* e) {
     const int VS = (V + 15) & ~15;
     size_t cb = (size_t)32 * AP * 9 * 8 + (size_t)32 * 16 * AP * 8 + (size_t)AP * 34 * 8 + 32 * (4 + 4 + 8) + (size_t)32 * 12 * 4 + (size_t)32 * VS;
     cb = (cb + 15) & ~(size_t)15;
-    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     auto slabs = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
 #define DMX_K2CN(NK, APP)                                                                                              \
   do {                                                                                                                 \
@@ -3957,7 +3979,7 @@ int launch_doublet(dmx_engine* e) {
     const int AP = A <= 4 ? 4 : 8;
     const int GS = (V * 3 + 3) & ~3;
     const size_t cell_bytes = (size_t)32 * AP * 9 * 8 + (size_t)32 * GS * 4 + (size_t)AP * 34 * 8 + 32 * (4 + 4 + 8);
-    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     const dim3 block(kThreads);
     auto slabs = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
     // gfx950 lets one workgroup use all 160 KB of a CU's LDS; above the traditional 64 KB the limit is raised explicitly
@@ -3986,7 +4008,7 @@ int launch_doublet(dmx_engine* e) {
   }
   // wide panels: the class kernel's LDS grows by 32 bytes per sample, the general A = 2 kernel's by 384 (64 KB at V = 128)
   if (A != 2 || force_generic || V > (use_cls ? 1024 : 128)) {
-    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     if (int rc = launch_doublet_generic_w<false>(e)) return rc;
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
@@ -4004,7 +4026,7 @@ int launch_doublet(dmx_engine* e) {
     if (NS == 2 && (D + Q - 1) / Q <= 33) NS = 1;
     if (const char* env = getenv("DMX_CLSYM_NED")) NS = (D + Q * atoi(env) - 1) / (Q * atoi(env));   // kernel experiments only
     const int need = (D + Q * NS - 1) / (Q * NS);
-    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     constexpr size_t cb = ((size_t)8 * 32 * 8 + 32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + 32 * 12 * 4 + 32 * 10 * 4 + 63) & ~(size_t)63;
     static_assert(cb % 64 == 0, "a barcode's LDS block keeps its class table 64-byte aligned (k_doublet_clsym ORs the class offset in)");
 #define DMX_K2CS(NED, MINW)                                                                                            \
@@ -4023,7 +4045,7 @@ int launch_doublet(dmx_engine* e) {
     size_t cb = (size_t)32 * 18 * 8 + (size_t)32 * 32 * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8) + (size_t)32 * 12 * 4 + (size_t)32 * VS;
     if (V > 32) cb += 32 * 16;                      // the pipelined form's second header buffer
     cb = (cb + 15) & ~(size_t)15;
-    HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+    HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     const dim3 blk(kThreads);
 #define DMX_K2C(TPC, NK, ...)                                                                                        \
   hipLaunchKernelGGL((k_doublet_cls<TPC, NK, ##__VA_ARGS__>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), blk,   \
@@ -4041,7 +4063,7 @@ int launch_doublet(dmx_engine* e) {
   }
   const int GS = (V * 3 + 3) & ~3;               // LDS row stride of a genotype row (floats), 16-byte multiple
   const size_t cell_bytes = (size_t)32 * 18 * 8 + (size_t)32 * GS * 4 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
-  HIP_TRY(hipMemsetAsync(e->d_flag, 0, (size_t)B, e->stream));
+  HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
   const dim3 block(kThreads);
 #define DMX_K2A(TPC, NK)                                                                                             \
   hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
@@ -4149,15 +4171,29 @@ int launch_doublet(dmx_engine* e) {
 
 }  // namespace
 
+namespace {
+int launch_certify(dmx_engine* e) {
+  const int32_t B = e->pv.B;
+  hipLaunchKernelGGL(k_certify, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_lut,
+                     e->d_alpha, e->V, e->d_sum);
+  HIP_TRY(hipGetLastError());
+  return DMX_OK;
+}
+}  // namespace
+
 extern "C" int dmx_engine_run_singlet(dmx_engine* e) {
   if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_run_singlet: null engine");
   if (!e->have_pileup || !e->d_g) return set_error(DMX_ERR_STATE, "dmx_engine_run_singlet: set genotypes and pileup first");
   HIP_TRY(hipSetDevice(e->device));
   if (e->pv.B == 0) { e->have_sing = true; return DMX_OK; }
+  hipEvent_t* rs = e->ring_s[e->n_ring_s % dmx_engine::kRing];
   HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+  HIP_TRY(hipEventRecord(rs[0], e->stream));
   if (int rc = launch_singlet(e)) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e->ev[3], e->stream));
+  HIP_TRY(hipEventRecord(rs[1], e->stream));
+  ++e->n_ring_s;
   e->timed[1] = true; e->have_sing = true;
   return DMX_OK;
 }
@@ -4170,30 +4206,34 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B;
   const size_t nAB = (size_t)e->V * e->V * e->A;
   if (!e->d_grid || e->grid_cap < B) {
-    if (e->d_grid) { (void)hipFree(e->d_grid); (void)hipFree(e->d_l00); (void)hipFree(e->d_sum); (void)hipFree(e->d_flag); (void)hipFree(e->d_sing); }
+    if (e->d_grid) { (void)hipFree(e->d_grid); (void)hipFree(e->d_l00); (void)hipFree(e->d_sum); if (e->d_flag) (void)hipFree(e->d_flag - kFlagHead); (void)hipFree(e->d_sing); }
     e->d_grid = e->d_l00 = e->d_sing = nullptr; e->d_sum = nullptr; e->d_flag = nullptr;
     const size_t cap = (size_t)e->out_cap;       // the singlet buffers' capacity (>= B)
     HIP_TRY(hipMalloc((void**)&e->d_grid, std::max<size_t>(sizeof(double) * nAB * cap, 16)));
     HIP_TRY(hipMalloc((void**)&e->d_l00, std::max<size_t>(sizeof(double) * (size_t)e->A * cap, 16)));
     HIP_TRY(hipMalloc((void**)&e->d_sum, std::max<size_t>(sizeof(dmx_cell_summary) * cap, 16)));
-    HIP_TRY(hipMalloc((void**)&e->d_flag, std::max<size_t>(cap, 16)));
+    { uint8_t* fb = nullptr; HIP_TRY(hipMalloc((void**)&fb, cap + 2 * kFlagHead)); e->d_flag = fb + kFlagHead; }
     HIP_TRY(hipMalloc((void**)&e->d_sing, std::max<size_t>(sizeof(double) * cap * e->V, 16)));
     e->grid_cap = (int32_t)cap;
   }
   if (B == 0) { e->have_grid = true; return DMX_OK; }
+  hipEvent_t* rd = e->ring_d[e->n_ring_d % dmx_engine::kRing];
   HIP_TRY(hipEventRecord(e->ev[4], e->stream));
+  HIP_TRY(hipEventRecord(rd[0], e->stream));
   if (int rc = launch_doublet(e)) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e->ev[5], e->stream));
+  HIP_TRY(hipEventRecord(rd[1], e->stream));
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)B), dim3(kThreads), 0, e->stream, e->d_grid, e->d_l00, e->pv.cell_pair_off,
                      e->d_alpha, e->V, e->A, e->prior, e->d_sum, e->d_sing);
   HIP_TRY(hipGetLastError());
-  if (e->certify && e->A == 2 && e->alpha[1] == 0.5) {
-    hipLaunchKernelGGL(k_certify, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_lut,
-                       e->d_alpha, e->V, e->d_sum);
-    HIP_TRY(hipGetLastError());
-  }
+  HIP_TRY(hipEventRecord(rd[2], e->stream));
+  const bool certify = e->certify && e->A == 2 && e->alpha[1] == 0.5;
+  if (certify) if (int rc = launch_certify(e)) return rc;
   HIP_TRY(hipEventRecord(e->ev[6], e->stream));
+  HIP_TRY(hipEventRecord(rd[3], e->stream));
+  e->ring_certified[e->n_ring_d % dmx_engine::kRing] = certify;
+  ++e->n_ring_d;
   e->timed[2] = e->timed[3] = true; e->have_grid = true;
   return DMX_OK;
 }
@@ -4254,6 +4294,32 @@ extern "C" int dmx_engine_last_kernel_times(dmx_engine* e, dmx_kernel_times* out
   if (e->timed[1]) HIP_TRY(hipEventElapsedTime(&out->singlet_ms, e->ev[2], e->ev[3]));
   if (e->timed[2]) HIP_TRY(hipEventElapsedTime(&out->doublet_ms, e->ev[4], e->ev[5]));
   if (e->timed[3]) HIP_TRY(hipEventElapsedTime(&out->reduce_ms, e->ev[5], e->ev[6]));
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_mean_kernel_times(dmx_engine* e, int32_t reset, dmx_kernel_time_means* out) {
+  if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_mean_kernel_times: null engine");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (out) {
+    dmx_kernel_time_means m{};
+    const int64_t ns = std::min<int64_t>(e->n_ring_s, dmx_engine::kRing), nd = std::min<int64_t>(e->n_ring_d, dmx_engine::kRing);
+    for (int64_t i = 0; i < ns; ++i) {
+      float ms = 0.f;
+      HIP_TRY(hipEventElapsedTime(&ms, e->ring_s[i][0], e->ring_s[i][1]));
+      m.singlet_ms += ms / (double)ns;
+    }
+    for (int64_t i = 0; i < nd; ++i) {
+      float a = 0.f, b = 0.f, c = 0.f;
+      HIP_TRY(hipEventElapsedTime(&a, e->ring_d[i][0], e->ring_d[i][1]));
+      HIP_TRY(hipEventElapsedTime(&b, e->ring_d[i][1], e->ring_d[i][2]));
+      HIP_TRY(hipEventElapsedTime(&c, e->ring_d[i][2], e->ring_d[i][3]));
+      m.doublet_ms += a / (double)nd; m.reduce_ms += b / (double)nd; m.certify_ms += c / (double)nd;
+    }
+    m.n_singlet = (int32_t)ns; m.n_doublet = (int32_t)nd;
+    *out = m;
+  }
+  if (reset) e->n_ring_s = e->n_ring_d = 0;
   return DMX_OK;
 }
 
@@ -4392,7 +4458,13 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     pl = *job->pileup;
     if (pl.memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup must be host memory");
     if (!pl.rd_totl || !pl.rd_pass || !pl.rd_uniq) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup needs the per-cell read counters");
+    // everything this function itself indexes before the engine's own checks run
+    if (pl.n_cells < 0 || pl.n_snps < 0 || pl.n_pairs < 0 || pl.n_reads < 0) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup has a negative size");
+    if (!pl.cell_pair_off || !pl.cell_read_off) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup needs cell_pair_off and cell_read_off");
+    for (int32_t c = 0; c < pl.n_cells; ++c) if (!job->barcodes[c]) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: barcodes[%d] is null", c);
   }
+  if (job->n_samples < 1 || job->n_alpha < 1) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: n_samples %d, n_alpha %d", job->n_samples, job->n_alpha);
+  for (int32_t j = 0; j < job->n_samples; ++j) if (!job->sample_ids[j]) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: sample_ids[%d] is null", j);
   tm.freeze_s = secs(t_begin, clk::now());
   const clk::time_point t_setup = clk::now();
   const int32_t B = pl.n_cells, V = job->n_samples, A = job->n_alpha;

@@ -915,14 +915,25 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
   const double tol = in->tie_tol > 0 ? in->tie_tol : 1e-7;
   const bool arbiter = in->tie_pileup && in->tie_g;
   dmx::ReadLut lut;
-  std::unique_ptr<dmx::MixTables> mix;
+  std::shared_ptr<const dmx::MixTables> mix;
   if (arbiter) {
     if (in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "%s: the tie arbiter needs a HOST pileup", who);
     double mat[256], err[256];
     dmx_phred_tables(mat, err);
     dmx::build_read_lut(mat, err, &lut);
-    mix.reset(new dmx::MixTables);
-    dmx::build_mix_tables(lut, A, in->alpha, mix.get());
+    // 128*128*A*9 doubles (75 MB at A = 64): built once per alpha grid, not once per appended range of a job
+    static std::mutex mix_mu;
+    static std::vector<double> mix_alpha;
+    static std::shared_ptr<const dmx::MixTables> mix_cached;
+    std::lock_guard<std::mutex> lk(mix_mu);
+    if (!mix_cached || mix_alpha.size() != (size_t)A || !std::equal(mix_alpha.begin(), mix_alpha.end(), in->alpha,
+                                                                       [](double a, double b) { return std::memcmp(&a, &b, sizeof a) == 0; })) {
+      std::shared_ptr<dmx::MixTables> m(new dmx::MixTables);
+      dmx::build_mix_tables(lut, A, in->alpha, m.get());
+      mix_cached = m;
+      mix_alpha.assign(in->alpha, in->alpha + A);
+    }
+    mix = mix_cached;
   }
   const std::vector<int32_t> cells = output_cells(in, true);
   FILE* const files[kOutFiles] = {sing2.f, pairf.f, best.f};
@@ -953,13 +964,14 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
     const double* sg = nullptr;                                            // singlet column when there is no grid
     dmx_cell_summary resolved;
     const dmx_cell_summary* smp = src.summary ? &src.summary[c] : nullptr;
-    if (arbiter && smp && (smp->flags & DMX_CELL_ORDER_RESOLVABLE)) {      // K3b left one log() per accumulator to the host's libm
+    if (smp && (smp->flags & DMX_CELL_ORDER_RESOLVABLE)) {                 // K3b left one log() per accumulator to the host's libm:
+                                                                           // no pileup needed, so with or without the arbiter (dmx.h)
       resolved = *smp;
       if (dmx::resolve_tie_order(&resolved)) smp = &resolved;
     }
     if (grid) {
       constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
-      if (arbiter && smp && (smp->flags & DMX_CELL_ORDER_CERTIFIED) && !(smp->flags & kNear)) {
+      if (smp && (smp->flags & DMX_CELL_ORDER_CERTIFIED) && !(smp->flags & kNear)) {
         // the device certified both accumulators of the best alpha = 0.5 pair (K3b) and K3 saw no other near-tie: the two
         // entries the arbiter would re-evaluate are known, bit for bit
         const dmx_cell_summary& sm = *smp;

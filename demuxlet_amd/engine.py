@@ -211,6 +211,15 @@ class Engine:
         check(self._L.dmx_engine_last_kernel_times(self._h, C.byref(t)))
         return t
 
+    def mean_kernel_times(self, reset: bool = False) -> capi.KernelTimeMeans:
+        """Mean HIP-event time of K1, K2, K3 and K3b over the launches since the last reset (at most the last 16)."""
+        t = capi.KernelTimeMeans()
+        check(self._L.dmx_engine_mean_kernel_times(self._h, int(reset), C.byref(t)))
+        return t
+
+    def reset_kernel_times(self) -> None:
+        check(self._L.dmx_engine_mean_kernel_times(self._h, 1, None))
+
     def algorithmic_bytes(self) -> capi.KernelBytes:
         b = capi.KernelBytes()
         check(self._L.dmx_engine_algorithmic_bytes(self._h, C.byref(b)))

@@ -181,6 +181,11 @@ int dmx_engine_device_view(dmx_engine*, dmx_device_view* out);
 /* HIP-event timing of the last launch of each kernel on the engine's stream, in milliseconds (0 when not run). */
 typedef struct { float gp0_ms, singlet_ms, doublet_ms, reduce_ms; } dmx_kernel_times;
 int dmx_engine_last_kernel_times(dmx_engine*, dmx_kernel_times* out);
+/* The same, averaged over the launches since the last reset (at most the last 16 of each kernel): what a benchmark divides a
+ * kernel's algorithmic bytes by.  doublet_ms is K2 alone, reduce_ms K3 alone, certify_ms K3b alone (0 when it does not run).
+ * Synchronises the engine's stream.  reset != 0 forgets the launches seen so far; out may be NULL (reset only). */
+typedef struct { double singlet_ms, doublet_ms, reduce_ms, certify_ms; int32_t n_singlet, n_doublet; } dmx_kernel_time_means;
+int dmx_engine_mean_kernel_times(dmx_engine*, int32_t reset, dmx_kernel_time_means* out);
 /* Algorithmic HBM bytes one launch of each kernel must move for the staged problem. */
 typedef struct { double singlet_bytes, doublet_bytes, reduce_bytes; } dmx_kernel_bytes;
 int dmx_engine_algorithmic_bytes(dmx_engine*, dmx_kernel_bytes* out);
@@ -258,7 +263,8 @@ typedef struct {
                                       engines (own HIP stream each) that alternate: the H2D of wave w + 2 overlaps the kernels of wave w + 1
                                       while the host arbitrates, formats and appends the rows of wave w.  Barcodes are independent
                                       (cmd_cram_demuxlet.cpp:576): no collective. */
-  int32_t      mode;               /* DMX_MODE_STRICT (0, default) or DMX_MODE_FAST */
+  int32_t      mode;               /* DMX_MODE_STRICT (0: the default of this struct, of the Python binding and of the `demuxlet`
+                                      binary) or DMX_MODE_FAST (`demuxlet --fast`) */
   /* Optional (ABI 2): a pileup that is already frozen (host memory, sparse or dense layout) instead of `store` (then NULL), with
    * its barcodes by cell id — what a caller that builds the CSR itself hands over (tools/e2e_bench.cpp, the benchmarks). */
   const dmx_pileup*  pileup;

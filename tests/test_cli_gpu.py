@@ -33,8 +33,9 @@ def compare_files(got_path, want_path, best=False):
 @pytest.mark.parametrize("field,fmt,extra", [("GT", "bam", ["--write-pair"]), ("GP", "sam", ["--alpha", "0", "--alpha", "0.25", "--alpha", "0.5"]),
                                               ("PL", "sam", ["--min-snp", "5", "--doublet-prior", "0.3"]),
                                               ("PL", "bam", ["--write-pair", "--gpus", "3"]),        # three engines (one device here)
-                                              ("PL", "sam", ["--write-pair", "--strict", "--gpus", "2"]),  # DMX_MODE_STRICT
-                                              ("GT", "sam", ["--strict"])])                                 # (the default is DMX_MODE_FAST)
+                                              ("PL", "sam", ["--write-pair", "--fast", "--gpus", "2"]),    # DMX_MODE_FAST (opt-in)
+                                              ("GT", "sam", ["--fast"]), ("GP", "bam", ["--fast"]),
+                                              ("GT", "sam", ["--strict"])])                                 # the default (DMX_MODE_STRICT), spelled out
 def test_cli_end_to_end(oracle, tmp_path, field, fmt, extra):
     from demuxlet_amd import build
     build.build()

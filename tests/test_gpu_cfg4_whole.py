@@ -1,0 +1,242 @@
+"""GPU (-m gpu): BASELINE.json configs[3] — 100 000 barcodes x 100 000 SNPs x 64 samples, GT, alpha {0, 0.5}, `--write-pair` — at
+its REAL size on one MI355X (1e10 covered pairs, 22.5 GB of pileup, 6.4e11 triples, 8.2e13 pair-evaluations; the reference's
+per-barcode loop cmd_cram_demuxlet.cpp:576 and its "HUGE" .pair file :772-797).
+
+Checked:
+* engine level, STRICT and FAST on the device pileup: six sampled barcodes — the first two, two in the middle, the last two of the
+  launch — through the oracle at the full 100k-SNP depth: every log-likelihood (FAST: every printed entry) within 1e-9, the K3
+  calls the oracle's;
+* product level: the whole job through ONE `dmx_demuxlet_run` call (FAST, `--write-pair`, tie arbiter on, frozen host pileup, barcode
+  names whose sorted order is not the id order): `.best` has one row per covered barcode, `.single`/`.sing2` B*V rows, `.pair`
+  B*(V + V(V-1)/2) rows, barcodes ascending across the appended ranges in every file, and the sampled barcodes' rows in all four
+  files are the oracle's (strings and BEST identical, numbers to the last printed digit).
+
+Nothing here reads /root/reference; the oracle is the checker only."""
+import os
+import subprocess
+import threading
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+CFG = 4
+
+
+@pytest.fixture(scope="module")
+def mods():
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    from demuxlet_amd import build, capi, engine, synth, synth_torch
+    build.build()
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    capi.load()
+    import bench
+    from oracle import oracle_py as O
+    O.build()
+    return dict(torch=torch, engine=engine, synth=synth, st=synth_torch, bench=bench, O=O, capi=capi)
+
+
+def oracle_cells(O, h, cells, S, barcodes, sm, g, alphas, counters, out_dir):
+    """The oracle on each sampled barcode at full depth, one host thread per barcode (ctypes drops the GIL): raw arrays + the
+    four files of a job made of just these barcodes (write_pair on)."""
+    plans = []
+    for c in cells:
+        p0, p1 = int(h["cell_pair_off"][c]), int(h["cell_pair_off"][c + 1])
+        r0, r1 = int(h["cell_read_off"][c]), int(h["cell_read_off"][c + 1])
+        assert p1 - p0 == S
+        reads = h["reads"][r0:r1]
+        words = ((reads >> 7).astype(np.uint32) << 24) | ((reads & 0x7F).astype(np.uint32) << 16) | 1
+        nrd = h["pair_nrd"][p0:p1].astype(np.int64)
+        csr = O.Csr([barcodes[c]], np.array([0, S], dtype=np.int64), np.arange(S, dtype=np.int32),
+                    np.concatenate([[0], np.cumsum(nrd)]), words, counters[c:c + 1], counters[c:c + 1], counters[c:c + 1])
+        plans.append(O.CsrPlan(csr, sm, g, O.Params(tuple(alphas), 0.5, 0, 0, 0, True), os.path.join(out_dir, f"r{c}")))
+    th = [threading.Thread(target=p.execute) for p in plans]
+    for t in th: t.start()
+    for t in th: t.join()
+    return [p.out for p in plans]
+
+
+def check_engine(m, dp, g, cfg, cells, want, fast):
+    from golden_util import printed_mask, summary_from_grid
+    torch, engine, st, capi = m["torch"], m["engine"], m["st"], m["capi"]
+    B, V, A = cfg["B"], cfg["V"], len(cfg["alphas"])
+    dev = torch.device("cuda", 0)
+    e = engine.Engine(V, cfg["alphas"], 0.5, device=0, mode=capi.DMX_MODE_FAST if fast else capi.DMX_MODE_STRICT)
+    e.set_genotypes(g)
+    e.set_pileup_struct(dp.as_struct(), keep=dp)
+    t0 = time.perf_counter()
+    e.run_singlet(); e.run_doublet(); e.sync()
+    secs = time.perf_counter() - t0
+    v = e.device_view()
+    idx = torch.from_numpy(cells).to(dev)
+    llks = st.tensor_from_ptr(v.llks, (B, V), torch.float64, dev)[idx].cpu().numpy()
+    llk0s = st.tensor_from_ptr(v.llk0s, (B,), torch.float64, dev)[idx].cpu().numpy()
+    grid = st.tensor_from_ptr(v.llksAB, (B, V, V, A), torch.float64, dev)[idx].cpu().numpy()
+    l00 = st.tensor_from_ptr(v.llks00, (B, A), torch.float64, dev)[idx].cpu().numpy()
+    words = capi.SUMMARY_DTYPE.itemsize // 8
+    summ_all = st.tensor_from_ptr(v.summary, (B, words), torch.float64, dev).cpu().numpy()
+    summ_all = np.ascontiguousarray(summ_all).view(capi.SUMMARY_DTYPE).reshape(-1)
+    finite = bool(torch.isfinite(st.tensor_from_ptr(v.llks, (B, V), torch.float64, dev)).all().item())
+    e.close()
+    assert finite
+    assert (summ_all["n_pairs"] == cfg["S"]).all()                       # every barcode covers every SNP and was reduced
+    assert ((summ_all["j_best"] >= 0) & (summ_all["k_best"] >= 0) & (summ_all["j_best"] != summ_all["k_best"])).all()
+    mask = printed_mask(V, A)
+    worst = 0.0
+    for i, c in enumerate(cells):
+        w = want[i]
+        d = [np.abs(llks[i] - w.llks[0]).max(), abs(llk0s[i] - w.llk0s[0]), np.abs(l00[i] - w.llks00[0]).max()]
+        dg = np.abs(grid[i] - w.llksAB[0])
+        d.append(dg[mask].max() if fast else dg.max())
+        assert max(d) <= TOL, (c, d)
+        worst = max(worst, max(d))
+        sm = summ_all[c]
+        ws = summary_from_grid(w.llksAB[0], w.llks00[0], cfg["alphas"], 0.5, int(sm["n_pairs"]), capi.SUMMARY_DTYPE)
+        assert (sm["i_sing1"], sm["i_sing2"], sm["n_best"]) == (ws["i_sing1"], ws["i_sing2"], ws["n_best"]), c
+        assert {int(sm["j_best"]), int(sm["k_best"])} == {int(ws["j_best"]), int(ws["k_best"])}, c
+        if sm["flags"] & capi.DMX_CELL_ORDER_CERTIFIED:                      # certified: the oracle's order and LLK12 bits
+            assert (int(sm["j_best"]), int(sm["k_best"])) == (int(ws["j_best"]), int(ws["k_best"])), c
+            assert sm["llk12"] == ws["llk12"], c
+    print(f"cfg4 whole, {'FAST' if fast else 'STRICT'}: K1+K2+K3(+K3b) over {B} barcodes {secs:.2f} s; {len(cells)} barcodes through the "
+          f"oracle at S={cfg['S']}: max |delta| = {worst:.3e}")
+    return worst
+
+
+def rows_of(path, wanted):
+    """Rows of a (possibly 10 GB) tab-separated file whose first column is one of `wanted`, via grep -F (then an exact filter)."""
+    pat = path + ".pat"
+    with open(pat, "w") as f:
+        f.write("\n".join(wanted) + "\n")
+    r = subprocess.run(["grep", "-F", "-f", pat, path], capture_output=True, text=True)
+    assert r.returncode in (0, 1), r.stderr
+    return [ln for ln in r.stdout.splitlines() if ln.split("\t", 1)[0] in wanted]
+
+
+def first_column_is_ascending(path, width):
+    """The barcode column ("BC" + `width` digits + "-1") never decreases from one row to the next, checked with numpy over
+    512 MB windows of the memory-mapped file (the .pair file of this job is 10 GB: no per-line Python)."""
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    n = mm.shape[0]
+    pos = int(np.flatnonzero(mm[:4096] == 10)[0]) + 1                       # skip the header line
+    last = -1
+    step = 512 << 20
+    pw = (10 ** np.arange(width - 1, -1, -1)).astype(np.int64)
+    while pos < n:
+        end = min(n, pos + step)
+        chunk = np.asarray(mm[pos:end])
+        nl = np.flatnonzero(chunk == 10)
+        if end < n:                                                         # keep whole lines: the window ends after its last newline
+            end = pos + int(nl[-1]) + 1
+            starts = np.concatenate([[0], nl[:-1] + 1])
+        else:
+            starts = np.concatenate([[0], nl[:-1] + 1]) if chunk[-1] == 10 else np.concatenate([[0], nl + 1])
+        if not (chunk[starts] == ord("B")).all():
+            return False
+        keys = np.zeros(len(starts), dtype=np.int64)
+        for i in range(width):
+            keys += (chunk[starts + 2 + i].astype(np.int64) - 48) * pw[i]
+        if keys[0] < last or (np.diff(keys) < 0).any():
+            return False
+        last = int(keys[-1])
+        pos = end
+    return True
+
+
+def test_cfg4_whole_job_on_one_gpu(mods, tmp_path):
+    torch, engine, bench, O, capi = mods["torch"], mods["engine"], mods["bench"], mods["O"], mods["capi"]
+    cfg = dict(bench.CONFIGS[CFG])
+    B, S, V = cfg["B"], cfg["S"], cfg["V"]
+    assert (B, S, V) == (100_000, 100_000, 64)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0xD3A00000 + CFG)                            # bench.py's panel and pileup for cfg4 (rank 0 of 1)
+    raw, g = bench.genotype_matrix(engine, mods["synth"], rng, S, V, cfg["field"])
+    dosage = torch.from_numpy(np.clip(raw.alleles, 0, 1).sum(axis=2).astype(np.float32)).to(dev)
+    t0 = time.perf_counter()
+    dp = mods["st"].make_device_pileup(dosage, B, cfg["delta"], cfg["rbar"], seed=0xD3A0 + 1000 * CFG, device=dev)
+    torch.cuda.synchronize()
+    del dosage
+    assert dp.n_pairs == B * S
+    print(f"cfg4 whole: {dp.n_pairs:.3e} covered pairs, {dp.n_reads:.3e} stored reads generated in HBM in {time.perf_counter() - t0:.1f} s")
+
+    cells = np.array([0, 1, B // 2 - 1, B // 2, B - 2, B - 1], dtype=np.int64)
+    barcodes = [f"BC{(i * 7919) % B:06d}-1" for i in range(B)]              # a permutation (7919 is prime): sorted order != id order
+    sm = [f"SM{j:02d}" for j in range(V)]
+    # host copies of the sampled barcodes for the oracle (the whole pileup follows below, for the product call)
+    po, ro = dp.cell_pair_off.cpu().numpy(), dp.cell_read_off.cpu().numpy()
+    counters = np.diff(ro).astype(np.int32)
+    hs = dict(cell_pair_off=po, cell_read_off=ro)
+    nrd_parts, rd_parts = {}, {}
+    for c in cells:
+        nrd_parts[c] = dp.pair_nrd[int(po[c]):int(po[c + 1])].cpu().numpy()
+        rd_parts[c] = dp.reads[int(ro[c]):int(ro[c + 1])].cpu().numpy()
+
+    class Sliced:                                                           # oracle_cells slices [p0:p1] / [r0:r1] of the sampled cells only
+        def __init__(self, parts, off): self.parts, self.off = parts, off
+        def __getitem__(self, sl):
+            for c, arr in self.parts.items():
+                if int(self.off[c]) == sl.start and int(self.off[c + 1]) == sl.stop:
+                    return arr
+            raise KeyError(sl)
+    hs["pair_nrd"] = Sliced(nrd_parts, po)
+    hs["reads"] = Sliced(rd_parts, ro)
+    t0 = time.perf_counter()
+    want = oracle_cells(O, hs, cells, S, barcodes, sm, g, cfg["alphas"], counters, str(tmp_path))
+    print(f"oracle: {len(cells)} barcodes x {S} SNPs x {V} samples in {time.perf_counter() - t0:.1f} s on {len(cells)} host threads")
+
+    # ---- engine level, both modes, on the device pileup
+    check_engine(mods, dp, g, cfg, cells, want, fast=False)
+    check_engine(mods, dp, g, cfg, cells, want, fast=True)
+
+    # ---- product level: one dmx_demuxlet_run call over the frozen host pileup, FAST, --write-pair
+    t0 = time.perf_counter()
+    pl = engine.HostPileup(B, S, po, ro, None, dp.pair_nrd.cpu().numpy(), dp.reads.cpu().numpy(), counters, counters, counters)
+    del dp
+    torch.cuda.empty_cache()
+    print(f"pileup to host memory in {time.perf_counter() - t0:.1f} s")
+    out = str(tmp_path / "o")
+    tm = engine.demuxlet_run(pl, g, sm, cfg["alphas"], out, write_pair=True, arbiter=True, barcodes=barcodes, timing=True,
+                             mode=capi.DMX_MODE_FAST)
+    print("cfg4 whole through dmx_demuxlet_run (FAST, --write-pair):", {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()})
+    assert tm["n_ranges"] >= 2
+    del pl
+
+    def n_rows(path):
+        return int(subprocess.check_output(["wc", "-l", path]).split()[0]) - 1
+    assert n_rows(out + ".best") == B                                        # one row per covered barcode (:592)
+    assert n_rows(out + ".single") == B * V
+    assert n_rows(out + ".sing2") == B * V
+    assert n_rows(out + ".pair") == B * (V + V * (V - 1) // 2)              # :772-797: V singlet rows + the j < k half at alpha 0.5
+    for suf in ("best", "single", "sing2", "pair"):
+        assert first_column_is_ascending(f"{out}.{suf}", 6), suf           # ascending barcodes across the appended ranges
+    best_keys = [ln.split("\t", 1)[0] for ln in open(out + ".best").read().splitlines()[1:]]
+    assert best_keys == sorted(barcodes)
+
+    want_bc = {barcodes[c] for c in cells}
+    n_num = n_diff = 0
+    for suf in ("single", "sing2", "best", "pair"):
+        got = rows_of(f"{out}.{suf}", want_bc)
+        ref = []
+        for c in cells:
+            ref += open(tmp_path / f"r{c}.{suf}").read().splitlines()[1:]
+        ref.sort(key=lambda ln: ln.split("\t", 1)[0])                       # stable: rows of a barcode keep their order
+        assert len(got) == len(ref), (suf, len(got), len(ref))
+        for a, b in zip(got, ref):
+            fa, fb = a.split("\t"), b.split("\t")
+            assert len(fa) == len(fb)
+            for x, y in zip(fa, fb):
+                try:
+                    fx, fy = float(x), float(y)
+                except ValueError:
+                    assert x == y, (suf, a, b)
+                    continue
+                n_num += 1
+                if x != y:
+                    n_diff += 1
+                    assert abs(fx - fy) <= 1e-3 * max(1e-3, abs(fy)) + 1.01e-4, (suf, a, b)
+    print(f"sampled barcodes' rows of all four files: {n_num} printed numbers, {n_diff} differ from the oracle's in the last digit")
+    assert n_diff <= max(2, n_num // 100000)

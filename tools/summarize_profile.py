@@ -64,6 +64,8 @@ d = res[dom]
 json.dump({"kernel": dom, "barcodes_per_gpu": bench["config"]["barcodes_per_gpu"], "mode": mode,
            "valu_wave_insts_per_launch": d.get("SQ_INSTS_VALU"), "valu_busy_quadcycles_per_launch": d.get("SQ_ACTIVE_INST_VALU"),
            "fp64_insts_per_launch": d.get("fp64_insts"), "other_valu_insts_per_launch": d.get("other_valu_insts"),
+           "fp64_add_per_launch": d.get("SQ_INSTS_VALU_ADD_F64"), "fp64_mul_per_launch": d.get("SQ_INSTS_VALU_MUL_F64"),
+           "fp64_fma_per_launch": d.get("SQ_INSTS_VALU_FMA_F64"), "fp64_trans_per_launch": d.get("SQ_INSTS_VALU_TRANS_F64"),
            "issue_cycles_per_launch": d.get("issue_cycles"), "issue_cycles_cvt4_per_launch": d.get("issue_cycles_cvt4"),
            "sq_inst_cycles_valu_per_launch": d.get("SQ_INST_CYCLES_VALU"),
            "lds_insts_per_launch": d.get("SQ_INSTS_LDS"), "lds_active_quadcycles_per_launch": d.get("SQ_ACTIVE_INST_LDS"),
