@@ -245,6 +245,16 @@ __device__ __forceinline__ double shfl_xor1(double x) {
   return __hiloint2double(hi, lo);
 }
 
+// One 8-byte LDS read that the compiler must not pair with a neighbour: ds_read2_b64 is serviced as two 4 x 16-lane accesses
+// (8 LDS cycles, 128 B/clk, MI355X_MICROARCH.md "LDS") where two ds_read_b64 take 2 + 2 — and the hot loops of the FAST doublet
+// kernels read three doubles 8*VUS bytes apart per evaluation, which the load/store optimiser merges whenever it can.
+__device__ __forceinline__ double lds_read_f64(const double* p) {
+  return *(const volatile __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)p;
+}
+#ifndef DMX_LDS_NOMERGE
+#define DMX_LDS_NOMERGE 1                         // cfg3 FAST K2 309 -> 291 ms (0 restores the merged reads: kernel experiments only)
+#endif
+
 __device__ __forceinline__ uint32_t load_nrd(const void* __restrict__ base, int64_t p, int width) {
   if (width == 1) return ((const uint8_t*)base)[p];
   if (width == 2) return ((const uint16_t*)base)[p];
@@ -1069,7 +1079,10 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 // flagged and recomputed by k_doublet_generic<FIXUP> with ocml's log().
 // GD: the genotype rows are widened to binary64 once, when they are staged (a conversion per element and tile instead of one per
 // use in phase 2); the LDS holds them as doubles.
-template <int TPC, int NK, int MINW = 1, bool GD = false>
+// CHK = false drops the per-term argument-class test of phase 2 (a v_cmp_class_f64 per log): launched only when every genotype row was
+// found finite, non-negative and not vanishing (k_check_geno) — then every phase-2 sum is >= max_l g_j[l] * (1e-6 / (1 + 1e-6)) *
+// max_m g_k[m] > 2^-830, a normal positive number, and the test cannot fire.
+template <int TPC, int NK, int MINW = 1, bool GD = false, bool CHK = true>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                          const double* __restrict__ alpha,
@@ -1126,6 +1139,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
   bool ok = true;
+  const DmxLogPins lk = dmx_log_pins();
   // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1; mixing weights of :613
   const int ti1 = tid >> 1, n1 = tid & 1;
   double acc00 = 0.0;                            // lane n1 == tid < 2 owns llks00[n]
@@ -1262,9 +1276,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
               s0 += (gp * P0[l * 3 + m]);                                     // alpha 0
               s1 += (gp * P1[l * 3 + m]);                                     // alpha 1
             }
-          ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-          acc[kk][0] += dmx_log_fast(s0, s_log);                              // :683
-          acc[kk][1] += dmx_log_fast(s1, s_log);
+          if (CHK) ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
+          acc[kk][0] += dmx_log_fast_pinned(s0, s_log, lk);                   // :683
+          acc[kk][1] += dmx_log_fast_pinned(s1, s_log, lk);
         }
       }
     }
@@ -1341,6 +1355,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
   bool ok = true;
+  const DmxLogPins lk = dmx_log_pins();
   // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1; mixing weights of :613
   const int ti1 = tid >> 1, n1 = tid & 1;
   double wA[9], wR[9];
@@ -1488,8 +1503,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             const double s0 = __builtin_fma(a2, x[2], __builtin_fma(a1, x[1], a0 * x[0]));
             const double s1 = __builtin_fma(a2, y[2], __builtin_fma(a1, y[1], a0 * y[0]));
             ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-            acc[kk][0] += dmx_log_lite(s0, s_log);
-            acc[kk][1] += dmx_log_lite(s1, s_log);
+            acc[kk][0] += dmx_log_fast_pinned(s0, s_log, lk);
+            acc[kk][1] += dmx_log_fast_pinned(s1, s_log, lk);
           }
         }
       }
@@ -1526,8 +1541,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             const double s0 = __builtin_fma(a2, x2, __builtin_fma(a1, x01.y, a0 * x01.x));
             const double s1 = __builtin_fma(a2, y2, __builtin_fma(a1, y01.y, a0 * y01.x));
             ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-            acc[kk][0] += dmx_log_lite(s0, s_log);
-            acc[kk][1] += dmx_log_lite(s1, s_log);
+            acc[kk][0] += dmx_log_fast_pinned(s0, s_log, lk);
+            acc[kk][1] += dmx_log_fast_pinned(s1, s_log, lk);
           }
         }
       }
@@ -1569,7 +1584,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 // For even V the offset d = V/2 is computed from both sides; only the j < k copy is stored.
 // Panels wider than 64 samples cut the entry list into slabs of NEP entries per lane, one workgroup (blockIdx.y) per slab: each slab
 // repeats the per-tile phases (cheap next to 256 * NEP evaluations per pair) and owns its entries' accumulators.
-template <int TPC, int VMAX, int SUB, bool FIXJ, int MINW = 3, int NEP = 0>
+template <int TPC, int VMAX, int SUB, bool FIXJ, int MINW = 3, int NEP = 0, bool CHK = true>   // CHK: see k_doublet_a2
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                           const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                           const int32_t* __restrict__ sched, int32_t V_and_flags,
@@ -1645,6 +1660,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #pragma unroll
   for (int i = 0; i < NE; ++i) acc[i] = 0.0;
   bool ok = true;
+  const DmxLogPins lk = dmx_log_pins();
   // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1
   const int ti1 = tid >> 1, n1 = tid & 1;
   double acc00 = 0.0;                            // lane n1 == tid < 2 owns llks00[n]
@@ -1847,10 +1863,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #pragma unroll
           for (int i = 0; i < NE; ++i) {
             if (!FIXJ) { a0 = (double)gr[ej[i] * 3]; a1 = (double)gr[ej[i] * 3 + 1]; a2 = (double)gr[ej[i] * 3 + 2]; }
-            const double x0 = up[ek[i]], x1 = up[VUS + ek[i]], x2 = up[2 * VUS + ek[i]];
+            const double x0 = DMX_LDS_NOMERGE ? lds_read_f64(&up[ek[i]]) : up[ek[i]], x1 = DMX_LDS_NOMERGE ? lds_read_f64(&up[VUS + ek[i]]) : up[VUS + ek[i]],
+                         x2 = DMX_LDS_NOMERGE ? lds_read_f64(&up[2 * VUS + ek[i]]) : up[2 * VUS + ek[i]];
             const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
-            ok &= __builtin_amdgcn_class(sj, 0x100);
-            acc[i] += dmx_log_lite(sj, s_log);
+            if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100);
+            acc[i] += dmx_log_fast_pinned(sj, s_log, lk);
           }
         }
       }
@@ -2760,12 +2777,20 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
       // ---- phase 2.  LDS byte address of an entry's table cell = (row base of this pair and this lane's class cj, a multiple of
       //      64) | (ck << 3): one shift and one and-or per entry.  Entries go in groups of GRP (their loads in flight together).
       if (lane_on) {
+#ifdef DMX_CLSYM_GRP
+        constexpr int GRP = NED <= DMX_CLSYM_GRP ? NED : (NED + (NED + DMX_CLSYM_GRP - 1) / DMX_CLSYM_GRP - 1) / ((NED + DMX_CLSYM_GRP - 1) / DMX_CLSYM_GRP);   // kernel experiments only
+#else
         constexpr int GRP = NED <= 12 ? NED : (NED + 2) / 3;
+#endif
         using lds_cd = const __attribute__((address_space(3))) double*;
         using lds_cu = const __attribute__((address_space(3))) uint32_t*;
         const uint32_t t_base = (uint32_t)(uintptr_t)(lds_cd)s_T;            // 64-byte aligned (checked by the launcher's layout)
         const uint32_t pk_lane = (uint32_t)(uintptr_t)(lds_cu)s_pk + 4u * w0, pk_j = (uint32_t)(uintptr_t)(lds_cu)s_pk + 4u * wj;
+#ifdef DMX_CLSYM_UNR
+        constexpr int UNR = DMX_CLSYM_UNR;             // kernel experiments only
+#else
         constexpr int UNR = NED >= 12 ? 1 : 2;
+#endif
 #pragma unroll UNR
         for (int pi = 0; pi < ns; ++pi) {
           const uint32_t po = (uint32_t)((sub + pi) * NW * 4);
@@ -3051,6 +3076,18 @@ __global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nr
 #undef DMX_K2_SYNC
 }
 
+// Which genotype matrices can make a phase-2 log() argument leave the normal positive range at all?  Only those with a row that
+// holds a NaN / infinity / negative entry or no entry above 2^-400 (see k_doublet_a2's CHK).  Sets *unsafe when it finds one.
+__global__ void k_check_geno(const float* __restrict__ g, int64_t n_rows, int32_t* __restrict__ unsafe) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * blockDim.x) {
+    const float a = g[3 * i], b = g[3 * i + 1], c = g[3 * i + 2];
+    const bool fin = (a >= 0.f) && (b >= 0.f) && (c >= 0.f) && (a <= 3.0e38f) && (b <= 3.0e38f) && (c <= 3.0e38f);   // false for NaN
+    bad |= !fin || !(fmaxf(a, fmaxf(b, c)) >= 1e-30f);             // float32: anything normal is far above 2^-400
+  }
+  if (bad) atomicOr(unsafe, 1);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K3.  One cell per workgroup over its finished grid.
 struct ArgMax { double v; int32_t i; };
@@ -3260,7 +3297,9 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
 // both operands).  When lower == upper for both, they ARE the reference's values and the order is decided here — for any such
 // libm; the host tie arbiter (which calls the host's log()) is left with the barcodes where a bracket stayed open, about one in
 // ten.  Requires A = 2 (phase 1 is k_doublet_a2's) and no other doublet entry within 1e-7 of the best (K3's flag).
-__global__ __launch_bounds__(kThreads, 4) void k_certify(PileupView pv, int nrd_width, const float* __restrict__ g,
+template <int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                      const float* __restrict__ gT,
                                                       const double* __restrict__ tabs, const double* __restrict__ alpha,
                                                       int32_t V, dmx_cell_summary* __restrict__ summ) {
   constexpr int TP = 32, T00 = TP + 2, TPC = 64, CPW = kThreads / TPC;
@@ -3311,7 +3350,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_certify(PileupView pv, int nrd_
   double acc = 0.0;
   bool clean[2] = {true, true};
   if (tid < 4) s_ev[cw][tid] = 0.0;               // [ab: log argument, lower candidate | ba: ...] of the open event
-  const int row_len = V * 3;
+  const size_t S = (size_t)pv.S;
+  const float* const colA = gT ? gT + (size_t)(ia * 3) * S : g + (size_t)ia * 3;
+  const float* const colB = gT ? gT + (size_t)(ib * 3) * S : g + (size_t)ib * 3;
+  const size_t estride = gT ? S : 1, sstride = gT ? 1 : (size_t)V * 3;
   uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
   if (tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
@@ -3334,9 +3376,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_certify(PileupView pv, int nrd_
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
       const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
-      const int32_t snp1 = on ? s_snp[ti1] : 0;
-      const float* gr = g + (size_t)snp1 * row_len;
-      const float fa0 = gr[ia * 3], fa1 = gr[ia * 3 + 1], fa2 = gr[ia * 3 + 2], fb0 = gr[ib * 3], fb1 = gr[ib * 3 + 1], fb2 = gr[ib * 3 + 2];
+      // The two samples' probabilities at the pair's SNP.  Dense pileups read them from the SNP-minor copy gT[row element][snp]: the
+      // 32 pairs of a tile are 32 consecutive SNPs, i.e. one 128-byte line per element, instead of two lines per PAIR out of
+      // V*12-byte rows (165 GB through the L2 per launch at the cfg4 shard, profiles/r02_cfg4_fast_pmc_summary.json).  Sparse
+      // pileups read the row of the lane's own SNP.
+      const size_t so = (size_t)(on ? s_snp[ti1] : 0) * sstride;
+      const float fa0 = colA[so], fa1 = colA[so + estride], fa2 = colA[so + 2 * estride];
+      const float fb0 = colB[so], fb1 = colB[so + estride], fb2 = colB[so + 2 * estride];
       double v[9];                                 // pG[1][l][m] of the pair (five: v[l + m])
       if (five) {
         double v5[5];
@@ -3455,6 +3501,7 @@ struct dmx_engine {
   int32_t* d_sched = nullptr; size_t sched_cap = 0;
   int32_t* d_bad = nullptr;                                          // set by k_check_snp_ids
   bool have_gT = false;                                              // d_gT / d_g0T hold the current genotype matrix
+  bool geno_safe = false;                                            // every genotype row finite, non-negative, max >= 2^-400 (k_check_geno)
   // host -> device staging of the big pileup arrays: two pinned chunks filled by host threads while the other one is in flight
   void* h_stage[2] = {nullptr, nullptr}; hipEvent_t ev_stage[2] = {nullptr, nullptr}; bool stage_busy[2] = {false, false}; int stage_cur = 0;
   // results
@@ -3635,6 +3682,7 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
   if (e->d_idw) { (void)hipFree(e->d_idw); e->d_idw = nullptr; }
   if (e->d_idd) { (void)hipFree(e->d_idd); e->d_idd = nullptr; }
   e->n_classes = 0;
+  e->geno_safe = false;
   if (n_snps > 0) {
     int32_t* d_max = nullptr;
     HIP_TRY(hipMalloc((void**)&e->d_rows, (size_t)n_snps * kMaxCls * 3 * sizeof(float)));
@@ -3647,10 +3695,17 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     hipLaunchKernelGGL(k_build_classes, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_g, n_snps, e->V,
                        e->d_rows, e->d_ids, e->d_idw, e->d_idd, e->nwd2, d_max);
     HIP_TRY(hipGetLastError());
-    int32_t h_max = 0;
+    int32_t* d_unsafe = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_unsafe, sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(d_unsafe, 0, sizeof(int32_t), e->stream));
+    hipLaunchKernelGGL(k_check_geno, dim3(1024), dim3(256), 0, e->stream, e->d_g, (int64_t)n_snps * e->V, d_unsafe);
+    HIP_TRY(hipGetLastError());
+    int32_t h_max = 0, h_unsafe = 1;
     HIP_TRY(hipMemcpyAsync(&h_max, d_max, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(&h_unsafe, d_unsafe, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    (void)hipFree(d_max);
+    (void)hipFree(d_max); (void)hipFree(d_unsafe);
+    e->geno_safe = h_unsafe == 0 && !getenv("DMX_FORCE_CHECK");
     e->n_classes = (h_max >= 1 && h_max <= kMaxCls) ? h_max : 0;
     if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); (void)hipFree(e->d_idw); (void)hipFree(e->d_idd); e->d_rows = nullptr; e->d_ids = nullptr; e->d_idw = nullptr; e->d_idd = nullptr; }
   }
@@ -4066,9 +4121,16 @@ int launch_doublet(dmx_engine* e) {
   HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
   const dim3 block(kThreads);
 #define DMX_K2A(TPC, NK)                                                                                             \
+  do {                                                                                                                \
+    if (e->geno_safe)                                                                                                 \
+      hipLaunchKernelGGL((k_doublet_a2<TPC, NK, 1, false, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
+                         cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,    \
+                         e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);                               \
+    else                                                                                                              \
   hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
-                     e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag)
+                     e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);                                   \
+  } while (0)
   if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 128 && !getenv("DMX_NO_SYM")) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
@@ -4076,8 +4138,17 @@ int launch_doublet(dmx_engine* e) {
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
     constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 32 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
-    if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX>), \
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
+    if (lds > 60 * 1024) {                                                                                             \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX>),                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX, 3, 0, false>),     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
+    }                                                                                                                  \
+    if (e->geno_safe)                                                                                                  \
+      hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX, 3, 0, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
+                         block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,         \
+                         e->d_grid, e->d_l00, e->d_flag);                                                              \
+    else                                                                                                               \
     hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
@@ -4119,6 +4190,12 @@ int launch_doublet(dmx_engine* e) {
     constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)2 * 8 * GSS_ * 4 + (size_t)8 * 3 * VUS_ * 8; \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, 8, FIX, 3, 9>),                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, 8, FIX, 3, 9, false>),         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
+    if (e->geno_safe)                                                                                                  \
+      hipLaunchKernelGGL((k_doublet_sym<256, VMAX, 8, FIX, 3, 9, false>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);      \
+    else                                                                                                               \
     hipLaunchKernelGGL((k_doublet_sym<256, VMAX, 8, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv,   \
                        e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);        \
   } while (0)
@@ -4156,6 +4233,10 @@ int launch_doublet(dmx_engine* e) {
     // 4 wavefronts per SIMD (128 VGPRs, a few spills outside the hot loop) measured 2.8 % faster than 3 (158 VGPRs) on cfg3
     if (!getenv("DMX_A2_NO_GD") && !getenv("DMX_A2_MINW1")) {   // rows widened to binary64 at staging: 1-2.5 % (cfg3, 5 000 barcodes: 741-753 vs 760 ms)
       const size_t cbd = (size_t)32 * 18 * 8 + (size_t)32 * GS * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
+      if (e->geno_safe)
+        hipLaunchKernelGGL((k_doublet_a2<256, 4, 4, true, false>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
+                           e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
+      else
       hipLaunchKernelGGL((k_doublet_a2<256, 4, 4, true>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
                          e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
     } else if (!getenv("DMX_A2_MINW1"))
@@ -4174,8 +4255,13 @@ int launch_doublet(dmx_engine* e) {
 namespace {
 int launch_certify(dmx_engine* e) {
   const int32_t B = e->pv.B;
-  hipLaunchKernelGGL(k_certify, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_lut,
-                     e->d_alpha, e->V, e->d_sum);
+  const float* gT = (!e->pv.pair_snp && e->have_gT && !getenv("DMX_CERTIFY_NO_GT")) ? e->d_gT : nullptr;   // dense pileups: SNP-minor columns
+  if (getenv("DMX_CERTIFY_MINW3"))                // kernel experiments only
+    hipLaunchKernelGGL(k_certify<3>, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
+                       e->d_alpha, e->V, e->d_sum);
+  else
+    hipLaunchKernelGGL(k_certify<4>, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
+                       e->d_alpha, e->V, e->d_sum);
   HIP_TRY(hipGetLastError());
   return DMX_OK;
 }
