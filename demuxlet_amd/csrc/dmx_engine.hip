@@ -285,7 +285,12 @@ template <int CW, int KC, bool DENSE>
 __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_width, const float* __restrict__ gq,
                                                          const double* __restrict__ g0q, const double* __restrict__ tabs,
                                                          const int32_t* __restrict__ sched, int32_t V, int32_t QS,
-                                                         double* __restrict__ llks, double* __restrict__ llk0s) {
+                                                         double* __restrict__ llks, double* __restrict__ llk0s,
+                                                         const int64_t* __restrict__ blk, int32_t blk_i, int32_t nblk) {
+  // blk != nullptr: this launch covers SNP block blk_i of nblk only (sparse pileups whose genotype matrix does not fit the L2:
+  // launch_singlet walks the SNP axis block by block so that the rows a launch gathers stay L2-resident).  blk[cell][b] = {first
+  // pair, first read byte} of the cell at the start of block b (k_snp_blocks); the running sums are parked in llks / llk0s
+  // between launches: same lanes, same order of additions, same bits as the one-launch walk.
   constexpr int ablate = DMX_ABLATE;             // profiling builds only (tools/build_variant.sh); 0 in the product
   constexpr int T = 64 / CW;
   constexpr int TS = T + 2;                      // row stride of a chain in LDS (doubles): keeps 16-byte alignment, and
@@ -318,9 +323,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
   const int c = lane / T, ti = lane % T;
   const bool cell_ok = slot0 + c < pv.B;
   const int32_t cell = cell_ok ? sched[slot0 + c] : 0;
-  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
-  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
-  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+  const int64_t* bt = blk ? blk + ((size_t)cell * (nblk + 1) + blk_i) * 2 : nullptr;
+  const int64_t p_beg = cell_ok ? (blk ? bt[0] : pv.cell_pair_off[cell]) : 0;
+  const int64_t np = cell_ok ? (blk ? bt[2] : pv.cell_pair_off[cell + 1]) - p_beg : 0;
+  int64_t rd_base = cell_ok ? (blk ? bt[1] : pv.cell_read_off[cell]) : 0;
   int64_t max_np = np;
 #pragma unroll
   for (int d = T; d < 64; d <<= 1) max_np = max(max_np, __shfl_xor(max_np, d));
@@ -330,6 +336,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
   const int64_t a_np = __shfl(np, (a_ok ? a_c : 0) * T);
   const int32_t a_cell = __shfl(cell, (a_ok ? a_c : 0) * T);
   const size_t S = (size_t)pv.S;
+  if (blk && blk_i > 0 && a_ok) {                // resume: the sums of the blocks before this one
+    for (int q = q_lo; q < q_hi; ++q) {
+      double v = 0.0;
+      if (a_kk < KC) { const int k = q * KC + a_kk; if (k < V) v = llks[(size_t)a_cell * V + k]; }
+      else if (q == 0) v = llk0s[a_cell];
+      accs[(q - q_lo) * (CW * NC) + lane] = v;
+    }
+  }
 
   // Dense genotype planes are read through buffer descriptors: address = descriptor base + scalar plane offset + lane
   // offset, one instruction per element and no per-lane 64-bit address arithmetic (S*V*12 < 4 GiB is checked at launch).
@@ -850,6 +864,34 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
     if (ch_k[i] < V) llks[(size_t)ch_cell[i] * V + ch_k[i]] = acc[i];
     else llk0s[ch_cell[i]] = acc[i];
   }
+}
+
+// Where every cell stands at the boundaries of the SNP blocks [b << shift, (b + 1) << shift): blk[cell][b] = {index of its first
+// pair with SNP id >= b << shift, first read byte of that pair}, b = 0..nblk (the last entry is the cell's end).  One wavefront per
+// cell, one pass over its pair headers; built once per staged pileup.
+__global__ __launch_bounds__(kThreads) void k_snp_blocks(PileupView pv, int nrd_width, int shift, int32_t nblk, int64_t* __restrict__ blk) {
+  const int lane = threadIdx.x & 63;
+  const int32_t cell = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (cell >= pv.B) return;
+  const int64_t p_beg = pv.cell_pair_off[cell], p_end = pv.cell_pair_off[cell + 1];
+  int64_t rd_base = pv.cell_read_off[cell];
+  int64_t* out = blk + (size_t)cell * (nblk + 1) * 2;
+  int32_t b_prev = -1;                            // block of the last pair seen (wave-uniform)
+  for (int64_t p0 = p_beg; p0 < p_end; p0 += 64) {
+    const int64_t p = p0 + lane;
+    const bool v = p < p_end;
+    const uint32_t n = v ? load_nrd(pv.pair_nrd, p, nrd_width) : 0u;
+    const int32_t b = v ? (pv.pair_snp[p] >> shift) : 0x7FFFFFFF;
+    const uint32_t incl = seg_scan_incl<64>(n);
+    const int64_t off = rd_base + (int64_t)(incl - n);
+    int32_t bp = __shfl_up(b, 1);
+    if (lane == 0) bp = b_prev;
+    if (v) for (int32_t bb = bp + 1; bb <= min(b, nblk); ++bb) { out[2 * bb] = p; out[2 * bb + 1] = off; }
+    rd_base += (int64_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const int last = (int)min((int64_t)63, p_end - p0 - 1);
+    b_prev = __shfl(b, last);
+  }
+  for (int32_t bb = b_prev + 1 + lane; bb <= nblk; bb += 64) { out[2 * bb] = p_end; out[2 * bb + 1] = rd_base; }
 }
 
 // SNP-minor copies for dense pileups: gT[r][s] = g[s][r] (r = k*3+l, float32 as stored) and g0T[l][s] = gp0s[s][l].
@@ -3501,6 +3543,7 @@ struct dmx_engine {
   int32_t* d_sched = nullptr; size_t sched_cap = 0;
   int32_t* d_bad = nullptr;                                          // set by k_check_snp_ids
   bool have_gT = false;                                              // d_gT / d_g0T hold the current genotype matrix
+  int64_t* d_blk = nullptr; size_t blk_cap = 0; int32_t blk_shift = 0, blk_n = 0;   // k_snp_blocks table of the staged (sparse) pileup; blk_n = 0: none
   bool geno_safe = false;                                            // every genotype row finite, non-negative, max >= 2^-400 (k_check_geno)
   // host -> device staging of the big pileup arrays: two pinned chunks filled by host threads while the other one is in flight
   void* h_stage[2] = {nullptr, nullptr}; hipEvent_t ev_stage[2] = {nullptr, nullptr}; bool stage_busy[2] = {false, false}; int stage_cur = 0;
@@ -3616,6 +3659,7 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_lut) (void)hipFree(e->d_lut);
   if (e->d_alpha) (void)hipFree(e->d_alpha);
   if (e->d_bad) (void)hipFree(e->d_bad);
+  if (e->d_blk) (void)hipFree(e->d_blk);
   for (int i = 0; i < 2; ++i) { if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]); if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]); }
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& r : e->ring_s) for (hipEvent_t& ev : r) if (ev) (void)hipEventDestroy(ev);
@@ -3894,6 +3938,24 @@ int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int3
     HIP_TRY(hipGetLastError());
     e->have_gT = true;
   }
+  // sparse pileups over a genotype matrix that does not fit the L2: the SNP-block table of the blocked K1 walk (launch_singlet)
+  e->blk_n = 0;
+  if (e->pv.pair_snp && e->P > 0 && e->S > 0 && !getenv("DMX_K1_NO_BLOCKS")) {
+    const double row_bytes = (double)e->V * 12.0 + 24.0;
+    double target = 2.0 * 1024 * 1024;                                  // bytes of genotype rows per block
+    const char* env = getenv("DMX_K1_BLOCK_BYTES");                     // tests / kernel experiments: any block size, no size heuristics
+    if (env) target = atof(env);
+    int shift = 0;
+    while (shift < 30 && (double)(2ll << shift) * row_bytes <= target) ++shift;
+    const int32_t nblk = (int32_t)(((int64_t)e->S + (1ll << shift) - 1) >> shift);
+    // worth it only when the matrix is well beyond one L2 and a barcode still has a few tiles of pairs per block
+    if (nblk > 1 && (env || ((double)e->S * row_bytes > 3.0 * 1024 * 1024 && (double)e->P / std::max(B, 1) / nblk >= 96.0))) {
+      if (int rc = ensure_dev((void**)&e->d_blk, &e->blk_cap, sizeof(int64_t) * 2 * (size_t)B * (nblk + 1))) return rc;
+      hipLaunchKernelGGL(k_snp_blocks, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, shift, nblk, e->d_blk);
+      HIP_TRY(hipGetLastError());
+      e->blk_shift = shift; e->blk_n = nblk;
+    }
+  }
   if (e->out_cap < B || !e->d_llks) {
     free_results(e);
     const int32_t cap = B + B / 16 + 16;
@@ -3955,9 +4017,16 @@ int launch_singlet(dmx_engine* e) {
   const float* gq = dense ? e->d_gT : e->d_g;
   const double* g0q = dense ? e->d_g0T : e->d_gp0;
   const dim3 block(kThreads), grid((unsigned)((B + NW * CW - 1) / (NW * CW)), q_slabs);
+  // Sparse pileups gather one genotype row per covered pair; when the matrix is larger than an XCD's L2 (4 MB) nearly every row
+  // comes out of the Infinity Cache (cfg5: 56 GB per launch for 1.5 GB of algorithmic bytes, profiles/r02_cfg5_pmc_summary.json).
+  // The SNP axis is then walked in blocks of 2^blk_shift SNPs (about 2 MB of rows), one launch per block over all barcodes: the
+  // rows of a launch stay L2-resident; the sums are parked in llks / llk0s between launches (see the kernel).
+  const int64_t* blk = (!dense && e->blk_n > 1) ? e->d_blk : nullptr;
+  const int n_launch = blk ? e->blk_n : 1;
 #define DMX_K1(CC, KK, DD)                                                                                            \
-  hipLaunchKernelGGL((k_singlet<CC, KK, DD>), grid, block, dyn, e->stream, e->pv, e->nrd_width, gq, g0q, e->d_lut,     \
-                     e->d_sched, V, QS, e->d_llks, e->d_llk0s)
+  for (int bi_ = 0; bi_ < n_launch; ++bi_)                                                                             \
+    hipLaunchKernelGGL((k_singlet<CC, KK, DD>), grid, block, dyn, e->stream, e->pv, e->nrd_width, gq, g0q, e->d_lut,   \
+                       e->d_sched, V, QS, e->d_llks, e->d_llk0s, blk, bi_, e->blk_n)
 #define DMX_K1_D(CC, KK) do { if (dense) DMX_K1(CC, KK, true); else DMX_K1(CC, KK, false); } while (0)
   if (KC == 4) { if (CW == 4) DMX_K1_D(4, 4); else if (CW == 2) DMX_K1_D(2, 4); else DMX_K1_D(1, 4); }
   else         { if (CW == 4) DMX_K1_D(4, 8); else if (CW == 2) DMX_K1_D(2, 8); else DMX_K1_D(1, 8); }

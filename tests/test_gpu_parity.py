@@ -614,14 +614,21 @@ def test_every_launch_geometry_gives_the_same_bits(eng, oracle, V, field, dense,
         g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, al)])
     sp = synth.make_pileup(rng, al, B, 1.0 if dense else 0.3, 2.0, dense_layout=dense, doublet_rate=0.3)
     pl = host_pileup(eng, sp)
-    for k in ("DMX_K1_CW", "DMX_K1_WIDE_V", "DMX_K2_GENERIC", "DMX_NO_CLASSES", "DMX_NO_K1_CLASSES"):
+    for k in ("DMX_K1_CW", "DMX_K1_WIDE_V", "DMX_K2_GENERIC", "DMX_NO_CLASSES", "DMX_NO_K1_CLASSES", "DMX_K1_BLOCK_BYTES", "DMX_K1_NO_BLOCKS",
+              "DMX_FORCE_CHECK"):
         monkeypatch.delenv(k, raising=False)
     base = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
     ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
     assert np.abs(base["grid"] - ref.llksAB).max() < TOL and np.abs(base["llks"] - ref.llks).max() < TOL
     variants = [{"DMX_K1_CW": "1"}, {"DMX_K1_CW": "2"}, {"DMX_K1_CW": "4"}, {"DMX_K1_WIDE_V": "2"}, {"DMX_K1_WIDE_V": "1000"},
                 {"DMX_K1_CW": "4", "DMX_NO_K1_CLASSES": "1"}, {"DMX_K1_CW": "2", "DMX_NO_K1_CLASSES": "1"}, {"DMX_K2_GENERIC": "1"},
-                {"DMX_NO_CLASSES": "1", "DMX_K1_CW": "4"}]
+                {"DMX_NO_CLASSES": "1", "DMX_K1_CW": "4"},
+                # sparse general K1 walked in SNP blocks (a launch per block, sums parked in between): 3, 11 and 40 blocks of this panel
+                {"DMX_NO_K1_CLASSES": "1", "DMX_K1_BLOCK_BYTES": str(256 * (12 * V + 24))},
+                {"DMX_NO_K1_CLASSES": "1", "DMX_K1_BLOCK_BYTES": str(64 * (12 * V + 24)), "DMX_K1_CW": "2"},
+                {"DMX_NO_K1_CLASSES": "1", "DMX_K1_BLOCK_BYTES": str(16 * (12 * V + 24)), "DMX_K1_CW": "4"},
+                # the per-term argument-class test kept although this panel is provably safe (k_check_geno)
+                {"DMX_FORCE_CHECK": "1"}, {"DMX_FORCE_CHECK": "1", "DMX_NO_CLASSES": "1"}]
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
