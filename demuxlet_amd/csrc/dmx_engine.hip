@@ -2179,6 +2179,259 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
 #undef DMX_K2_SYNC
 }
 
+// FAST mode for any alpha grid with alpha[0] == 0 (soft fields; the default grid {0, 0.5} has its own kernel, k_doublet_sym):
+// k_doublet_an's ownership, phase 1 and accumulation order with the entry set demuxlet prints or decides on — the singlet column
+// llksAB[j][0][0] and every (j, k) of the doublet alphas n >= 1 (cmd_cram_demuxlet.cpp:772-797,:799-814) — in the bilinear form
+// g_j . (pG[n] g_k), u = pG[n] g_k formed once per (pair, n, k) in the LDS and shared by the V rows j.  llksAB[j][k != 0][0], which
+// only the maxLLK scan reads (:713-721), is filled with llksAB[j][0][0].  A * V * V evaluations of 33.5 FP64 instructions become
+// (A - 1) * V * V + V of 15.
+template <int TPC, int NK, int AP, int VUS, int SUBP = 4, int MINW = 2, bool CHK = true>   // VUS: row stride of u in doubles (>= V + NK - 1,
+                                                               // even): compile-time so that the reads use immediate offsets; CHK: see k_doublet_a2
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_anf(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                         const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                         const double* __restrict__ alpha,
+                                                         const int32_t* __restrict__ sched, int32_t V, int32_t A, int32_t GS,
+                                                         double* __restrict__ grid, double* __restrict__ l00,
+                                                         uint8_t* __restrict__ flagged) {
+  static_assert(AP == 2 || AP == 4 || AP == 8, "alphas per pair padded to a power of two");
+  constexpr int TP = 32;
+  constexpr int CPW = kThreads / TPC;
+  constexpr int T00 = TP + 2;
+#define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  __syncthreads();
+
+  const int cw = t / TPC, tid = t % TPC;
+  constexpr int VU = VUS;
+  const int NU = (A - 1) * 3 * VU + 4;           // doubles of u per pair: [n-1][l][k], then the alpha-0 u of sample 0 (3) + pad
+  const size_t cell_bytes = (size_t)TP * AP * 9 * 8 + (size_t)TP * GS * 4 + (size_t)AP * T00 * 8 + TP * (4 + 4 + 8) +
+                            (size_t)SUBP * NU * 8 + (size_t)TPC * 8;
+  unsigned char* base = s_raw + (size_t)cw * cell_bytes;
+  double* s_pG = (double*)base;                                  // [TP][AP][9]
+  float* s_g = (float*)(base + (size_t)TP * AP * 9 * 8);         // [TP][GS]
+  double* s_t00 = (double*)((unsigned char*)s_g + (size_t)TP * GS * 4);   // [AP][T00]
+  int64_t* s_off = (int64_t*)(s_t00 + AP * T00);                 // [TP]
+  int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
+  uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
+  double* s_u = (double*)(s_cnt + TP);                           // [SUBP][NU]
+  double* s_sing = s_u + (size_t)SUBP * NU;                      // [TPC]  the singlet column at the end (row j -> its k-block threads)
+
+  const int slot = blockIdx.x * CPW + cw;
+  if (TPC == 64 && slot >= pv.B) return;
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+
+  const int KB = (V + NK - 1) / NK;
+  const int JS = TPC / KB;
+  const int jl = tid / KB, kb = tid % KB;
+  const int j = (int)blockIdx.y * JS + jl;
+  const bool owner = jl < JS && j < V;
+  double acc[NK][AP - 1], accS = 0.0;            // [k of the block][alpha n >= 1]; accS: llksAB[j][0][0] (threads kb == 0)
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk)
+#pragma unroll
+    for (int n = 0; n < AP - 1; ++n) acc[kk][n] = 0.0;
+  bool ok = true;
+  const DmxLogPins lk = dmx_log_pins();
+  double acc00 = 0.0;                            // lane tid < A owns llks00[tid]
+  const int row_len = V * 3;
+  constexpr int P1 = TP * AP;                    // phase-1 lanes per tile
+  constexpr int NPASS = (P1 + TPC - 1) / TPC;
+  const int n1 = tid % AP;                       // this thread's alpha in phase 1 (TPC is a multiple of AP)
+  const bool n_ok = n1 < A;
+  double wA[9], wR[9];
+  {
+    const double al = n_ok ? alpha[n1] : 0.0;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+      for (int m = 0; m < 3; ++m) {
+        const double p = 0.5 * l + (m - l) * 0.5 * al;                       // :613
+        wA[l * 3 + m] = p;
+        wR[l * 3 + m] = 1.0 - p;
+      }
+  }
+
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const uint32_t incl = seg_scan_incl<32>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+    }
+    DMX_K2_SYNC();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    {
+      int r = tid % row_len, ti = tid / row_len;
+      const int dr = TPC % row_len, dt = TPC / row_len;
+      while (ti < tp) {
+        s_g[ti * GS + r] = g[(size_t)s_snp[ti] * row_len + r];
+        r += dr; ti += dt;
+        if (r >= row_len) { r -= row_len; ++ti; }
+      }
+    }
+    // ---- phase 1: lane u = (pair u / AP, alpha u % AP)
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+      const int u = tid + pass * TPC;
+      if (u >= P1) break;                          // uniform per wavefront (P1 and TPC are multiples of 64)
+      const int ti1 = u / AP;
+      const bool on = ti1 < tp && n_ok;
+      const uint32_t cnt = (ti1 < tp) ? s_cnt[ti1] : 0u;
+      const int64_t off = (ti1 < tp) ? s_off[ti1] : 0;
+      double pG[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) pG[i] = 1.0;                               // :597
+      for (uint32_t r = 0; __any(r < cnt); ++r) {
+        const bool live = r < cnt && n_ok;
+        const uint32_t byte = (r < cnt) ? pv.reads[off + r] : 0u;
+        const uint32_t bq = byte & 127u;
+        const bool alt = (byte >> 7) != 0;
+        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+          for (int i = 0; i < 9; ++i) {
+            pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+            mx = fmax(mx, pG[i]);                                 // :626-627
+          }
+        }
+#pragma unroll
+        for (int d = 1; d < AP; d <<= 1) {                                  // one max across ALL alphas of the pair
+          const double o = __shfl_xor(mx, d);
+          mx = fmax(mx, o);
+        }
+        if (live) {
+          if (cnt <= kSafeReads) {
+            const double y = rcp_refined(mx);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);       // :632-639
+          } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) pG[i] /= mx;
+          }
+        }
+      }
+      double mx = 0.0;
+      if (n_ok) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          pG[i] += 1e-6;                                                     // :649
+          mx = fmax(mx, pG[i]);
+        }
+      }
+#pragma unroll
+      for (int d = 1; d < AP; d <<= 1) {
+        const double o = __shfl_xor(mx, d);
+        mx = fmax(mx, o);
+      }
+      if (on) {
+        const double y = rcp_refined(mx);
+        const double* g0 = gp0 + (size_t)s_snp[ti1] * 3;
+        const double qq[3] = {g0[0], g0[1], g0[2]};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = div_by(pG[l * 3 + m], mx, y);                   // :656-663
+            s_pG[(ti1 * AP + n1) * 9 + l * 3 + m] = v;
+            sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
+          }
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+      }
+    }
+    DMX_K2_SYNC();
+    if (tid < A) {                                 // llks00[n]: lane n adds its alpha's terms in pair order
+      const double* row = &s_t00[tid * T00];
+      for (int i = 0; i < tp; ++i) acc00 += row[i];
+    }
+    // ---- phase 2 in sub-tiles of SUBP pairs: u[n][l][k] = sum_m pG[n][l][m] g_k[m] once per (pair, n >= 1, k), then every printed
+    //      entry is log(g_j . u_k) (bilinear form, fused multiply-adds)
+#pragma unroll 1
+    for (int sub = 0; sub < tp; sub += SUBP) {
+      const int ns = min(SUBP, tp - sub);
+      const int NI = (A - 1) * V + 1;              // items per pair: (n, k) for n >= 1, then the alpha-0 u of sample 0
+#pragma unroll 1
+      for (int e = tid; e < ns * NI; e += TPC) {
+        const int pi = e / NI, it = e % NI;
+        const bool sing = it == NI - 1;
+        const int n = sing ? 0 : 1 + it / V, k = sing ? 0 : it % V;
+        const double* P = &s_pG[((sub + pi) * AP + n) * 9];
+        const float* gr = &s_g[(sub + pi) * GS + k * 3];
+        const double b0 = (double)gr[0], b1 = (double)gr[1], b2 = (double)gr[2];
+        double* u = sing ? &s_u[(size_t)pi * NU + (A - 1) * 3 * VU] : &s_u[(size_t)pi * NU + (size_t)(n - 1) * 3 * VU + k];
+        const int us = sing ? 1 : VU;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) u[l * us] = __builtin_fma(P[l * 3 + 2], b2, __builtin_fma(P[l * 3 + 1], b1, P[l * 3] * b0));
+      }
+      DMX_K2_SYNC();
+      if (owner) {
+        const int k0 = min(kb * NK, V - 1);
+        const double* up = s_u + k0;               // this thread's first k; rows are VU apart, alphas 3 VU, pairs NU
+#pragma unroll 1
+        for (int pi = 0; pi < ns; ++pi, up += NU) {
+          const float* gr = &s_g[(sub + pi) * GS];
+          const double a0 = (double)gr[j * 3], a1 = (double)gr[j * 3 + 1], a2 = (double)gr[j * 3 + 2];
+#pragma unroll
+          for (int n = 1; n < AP; ++n) {
+            if (n >= A) break;
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) {
+              // (k-blocks past the panel's end re-read its last columns: never stored)
+              const int o = (n - 1) * 3 * VU + kk;
+              const double x0 = lds_read_f64(&up[o]), x1 = lds_read_f64(&up[o + VU]), x2 = lds_read_f64(&up[o + 2 * VU]);
+              const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
+              if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100) || kb * NK + kk >= V;
+              acc[kk][n - 1] += dmx_log_fast_pinned(sj, s_log, lk);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // one alpha's NK evaluations in flight at a time (register budget)
+          }
+          if (kb == 0) {
+            const double* u0 = s_u + (size_t)pi * NU + (A - 1) * 3 * VU;
+            const double sj = __builtin_fma(a2, u0[2], __builtin_fma(a1, u0[1], a0 * u0[0]));
+            ok &= __builtin_amdgcn_class(sj, 0x100);
+            accS += dmx_log_fast_pinned(sj, s_log, lk);
+          }
+        }
+      }
+      DMX_K2_SYNC();
+    }
+  }
+  if (owner && kb == 0) s_sing[jl] = accS;
+  DMX_K2_SYNC();
+  if (cell_ok) {
+    if (owner) {
+      const double sj = s_sing[jl];                // llksAB[j][k != 0][0] is filled with llksAB[j][0][0]
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+        const int k = kb * NK + kk;
+        if (k < V) {
+          double* o = grid + (((size_t)cell * V + j) * V + k) * A;
+          o[0] = sj;
+#pragma unroll
+          for (int n = 1; n < AP; ++n) if (n < A) o[n] = acc[kk][n - 1];
+        }
+      }
+    }
+    if (tid < A && blockIdx.y == 0) l00[(size_t)cell * A + tid] = acc00;
+    if (!ok) flag_cell(flagged, cell);
+  }
+#undef DMX_K2_SYNC
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Genotype classes.  With --field GT every sample's probability row at a SNP is one of at most four float triplets
 // (the three one-hot rows and the HWE row shared by all missing genotypes, bcf_filtered_reader.cpp:381-400), so
@@ -4095,6 +4348,46 @@ int launch_doublet(dmx_engine* e) {
     if (AP == 4) { if (V <= 16) DMX_K2CN(1, 4); else if (V <= 32) DMX_K2CN(4, 4); else DMX_K2CN(8, 4); }
     else         { if (V <= 16) DMX_K2CN(1, 8); else DMX_K2CN(4, 8); }
 #undef DMX_K2CN
+    HIP_TRY(hipGetLastError());
+    return launch_doublet_generic_w<true>(e);
+  }
+  if (e->mode == DMX_MODE_FAST && !use_cls && A >= 2 && A <= 8 && V <= 128 && e->alpha[0] == 0.0 && !(A == 2 && e->alpha[1] == 0.5) &&
+      !force_generic && !getenv("DMX_NO_ANF")) {
+    // FAST, soft fields, any alpha grid that starts with 0 (the default grid {0, 0.5} has k_doublet_sym): the printed entries only,
+    // bilinear form
+    const int AP = A <= 2 ? 2 : (A <= 4 ? 4 : 8);
+    const int GS = (V * 3 + 3) & ~3;
+    HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
+    const dim3 block(kThreads);
+    auto slabs = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
+#define DMX_K2NF_(TPC, NK, APP, VUS, SUBP, MINW, CHK)                                                                  \
+  do {                                                                                                                 \
+    const int NU = (A - 1) * 3 * VUS + 4;                                                                              \
+    const size_t cell_bytes = (size_t)32 * APP * 9 * 8 + (size_t)32 * GS * 4 + (size_t)APP * 34 * 8 + 32 * (4 + 4 + 8) +  \
+                              (size_t)SUBP * NU * 8 + (size_t)TPC * 8;                                                 \
+    const size_t lds = cell_bytes * (kThreads / TPC);                                                                  \
+    if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_anf<TPC, NK, APP, VUS, SUBP, MINW, CHK>),  \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+    hipLaunchKernelGGL((k_doublet_anf<TPC, NK, APP, VUS, SUBP, MINW, CHK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs(TPC, NK)), \
+                       block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,                            \
+                       e->d_alpha, e->d_sched, V, A, GS, e->d_grid, e->d_l00, e->d_flag);                                \
+  } while (0)
+#define DMX_K2NF(TPC, NK, APP, VUS, SUBP, MINW) do { if (e->geno_safe) DMX_K2NF_(TPC, NK, APP, VUS, SUBP, MINW, false); else DMX_K2NF_(TPC, NK, APP, VUS, SUBP, MINW, true); } while (0)
+    // u rows: V entries plus the slack a k-block may read past the panel's end (NK - 1), even; pairs per sub-tile by the LDS they need
+    // (one barcode per workgroup throughout: the narrow-panel forms with four barcodes per workgroup need ~86 KB of LDS, i.e. one
+    //  workgroup per CU; sub-tiles of 8 pairs and 3 wavefronts per SIMD measured 529 -> 418 ms at V = 32, A = 3, 4 000 barcodes)
+    if (AP == 2) {
+      if (V <= 16) DMX_K2NF(256, 1, 2, 16, 8, 3); else if (V <= 32) DMX_K2NF(256, 4, 2, 36, 8, 3);
+      else if (V <= 64) DMX_K2NF(256, 8, 2, 72, 4, 2); else DMX_K2NF(256, 8, 2, 136, 2, 2);
+    } else if (AP == 4) {
+      if (V <= 16) DMX_K2NF(256, 1, 4, 16, 8, 3); else if (V <= 32) DMX_K2NF(256, 4, 4, 36, 8, 3);
+      else if (V <= 64) DMX_K2NF(256, 8, 4, 72, 4, 2); else DMX_K2NF(256, 8, 4, 136, 2, 2);
+    } else {
+      if (V <= 16) DMX_K2NF(256, 1, 8, 16, 8, 2); else if (V <= 64) DMX_K2NF(256, 4, 8, 68, 2, 2);
+      else DMX_K2NF(256, 4, 8, 132, 1, 2);
+    }
+#undef DMX_K2NF_
+#undef DMX_K2NF
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
   }

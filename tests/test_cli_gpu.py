@@ -35,6 +35,8 @@ def compare_files(got_path, want_path, best=False):
                                               ("PL", "bam", ["--write-pair", "--gpus", "3"]),        # three engines (one device here)
                                               ("PL", "sam", ["--write-pair", "--fast", "--gpus", "2"]),    # DMX_MODE_FAST (opt-in)
                                               ("GT", "sam", ["--fast"]), ("GP", "bam", ["--fast"]),
+                                              ("GP", "sam", ["--alpha", "0", "--alpha", "0.25", "--alpha", "0.5", "--fast"]),   # k_doublet_anf
+                                              ("PL", "bam", ["--alpha", "0", "--alpha", "0.3", "--fast", "--write-pair"]),
                                               ("GT", "sam", ["--strict"])])                                 # the default (DMX_MODE_STRICT), spelled out
 def test_cli_end_to_end(oracle, tmp_path, field, fmt, extra):
     from demuxlet_amd import build
@@ -58,14 +60,10 @@ def test_cli_end_to_end(oracle, tmp_path, field, fmt, extra):
     ev = oracle.Events([e[0] for e in events], np.array([e[1] for e in events], dtype=np.int32), [e[2] for e in events],
                        np.array([e[3] for e in events], dtype=np.uint8), np.array([e[4] for e in events], dtype=np.uint8),
                        np.array([e[5] for e in events], dtype=np.uint8))
-    alphas = (0.0, 0.5)
-    params = oracle.Params()
-    if "--alpha" in extra:
-        params = oracle.Params(alphas=(0.0, 0.25, 0.5))
-    if "--min-snp" in extra:
-        params = oracle.Params(min_snp=5, doublet_prior=0.3)
-    if "--write-pair" in extra:
-        params = oracle.Params(write_pair=True)
+    alphas = tuple(float(extra[i + 1]) for i, x in enumerate(extra) if x == "--alpha") or (0.0, 0.5)
+    params = oracle.Params(alphas=alphas, write_pair="--write-pair" in extra,
+                           min_snp=int(extra[extra.index("--min-snp") + 1]) if "--min-snp" in extra else 0,
+                           doublet_prior=float(extra[extra.index("--doublet-prior") + 1]) if "--doublet-prior" in extra else 0.5)
     pb = oracle.Problem(SAMPLES, np.nan_to_num(g.astype(np.float32)), ev, params)
     oracle.run_problem(pb, str(tmp_path / "orc"))
     for suf in ["single", "sing2", "best"] + (["pair"] if "--write-pair" in extra else []):

@@ -555,6 +555,63 @@ def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
             assert abs(summ[c][f] - want[fs if swap else f]) < TOL, (c, f)
 
 
+@pytest.mark.parametrize("V,alphas,field,B,S", [
+    (5, (0.0, 0.25, 0.5), "GP", 20, 400), (16, (0.0, 0.1, 0.3, 0.5), "GP", 12, 300), (12, (0.0, 0.1, 0.2, 0.3, 0.4, 0.5), "PL", 10, 300),
+    (32, (0.0, 0.2, 0.5), "GP", 6, 300), (64, (0.0, 0.1, 0.2, 0.3, 0.5), "GP", 4, 200), (100, (0.0, 0.25, 0.5), "GP", 3, 150),
+    (128, (0.0, 0.1, 0.2, 0.3, 0.4, 0.45, 0.48, 0.5), "PL", 2, 120),
+    (8, (0.0, 0.3), "GP", 20, 400), (24, (0.0, 0.25), "PL", 8, 300), (40, (0.0, 0.5, 0.25), "GP", 4, 200), (7, (0.0, 0.5, 0.5), "GP", 10, 300),
+    (13, (0.0, 0.05, 0.15, 0.25, 0.35, 0.45, 0.5), "GP", 6, 250), (77, (0.0, 0.4), "GP", 3, 150),
+    # GT inputs with these grids keep the (bit-exact) class kernels in both modes
+    (5, (0.0, 0.25, 0.5), "GT", 20, 400), (48, (0.0, 0.3), "GT", 4, 200)])
+def test_fast_mode_other_alpha_grids(eng, oracle, V, alphas, field, B, S):
+    """DMX_MODE_FAST on alpha grids other than demuxlet's default {0, 0.5} (`--alpha` is a multi-valued option,
+    cmd_cram_demuxlet.cpp:57,78-90): k_doublet_anf evaluates the singlet column and every (j, k) of the alphas n >= 1 in bilinear
+    form and fills llksAB[j][k != 0][0] with llksAB[j][0][0].  Every printed entry within 1e-9 of the oracle, the singlet stage
+    bit-equal to STRICT, the K3 calls the reference's."""
+    from demuxlet_amd import synth, capi
+    from golden_util import printed_mask, summary_from_grid as ref_summary
+    rng = np.random.default_rng(7300 + V + len(alphas))
+    raw = synth.make_raw_genotypes(rng, S, V)
+    if field == "GT":
+        g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    elif field == "GP":
+        g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+    else:
+        g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, raw.alleles)])
+    sp = synth.make_pileup(rng, raw.alleles, B, 0.4, 2.0, dense_layout=False, doublet_rate=0.3)
+    ref = oracle_from_pileup(oracle, sp, g, alphas, 0.5)
+    strict = run_engine(eng, host_pileup(eng, sp), g, alphas, 0.5)
+    e = eng.Engine(V, alphas, 0.5, mode=capi.DMX_MODE_FAST)
+    e.set_genotypes(g); e.set_pileup(host_pileup(eng, sp))
+    e.run_singlet(); e.run_doublet()
+    llks, llk0s = e.get_singlet()
+    grid, l00, summ = e.get_doublet()
+    e.close()
+    A = len(alphas)
+    assert np.array_equal(llks, strict["llks"]) and np.array_equal(llk0s, strict["llk0s"]) and np.array_equal(l00, strict["l00"])
+    m = np.broadcast_to(printed_mask(V, A)[None], grid.shape)
+    d_ref, d_strict = np.abs(grid - ref.llksAB)[m].max(), np.abs(grid - strict["grid"])[m].max()
+    print(f"V={V} A={A} {field}: FAST vs reference {d_ref:.2e}, FAST vs STRICT {d_strict:.2e} (printed entries)")
+    assert d_ref < TOL and d_strict < 1e-10
+    if field != "GT":
+        assert not np.array_equal(grid, strict["grid"])      # a different operation sequence, not the STRICT kernel under another name
+        assert np.array_equal(grid[:, :, :, 0], np.broadcast_to(grid[:, :, 0:1, 0], grid[:, :, :, 0].shape))
+    for c in range(B):
+        if sp.cell_pair_off[c + 1] == sp.cell_pair_off[c]:
+            continue
+        want = ref_summary(ref.llksAB[c], ref.llks00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)
+        assert (summ[c]["i_sing1"], summ[c]["i_sing2"]) == (want["i_sing1"], want["i_sing2"]), c
+        # the best doublet: same (unordered where alpha = 0.5) pair and alpha unless the reference's own maximum is a near-tie
+        if abs(summ[c]["llk12"] - want["llk12"]) < TOL and not (summ[c]["flags"] & capi.DMX_CELL_NEAR_DOUBLET):
+            assert summ[c]["n_best"] == want["n_best"], c
+            if alphas[int(want["n_best"])] == 0.5:
+                assert {int(summ[c]["j_best"]), int(summ[c]["k_best"])} == {int(want["j_best"]), int(want["k_best"])}, c
+            else:
+                assert (int(summ[c]["j_best"]), int(summ[c]["k_best"])) == (int(want["j_best"]), int(want["k_best"])), c
+        for f in ("sing_llk1", "sing_llk2", "llk12", "llk00_0"):
+            assert abs(summ[c][f] - want[f]) < TOL, (c, f)
+
+
 def test_fast_mode_end_to_end_files(eng, oracle, tmp_path):
     """dmx_demuxlet_run in DMX_MODE_FAST (with the tie arbiter) against the oracle's files on a soft-field 24-sample job: every
     string field — barcodes, ids, the BEST call — identical, printed numbers equal up to their last digit."""
