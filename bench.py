@@ -214,6 +214,35 @@ def pmc_profile(cfgno, B, mode, dense):
     return None
 
 
+def shard_range(B_total, world, rank):
+    """Strong scaling: rank r owns barcodes [lo, hi) of the B_total (contiguous, equal counts: equal work on a dense pileup)."""
+    return (B_total * rank) // world, (B_total * (rank + 1)) // world
+
+
+def gather_records(torch, dist, rec, counts, rank, world):
+    """THE collective of the job: one fixed-size record per barcode -> rank 0 (RCCL gather over xGMI; gloo in the CPU test).  Ranks may
+    own B/N or B/N + 1 barcodes, so the records are padded to the largest count (gather wants equal shapes).  Returns the list of
+    per-rank matrices on rank 0 (still padded; counts[r] rows of matrix r are real), None elsewhere."""
+    pad = max(counts) - rec.shape[0]
+    if pad:
+        rec = torch.cat([rec, rec.new_zeros((pad, rec.shape[1]))], dim=0)
+    outs = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
+    dist.gather(rec, outs, dst=0)
+    return outs
+
+
+def collect_timing(torch, dist, dev, elapsed, own_elapsed, n_pairs, steps, world):
+    """max-over-ranks wall time of the timed region, the job's covered pairs and every rank's own ms per step (all ranks call this)."""
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    cnt = torch.tensor([float(n_pairs)], dtype=torch.float64, device=dev)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([1e3 * own_elapsed / steps], dtype=torch.float64, device=dev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    return float(tmax.item()), float(cnt.item()), [float(x.item()) for x in allr]
+
+
 class Ctx:
     pass
 
@@ -225,7 +254,7 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
     fast = mode == "fast"
     B_total, S, V, A = cfg["B"], cfg["S"], cfg["V"], len(cfg["alphas"])
     # strong scaling: rank r owns barcodes [lo, hi) of the B_total (contiguous, equal counts: equal work on a dense pileup)
-    lo, hi = (B_total * rank) // world, (B_total * (rank + 1)) // world
+    lo, hi = shard_range(B_total, world, rank)
     B = hi - lo
     # the workload of the last call is kept (one entry): the same configuration in the other mode does not generate it again
     key = (cfgno, B_total, S, V, cfg["field"], cfg["delta"], cfg["rbar"], world, rank)
@@ -266,7 +295,7 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                      synth_torch.tensor_from_ptr(v.summary, (B, engine.capi.SUMMARY_DTYPE.itemsize // 8), torch.float64, dev)]
         return torch.cat(cols, dim=1)
 
-    counts = [(B_total * (r + 1)) // world - (B_total * r) // world for r in range(world)]
+    counts = [shard_range(B_total, world, r)[1] - shard_range(B_total, world, r)[0] for r in range(world)]
     gathered = None
 
     def step(ev=None):
@@ -278,15 +307,7 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
             eng.run_doublet()
         if ev: ev[2].record()
         if cx.use_dist:
-            # THE collective of the job: one fixed-size record per barcode -> rank 0 (RCCL gather over xGMI).  Ranks may own
-            # B/N or B/N+1 barcodes, so the records are padded to the largest count (gather wants equal shapes).
-            rec = record_matrix()
-            pad = max(counts) - B
-            if pad:
-                rec = torch.cat([rec, rec.new_zeros((pad, rec.shape[1]))], dim=0)
-            outs = [torch.empty_like(rec) for _ in range(world)] if rank == 0 else None
-            dist.gather(rec, outs, dst=0)
-            gathered = outs
+            gathered = gather_records(torch, dist, record_matrix(), counts, rank, world)
         if ev: ev[3].record()
 
     for _ in range(warmup):
@@ -308,16 +329,7 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
     elapsed = time.perf_counter() - t0
     per_rank_ms = [1e3 * own_elapsed / steps]
     if cx.use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        cnt = torch.tensor([dp.n_pairs], dtype=torch.float64, device=dev)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_pairs = float(cnt.item())
-        mine = torch.tensor([1e3 * own_elapsed / steps], dtype=torch.float64, device=dev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank_ms = [float(x.item()) for x in allr]
+        elapsed, total_pairs, per_rank_ms = collect_timing(torch, dist, dev, elapsed, own_elapsed, dp.n_pairs, steps, world)
     else:
         total_pairs = float(dp.n_pairs)
 

@@ -232,7 +232,21 @@ def test_cfg5_full_size_fast_mode(mods):
     assert worst < 1e-9
 
 
+def test_cfg4_slice_on_distinct_devices_with_write_pair(mods, tmp_path, monkeypatch):
+    """The same slice with dmx_job.n_gpus = min(8, visible devices) (what `demuxlet --gpus N --write-pair` runs): two engines per
+    DEVICE, ranges of the sorted barcodes alternating between them, the `.pair` rows appended in barcode order.  Skipped on a 1-GPU box
+    (there the multi-engine tests put every engine on device 0)."""
+    n = min(8, mods["torch"].cuda.device_count())
+    if n < 2:
+        pytest.skip("one visible device")
+    run_cfg4_slice(mods, tmp_path, monkeypatch, n_gpus=n)
+
+
 def test_cfg4_slice_streamed_with_write_pair(mods, tmp_path, monkeypatch):
+    run_cfg4_slice(mods, tmp_path, monkeypatch, n_gpus=1)
+
+
+def run_cfg4_slice(mods, tmp_path, monkeypatch, n_gpus):
     """A slice of cfg4's per-GPU shard (2 000 of its barcodes x 100 k SNPs x 64 samples, GT, dense) through dmx_demuxlet_run with
     `--write-pair` and a forced 16 MiB range budget: the barcodes stream through the engine in ~8 ranges of the sorted order, the
     4.2 M rows are appended range by range.  Three sampled barcodes are pushed through the oracle at full depth: their rows of all
@@ -255,8 +269,9 @@ def test_cfg4_slice_streamed_with_write_pair(mods, tmp_path, monkeypatch):
     del dp, dosage
     torch.cuda.empty_cache()
     monkeypatch.setenv("DMX_RANGE_BYTES", str(16 << 20))
-    tm = engine.demuxlet_run(pl, g, sm, cfg["alphas"], str(tmp_path / "o"), write_pair=True, arbiter=True, barcodes=barcodes, timing=True)
-    assert tm["n_ranges"] >= 8
+    tm = engine.demuxlet_run(pl, g, sm, cfg["alphas"], str(tmp_path / "o"), write_pair=True, arbiter=True, barcodes=barcodes, timing=True,
+                             n_gpus=n_gpus)
+    assert tm["n_ranges"] >= 8 and tm["n_engines"] == (2 * n_gpus if tm["n_ranges"] > n_gpus else n_gpus)
     print("cfg4 slice, --write-pair, streamed:", {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()})
     cells = np.array([3, 977, 1999])
     pidx = np.concatenate([np.arange(h["cell_pair_off"][c], h["cell_pair_off"][c + 1]) for c in cells])
