@@ -243,23 +243,27 @@ void parse_options(int argc, char** argv, Options& o) {
       for (const OptDef& c : defs) if (strcmp(c.name, name) == 0) { d = &c; break; }
       if (!d) { snprintf(ebuf, sizeof ebuf, "Command line parameter %s (#%d) not recognized\n", a, i); errors += ebuf; continue; }
       const char* extra = (i + 1 < argc) ? argv[i + 1] : nullptr;
-      const bool multi = d->type == O_MULTI_DOUBLE || d->type == O_MULTI_STRING;
-      if (!multi && touched.count(name)) fatal("Redundant use of option --%s is not allowed", name);               // params.cpp:124,143...
-      touched.insert(name);
+      // longParams::TranslateExtras (params.cpp:113-186): an invalid or repeated option does NOT stop the parse — param::error
+      // appends the message (no newline) to the list that paramList::Status reports AFTER the status echo (:562-567); a repeated
+      // option keeps its first value; the value argument is consumed either way.  The "[E:file:line function]" prefix of the
+      // reference carries its __FILE__, i.e. the path it was compiled from: written here as a build in the source directory has it.
+      auto bad = [&](int line, const char* what) { snprintf(ebuf, sizeof ebuf, "[E:params.cpp:%d TranslateExtras] Invalid argument --%s %s. %s was expected", line, name, extra ? extra : "(null)", what); errors += ebuf; };
+      auto again = [&](int line, const char* tail) { snprintf(ebuf, sizeof ebuf, "[E:params.cpp:%d TranslateExtras] Redundant use of option --%s%s is not allowed", line, name, tail); errors += ebuf; };
+      const bool seen = touched.count(name) != 0;
       switch (d->type) {
-        case O_BOOL: *(bool*)d->ptr = true; break;
-        case O_INT: if (!check_integer(extra)) fatal("Invalid argument --%s %s. Integer was expected", name, extra ? extra : "(null)"); *(int*)d->ptr = atoi(extra); ++i; break;
-        case O_DOUBLE: if (!check_double(extra)) fatal("Invalid argument --%s %s. Double was expected", name, extra ? extra : "(null)"); *(double*)d->ptr = atof(extra); ++i; break;
-        case O_STRING: if (!extra) fatal("Invalid argument --%s (null). String was expected", name); *(std::string*)d->ptr = extra; ++i; break;
-        case O_MULTI_DOUBLE: if (!check_double(extra)) fatal("Invalid argument --%s %s. Double was expected", name, extra ? extra : "(null)"); ((std::vector<double>*)d->ptr)->push_back(atof(extra)); ++i; break;
-        case O_MULTI_STRING: if (!extra) fatal("Invalid argument --%s (null). String was expected", name); ((std::vector<std::string>*)d->ptr)->push_back(extra); ++i; break;
+        case O_BOOL: if (seen) again(122, " or its exclusive neighbor"); *(bool*)d->ptr = true; touched.insert(name); break;
+        case O_INT: if (!check_integer(extra)) bad(139, "Integer"); else if (seen) again(140, ""); else { *(int*)d->ptr = atoi(extra); touched.insert(name); } ++i; break;
+        case O_DOUBLE: if (!check_double(extra)) bad(147, "Double"); else if (seen) again(148, ""); else { *(double*)d->ptr = atof(extra); touched.insert(name); } ++i; break;
+        case O_STRING: if (!extra) bad(155, "String"); else if (seen) again(156, ""); else { *(std::string*)d->ptr = extra; touched.insert(name); } ++i; break;
+        case O_MULTI_DOUBLE: if (!check_double(extra)) bad(168, "Double"); else ((std::vector<double>*)d->ptr)->push_back(atof(extra)); ++i; break;
+        case O_MULTI_STRING: if (!extra) bad(174, "String"); else ((std::vector<std::string>*)d->ptr)->push_back(extra); ++i; break;
       }
     } else {
       snprintf(ebuf, sizeof ebuf, "Cannot correspond command line parameter %s (#%d) to any of the options\n", a, i); errors += ebuf;
     }
   }
   print_status(defs);                                                                                                // params.cpp:552-560
-  if (!errors.empty()) fatal("Problems encountered parsing command line:\n\n%s", errors.c_str());                   // params.cpp:562-567
+  if (!errors.empty()) fatal("[E:params.cpp:564 Status] Problems encountered parsing command line:\n\n%s", errors.c_str());   // params.cpp:562-567
 }
 
 // ---- line / byte input: plain files, gzip, and BGZF (bgzip'd VCF, BAM) ------------------------------------------------

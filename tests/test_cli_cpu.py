@@ -345,3 +345,64 @@ def test_help_and_status_text_are_the_reference_layout(cli, tmp_path):
     # parse errors are reported AFTER the status echo, as paramList::Status does (:562-567)
     r = subprocess.run([cli, "--sam", "r.sam", "--bogus"], capture_output=True, text=True, cwd=tmp_path)
     assert r.returncode != 0 and r.stderr.index("Run with --help") < r.stderr.index("Command line parameter --bogus (#3) not recognized")
+
+
+REF_PARAMS = ROOT / "oracle" / "_ref" / "ref_params_driver"
+
+
+def _strip_own_group(text):
+    """Our binary adds ONE option group ("MI355X build") behind the reference's: drop it from the status echo / the help text."""
+    out, skip = [], False
+    for ln in text.split("\n"):
+        if ln.strip().startswith("MI355X build :") or ln == "MI355X build":
+            skip = True                                   # status: the group's first line; help: its title line
+            if out and out[-1] == "" and ln == "MI355X build":
+                out.pop()                                 # help: the blank line in front of the title
+            continue
+        if skip:
+            if ln.startswith("  --") or (ln.startswith(" " * 30) and ln.strip().startswith("--")):
+                continue                                  # help rows / status continuation rows of that group
+            skip = False
+        out.append(ln)
+    return "\n".join(out)
+
+
+@pytest.mark.parametrize("args", [
+    ["--help"],
+    ["--sam", "r.sam", "--vcf", "v.vcf", "--field", "GT", "--out", "o", "--pileup-only"],
+    ["--sam", "r.sam", "--vcf", "v.vcf", "--field", "GT", "--geno-error", "0.001", "--sm", "smA", "--sm", "smC", "--out", "o", "--alpha", "0", "--alpha",
+     "0.25", "--alpha", "0.5", "--write-pair", "--min-snp", "5", "--pileup-only"],
+    ["--sam", "r.sam", "--vcf", "v.vcf", "--out", "some/long/prefix/for/the/output/files", "--tag-group", "XC", "--tag-UMI", "XM", "--min-mac", "3",
+     "--min-callrate", "0.95", "--doublet-prior", "0.0625", "--cap-BQ", "30", "--min-BQ", "20", "--min-MQ", "30", "--min-TD", "5", "--excl-flag", "1796",
+     "--min-total", "100", "--min-uniq", "50", "--sam-verbose", "5000", "--vcf-verbose", "7", "--geno-error", "0.00001", "--pileup-only"],
+    ["--sam", "r.sam", "--bogus"], ["--sam", "a", "--sam", "b"], ["--min-mac", "x1"], ["--min-mac", "x1", "--write-pair", "3", "--write-pair"],
+    ["--alpha", "zero", "--geno-error", "1e-3", "--geno-error", "2", "-x", "--out"], ["--sm"], ["--min-snp"]])
+def test_help_status_and_errors_equal_the_reference_parser(cli, tmp_path, args):
+    """f4 pinned by the reference itself: params.cpp + Error.cpp compiled alone (oracle/Makefile: ref_params_driver) and driven by the
+    reference's own option table (cmd_cram_demuxlet.cpp:9-76) print the --help text, the status echo and the option errors; the
+    `demuxlet` binary must print the same characters — apart from its one extra option group — and exit the same way."""
+    if not REF_PARAMS.exists():
+        pytest.skip("oracle/_ref/ref_params_driver not built (needs /root/reference)")
+    (tmp_path / "r.sam").write_text("@HD\tVN:1.5\tSO:coordinate\n@SQ\tSN:1\tLN:1000\n")
+    (tmp_path / "v.vcf").write_text("##fileformat=VCFv4.2\n##contig=<ID=1,length=1000>\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tsmA\tsmC\n")
+    ref_args = [a for a in args if a != "--pileup-only"]
+    want = subprocess.run([str(REF_PARAMS)] + ref_args, capture_output=True, text=True, cwd=tmp_path)
+    got = subprocess.run([cli] + args, capture_output=True, text=True, cwd=tmp_path)
+    w = want.stderr
+    g = _strip_own_group(got.stderr)
+    if "--help" in args:
+        assert got.returncode == 1 and got.stdout == want.stdout == ""
+        assert g == w
+        return
+    # the status echo is the first thing either program prints; ours goes on with the scan's own messages
+    head = w[:w.index("Run with --help for more detailed help messages of each argument.\n\n") + len("Run with --help for more detailed help messages of each argument.\n\n")]
+    assert g.startswith(head), (g[:600], head[:600])
+    if want.returncode != 0:                                # option errors: same wording, same place (after the echo), failure status
+        assert got.returncode != 0
+        import re
+        tail = w[len(head):]
+        # the reference's messages carry its __FILE__ ("[E:<the path it was compiled from>/params.cpp:564 Status] "): the directory part is
+        # the build's, not the program's; its uncaught exception makes the C++ runtime add two lines of its own
+        tail = re.sub(r"\[E:[^\]:]*/params\.cpp:", "[E:params.cpp:", tail)
+        tail = tail.split("terminate called after throwing")[0]
+        assert tail.strip() and g[len(head):].startswith(tail.rstrip("\n")), (g[len(head):][:400], tail[:400])
