@@ -31,7 +31,7 @@ SYMBOLS = [
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
     "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_write_doublet_summary", "dmx_debug_log_dd",
-    "dmx_resolve_tie_order", "dmx_engine_mean_kernel_times",
+    "dmx_resolve_tie_order", "dmx_engine_mean_kernel_times", "dmx_store_add_batch",
 ]
 
 
@@ -151,6 +151,7 @@ def load() -> C.CDLL:
         "dmx_debug_log_dd": [vp, vp, vp, vp, vp, C.c_int64],
         "dmx_resolve_tie_order": [vp, C.c_int64],
         "dmx_engine_mean_kernel_times": [vp, i32, vp],
+        "dmx_store_add_batch": [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, i32],
     }
     for name, args in sig.items():
         f = getattr(L, name)

@@ -320,10 +320,48 @@ struct dmx_store {
                                        // the caller's C string as it is (no temporary std::string per read)
   std::vector<int32_t> totl, pass, uniq;
   int32_t n_snps = 0;
-  std::vector<Obs> obs;
-  std::string umi_pool;
-  std::vector<uint64_t> index;         // open addressing over obs: (hash's high 32 bits << 32) | obs id; kEmpty = free.  The
+  // The observations live in kShards sub-stores selected by the cell id: a (snp, cell, umi) key belongs to exactly one of them, so
+  // "first observation wins" (sc_drop_seq.cpp:44,53,57) only needs the order WITHIN a shard — dmx_store_add_batch inserts a whole
+  // batch with one host thread per group of shards and gives the results of the same calls made one by one.
+  static constexpr int kShards = 64;
+  struct Shard {
+    std::vector<Obs> obs;
+    std::string umi_pool;
+    std::vector<uint64_t> index;       // open addressing over obs: (hash's high 32 bits << 32) | obs id; kEmpty = free.  The
                                        // fingerprint settles almost every probe without touching obs (one cache miss per call)
+    void rehash(size_t cap) {
+      index.assign(cap, kEmpty);
+      for (size_t i = 0; i < obs.size(); ++i) {
+        const Obs& o = obs[i];
+        const uint64_t h = hash(o.cell, o.snp, umi_pool.data() + o.umi_off(), o.umi_len());
+        size_t p = h & (cap - 1);
+        while (index[p] != kEmpty) p = (p + 1) & (cap - 1);
+        index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
+      }
+    }
+    // one observation: 1 = new key, 0 = duplicate (its count moves), -1 = a limit was hit
+    int add(int32_t cell, int32_t snp, const char* umi, size_t len, int allele, int bq) {
+      const size_t cap = index.size();
+      const uint64_t h = hash(cell, snp, umi, len);
+      size_t p = h & (cap - 1);
+      for (; index[p] != kEmpty; p = (p + 1) & (cap - 1)) {
+        if ((index[p] ^ h) >> 32) continue;                                        // another key's fingerprint
+        Obs& o = obs[(size_t)(index[p] & 0xFFFFFFFFull)];
+        if (o.cell == cell && o.snp == snp && o.umi_len() == len && std::memcmp(umi_pool.data() + o.umi_off(), umi, len) == 0) {
+          ++o.count;                                                               // :57 duplicate: only the count moves
+          return 0;
+        }
+      }
+      if (obs.size() >= 0xFFFFFFF0ull || len >= (1u << 24) || umi_pool.size() + len >= (1ull << 40)) return -1;
+      Obs o{cell, snp, (uint64_t)umi_pool.size() | ((uint64_t)len << 40), (uint8_t)allele, (uint8_t)bq, 1u};
+      umi_pool.append(umi, len);
+      index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)obs.size();
+      obs.push_back(o);
+      if (obs.size() * 2 > cap) rehash(cap * 2);
+      return 1;
+    }
+  };
+  Shard shard[kShards];
   static constexpr uint64_t kEmpty = ~0ull;
   // frozen CSR
   bool frozen = false;
@@ -358,22 +396,12 @@ struct dmx_store {
       bc_index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
     }
   }
-  void rehash(size_t cap) {
-    index.assign(cap, kEmpty);
-    for (size_t i = 0; i < obs.size(); ++i) {
-      const Obs& o = obs[i];
-      const uint64_t h = hash(o.cell, o.snp, umi_pool.data() + o.umi_off(), o.umi_len());
-      size_t p = h & (cap - 1);
-      while (index[p] != kEmpty) p = (p + 1) & (cap - 1);
-      index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
-    }
-  }
 };
 
 extern "C" dmx_store* dmx_store_new(void) {
   dmx_store* s = new (std::nothrow) dmx_store;
   if (!s) { set_error(DMX_ERR_NOMEM, "dmx_store_new: out of memory"); return nullptr; }
-  s->rehash(1 << 12);
+  for (dmx_store::Shard& sh : s->shard) sh.rehash(1 << 8);
   s->bc_rehash(1 << 10);
   return s;
 }
@@ -415,28 +443,60 @@ extern "C" int dmx_store_add_read(dmx_store* s, int32_t snp, int32_t cell, const
   if (allele < 0 || allele > 2) return set_error(DMX_ERR_ARG, "dmx_store_add_read: allele %d not in {0,1,2}", allele);
   if (bq < 0 || bq > 127) return set_error(DMX_ERR_ARG, "dmx_store_add_read: base quality %d not in [0,127]", bq);
   ++s->pass[cell];                                                                 // sc_drop_seq.cpp:39
-  const size_t len = std::strlen(umi);
-  const size_t cap = s->index.size();
-  const uint64_t h = dmx_store::hash(cell, snp, umi, len);
-  if (s->obs.size() >= 0xFFFFFFF0ull) return set_error(DMX_ERR_ARG, "dmx_store_add_read: more than 2^32 unique observations");
-  size_t p = h & (cap - 1);
-  for (; s->index[p] != dmx_store::kEmpty; p = (p + 1) & (cap - 1)) {
-    if ((s->index[p] ^ h) >> 32) continue;                                        // another key's fingerprint
-    dmx_store::Obs& o = s->obs[(size_t)(s->index[p] & 0xFFFFFFFFull)];
-    if (o.cell == cell && o.snp == snp && o.umi_len() == len && std::memcmp(s->umi_pool.data() + o.umi_off(), umi, len) == 0) {
-      ++o.count;                                                                   // :57 duplicate: only the count moves
-      return 0;
-    }
-  }
-  if (len >= (1u << 24) || s->umi_pool.size() + len >= (1ull << 40)) return set_error(DMX_ERR_ARG, "dmx_store_add_read: UMI of %zu bytes / UMI pool over 1 TiB", len);
-  dmx_store::Obs o{cell, snp, (uint64_t)s->umi_pool.size() | ((uint64_t)len << 40), (uint8_t)allele, (uint8_t)bq, 1u};
-  s->umi_pool.append(umi, len);
-  s->index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)s->obs.size();
-  s->obs.push_back(o);
-  if (s->obs.size() * 2 > cap) s->rehash(cap * 2);
-  ++s->uniq[cell];                                                                 // :75
+  const int r = s->shard[cell & (dmx_store::kShards - 1)].add(cell, snp, umi, std::strlen(umi), allele, bq);
+  if (r < 0) return set_error(DMX_ERR_ARG, "dmx_store_add_read: more than 2^32 unique observations, a UMI over 16 MiB or a UMI pool over 1 TiB");
+  if (r) ++s->uniq[cell];                                                          // :75
   s->frozen = false;
-  return 1;
+  return r;
+}
+
+// n calls of dmx_store_add_read in the given order, with the observations of different cell shards inserted on different host
+// threads (the order inside a shard — all that "first observation wins" can see — is the given one).
+extern "C" int dmx_store_add_batch(dmx_store* s, int64_t n, const int32_t* snp, const int32_t* cell, const char* umi_pool,
+                                   const uint64_t* umi_off, const uint32_t* umi_len, const uint8_t* allele, const uint8_t* bq,
+                                   uint8_t* is_new, int32_t n_threads) {
+  if (!s || n < 0 || (n && (!snp || !cell || !umi_pool || !umi_off || !umi_len || !allele || !bq)))
+    return set_error(DMX_ERR_ARG, "dmx_store_add_batch: null argument");
+  const int32_t B = (int32_t)s->barcodes.size();
+  for (int64_t i = 0; i < n; ++i) {
+    if (snp[i] < 0 || snp[i] >= s->n_snps) return set_error(DMX_ERR_ARG, "dmx_store_add_batch: snp %d out of range (item %lld)", snp[i], (long long)i);
+    if (cell[i] < 0 || cell[i] >= B) return set_error(DMX_ERR_ARG, "dmx_store_add_batch: cell %d out of range (item %lld)", cell[i], (long long)i);
+    if (allele[i] > 2 || bq[i] > 127) return set_error(DMX_ERR_ARG, "dmx_store_add_batch: allele %d / base quality %d out of range (item %lld)", allele[i], bq[i], (long long)i);
+  }
+  constexpr int K = dmx_store::kShards;
+  // items of each shard, in the given order (counting sort by shard)
+  std::vector<int64_t> first(K + 1, 0);
+  for (int64_t i = 0; i < n; ++i) ++first[(cell[i] & (K - 1)) + 1];
+  for (int k = 0; k < K; ++k) first[k + 1] += first[k];
+  std::vector<uint32_t> item((size_t)n);
+  if (n > 0xFFFFFFFFll) return set_error(DMX_ERR_ARG, "dmx_store_add_batch: more than 2^32 items in one batch");
+  {
+    std::vector<int64_t> at(first.begin(), first.end() - 1);
+    for (int64_t i = 0; i < n; ++i) item[(size_t)at[cell[i] & (K - 1)]++] = (uint32_t)i;
+  }
+  std::atomic<int> next{0};
+  std::atomic<bool> failed{false};
+  auto work = [&]() {
+    for (int k; (k = next.fetch_add(1)) < K;) {
+      dmx_store::Shard& sh = s->shard[k];
+      for (int64_t q = first[k]; q < first[k + 1]; ++q) {
+        const uint32_t i = item[(size_t)q];
+        ++s->pass[cell[i]];                                                        // a cell belongs to one shard: no two threads share a counter
+        const int r = sh.add(cell[i], snp[i], umi_pool + umi_off[i], umi_len[i], allele[i], bq[i]);
+        if (r < 0) { failed = true; return; }
+        if (r) ++s->uniq[cell[i]];
+        if (is_new) is_new[i] = (uint8_t)r;
+      }
+    }
+  };
+  const int T = std::max(1, std::min(n_threads > 0 ? n_threads : host_threads(), K));
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work);
+  work();
+  for (std::thread& t : th) t.join();
+  s->frozen = false;
+  if (failed) return set_error(DMX_ERR_ARG, "dmx_store_add_batch: more than 2^32 unique observations in a shard, a UMI over 16 MiB or a UMI pool over 1 TiB");
+  return DMX_OK;
 }
 extern "C" int32_t dmx_store_n_cells(const dmx_store* s) { return s ? (int32_t)s->barcodes.size() : 0; }
 extern "C" int32_t dmx_store_n_snps(const dmx_store* s) { return s ? s->n_snps : 0; }
@@ -449,9 +509,22 @@ extern "C" int dmx_store_freeze(dmx_store* s, dmx_pileup* out) {
   if (!s || !out) return set_error(DMX_ERR_ARG, "dmx_store_freeze: null argument");
   const int32_t B = (int32_t)s->barcodes.size();
   if (!s->frozen) {
-    if (s->obs.size() > 0xFFFFFFFFull) return set_error(DMX_ERR_ARG, "dmx_store_freeze: more than 2^32 unique observations");
-    const char* pool = s->umi_pool.data();
-    const std::vector<dmx_store::Obs>& obs = s->obs;
+    // the shards' logs side by side (a cell's observations are in one shard, in arrival order), UMI offsets re-based
+    std::vector<dmx_store::Obs> obs;
+    std::string pool_s;
+    {
+      size_t no = 0, np = 0;
+      for (const dmx_store::Shard& sh : s->shard) { no += sh.obs.size(); np += sh.umi_pool.size(); }
+      if (no > 0xFFFFFFFFull) return set_error(DMX_ERR_ARG, "dmx_store_freeze: more than 2^32 unique observations");
+      if (np >= (1ull << 40)) return set_error(DMX_ERR_ARG, "dmx_store_freeze: UMI pool over 1 TiB");
+      obs.reserve(no); pool_s.reserve(np);
+      for (const dmx_store::Shard& sh : s->shard) {
+        const uint64_t base = pool_s.size();
+        for (dmx_store::Obs o : sh.obs) { o.umi += base; obs.push_back(o); }      // offset in the low 40 bits: no carry into the length (checked above)
+        pool_s.append(sh.umi_pool);
+      }
+    }
+    const char* pool = pool_s.data();
     const size_t n = obs.size();
     // (1) stable counting sort by cell id: a cell's observations become one contiguous segment (still in arrival order, which
     //     for a coordinate-sorted BAM is already nearly SNP order)

@@ -105,6 +105,20 @@ class Store:
     def add_read(self, snp: int, cell: int, umi: str, allele: int, bq: int) -> bool:
         return bool(check(self._L.dmx_store_add_read(self._h, snp, cell, umi.encode(), allele, bq)))
 
+    def add_batch(self, snp, cell, umis: Sequence[str], allele, bq, n_threads: int = 0) -> np.ndarray:
+        """len(umis) add_read calls in order, inserted on several host threads (dmx_store_add_batch); returns their return values."""
+        n = len(umis)
+        snp = np.ascontiguousarray(snp, dtype=np.int32); cell = np.ascontiguousarray(cell, dtype=np.int32)
+        allele = np.ascontiguousarray(allele, dtype=np.uint8); bq = np.ascontiguousarray(bq, dtype=np.uint8)
+        enc = [u.encode() for u in umis]
+        lens = np.array([len(b) for b in enc], dtype=np.uint32)
+        offs = np.concatenate([[0], np.cumsum(lens[:-1], dtype=np.uint64)]).astype(np.uint64) if n else np.zeros(0, np.uint64)
+        pool = b"".join(enc) + b"\0"
+        new = np.zeros(n, dtype=np.uint8)
+        check(self._L.dmx_store_add_batch(self._h, n, snp.ctypes.data, cell.ctypes.data, pool, offs.ctypes.data, lens.ctypes.data,
+                                          allele.ctypes.data, bq.ctypes.data, new.ctypes.data, n_threads))
+        return new
+
     @property
     def n_cells(self) -> int: return self._L.dmx_store_n_cells(self._h)
     @property

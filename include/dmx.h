@@ -69,6 +69,13 @@ int32_t    dmx_store_add_snp(dmx_store*);                              /* return
 int32_t    dmx_store_add_cell(dmx_store*, const char* barcode);        /* returns the (new or existing) cell id */
 int        dmx_store_count_read(dmx_store*, int32_t cell);
 int        dmx_store_add_read(dmx_store*, int32_t snp, int32_t cell, const char* umi, int32_t allele, int32_t bq);
+/* n dmx_store_add_read calls in the order given (item i: snp[i], cell[i], the umi_len[i] bytes at umi_pool + umi_off[i], allele[i],
+ * bq[i]); is_new[i] (optional) receives what the i-th call would have returned.  Observations of different cells are inserted on up to
+ * n_threads host threads (0 = all): a (snp, cell, umi) key lives in one cell shard, and inside a shard the given order is kept, which is
+ * all that "first observation wins" can see — the store ends up exactly as after the n single calls.  Used by the `demuxlet` binary's
+ * scan, which overlaps reads and SNPs on all host cores and hands the observations over window by window, in BAM order. */
+int        dmx_store_add_batch(dmx_store*, int64_t n, const int32_t* snp, const int32_t* cell, const char* umi_pool, const uint64_t* umi_off,
+                               const uint32_t* umi_len, const uint8_t* allele, const uint8_t* bq, uint8_t* is_new, int32_t n_threads);
 int32_t    dmx_store_n_cells(const dmx_store*);
 int32_t    dmx_store_n_snps(const dmx_store*);
 const char* dmx_store_barcode(const dmx_store*, int32_t cell);

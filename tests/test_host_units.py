@@ -44,6 +44,69 @@ def test_store_trace_matches_reference_units(eng):
     assert np.array_equal(pl.pair_nrd, np.bincount(pair_of_word[keep], minlength=len(z["flat_nper"])))
 
 
+@pytest.mark.parametrize("threads,pieces", [(1, 1), (4, 1), (8, 3), (3, 7)])
+def test_store_batch_insert_equals_the_single_calls(eng, threads, pieces):
+    """dmx_store_add_batch (observations of different cell shards inserted on different host threads) against the reference trace
+    (sc_drop_seq.cpp compiled alone) and against dmx_store_add_read called one by one: same return values, counters and CSR — also
+    when the trace arrives in several batches and single calls are mixed in between."""
+    z = np.load(GOLDEN / "ref_units.npz")
+    n = len(z["ev_cell"])
+    st = eng.Store()
+    for _ in range(12):
+        st.add_snp()
+    ids = np.array([st.add_cell(str(c)) for c in z["ev_cell"]], dtype=np.int32)
+    assert np.array_equal(ids, z["ret_cellid"])
+    rets = np.zeros(n, dtype=np.int64)
+    cuts = np.linspace(0, n, pieces + 1).astype(int)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b - a > 2:                                 # the last item of a piece goes through the single call
+            rets[a:b - 1] = st.add_batch(z["ev_snp"][a:b - 1], ids[a:b - 1], [str(u) for u in z["ev_umi"][a:b - 1]], z["ev_allele"][a:b - 1],
+                                         z["ev_bq"][a:b - 1], n_threads=threads)
+            a = b - 1
+        for i in range(a, b):
+            rets[i] = int(st.add_read(int(z["ev_snp"][i]), int(ids[i]), str(z["ev_umi"][i]), int(z["ev_allele"][i]), int(z["ev_bq"][i])))
+    assert np.array_equal(rets, z["ret_new"])
+    pl = st.freeze()
+    cnt = z["counters"]
+    assert np.array_equal(pl.rd_pass, cnt[:, 0]) and np.array_equal(pl.rd_uniq, cnt[:, 1]) and np.array_equal(pl.n_snp_per_cell, cnt[:, 2])
+    assert np.array_equal(pl.pair_snp, z["flat_snp"])
+    words = z["flat_words"]
+    al, bq = (words >> 24) & 0xFF, (words >> 16) & 0xFF
+    keep = al != 2
+    assert np.array_equal(pl.reads, ((al[keep] << 7) | bq[keep]).astype(np.uint8))
+
+
+def test_store_batch_insert_on_a_large_random_trace(eng):
+    """2e5 observations over 3 000 barcodes with 30 % repeated keys: the batch path on 8 threads == the single calls."""
+    rng = np.random.default_rng(11)
+    n, B, S = 200_000, 3000, 5000
+    cell = rng.integers(0, B, n).astype(np.int32); snp = rng.integers(0, S, n).astype(np.int32)
+    umi = [f"U{x:05d}" for x in rng.integers(0, 40, n)]
+    dup = rng.random(n) < 0.3
+    src = rng.integers(0, n, n)
+    for i in np.flatnonzero(dup):
+        j = src[i] % (i + 1)
+        cell[i], snp[i], umi[i] = cell[j], snp[j], umi[j]
+    allele = rng.integers(0, 3, n).astype(np.uint8); bq = rng.integers(2, 41, n).astype(np.uint8)
+    stores = []
+    for mode in ("single", "batch"):
+        st = eng.Store()
+        for _ in range(S):
+            st.add_snp()
+        for c in range(B):
+            assert st.add_cell(f"BC{c:05d}") == c
+        if mode == "single":
+            r = np.array([int(st.add_read(int(snp[i]), int(cell[i]), umi[i], int(allele[i]), int(bq[i]))) for i in range(n)])
+        else:
+            r = np.concatenate([st.add_batch(snp[a:a + 70_000], cell[a:a + 70_000], umi[a:a + 70_000], allele[a:a + 70_000], bq[a:a + 70_000], n_threads=8)
+                                for a in range(0, n, 70_000)])
+        stores.append((r, st.freeze()))
+    (r0, p0), (r1, p1) = stores
+    assert np.array_equal(r0, r1) and r0.sum() < n
+    for f in ("cell_pair_off", "cell_read_off", "pair_snp", "pair_nrd", "reads", "rd_pass", "rd_uniq"):
+        assert np.array_equal(getattr(p0, f), getattr(p1, f)), f
+
+
 def build_store(eng, pb):
     st = eng.Store()
     for _ in range(pb.n_snps):
