@@ -24,11 +24,13 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
 #include <map>
 #include <set>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -826,6 +828,11 @@ struct Read {
   // decoded per queried base (a read overlaps 0-2 SNPs), names and tags are views into the record.
   std::string cb, ub;           // group / UMI tag values (copied: the store and the warnings want C strings)
   bool has_cb = false, has_ub = false;
+  int64_t endpos_c = 0;         // SamReader::endpos(*this), and the barcode as (worker slot, id in that slot's dictionary): filled by the
+  int32_t cb_slot = -1, cb_lid = -1;   // parallel record parsing of the windowed scan, so that the in-order stage need not hash strings
+  std::vector<uint8_t> own;     // the BAM record's bytes / ...
+  std::string own_line;         // ... the SAM line the views below point into (a Read owns its record: windows of reads are parsed
+                                // and overlapped with the SNPs on several host threads)
   int flag = 0, tid = -1, mapq = 0;
   int64_t pos = 0;              // 0-based
   std::vector<std::pair<char, uint32_t>> cigar;
@@ -854,9 +861,6 @@ struct SamReader {
   std::map<std::string, int> target_id;
   std::string pending;          // first alignment line of a SAM text file
   bool have_pending = false;
-  std::string last_rname; int last_tid = -1;
-  std::string line_buf;         // current SAM line (the Read's views point into it)
-  std::vector<uint8_t> rec_buf; // current BAM record
   char gtag[3] = {0, 0, 0}, utag[3] = {0, 0, 0};
   int min_mq = 20, excl_flag = 0x0f04, verbose = 1000000;
   int64_t n_read = 0, n_skip = 0;
@@ -901,7 +905,7 @@ struct SamReader {
     return r.pos + (rl > 0 ? rl : 1);
   }
 
-  bool parse_sam_line(const std::string& line, Read& r) {
+  bool parse_sam_line(const std::string& line, Read& r) const {
     // fields in place: [b[i], b[i+1]-1) without copying
     const char* p = line.data();
     const char* const end = p + line.size();
@@ -920,7 +924,9 @@ struct SamReader {
     r.flag = atoi(fb[1]);
     if (eq(2, "*")) r.tid = -1;
     else {
-      if (fn[2] != last_rname.size() || memcmp(fb[2], last_rname.data(), fn[2]) != 0) {     // reads come sorted: one lookup per contig
+      static thread_local std::string last_rname;                                           // reads come sorted: one lookup per contig
+      static thread_local int last_tid = -1;                                                // (and thread; there is one SamReader per process)
+      if (fn[2] != last_rname.size() || memcmp(fb[2], last_rname.data(), fn[2]) != 0) {
         last_rname.assign(fb[2], fn[2]);
         auto it = target_id.find(last_rname);
         last_tid = it == target_id.end() ? -1 : it->second;
@@ -950,15 +956,29 @@ struct SamReader {
     return true;
   }
 
-  bool parse_bam_record(Read& r) {
-    int32_t block = 0;
-    const int got = in.read_prefix(&block, 4);
-    if (got == 0) return false;
-    if (got < 0) fatal("[E:%s] truncated BAM record (the file ends inside a record's block size)", __func__);
-    if (block < 32) fatal("[E:%s] corrupt BAM record (block size %d)", __func__, block);
-    std::vector<uint8_t>& b = rec_buf;
-    b.resize((size_t)block);
-    if (!in.read(b.data(), (size_t)block)) fatal("[E:%s] truncated BAM record", __func__);
+  // the next record's bytes into r.own (BAM) / r.own_line (SAM), unparsed; false at EOF
+  bool next_raw(Read& r) {
+    if (is_bam) {
+      int32_t block = 0;
+      const int got = in.read_prefix(&block, 4);
+      if (got == 0) return false;
+      if (got < 0) fatal("[E:%s] truncated BAM record (the file ends inside a record's block size)", __func__);
+      if (block < 32) fatal("[E:%s] corrupt BAM record (block size %d)", __func__, block);
+      r.own.resize((size_t)block);
+      if (!in.read(r.own.data(), (size_t)block)) fatal("[E:%s] truncated BAM record", __func__);
+      return true;
+    }
+    for (;;) {
+      if (have_pending) { r.own_line.swap(pending); have_pending = false; }
+      else if (!in.getline(r.own_line)) return false;
+      if (!r.own_line.empty()) return true;
+    }
+  }
+  // the fields of the record next_raw left in r (no reader state is touched: callable from several threads for different reads)
+  void parse_raw(Read& r) const { if (is_bam) parse_bam_record(r); else parse_sam_line(r.own_line, r); }
+
+  void parse_bam_record(Read& r) const {
+    std::vector<uint8_t>& b = r.own;
     auto i32 = [&](size_t o) { int32_t v; memcpy(&v, &b[o], 4); return v; };
     auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, &b[o], 2); return v; };
     r.tid = i32(0); r.pos = i32(4);
@@ -1001,23 +1021,21 @@ struct SamReader {
       if (len > b.size() - o) fatal("[E:%s] corrupt BAM record: aux field %c%c runs past the record", __func__, t0, t1);
       o += len;
     }
-    return true;
   }
 
-  // next read passing the filter (sam_filtered_reader.cpp:233-258, passed_filter :284-296); false at EOF
+  // counts a parsed read and applies the read filter (sam_filtered_reader.cpp:233-258, passed_filter :284-296)
+  bool count_and_filter(const Read& r) {
+    ++n_read;
+    if (verbose > 0 && n_read % verbose == 0) notice("Reading %lld reads at %s:%lld and skipping %lld", (long long)n_read, r.tid >= 0 ? targets[r.tid].c_str() : "*", (long long)r.pos + 1, (long long)n_skip);
+    if (r.mapq < min_mq || (excl_flag & r.flag)) { ++n_skip; return false; }
+    return true;
+  }
+  // next read passing the filter; false at EOF
   bool read(Read& r) {
     for (;;) {
-      if (is_bam) { if (!parse_bam_record(r)) return false; }
-      else {
-        if (have_pending) { line_buf.swap(pending); have_pending = false; }
-        else if (!in.getline(line_buf)) return false;
-        if (line_buf.empty()) continue;
-        parse_sam_line(line_buf, r);
-      }
-      ++n_read;
-      if (verbose > 0 && n_read % verbose == 0) notice("Reading %lld reads at %s:%lld and skipping %lld", (long long)n_read, r.tid >= 0 ? targets[r.tid].c_str() : "*", (long long)r.pos + 1, (long long)n_skip);
-      if (r.mapq < min_mq || (excl_flag & r.flag)) { ++n_skip; continue; }
-      return true;
+      if (!next_raw(r)) return false;
+      parse_raw(r);
+      if (count_and_filter(r)) return true;
     }
   }
 };
@@ -1058,7 +1076,7 @@ void base_at(const Read& r, int64_t pos, char& base, char& qual, int& rpos) {
 namespace {
 struct Stopwatch {             // DMX_CLI_TIMING=1: where the scan's wall-clock goes (reported as NOTICE lines)
   bool on = getenv("DMX_CLI_TIMING") != nullptr;
-  double acc[4] = {0, 0, 0, 0};
+  double acc[6] = {0, 0, 0, 0, 0, 0};
   std::chrono::steady_clock::time_point t0;
   void start() { if (on) t0 = std::chrono::steady_clock::now(); }
   void stop(int i) { if (on) acc[i] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
@@ -1139,22 +1157,67 @@ int main(int argc, char** argv) {
   long nReadsMultiSNPs = 0, nReadsSkipBCD = 0, nReadsPass = 0, nReadsRedundant = 0, nReadsN = 0, nReadsLQ = 0, nReadsTMP = 0, nNonBiallelic = 0;
   int n_warn_g = 0, n_warn_u = 0;
 
-  std::vector<int> tid_rid(sr.targets.size());                 // SAM target id -> VCF contig id; VCFs without ##contig lines
-  size_t tid_rid_for = (size_t)-1;                             // learn their contigs while being read, so refresh on growth
-  Read rd;
+  // ---- the scan (cmd_cram_demuxlet.cpp:195-338).  Per read, in BAM order: (S) the lock-step bookkeeping of the reference — SNP buffer
+  // window, VCF reads, barcode and UMI, RD.TOTL — and (O) the overlap of the read with the buffered SNPs (hts_utils.cpp:279-359), whose
+  // observations go into the store.  With one host thread both happen read by read.  With several, reads are taken in windows: their
+  // records are parsed on all threads, (S) runs over the window in order, (O) runs on all threads, and the window's observations enter
+  // the store in BAM order through dmx_store_add_batch (cell-sharded, so "first UMI wins" sees the same order); the VCF is parsed ahead
+  // on its own thread.  Every counter, id and stored byte is the one-thread path's (tests/test_cli_cpu.py compares the dumps).
+  std::map<std::string, int> contig_seen = vr.contig_rid;      // the VCF contigs known so far AS THE READS SEE THEM: a VCF without ##contig
+  std::vector<int> tid_rid(sr.targets.size());                 // lines teaches its contigs record by record, and a read whose contig has not
+  size_t tid_rid_for = (size_t)-1;                             // appeared yet is skipped (:198-200) — also when the VCF is parsed ahead
+  const int n_threads = cli_threads();
+  const bool windowed = n_threads > 1 && !getenv("DMX_SCAN_SEQUENTIAL");
   Stopwatch sw;
-  for (;;) {                                                                                               // :195
-    sw.start();
-    const bool more = sr.read(rd);
-    sw.stop(0);
-    if (!more) break;
-    if (tid_rid_for != vr.contig_rid.size()) {
-      for (size_t t = 0; t < sr.targets.size(); ++t) tid_rid[t] = vr.name2id(sr.targets[t]);
-      tid_rid_for = vr.contig_rid.size();
+  const std::chrono::steady_clock::time_point scan_t0 = std::chrono::steady_clock::now();
+
+  // variants in file order, parsed ahead by a producer thread in the windowed mode; each comes with the contig names its vr.read call registered
+  struct Fed { Variant v; std::vector<std::pair<std::string, int>> new_contigs; bool eof = false; };
+  std::mutex feed_mu; std::condition_variable feed_cv_put, feed_cv_get; std::deque<Fed> feed_q; bool feed_stop = false;
+  std::thread feed_th;
+  auto read_variant = [&](Fed& f) {                            // one vr.read call + what it did to the contig dictionary
+    const size_t before = vr.contig_rid.size();
+    f.eof = !vr.read(f.v);
+    f.new_contigs.clear();
+    if (vr.contig_rid.size() != before) for (const auto& kv : vr.contig_rid) if ((size_t)kv.second >= before) f.new_contigs.push_back(kv);
+  };
+  if (windowed) feed_th = std::thread([&] {
+    for (;;) {
+      Fed f;
+      read_variant(f);
+      const bool last = f.eof;
+      { std::unique_lock<std::mutex> lk(feed_mu); feed_cv_put.wait(lk, [&] { return feed_q.size() < 4096 || feed_stop; }); if (feed_stop) return; feed_q.push_back(std::move(f)); }
+      feed_cv_get.notify_one();
+      if (last) return;
     }
-    const int64_t endpos = SamReader::endpos(rd);
+  });
+  struct FeedGuard { std::mutex& mu; std::condition_variable& cv; bool& stop; std::thread& th; ~FeedGuard() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); } } feed_guard{feed_mu, feed_cv_put, feed_stop, feed_th};
+  auto next_variant = [&](Variant& v) -> bool {                // the reference's vr.read at :211
+    Fed f;
+    if (windowed) {
+      { std::unique_lock<std::mutex> lk(feed_mu); feed_cv_get.wait(lk, [&] { return !feed_q.empty(); }); f = std::move(feed_q.front()); feed_q.pop_front(); }
+      feed_cv_put.notify_one();
+    } else read_variant(f);
+    for (auto& kv : f.new_contigs) contig_seen.insert(kv);
+    if (f.eof) return false;
+    v = std::move(f.v);
+    return true;
+  };
+  for (const auto& kv : vr.contig_rid) contig_seen.insert(kv);  // (the first record, read above, may have registered its contig)
+
+  std::vector<std::vector<int32_t>>* slot_cell_p = nullptr;     // (windowed scan: see slot_cell below)
+  struct Hit { int32_t snp; uint8_t allele, bq; };
+  struct Staged { int64_t ibeg = 0, nbuf = 0; int32_t ibcd = 0; bool used = false; std::string umi; std::vector<Hit> hits; int nv_valid = 0; };
+  // (S) for one parsed read that passed the read filter; false = the read contributes nothing (:198-200, :263)
+  auto stage = [&](const Read& rd, Staged& st) -> bool {
+    st.used = false;
+    if (tid_rid_for != contig_seen.size()) {
+      for (size_t t = 0; t < sr.targets.size(); ++t) { auto it = contig_seen.find(sr.targets[t]); tid_rid[t] = it == contig_seen.end() ? -1 : it->second; }
+      tid_rid_for = contig_seen.size();
+    }
+    const int64_t endpos = windowed ? rd.endpos_c : SamReader::endpos(rd);
     const int tid2rid = (rd.tid >= 0 && (size_t)rd.tid < tid_rid.size()) ? tid_rid[(size_t)rd.tid] : -1;
-    if (tid2rid < 0) continue;                                                                             // :198-200
+    if (tid2rid < 0) return false;                                                                         // :198-200
     {   // clear_buffer_before(chrom, read start) — bcf_filtered_reader.cpp:649-669
       int64_t n_rm = 0;
       for (int64_t i = 0; i < nbuf; ++i) {
@@ -1168,7 +1231,7 @@ int main(int argc, char** argv) {
     while (!veof && (snps.back().rid < tid2rid || (snps.back().rid == tid2rid && snps.back().pos < endpos))) {    // :209
       Variant v;
       sw.start();
-      const bool got = vr.read(v);
+      const bool got = next_variant(v);
       sw.stop(1);
       if (got) {
         if (v.rlen > 1 || v.n_allele != 2 || v.ref.size() > 1) {                                           // :215-225 (warn only)
@@ -1193,47 +1256,206 @@ int main(int argc, char** argv) {
         else if (n_warn_g == 10) notice("WARNING: Suppressing 10+ missing Droplet/Cell tag warnings...");
         ++n_warn_g;
       }
-      if (bcd_set.empty() || bcd_set.count(sbcd)) {
+      int32_t* known = nullptr;                  // windowed scan: what this (worker slot, barcode) turned out to be at its first read
+      if (rd.cb_slot >= 0 && slot_cell_p) {
+        std::vector<int32_t>& sc = (*slot_cell_p)[(size_t)rd.cb_slot];
+        if ((size_t)rd.cb_lid >= sc.size()) sc.resize((size_t)rd.cb_lid + 1 + sc.size() / 2, -1);
+        known = &sc[(size_t)rd.cb_lid];
+      }
+      if (known && *known >= 0) ibcd = *known;
+      else if (known && *known == -2) { ++nReadsSkipBCD; return false; }
+      else if (bcd_set.empty() || bcd_set.count(sbcd)) {
         ibcd = dmx_store_add_cell(scl, sbcd);
         const int32_t nb = dmx_store_n_cells(scl);
         if (ibcd + 1 == nb && nb % 1000 == 0) notice("Observed %d droplets with unique cell barcode", nb);
-      } else { ++nReadsSkipBCD; continue; }
+        if (known) *known = ibcd;
+      } else { if (known) *known = -2; ++nReadsSkipBCD; return false; }
     }
     ++nReadsTMP;
     // UMI (:272-293)
-    std::string sumi(".");
-    if (o.tag_umi.empty()) { char b[32]; snprintf(b, sizeof b, "%x", rand()); sumi += b; }
-    else if (rd.has_ub) sumi = rd.ub;
+    st.umi.assign(".");
+    if (o.tag_umi.empty()) { char b[32]; snprintf(b, sizeof b, "%x", rand()); st.umi += b; }
+    else if (rd.has_ub) st.umi = rd.ub;
     else {
       if (n_warn_u < 10) notice("WARNING: Cannot find UMI tag %s from %lld-th read %s at %s:%lld-%lld. Treating all of them as a single UMI", o.tag_umi.c_str(), (long long)sr.n_read, rd.qname().c_str(), sr.targets[(size_t)rd.tid].c_str(), (long long)rd.pos, (long long)endpos);
       else if (n_warn_u == 10) notice("WARNING: Suppressing 10+ UMI warnings...");
       ++n_warn_u;
     }
     dmx_store_count_read(scl, ibcd);                                                                       // :295
-    int nv_pass = 0, nv_red = 0, nv_valid = 0;
-    sw.start();
-    for (int64_t i = ibeg; i < ibeg + nbuf; ++i) {                                                         // :306
+    st.ibeg = ibeg; st.nbuf = nbuf; st.ibcd = ibcd; st.used = true;
+    return true;
+  };
+  // (O) the read against the SNPs its buffer held (:306-329): what it would hand to add_read, and how many SNPs gave a base at all
+  auto overlap = [&](const Read& rd, Staged& st, const Snp* snps) {     // snps[i] = SNP i (the list itself, or a window's snapshot of its span)
+    st.hits.clear(); st.nv_valid = 0;
+    for (int64_t i = st.ibeg; i < st.ibeg + st.nbuf; ++i) {                                                // :306
       char base, qual; int rpos;
       base_at(rd, snps[(size_t)i].pos, base, qual, rpos);
       if (rpos == kNA) continue;
       if (base == 'N') continue;
-      ++nv_valid;
+      ++st.nv_valid;
       if (qual - 33 < o.min_bq) continue;                                                                  // :316
       if (rpos < o.min_td - 1) continue;
       if (rpos + o.min_td > rd.l_qseq) continue;
       const int allele = (base == snps[(size_t)i].ref) ? 0 : ((base == snps[(size_t)i].alt) ? 1 : 2);     // :322
       const int bq = qual - 33 > o.cap_bq ? o.cap_bq : qual - 33;
-      const int ret = dmx_store_add_read(scl, (int32_t)i, ibcd, sumi.c_str(), allele, bq);                // :325
-      if (ret < 0) fatal("%s", dmx_last_error());
-      if (ret) ++nv_pass; else ++nv_red;
+      if (bq < 0 || bq > 127) fatal("dmx_store_add_read: base quality %d not in [0,127]", bq);
+      st.hits.push_back({(int32_t)i, (uint8_t)allele, (uint8_t)bq});
     }
-    sw.stop(2);
+  };
+  auto classify = [&](int nv_pass, int nv_red, int nv_valid) {                                             // :331-335
     if (nv_pass > 1) ++nReadsMultiSNPs;
     if (nv_pass > 0) ++nReadsPass; else if (nv_red > 0) ++nReadsRedundant; else if (nv_valid > 0) ++nReadsLQ; else ++nReadsN;
+  };
+
+  if (!windowed) {
+    Read rd;
+    Staged st;
+    for (;;) {                                                                                             // :195
+      sw.start();
+      const bool more = sr.read(rd);
+      sw.stop(0);
+      if (!more) break;
+      if (!stage(rd, st)) continue;
+      sw.start();
+      overlap(rd, st, snps.data());
+      int nv_pass = 0, nv_red = 0;
+      for (const Hit& h : st.hits) {
+        const int ret = dmx_store_add_read(scl, h.snp, st.ibcd, st.umi.c_str(), h.allele, h.bq);         // :325
+        if (ret < 0) fatal("%s", dmx_last_error());
+        if (ret) ++nv_pass; else ++nv_red;
+      }
+      sw.stop(2);
+      classify(nv_pass, nv_red, st.nv_valid);
+    }
+  } else {
+    const size_t W = getenv("DMX_SCAN_WINDOW") ? (size_t)std::max(1, atoi(getenv("DMX_SCAN_WINDOW"))) : ((size_t)1 << 16);
+    auto parallel_for = [&](size_t n, const std::function<void(size_t, size_t, int)>& fn) {               // fn(first, last, worker slot) on chunks of the range
+      const size_t T = std::min<size_t>((size_t)n_threads, std::max<size_t>(1, n / 256));
+      if (T <= 1) { fn(0, n, 0); return; }
+      std::atomic<size_t> next{0};
+      const size_t step = std::max<size_t>(256, n / (T * 8));
+      auto work = [&](int slot) { for (size_t a; (a = next.fetch_add(step)) < n;) fn(a, std::min(n, a + step), slot); };
+      std::vector<std::thread> th;
+      for (size_t t = 1; t < T; ++t) th.emplace_back(work, (int)t);
+      work(0);
+      for (std::thread& x : th) x.join();
+    };
+    // barcode dictionaries of the parsing workers (slot -> barcode -> id in the slot) and, owned by the in-order stage, what each of
+    // those ids is in the store: -1 not seen yet, -2 not in --group-list.  dmx_store_add_cell is then called once per (slot, barcode),
+    // at the barcode's first read in BAM order as before.
+    std::vector<std::unordered_map<std::string, int32_t>> slot_dict((size_t)n_threads);
+    std::vector<std::vector<int32_t>> slot_cell((size_t)n_threads);
+    slot_cell_p = &slot_cell;
+    // Three threads work on consecutive windows at the same time:
+    //   reader   takes a window's records off the (already parallel) BGZF inflater and parses them on the worker threads;
+    //   this one runs (S) over the parsed window in BAM order and snapshots the SNPs its reads' buffers span;
+    //   sink     runs (O) on the worker threads and hands the window's observations to the store, in BAM order, then classifies the reads.
+    // The reader touches nothing but the SamReader and its window; the sink reads the window, its SNP snapshot and the store's
+    // observation shards and RD.PASS / RD.UNIQ counters of cells that existed when the window was staged (this thread only adds
+    // cells and moves RD.TOTL meanwhile: dmx_store_add_batch is made for that).  A window's store batch is complete before the next
+    // window's begins: "first UMI wins" sees the BAM order.
+    constexpr int NW = 4;
+    struct Window { std::vector<Read> rd; std::vector<Staged> st; std::vector<Snp> snps; int64_t snp_lo = 0; size_t n = 0; bool last = false; int state = 0; };
+    Window wins[NW];                                             // state: 0 free, 1 parsed, 2 staged
+    for (Window& w : wins) { w.rd.resize(W); w.st.resize(W); }
+    std::mutex w_mu; std::condition_variable w_cv;
+    bool w_stop = false;
+    std::thread reader([&] {
+      for (int i = 0;; i = (i + 1) % NW) {
+        { std::unique_lock<std::mutex> lk(w_mu); w_cv.wait(lk, [&] { return wins[i].state == 0 || w_stop; }); if (w_stop) return; }
+        Window& w = wins[i];
+        w.n = 0; w.last = false;
+        while (w.n < W) { if (!sr.next_raw(w.rd[w.n])) { w.last = true; break; } ++w.n; }
+        parallel_for(w.n, [&](size_t a, size_t b, int slot) {
+          std::unordered_map<std::string, int32_t>& dict = slot_dict[(size_t)slot];
+          for (size_t k = a; k < b; ++k) {
+            Read& r = w.rd[k];
+            sr.parse_raw(r);
+            r.endpos_c = SamReader::endpos(r);
+            r.cb_slot = -1;
+            if (r.has_cb && !o.tag_group.empty()) {
+              auto it = dict.find(r.cb);
+              if (it == dict.end()) it = dict.emplace(r.cb, (int32_t)dict.size()).first;
+              r.cb_slot = slot; r.cb_lid = it->second;
+            }
+          }
+        });
+        { std::lock_guard<std::mutex> lk(w_mu); w.state = 1; }
+        w_cv.notify_all();
+        if (w.last) return;
+      }
+    });
+    std::thread sink([&] {
+      std::vector<int32_t> b_snp, b_cell; std::vector<uint64_t> b_off; std::vector<uint32_t> b_len; std::vector<uint8_t> b_al, b_bq, b_new;
+      std::string b_pool;
+      for (int i = 0;; i = (i + 1) % NW) {
+        { std::unique_lock<std::mutex> lk(w_mu); w_cv.wait(lk, [&] { return wins[i].state == 2 || w_stop; }); if (w_stop) return; }
+        Window& w = wins[i];
+        const size_t n = w.n;
+        parallel_for(n, [&](size_t a, size_t b, int) {
+          for (size_t k = a; k < b; ++k) if (w.st[k].used) overlap(w.rd[k], w.st[k], w.snps.data() - w.snp_lo);
+        });
+        // the window's observations, in BAM order, into the store
+        b_snp.clear(); b_cell.clear(); b_off.clear(); b_len.clear(); b_al.clear(); b_bq.clear(); b_pool.clear();
+        for (size_t k = 0; k < n; ++k) {
+          const Staged& st = w.st[k];
+          if (!st.used || st.hits.empty()) continue;
+          const uint64_t off = b_pool.size();
+          b_pool.append(st.umi);
+          for (const Hit& h : st.hits) { b_snp.push_back(h.snp); b_cell.push_back(st.ibcd); b_off.push_back(off); b_len.push_back((uint32_t)st.umi.size()); b_al.push_back(h.allele); b_bq.push_back(h.bq); }
+        }
+        b_new.assign(b_snp.size(), 0);
+        b_pool.push_back('\0');
+        if (dmx_store_add_batch(scl, (int64_t)b_snp.size(), b_snp.data(), b_cell.data(), b_pool.data(), b_off.data(), b_len.data(), b_al.data(), b_bq.data(),
+                                b_new.data(), n_threads) != DMX_OK) fatal("%s", dmx_last_error());
+        size_t q = 0;
+        for (size_t k = 0; k < n; ++k) {
+          const Staged& st = w.st[k];
+          if (!st.used) continue;
+          int nv_pass = 0, nv_red = 0;
+          for (size_t h = 0; h < st.hits.size(); ++h, ++q) { if (b_new[q]) ++nv_pass; else ++nv_red; }
+          classify(nv_pass, nv_red, st.nv_valid);
+        }
+        const bool last = w.last;
+        { std::lock_guard<std::mutex> lk(w_mu); w.state = 0; }
+        w_cv.notify_all();
+        if (last) return;
+      }
+    });
+    struct PipeGuard { std::mutex& mu; std::condition_variable& cv; bool& stop; std::thread &a, &b; ~PipeGuard() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); } } pipe_guard{w_mu, w_cv, w_stop, reader, sink};
+    for (int wi = 0;; wi = (wi + 1) % NW) {
+      sw.start();
+      { std::unique_lock<std::mutex> lk(w_mu); w_cv.wait(lk, [&] { return wins[wi].state == 1; }); }
+      sw.stop(0);                                                // (time this thread WAITED for parsed records)
+      Window& w = wins[wi];
+      const size_t n = w.n;
+      const bool last_window = w.last;
+      {
+        const double vcf_before = sw.acc[1];
+        const std::chrono::steady_clock::time_point s0 = std::chrono::steady_clock::now();
+        int64_t lo = INT64_MAX, hi = 0;
+        for (size_t k = 0; k < n; ++k) {
+          w.st[k].used = false;
+          if (sr.count_and_filter(w.rd[k]) && stage(w.rd[k], w.st[k])) { lo = std::min(lo, w.st[k].ibeg); hi = std::max(hi, w.st[k].ibeg + w.st[k].nbuf); }
+        }
+        if (lo > hi) { lo = 0; hi = 0; }
+        w.snp_lo = lo;
+        w.snps.assign(snps.begin() + lo, snps.begin() + hi);       // the sink reads this copy: `snps` keeps growing under this thread
+        if (sw.on) sw.acc[4] += std::chrono::duration<double>(std::chrono::steady_clock::now() - s0).count() - (sw.acc[1] - vcf_before);
+      }
+      { std::lock_guard<std::mutex> lk(w_mu); w.state = 2; }
+      w_cv.notify_all();
+      if (last_window) break;
+    }
+    sink.join();                                                  // (the guard then finds both threads finished)
+    reader.join();
   }
   if (n_warn_u > 10) notice("WARNING: Suppressed a total of %d UMI warnings...", n_warn_u);
   if (n_warn_g > 10) notice("WARNING: Suppressed a total of %d droplet/cell barcode warnings...", n_warn_g);
-  if (sw.on) notice("scan timing: alignment reader %.3f s, VCF reader %.3f s, overlap + store %.3f s", sw.acc[0], sw.acc[1], sw.acc[2]);
+  const double scan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - scan_t0).count();
+  if (sw.on) notice("scan timing (%d threads, %s): total %.3f s = %.3g reads/s; alignment reader %.3f s, record parsing %.3f s, lock-step bookkeeping %.3f s, VCF reader (wait) %.3f s, overlap + store %.3f s",
+                    n_threads, windowed ? "windowed" : "read by read", scan_s, (double)sr.n_read / scan_s, sw.acc[0], sw.acc[3], sw.acc[4], sw.acc[1], sw.acc[2]);
   notice("Finished reading %d markers from the VCF file", (int)snps.size());
   notice("Total number input reads : %lld", (long long)sr.n_read);
   notice("Total number valid droplets observed : %d", dmx_store_n_cells(scl));

@@ -318,8 +318,22 @@ struct dmx_store {
   std::vector<std::string> barcodes;
   std::vector<uint64_t> bc_index;      // open addressing over barcodes: (hash's high 32 bits << 32) | cell id; looked up with
                                        // the caller's C string as it is (no temporary std::string per read)
-  std::vector<int32_t> totl, pass, uniq;
-  int32_t n_snps = 0;
+  // Per-cell counters in blocks that never move: dmx_store_add_cell (new cells, RD.TOTL) may run on one host thread while
+  // dmx_store_add_batch (RD.PASS / RD.UNIQ of cells that already existed when the batch was built) runs on others — the `demuxlet`
+  // binary's scan overlaps the two for consecutive windows of reads.
+  struct Counters {
+    static constexpr size_t kBlock = 1 << 16, kBlocks = 1 << 15;   // 2^31 cells
+    std::unique_ptr<std::unique_ptr<int32_t[]>[]> blk{new std::unique_ptr<int32_t[]>[kBlocks]};
+    size_t n = 0;
+    void push_back(int32_t v) { if (n % kBlock == 0) blk[n / kBlock].reset(new int32_t[kBlock]()); blk[n / kBlock][n % kBlock] = v; ++n; }
+    int32_t& operator[](size_t i) { return blk[i / kBlock][i % kBlock]; }
+    int32_t operator[](size_t i) const { return blk[i / kBlock][i % kBlock]; }
+    void copy_to(std::vector<int32_t>& out) const { out.resize(n); for (size_t i = 0; i < n; ++i) out[i] = (*this)[i]; }
+  };
+  Counters totl, pass, uniq;
+  std::vector<int32_t> f_totl, f_pass, f_uniq;   // contiguous copies made by dmx_store_freeze (what dmx_pileup points at)
+  std::atomic<int32_t> n_cells_pub{0};           // barcodes.size(), readable while another thread adds cells
+  std::atomic<int32_t> n_snps{0};                 // (added to by dmx_store_add_snp while a batch of the window before is being inserted)
   // The observations live in kShards sub-stores selected by the cell id: a (snp, cell, umi) key belongs to exactly one of them, so
   // "first observation wins" (sc_drop_seq.cpp:44,53,57) only needs the order WITHIN a shard — dmx_store_add_batch inserts a whole
   // batch with one host thread per group of shards and gives the results of the same calls made one by one.
@@ -364,7 +378,7 @@ struct dmx_store {
   Shard shard[kShards];
   static constexpr uint64_t kEmpty = ~0ull;
   // frozen CSR
-  bool frozen = false;
+  std::atomic<bool> frozen{false};
   std::vector<int64_t> cell_pair_off, cell_read_off;
   std::vector<int32_t> pair_snp;
   std::vector<uint8_t> pair_nrd_bytes;
@@ -428,6 +442,7 @@ extern "C" int32_t dmx_store_add_cell(dmx_store* s, const char* barcode) {      
   s->bc_index[p] = (h & 0xFFFFFFFF00000000ull) | (uint64_t)id;
   if (s->barcodes.size() * 2 > cap) s->bc_rehash(cap * 2);
   s->totl.push_back(0); s->pass.push_back(0); s->uniq.push_back(0);
+  s->n_cells_pub.store((int32_t)s->barcodes.size(), std::memory_order_release);
   s->frozen = false;
   return id;
 }
@@ -457,7 +472,7 @@ extern "C" int dmx_store_add_batch(dmx_store* s, int64_t n, const int32_t* snp, 
                                    uint8_t* is_new, int32_t n_threads) {
   if (!s || n < 0 || (n && (!snp || !cell || !umi_pool || !umi_off || !umi_len || !allele || !bq)))
     return set_error(DMX_ERR_ARG, "dmx_store_add_batch: null argument");
-  const int32_t B = (int32_t)s->barcodes.size();
+  const int32_t B = s->n_cells_pub.load(std::memory_order_acquire);
   for (int64_t i = 0; i < n; ++i) {
     if (snp[i] < 0 || snp[i] >= s->n_snps) return set_error(DMX_ERR_ARG, "dmx_store_add_batch: snp %d out of range (item %lld)", snp[i], (long long)i);
     if (cell[i] < 0 || cell[i] >= B) return set_error(DMX_ERR_ARG, "dmx_store_add_batch: cell %d out of range (item %lld)", cell[i], (long long)i);
@@ -499,7 +514,7 @@ extern "C" int dmx_store_add_batch(dmx_store* s, int64_t n, const int32_t* snp, 
   return DMX_OK;
 }
 extern "C" int32_t dmx_store_n_cells(const dmx_store* s) { return s ? (int32_t)s->barcodes.size() : 0; }
-extern "C" int32_t dmx_store_n_snps(const dmx_store* s) { return s ? s->n_snps : 0; }
+extern "C" int32_t dmx_store_n_snps(const dmx_store* s) { return s ? s->n_snps.load() : 0; }
 extern "C" const char* dmx_store_barcode(const dmx_store* s, int32_t cell) {
   if (!s || cell < 0 || cell >= (int32_t)s->barcodes.size()) return nullptr;
   return s->barcodes[cell].c_str();
@@ -597,7 +612,8 @@ extern "C" int dmx_store_freeze(dmx_store* s, dmx_pileup* out) {
   static const int32_t kNoPairs[1] = {0};       // a store without any pair still hands out the sparse layout (NULL = dense, dmx.h)
   out->pair_snp = s->pair_snp.empty() ? kNoPairs : s->pair_snp.data(); out->pair_nrd = s->pair_nrd_bytes.data(); out->nrd_width = s->nrd_width;
   out->memory = DMX_MEM_HOST; out->reads = s->reads.data();
-  out->rd_totl = s->totl.data(); out->rd_pass = s->pass.data(); out->rd_uniq = s->uniq.data();
+  s->totl.copy_to(s->f_totl); s->pass.copy_to(s->f_pass); s->uniq.copy_to(s->f_uniq);     // (the counters move with every add_*: copied at every freeze)
+  out->rd_totl = s->f_totl.data(); out->rd_pass = s->f_pass.data(); out->rd_uniq = s->f_uniq.data();
   return DMX_OK;
 }
 

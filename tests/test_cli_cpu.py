@@ -406,3 +406,29 @@ def test_help_status_and_errors_equal_the_reference_parser(cli, tmp_path, args):
         tail = re.sub(r"\[E:[^\]:]*/params\.cpp:", "[E:params.cpp:", tail)
         tail = tail.split("terminate called after throwing")[0]
         assert tail.strip() and g[len(head):].startswith(tail.rstrip("\n")), (g[len(head):][:400], tail[:400])
+
+
+@pytest.mark.parametrize("fmt,field,extra", [("bam", "GT", []), ("sam", "PL", ["--min-TD", "3", "--min-BQ", "20", "--cap-BQ", "35"]),
+                                             ("bam", "GP", ["--group-list", "groups.txt"]), ("sam", "GT", ["--tag-group", "XX", "--tag-UMI", "YY"])])
+def test_windowed_scan_equals_the_read_by_read_scan(cli, tmp_path, fmt, field, extra):
+    """f1 on several host threads: windows of reads parsed, overlapped with the SNPs and stored in parallel (three pipeline stages,
+    cell-sharded store batches) must leave the SAME pileup, counters and messages as the read-by-read scan on one thread — whatever the
+    window size, also with a barcode list, missing tags (every read in one group / one UMI) and a VCF read ahead on its own thread."""
+    rng = np.random.default_rng(4242 + len(field) + len(extra))
+    recs = sv.make_vcf(rng, CONTIGS, 200, SAMPLES, tmp_path / "v.vcf.gz", with_noise=(field != "GP"))
+    bcs = [f"BC{i:02d}-1" for i in range(30)]
+    sv.make_reads(rng, CONTIGS, recs, 5000, bcs, tmp_path / "r.sam", tmp_path / "r.bam")
+    (tmp_path / "groups.txt").write_text("\n".join(bcs[::3]) + "\n")
+    outs = []
+    for i, env_extra in enumerate(({"DMX_THREADS": "1"}, {"DMX_THREADS": "4", "DMX_SCAN_WINDOW": "37"}, {"DMX_THREADS": "3", "DMX_SCAN_WINDOW": "1000"},
+                                   {"DMX_THREADS": "6"}, {"DMX_THREADS": "5", "DMX_SCAN_SEQUENTIAL": "1"})):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([cli, "--sam", f"r.{fmt}", "--vcf", "v.vcf.gz", "--field", field, "--out", f"o{i}", "--pileup-only"] + extra,
+                           capture_output=True, text=True, cwd=tmp_path, env=env)
+        assert r.returncode == 0, r.stderr[-400:]
+        totals = [ln.split("] - ", 1)[1] for ln in r.stderr.splitlines() if "Total number" in ln or "Finished reading" in ln]
+        outs.append(((tmp_path / f"o{i}.pileup.txt").read_bytes(), totals))
+    assert len(outs[0][1]) >= 10 and b"PAIR" in outs[0][0]
+    for got in outs[1:]:
+        assert got[0] == outs[0][0]
+        assert got[1] == outs[0][1]
