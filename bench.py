@@ -192,6 +192,42 @@ def reference_slice_leg(dp, g, cfg, n_cells=24, n_snps=2000):
                        f"S*V^2*9 pair-table precompute and its four text files")
 
 
+def cli_leg(n_reads=600_000, n_snps=30_000, n_samples=16, n_barcodes=2_000):
+    """BAM + VCF in, four files out through the `demuxlet` binary (rows f1-f3 + the engine): the scan's reads/s on this box's host cores
+    (windowed, all cores; and read by read on one thread) and the stage seconds of the dmx_demuxlet_run call behind it.  The inputs are
+    tools/make_cli_bench.py's synthetic coordinate-sorted BAM and GT VCF, made here in a temporary directory (no reference data)."""
+    import re
+    import subprocess
+    import tempfile
+    cli = ROOT / "demuxlet_amd" / "demuxlet"
+    if not cli.exists():
+        return None
+    out = {"what": f"demuxlet --sam bench.bam --vcf bench.vcf --field GT: {n_reads} reads x {n_snps} SNPs x {n_samples} samples x {n_barcodes} barcodes "
+                   f"(tools/make_cli_bench.py), STRICT, tie arbiter on", "host_cores": host_cores()}
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run([sys.executable, str(ROOT / "tools" / "make_cli_bench.py"), td, str(n_reads), str(n_snps), str(n_samples), str(n_barcodes)],
+                       check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for name, env_extra in (("all_cores", {}), ("one_thread", {"DMX_THREADS": "1"})):
+            env = dict(os.environ, DMX_CLI_TIMING="1", DMX_E2E_TIMING="1", **env_extra)
+            t0 = time.perf_counter()
+            r = subprocess.run([str(cli), "--sam", f"{td}/bench.bam", "--vcf", f"{td}/bench.vcf", "--field", "GT", "--out", f"{td}/o_{name}"],
+                               capture_output=True, text=True, env=env)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0:
+                return None
+            rec = {"wall_s": wall}
+            m = re.search(r"scan timing \((\d+) threads, ([a-z ]+)\): total ([0-9.]+) s = ([0-9.e+]+) reads/s", r.stderr)
+            if m:
+                rec.update(scan_threads=int(m.group(1)), scan_mode=m.group(2), scan_s=float(m.group(3)), scan_reads_per_s=float(m.group(4)))
+            m = re.search(r'\{"dmx_demuxlet_run": (\{.*?\})\}', r.stderr)
+            if m:
+                rec["dmx_demuxlet_run"] = json.loads(m.group(1))
+            out[name] = rec
+        same = all(open(f"{td}/o_all_cores.{suf}", "rb").read() == open(f"{td}/o_one_thread.{suf}", "rb").read() for suf in ("single", "sing2", "best"))
+        out["files_identical_between_the_two_scans"] = same
+    return out
+
+
 def pmc_profile(cfgno, B, mode, dense):
     """HBM traffic and VALU instruction counts of one launch of the dominant kernel are properties of the workload; they come
     from the committed rocprofv3 PMC passes of the SAME workload (profiles/, tools/profile_round.sh).  A dense configuration does
@@ -461,6 +497,10 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                     tm["arbiter_format_write_frac"] = tm["write_s"] / tm["total_s"]
                     tm["triples_per_s"] = dp.n_pairs * V / tm["total_s"]
                     e2e[name] = tm
+            try:
+                e2e["from_bam_and_vcf"] = cli_leg()
+            except Exception as ex:                      # the leg is a side record: never let it take the bench line down
+                e2e["from_bam_and_vcf"] = {"error": repr(ex)}
             out["end_to_end"] = e2e
             del hp, h
         if with_cpu:                                     # the CPU baseline is a rank-0, N=1 leg only

@@ -1393,9 +1393,11 @@ int main(int argc, char** argv) {
         { std::unique_lock<std::mutex> lk(w_mu); w_cv.wait(lk, [&] { return wins[i].state == 2 || w_stop; }); if (w_stop) return; }
         Window& w = wins[i];
         const size_t n = w.n;
+        const std::chrono::steady_clock::time_point k0 = std::chrono::steady_clock::now();
         parallel_for(n, [&](size_t a, size_t b, int) {
           for (size_t k = a; k < b; ++k) if (w.st[k].used) overlap(w.rd[k], w.st[k], w.snps.data() - w.snp_lo);
         });
+        const std::chrono::steady_clock::time_point k1 = std::chrono::steady_clock::now();
         // the window's observations, in BAM order, into the store
         b_snp.clear(); b_cell.clear(); b_off.clear(); b_len.clear(); b_al.clear(); b_bq.clear(); b_pool.clear();
         for (size_t k = 0; k < n; ++k) {
@@ -1417,6 +1419,7 @@ int main(int argc, char** argv) {
           for (size_t h = 0; h < st.hits.size(); ++h, ++q) { if (b_new[q]) ++nv_pass; else ++nv_red; }
           classify(nv_pass, nv_red, st.nv_valid);
         }
+        if (sw.on) { sw.acc[2] += std::chrono::duration<double>(k1 - k0).count(); sw.acc[5] += std::chrono::duration<double>(std::chrono::steady_clock::now() - k1).count(); }
         const bool last = w.last;
         { std::lock_guard<std::mutex> lk(w_mu); w.state = 0; }
         w_cv.notify_all();
@@ -1454,8 +1457,8 @@ int main(int argc, char** argv) {
   if (n_warn_u > 10) notice("WARNING: Suppressed a total of %d UMI warnings...", n_warn_u);
   if (n_warn_g > 10) notice("WARNING: Suppressed a total of %d droplet/cell barcode warnings...", n_warn_g);
   const double scan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - scan_t0).count();
-  if (sw.on) notice("scan timing (%d threads, %s): total %.3f s = %.3g reads/s; alignment reader %.3f s, record parsing %.3f s, lock-step bookkeeping %.3f s, VCF reader (wait) %.3f s, overlap + store %.3f s",
-                    n_threads, windowed ? "windowed" : "read by read", scan_s, (double)sr.n_read / scan_s, sw.acc[0], sw.acc[3], sw.acc[4], sw.acc[1], sw.acc[2]);
+  if (sw.on) notice("scan timing (%d threads, %s): total %.3f s = %.3g reads/s; alignment reader %.3f s, record parsing %.3f s, lock-step bookkeeping %.3f s, VCF reader (wait) %.3f s, overlap%s %.3f s, store batches %.3f s",
+                    n_threads, windowed ? "windowed" : "read by read", scan_s, (double)sr.n_read / scan_s, sw.acc[0], sw.acc[3], sw.acc[4], sw.acc[1], windowed ? "" : " + store", sw.acc[2], sw.acc[5]);
   notice("Finished reading %d markers from the VCF file", (int)snps.size());
   notice("Total number input reads : %lld", (long long)sr.n_read);
   notice("Total number valid droplets observed : %d", dmx_store_n_cells(scl));
