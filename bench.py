@@ -400,8 +400,14 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                         "frac": rate / (SIMDS * CLOCK_HZ), "kernel": pj.get("kernel"), "counts_scaled_from_barcodes": pj.get("scaled_from_barcodes"),
                         "fp64_insts_per_launch": pj.get("fp64_insts_per_launch"), "other_valu_insts_per_launch": pj.get("other_valu_insts_per_launch"),
                         "upper_bound_all_insts_at_4_cycles": pj.get("valu_wave_insts_per_launch", 0) / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS,
+                        "frac_measured_costs": (pj["issue_cycles_measured_costs_per_launch"] / (dom_ms * 1e-3) / (SIMDS * CLOCK_HZ)
+                                                if pj.get("issue_cycles_measured_costs_per_launch") else None),
+                        "cycles_per_other_valu_inst": pj.get("cycles_per_other_valu_inst"),
                         "note": "the binding roofline of this path (SURVEY 8d): VALU issue. issue cycles = 4 x (FP64 + transcendental wave-"
-                                "instructions) + 2 x (all other VALU wave-instructions), per-type counts from profiles/ PMC"}
+                                "instructions) + 2 x (all other VALU wave-instructions), per-type counts from profiles/ PMC.  frac_measured_costs prices "
+                                "the other instructions at their MEASURED average issue cost in this kernel's loops (tools/micro/valu_rate.hip: "
+                                "three-source integer ops, conversions, compares, v_mov_b64, DPP hold the port 4 cycles like FP64; tools/isa_mix.py) "
+                                "and is the better estimate; both are against the nominal 2.4 GHz"}
             elif pj.get("valu_wave_insts_per_launch"):
                 rate = pj["valu_wave_insts_per_launch"] / (dom_ms * 1e-3)
                 valu = {"bound": "valu_issue", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave-instructions/s",

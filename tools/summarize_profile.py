@@ -39,6 +39,12 @@ for p in sorted(list(src.glob("pmc_*.csv")) + list(src.glob("pmc_*.csv.gz"))):
         k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         summ[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         meta[k] = dict(vgpr=r["VGPR_Count"], agpr=r["Accum_VGPR_Count"], sgpr=r["SGPR_Count"], lds=r["LDS_Block_Size"], grid=r["Grid_Size"], wg=r["Workgroup_Size"])
+# average issue cost of a NON-FP64 VALU instruction per kernel, from its ISA and the measured per-instruction costs (tools/isa_mix.py,
+# tools/micro/valu_rate.hip); 3.0 where the kernel has no entry
+try:
+    isa_mix = json.load(open(out / f"{tag}_isa_mix.json"))
+except OSError:
+    isa_mix = {}
 res = {}
 for k, cs in summ.items():
     d = res[k] = {c: sum(v) / len(v) for c, v in cs.items()}
@@ -56,6 +62,9 @@ for k, cs in summ.items():
         d["other_valu_insts"] = d["SQ_INSTS_VALU"] - d["fp64_insts"]
         d["issue_cycles"] = 4 * d["fp64_insts"] + 2 * d["other_valu_insts"]
         d["issue_cycles_cvt4"] = d["issue_cycles"] + 2 * d.get("SQ_INSTS_VALU_CVT", 0.0)
+        w = isa_mix.get(k, {}).get("cycles_per_other_valu_inst", 3.0)
+        d["cycles_per_other_valu_inst"] = w
+        d["issue_cycles_measured_costs"] = 4 * d["fp64_insts"] + w * d["other_valu_insts"]
 json.dump(res, open(out / f"{tag}_cfg{cfg}{sfx}_pmc_summary.json", "w"), indent=1)
 json.dump(bench, open(out / f"{tag}_cfg{cfg}{sfx}_bench.json", "w"))
 dom = [k for k in res if "k_doublet" in k] or [k for k in res if "k_singlet" in k]
@@ -67,6 +76,9 @@ json.dump({"kernel": dom, "barcodes_per_gpu": bench["config"]["barcodes_per_gpu"
            "fp64_add_per_launch": d.get("SQ_INSTS_VALU_ADD_F64"), "fp64_mul_per_launch": d.get("SQ_INSTS_VALU_MUL_F64"),
            "fp64_fma_per_launch": d.get("SQ_INSTS_VALU_FMA_F64"), "fp64_trans_per_launch": d.get("SQ_INSTS_VALU_TRANS_F64"),
            "issue_cycles_per_launch": d.get("issue_cycles"), "issue_cycles_cvt4_per_launch": d.get("issue_cycles_cvt4"),
+           "issue_cycles_measured_costs_per_launch": d.get("issue_cycles_measured_costs"), "cycles_per_other_valu_inst": d.get("cycles_per_other_valu_inst"),
+           "lds_wait_inst_quadcycles_per_launch": d.get("SQ_WAIT_INST_LDS"), "wave_quadcycles_per_launch": d.get("SQ_WAVE_CYCLES"),
+           "wait_any_quadcycles_per_launch": d.get("SQ_WAIT_ANY"), "wait_inst_any_quadcycles_per_launch": d.get("SQ_WAIT_INST_ANY"),
            "sq_inst_cycles_valu_per_launch": d.get("SQ_INST_CYCLES_VALU"),
            "lds_insts_per_launch": d.get("SQ_INSTS_LDS"), "lds_active_quadcycles_per_launch": d.get("SQ_ACTIVE_INST_LDS"),
            "lds_idx_active_per_launch": d.get("SQ_LDS_IDX_ACTIVE"), "lds_bank_conflict_per_launch": d.get("SQ_LDS_BANK_CONFLICT"),
