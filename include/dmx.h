@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 3
+#define DMX_ABI_VERSION 4   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times (additions only: a caller of ABI 3 runs unchanged) */
 
 typedef enum {
   DMX_OK = 0,
