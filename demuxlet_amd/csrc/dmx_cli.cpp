@@ -9,6 +9,7 @@
 //   f3  VCF reader+filter  bcf_filtered_reader.cpp:498-574 (n_allele, call rate, MAC), :98-141 (--sm / --sm-list: a std::set,
 //                          so selected samples come in SORTED id order), :671-765 (buffering)
 //   f1  scan               cmd_cram_demuxlet.cpp:142-338, CIGAR walk hts_utils.cpp:279-359 (M, D/N, S/I only)
+#include <sys/resource.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -35,6 +36,7 @@
 #include <vector>
 
 #include "dmx.h"
+#include "dmx_inflate.hpp"
 
 namespace {
 
@@ -285,17 +287,44 @@ int cli_threads() {
   return std::min(n, 32);
 }
 
+// A run of decompressed bytes.  Readers hand out views into it (BAM records are parsed where the inflater wrote them), so it is
+// shared: it lives until the last window of reads that points into it has been through the store.
+struct Chunk {
+  std::unique_ptr<uint8_t[]> p;
+  size_t n = 0, cap = 0;
+  const uint8_t* data() const { return p.get(); }
+  uint8_t* data() { return p.get(); }
+  size_t size() const { return n; }
+  // Full-size BGZF batches (256 members x 64 KiB) come from and go back to a free list: a fresh 16 MiB allocation is 4 096 page
+  // faults, 0.3 CPU-seconds over a 440 MB BAM.
+  static constexpr size_t kPooled = (size_t)256 << 16;
+  struct Pool { std::mutex mu; std::vector<std::unique_ptr<uint8_t[]>> free; };
+  static Pool& pool() { static Pool* p = new Pool; return *p; }
+  void alloc(size_t bytes) {
+    if (bytes <= kPooled) {
+      cap = kPooled;
+      Pool& q = pool();
+      { std::lock_guard<std::mutex> lk(q.mu); if (!q.free.empty()) { p = std::move(q.free.back()); q.free.pop_back(); } }
+      if (!p) p.reset(new uint8_t[kPooled]);
+    } else { cap = bytes; p.reset(new uint8_t[bytes]); }
+  }
+  ~Chunk() {
+    if (p && cap == kPooled) { Pool& q = pool(); std::lock_guard<std::mutex> lk(q.mu); if (q.free.size() < 16) q.free.push_back(std::move(p)); }
+  }
+};
+using ChunkP = std::shared_ptr<Chunk>;
+
 struct BgzfPipe {
   FILE* fp = nullptr;
   std::thread producer;
   std::mutex mu;
   std::condition_variable cv_put, cv_get;
-  std::deque<std::vector<uint8_t>> queue;       // inflated batches, in file order
+  std::deque<ChunkP> queue;                     // inflated batches, in file order
   bool done = false, stop = false;
   std::string error;
   static constexpr size_t kBatchBlocks = 256, kQueueDepth = 3;
 
-  struct Block { std::vector<uint8_t> raw; size_t data_off = 0, data_len = 0; uint32_t crc = 0, isize = 0; std::vector<uint8_t> out; std::string err; };
+  struct Block { std::vector<uint8_t> raw; size_t data_off = 0, data_len = 0; uint32_t crc = 0, isize = 0; std::string err; };
 
   // one BGZF member into b.raw; false at a clean EOF
   bool read_block(Block& b) {
@@ -314,44 +343,69 @@ struct BgzfPipe {
     }
     if (bsize < 12 + xlen + 8) { error = "BGZF block without a BC field"; return false; }
     const size_t rest = bsize - 12 - xlen;          // deflate data + CRC32 + ISIZE
-    b.raw.resize(rest);
+    b.raw.resize(rest + 56);                         // (dmxz::inflate_raw reads ahead: 64 readable bytes past the deflate data)
     if (fread(b.raw.data(), 1, rest, fp) != rest) { error = "truncated BGZF block"; return false; }
+    memset(b.raw.data() + rest, 0, 56);
     b.data_off = 0; b.data_len = rest - 8;
     memcpy(&b.crc, &b.raw[rest - 8], 4); memcpy(&b.isize, &b.raw[rest - 4], 4);
     return true;
   }
-  static void inflate_block(Block& b) {
-    b.out.resize(b.isize);
+  static void inflate_block(Block& b, uint8_t* out) {            // into the block's place in its batch (ISIZE bytes)
     if (b.isize == 0) return;
+    // our decoder first (dmx_inflate.hpp: 2-3x zlib 1.2.11 on BAM records); anything it does not accept goes to zlib, which decides
+    static const bool zlib_only = getenv("DMX_ZLIB_INFLATE") != nullptr;
+    if (!zlib_only && dmxz::inflate_raw(b.raw.data() + b.data_off, b.data_len, out, b.isize) && dmxz::crc32_of(out, b.isize) == b.crc) return;
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) { b.err = "inflateInit2 failed"; return; }
     zs.next_in = b.raw.data() + b.data_off; zs.avail_in = (uInt)b.data_len;
-    zs.next_out = b.out.data(); zs.avail_out = (uInt)b.out.size();
+    zs.next_out = out; zs.avail_out = (uInt)b.isize;
     const int rc = inflate(&zs, Z_FINISH);
     inflateEnd(&zs);
     if (rc != Z_STREAM_END || zs.avail_out != 0) { b.err = "BGZF block does not inflate to its ISIZE"; return; }
-    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), b.out.data(), (uInt)b.out.size()) != b.crc) b.err = "BGZF block CRC mismatch";
+    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), out, (uInt)b.isize) != b.crc) b.err = "BGZF block CRC mismatch";
   }
+  // Two threads: one reads the members of batch i + 1 from the file while this one has batch i inflated on the host's threads,
+  // every member straight into its place in the batch (the ISIZE fields give the places before anything is inflated).
   void run(int nthreads) {
-    std::vector<Block> blocks(kBatchBlocks);
-    for (;;) {
-      size_t n = 0;
-      while (n < kBatchBlocks && read_block(blocks[n])) ++n;
-      std::string err = error;
+    struct RawBatch { std::vector<Block> blocks; size_t n = 0; std::string err; int state = 0; };   // state: 0 free, 1 read
+    RawBatch rb[2];
+    for (RawBatch& r : rb) r.blocks.resize(kBatchBlocks);
+    std::mutex io_mu; std::condition_variable io_cv;
+    bool io_stop = false;
+    std::thread io([&] {
+      for (int i = 0;; i ^= 1) {
+        { std::unique_lock<std::mutex> lk(io_mu); io_cv.wait(lk, [&] { return rb[i].state == 0 || io_stop; }); if (io_stop) return; }
+        size_t n = 0;
+        while (n < kBatchBlocks && read_block(rb[i].blocks[n])) ++n;
+        rb[i].n = n; rb[i].err = error;
+        { std::lock_guard<std::mutex> lk(io_mu); rb[i].state = 1; }
+        io_cv.notify_all();
+        if (n < kBatchBlocks || !error.empty()) return;
+      }
+    });
+    struct IoGuard { std::mutex& mu; std::condition_variable& cv; bool& stop; std::thread& th; ~IoGuard() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); } } io_guard{io_mu, io_cv, io_stop, io};
+    for (int bi = 0;; bi ^= 1) {
+      { std::unique_lock<std::mutex> lk(io_mu); io_cv.wait(lk, [&] { return rb[bi].state == 1; }); }
+      std::vector<Block>& blocks = rb[bi].blocks;
+      const size_t n = rb[bi].n;
+      std::string err = rb[bi].err;
       if (n) {
+        std::vector<size_t> off(n + 1, 0);
+        for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + blocks[i].isize;
+        ChunkP batch = std::make_shared<Chunk>();
+        batch->alloc(off[n]);
+        batch->n = off[n];
         const int nt = (int)std::min<size_t>((size_t)nthreads, n);
         std::atomic<size_t> next{0};
-        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) inflate_block(blocks[i]); };
+        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) inflate_block(blocks[i], batch->p.get() + off[i]); };
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(work);
         work();
         for (std::thread& t : pool) t.join();
-        size_t total = 0;
-        for (size_t i = 0; i < n; ++i) { total += blocks[i].out.size(); if (err.empty() && !blocks[i].err.empty()) err = blocks[i].err; }
-        std::vector<uint8_t> batch(total);
-        size_t o = 0;
-        for (size_t i = 0; i < n; ++i) { if (!blocks[i].out.empty()) memcpy(&batch[o], blocks[i].out.data(), blocks[i].out.size()); o += blocks[i].out.size(); }
+        for (size_t i = 0; i < n; ++i) if (err.empty() && !blocks[i].err.empty()) { err = blocks[i].err; blocks[i].err.clear(); }
+        { std::lock_guard<std::mutex> lk(io_mu); rb[bi].state = 0; }
+        io_cv.notify_all();
         std::unique_lock<std::mutex> lk(mu);
         cv_put.wait(lk, [&] { return queue.size() < kQueueDepth || stop; });
         if (stop) return;
@@ -368,7 +422,7 @@ struct BgzfPipe {
   }
   void start(FILE* f, int nthreads) { fp = f; producer = std::thread([this, nthreads] { run(nthreads); }); }
   // next inflated batch; false at EOF (or error: see `error`)
-  bool next(std::vector<uint8_t>& out) {
+  bool next(ChunkP& out) {
     std::unique_lock<std::mutex> lk(mu);
     cv_get.wait(lk, [&] { return !queue.empty() || done; });
     if (queue.empty()) return false;
@@ -389,7 +443,7 @@ struct GzIn {
   gzFile f = nullptr;                            // plain text / ordinary gzip
   std::unique_ptr<BgzfPipe> bgzf;                // BGZF
   std::string path;
-  std::vector<uint8_t> cur;                      // current decompressed chunk
+  ChunkP cur_p = std::make_shared<Chunk>();      // current decompressed chunk (shared: BAM records are parsed in place)
   size_t pos = 0;
   bool open(const std::string& p) {
     path = p;
@@ -413,42 +467,42 @@ struct GzIn {
   bool fill() {                                  // next chunk into cur; false at EOF
     pos = 0;
     if (bgzf) {
-      if (bgzf->next(cur)) return true;
+      if (bgzf->next(cur_p)) return true;
       if (!bgzf->error.empty()) fatal("[E:%s] %s: %s", __func__, path.c_str(), bgzf->error.c_str());
-      cur.clear();
+      cur_p = std::make_shared<Chunk>();
       return false;
     }
-    cur.resize(1 << 20);
-    const int n = gzread(f, cur.data(), (unsigned)cur.size());
+    if (cur_p.use_count() != 1 || !cur_p->p) { cur_p = std::make_shared<Chunk>(); cur_p->p.reset(new uint8_t[1 << 20]); }
+    const int n = gzread(f, cur_p->data(), 1u << 20);
     if (n < 0) fatal("[E:%s] %s: read error", __func__, path.c_str());
-    cur.resize((size_t)n);
+    cur_p->n = (size_t)n;
     return n > 0;
   }
   bool getline(std::string& line) {
     line.clear();
     bool any = false;
     for (;;) {
-      if (pos >= cur.size() && !fill()) break;
+      if (pos >= cur_p->size() && !fill()) break;
       any = true;
-      const uint8_t* b = cur.data() + pos;
-      const uint8_t* nl = (const uint8_t*)memchr(b, '\n', cur.size() - pos);
+      const uint8_t* b = cur_p->data() + pos;
+      const uint8_t* nl = (const uint8_t*)memchr(b, '\n', cur_p->size() - pos);
       if (nl) {
         line.append((const char*)b, (size_t)(nl - b));
         pos += (size_t)(nl - b) + 1;
         if (!line.empty() && line.back() == '\r') line.pop_back();
         return true;
       }
-      line.append((const char*)b, cur.size() - pos);
-      pos = cur.size();
+      line.append((const char*)b, cur_p->size() - pos);
+      pos = cur_p->size();
     }
     return any && !line.empty();
   }
   bool read(void* dst, size_t n) {
     uint8_t* d = (uint8_t*)dst;
     while (n) {
-      if (pos >= cur.size() && !fill()) return false;
-      const size_t k = std::min(n, cur.size() - pos);
-      memcpy(d, cur.data() + pos, k);
+      if (pos >= cur_p->size() && !fill()) return false;
+      const size_t k = std::min(n, cur_p->size() - pos);
+      memcpy(d, cur_p->data() + pos, k);
       d += k; pos += k; n -= k;
     }
     return true;
@@ -458,9 +512,9 @@ struct GzIn {
     uint8_t* d = (uint8_t*)dst;
     size_t got = 0;
     while (got < n) {
-      if (pos >= cur.size() && !fill()) return got ? -1 : 0;
-      const size_t k = std::min(n - got, cur.size() - pos);
-      memcpy(d + got, cur.data() + pos, k);
+      if (pos >= cur_p->size() && !fill()) return got ? -1 : 0;
+      const size_t k = std::min(n - got, cur_p->size() - pos);
+      memcpy(d + got, cur_p->data() + pos, k);
       got += k; pos += k;
     }
     return 1;
@@ -509,7 +563,7 @@ struct VcfReader {
     bool have_header = false;
     dict.assign(1, "PASS");                      // the implicit first dictionary entry
     in.fill();
-    is_bcf = in.cur.size() >= 5 && memcmp(in.cur.data(), "BCF\2\2", 5) == 0;
+    is_bcf = in.cur_p->size() >= 5 && memcmp(in.cur_p->data(), "BCF\2\2", 5) == 0;
     if (is_bcf) {                                // BCF2: magic, l_text, the VCF header as text (NUL-terminated), then binary records
       uint8_t magic[5]; uint32_t l_text = 0;
       if (!in.read(magic, 5) || !in.read(&l_text, 4) || l_text > (1u << 30)) fatal("[E:%s] %s: truncated BCF header", __func__, path.c_str());
@@ -830,9 +884,11 @@ struct Read {
   bool has_cb = false, has_ub = false;
   int64_t endpos_c = 0;         // SamReader::endpos(*this), and the barcode as (worker slot, id in that slot's dictionary): filled by the
   int32_t cb_slot = -1, cb_lid = -1;   // parallel record parsing of the windowed scan, so that the in-order stage need not hash strings
-  std::vector<uint8_t> own;     // the BAM record's bytes / ...
-  std::string own_line;         // ... the SAM line the views below point into (a Read owns its record: windows of reads are parsed
-                                // and overlapped with the SNPs on several host threads)
+  const uint8_t* rec = nullptr; // the BAM record's bytes: where the inflater wrote them (SamReader::next_raw's `keep` holds that
+  size_t rec_n = 0;             // chunk alive), or in `own` for a record that straddles two chunks / ...
+  std::vector<uint8_t> own;
+  std::string own_line;         // ... the SAM line the views below point into (a window of reads is parsed and overlapped with
+                                // the SNPs on several host threads while the reader moves on)
   int flag = 0, tid = -1, mapq = 0;
   int64_t pos = 0;              // 0-based
   std::vector<std::pair<char, uint32_t>> cigar;
@@ -956,16 +1012,29 @@ struct SamReader {
     return true;
   }
 
-  // the next record's bytes into r.own (BAM) / r.own_line (SAM), unparsed; false at EOF
-  bool next_raw(Read& r) {
+  // the next record, unparsed: r.rec / r.rec_n (BAM) or r.own_line (SAM); false at EOF.  A BAM record that lies inside one
+  // inflated chunk is not copied: r.rec points into the chunk, which stays alive until the reader's next call — or, when the
+  // caller collects records (windowed scan), for as long as `keep` holds it.
+  bool next_raw(Read& r, std::vector<ChunkP>* keep = nullptr) {
     if (is_bam) {
       int32_t block = 0;
+      if (in.pos + 4 <= in.cur_p->size()) {
+        memcpy(&block, in.cur_p->data() + in.pos, 4);
+        if (block < 32) fatal("[E:%s] corrupt BAM record (block size %d)", __func__, block);
+        if (in.pos + 4 + (size_t)block <= in.cur_p->size()) {
+          r.rec = in.cur_p->data() + in.pos + 4; r.rec_n = (size_t)block;
+          in.pos += 4 + (size_t)block;
+          if (keep && (keep->empty() || keep->back() != in.cur_p)) keep->push_back(in.cur_p);
+          return true;
+        }
+      }
       const int got = in.read_prefix(&block, 4);
       if (got == 0) return false;
       if (got < 0) fatal("[E:%s] truncated BAM record (the file ends inside a record's block size)", __func__);
       if (block < 32) fatal("[E:%s] corrupt BAM record (block size %d)", __func__, block);
       r.own.resize((size_t)block);
       if (!in.read(r.own.data(), (size_t)block)) fatal("[E:%s] truncated BAM record", __func__);
+      r.rec = r.own.data(); r.rec_n = (size_t)block;
       return true;
     }
     for (;;) {
@@ -978,7 +1047,8 @@ struct SamReader {
   void parse_raw(Read& r) const { if (is_bam) parse_bam_record(r); else parse_sam_line(r.own_line, r); }
 
   void parse_bam_record(Read& r) const {
-    std::vector<uint8_t>& b = r.own;
+    struct Bytes { const uint8_t* p; size_t n; const uint8_t& operator[](size_t i) const { return p[i]; } size_t size() const { return n; } };
+    const Bytes b{r.rec, r.rec_n};
     auto i32 = [&](size_t o) { int32_t v; memcpy(&v, &b[o], 4); return v; };
     auto u16 = [&](size_t o) { uint16_t v; memcpy(&v, &b[o], 2); return v; };
     r.tid = i32(0); r.pos = i32(4);
@@ -1173,7 +1243,8 @@ int main(int argc, char** argv) {
 
   // variants in file order, parsed ahead by a producer thread in the windowed mode; each comes with the contig names its vr.read call registered
   struct Fed { Variant v; std::vector<std::pair<std::string, int>> new_contigs; bool eof = false; };
-  std::mutex feed_mu; std::condition_variable feed_cv_put, feed_cv_get; std::deque<Fed> feed_q; bool feed_stop = false;
+  std::mutex feed_mu; std::condition_variable feed_cv_put, feed_cv_get; std::deque<std::vector<Fed>> feed_q; bool feed_stop = false;   // (batches of 256: one lock per batch)
+  std::vector<Fed> feed_cur; size_t feed_i = 0;
   std::thread feed_th;
   auto read_variant = [&](Fed& f) {                            // one vr.read call + what it did to the contig dictionary
     const size_t before = vr.contig_rid.size();
@@ -1183,10 +1254,11 @@ int main(int argc, char** argv) {
   };
   if (windowed) feed_th = std::thread([&] {
     for (;;) {
-      Fed f;
-      read_variant(f);
-      const bool last = f.eof;
-      { std::unique_lock<std::mutex> lk(feed_mu); feed_cv_put.wait(lk, [&] { return feed_q.size() < 4096 || feed_stop; }); if (feed_stop) return; feed_q.push_back(std::move(f)); }
+      std::vector<Fed> batch;
+      batch.reserve(256);
+      bool last = false;
+      while (batch.size() < 256 && !last) { batch.emplace_back(); read_variant(batch.back()); last = batch.back().eof; }
+      { std::unique_lock<std::mutex> lk(feed_mu); feed_cv_put.wait(lk, [&] { return feed_q.size() < 64 || feed_stop; }); if (feed_stop) return; feed_q.push_back(std::move(batch)); }
       feed_cv_get.notify_one();
       if (last) return;
     }
@@ -1195,8 +1267,12 @@ int main(int argc, char** argv) {
   auto next_variant = [&](Variant& v) -> bool {                // the reference's vr.read at :211
     Fed f;
     if (windowed) {
-      { std::unique_lock<std::mutex> lk(feed_mu); feed_cv_get.wait(lk, [&] { return !feed_q.empty(); }); f = std::move(feed_q.front()); feed_q.pop_front(); }
-      feed_cv_put.notify_one();
+      if (feed_i >= feed_cur.size()) {
+        { std::unique_lock<std::mutex> lk(feed_mu); feed_cv_get.wait(lk, [&] { return !feed_q.empty(); }); feed_cur = std::move(feed_q.front()); feed_q.pop_front(); }
+        feed_cv_put.notify_one();
+        feed_i = 0;
+      }
+      f = std::move(feed_cur[feed_i++]);
     } else read_variant(f);
     for (auto& kv : f.new_contigs) contig_seen.insert(kv);
     if (f.eof) return false;
@@ -1207,7 +1283,7 @@ int main(int argc, char** argv) {
 
   std::vector<std::vector<int32_t>>* slot_cell_p = nullptr;     // (windowed scan: see slot_cell below)
   struct Hit { int32_t snp; uint8_t allele, bq; };
-  struct Staged { int64_t ibeg = 0, nbuf = 0; int32_t ibcd = 0; bool used = false; std::string umi; std::vector<Hit> hits; int nv_valid = 0; };
+  struct Staged { int64_t ibeg = 0, nbuf = 0; int32_t ibcd = 0; bool used = false, umi_in_read = false; std::string umi; std::vector<Hit> hits; int nv_valid = 0; };   // umi_in_read: the UMI is the read's own tag value (windowed scan: not copied)
   // (S) for one parsed read that passed the read filter; false = the read contributes nothing (:198-200, :263)
   auto stage = [&](const Read& rd, Staged& st) -> bool {
     st.used = false;
@@ -1273,10 +1349,11 @@ int main(int argc, char** argv) {
     }
     ++nReadsTMP;
     // UMI (:272-293)
-    st.umi.assign(".");
-    if (o.tag_umi.empty()) { char b[32]; snprintf(b, sizeof b, "%x", rand()); st.umi += b; }
-    else if (rd.has_ub) st.umi = rd.ub;
+    st.umi_in_read = false;
+    if (o.tag_umi.empty()) { char b[32]; snprintf(b, sizeof b, "%x", rand()); st.umi.assign("."); st.umi += b; }
+    else if (rd.has_ub) { if (windowed) st.umi_in_read = true; else st.umi = rd.ub; }
     else {
+      st.umi.assign(".");
       if (n_warn_u < 10) notice("WARNING: Cannot find UMI tag %s from %lld-th read %s at %s:%lld-%lld. Treating all of them as a single UMI", o.tag_umi.c_str(), (long long)sr.n_read, rd.qname().c_str(), sr.targets[(size_t)rd.tid].c_str(), (long long)rd.pos, (long long)endpos);
       else if (n_warn_u == 10) notice("WARNING: Suppressing 10+ UMI warnings...");
       ++n_warn_u;
@@ -1356,17 +1433,28 @@ int main(int argc, char** argv) {
     // cells and moves RD.TOTL meanwhile: dmx_store_add_batch is made for that).  A window's store batch is complete before the next
     // window's begins: "first UMI wins" sees the BAM order.
     constexpr int NW = 4;
-    struct Window { std::vector<Read> rd; std::vector<Staged> st; std::vector<Snp> snps; int64_t snp_lo = 0; size_t n = 0; bool last = false; int state = 0; };
-    Window wins[NW];                                             // state: 0 free, 1 parsed, 2 staged
-    for (Window& w : wins) { w.rd.resize(W); w.st.resize(W); }
+    struct Window { std::vector<Read> rd; std::vector<Staged> st; std::vector<Snp> snps; std::vector<ChunkP> keep; int64_t snp_lo = 0; size_t n = 0; bool last = false; int state = 0; };
+    // state: 0 free, 1 parsed, 2 staged.  (On the heap and torn down by a thread of its own after the scan: destroying 4 x W reads
+    // with their strings and vectors is 50-70 ms that nothing has to wait for.)
+    std::unique_ptr<Window[]> wins_owner(new Window[NW]);
+    Window* const wins = wins_owner.get();
+    // (a window's W records are constructed by the thread that first fills them: 4 x W x ~350 bytes is 50 ms of page faults in one go)
     std::mutex w_mu; std::condition_variable w_cv;
     bool w_stop = false;
+    double px[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // DMX_CLI_TIMING: reader wait / slice / parse, sink wait / assemble / store / classify (one writer each)
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tsec = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     std::thread reader([&] {
       for (int i = 0;; i = (i + 1) % NW) {
+        const auto r0 = tnow();
         { std::unique_lock<std::mutex> lk(w_mu); w_cv.wait(lk, [&] { return wins[i].state == 0 || w_stop; }); if (w_stop) return; }
         Window& w = wins[i];
         w.n = 0; w.last = false;
-        while (w.n < W) { if (!sr.next_raw(w.rd[w.n])) { w.last = true; break; } ++w.n; }
+        if (w.rd.size() < W) w.rd.resize(W);
+        w.keep.clear();                                          // (the inflated chunks the window's previous records lay in)
+        const auto r1 = tnow();
+        while (w.n < W) { if (!sr.next_raw(w.rd[w.n], &w.keep)) { w.last = true; break; } ++w.n; }
+        const auto r2 = tnow();
         parallel_for(w.n, [&](size_t a, size_t b, int slot) {
           std::unordered_map<std::string, int32_t>& dict = slot_dict[(size_t)slot];
           for (size_t k = a; k < b; ++k) {
@@ -1381,6 +1469,7 @@ int main(int argc, char** argv) {
             }
           }
         });
+        if (sw.on) { px[0] += tsec(r0, r1); px[1] += tsec(r1, r2); px[2] += tsec(r2, tnow()); }
         { std::lock_guard<std::mutex> lk(w_mu); w.state = 1; }
         w_cv.notify_all();
         if (w.last) return;
@@ -1390,10 +1479,12 @@ int main(int argc, char** argv) {
       std::vector<int32_t> b_snp, b_cell; std::vector<uint64_t> b_off; std::vector<uint32_t> b_len; std::vector<uint8_t> b_al, b_bq, b_new;
       std::string b_pool;
       for (int i = 0;; i = (i + 1) % NW) {
+        const auto q0 = tnow();
         { std::unique_lock<std::mutex> lk(w_mu); w_cv.wait(lk, [&] { return wins[i].state == 2 || w_stop; }); if (w_stop) return; }
         Window& w = wins[i];
         const size_t n = w.n;
         const std::chrono::steady_clock::time_point k0 = std::chrono::steady_clock::now();
+        if (sw.on) px[3] += tsec(q0, k0);
         parallel_for(n, [&](size_t a, size_t b, int) {
           for (size_t k = a; k < b; ++k) if (w.st[k].used) overlap(w.rd[k], w.st[k], w.snps.data() - w.snp_lo);
         });
@@ -1404,13 +1495,16 @@ int main(int argc, char** argv) {
           const Staged& st = w.st[k];
           if (!st.used || st.hits.empty()) continue;
           const uint64_t off = b_pool.size();
-          b_pool.append(st.umi);
-          for (const Hit& h : st.hits) { b_snp.push_back(h.snp); b_cell.push_back(st.ibcd); b_off.push_back(off); b_len.push_back((uint32_t)st.umi.size()); b_al.push_back(h.allele); b_bq.push_back(h.bq); }
+          const std::string& umi = st.umi_in_read ? w.rd[k].ub : st.umi;
+          b_pool.append(umi);
+          for (const Hit& h : st.hits) { b_snp.push_back(h.snp); b_cell.push_back(st.ibcd); b_off.push_back(off); b_len.push_back((uint32_t)umi.size()); b_al.push_back(h.allele); b_bq.push_back(h.bq); }
         }
         b_new.assign(b_snp.size(), 0);
         b_pool.push_back('\0');
+        const auto k2 = tnow();
         if (dmx_store_add_batch(scl, (int64_t)b_snp.size(), b_snp.data(), b_cell.data(), b_pool.data(), b_off.data(), b_len.data(), b_al.data(), b_bq.data(),
                                 b_new.data(), n_threads) != DMX_OK) fatal("%s", dmx_last_error());
+        const auto k3 = tnow();
         size_t q = 0;
         for (size_t k = 0; k < n; ++k) {
           const Staged& st = w.st[k];
@@ -1419,6 +1513,7 @@ int main(int argc, char** argv) {
           for (size_t h = 0; h < st.hits.size(); ++h, ++q) { if (b_new[q]) ++nv_pass; else ++nv_red; }
           classify(nv_pass, nv_red, st.nv_valid);
         }
+        if (sw.on) { px[4] += tsec(k1, k2); px[5] += tsec(k2, k3); px[6] += tsec(k3, tnow()); }
         if (sw.on) { sw.acc[2] += std::chrono::duration<double>(k1 - k0).count(); sw.acc[5] += std::chrono::duration<double>(std::chrono::steady_clock::now() - k1).count(); }
         const bool last = w.last;
         { std::lock_guard<std::mutex> lk(w_mu); w.state = 0; }
@@ -1427,6 +1522,7 @@ int main(int argc, char** argv) {
       }
     });
     struct PipeGuard { std::mutex& mu; std::condition_variable& cv; bool& stop; std::thread &a, &b; ~PipeGuard() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); if (a.joinable()) a.join(); if (b.joinable()) b.join(); } } pipe_guard{w_mu, w_cv, w_stop, reader, sink};
+    const auto loop_t0 = tnow();
     for (int wi = 0;; wi = (wi + 1) % NW) {
       sw.start();
       { std::unique_lock<std::mutex> lk(w_mu); w_cv.wait(lk, [&] { return wins[wi].state == 1; }); }
@@ -1438,6 +1534,7 @@ int main(int argc, char** argv) {
         const double vcf_before = sw.acc[1];
         const std::chrono::steady_clock::time_point s0 = std::chrono::steady_clock::now();
         int64_t lo = INT64_MAX, hi = 0;
+        if (w.st.size() < W) w.st.resize(W);
         for (size_t k = 0; k < n; ++k) {
           w.st[k].used = false;
           if (sr.count_and_filter(w.rd[k]) && stage(w.rd[k], w.st[k])) { lo = std::min(lo, w.st[k].ibeg); hi = std::max(hi, w.st[k].ibeg + w.st[k].nbuf); }
@@ -1451,12 +1548,21 @@ int main(int argc, char** argv) {
       w_cv.notify_all();
       if (last_window) break;
     }
+    const auto loop_t1 = tnow();
     sink.join();                                                  // (the guard then finds both threads finished)
     reader.join();
+    std::thread([](Window* w) { delete[] w; }, wins_owner.release()).detach();
+    if (sw.on) notice("scan threads: reader waited %.3f s, sliced records %.3f s, parsed %.3f s; sink waited %.3f s, assembled %.3f s, stored %.3f s, classified %.3f s; set-up %.3f s, in-order loop %.3f s, drain %.3f s",
+                      px[0], px[1], px[2], px[3], px[4], px[5], px[6], tsec(scan_t0, loop_t0), tsec(loop_t0, loop_t1), tsec(loop_t1, tnow()));
   }
   if (n_warn_u > 10) notice("WARNING: Suppressed a total of %d UMI warnings...", n_warn_u);
   if (n_warn_g > 10) notice("WARNING: Suppressed a total of %d droplet/cell barcode warnings...", n_warn_g);
   const double scan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - scan_t0).count();
+  if (sw.on) {
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    notice("process CPU so far: %.3f s user + %.3f s system", ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec, ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec);
+  }
   if (sw.on) notice("scan timing (%d threads, %s): total %.3f s = %.3g reads/s; alignment reader %.3f s, record parsing %.3f s, lock-step bookkeeping %.3f s, VCF reader (wait) %.3f s, overlap%s %.3f s, store batches %.3f s",
                     n_threads, windowed ? "windowed" : "read by read", scan_s, (double)sr.n_read / scan_s, sw.acc[0], sw.acc[3], sw.acc[4], sw.acc[1], windowed ? "" : " + store", sw.acc[2], sw.acc[5]);
   notice("Finished reading %d markers from the VCF file", (int)snps.size());
