@@ -314,6 +314,12 @@ struct Chunk {
 };
 using ChunkP = std::shared_ptr<Chunk>;
 
+// DMX_CLI_TIMING: CPU seconds (CLOCK_THREAD_CPUTIME_ID) spent inside the parallel sections, summed over their worker threads
+std::atomic<int64_t> g_cpu_ns[4];                    // 0 inflate, 1 record parsing, 2 overlap
+static const bool g_cpu_on = getenv("DMX_CLI_TIMING") != nullptr;
+inline int64_t thread_cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec; }
+struct CpuScope { int i; int64_t t0; explicit CpuScope(int i_) : i(i_), t0(g_cpu_on ? thread_cpu_ns() : 0) {} ~CpuScope() { if (g_cpu_on) g_cpu_ns[i] += thread_cpu_ns() - t0; } };
+
 struct BgzfPipe {
   FILE* fp = nullptr;
   std::thread producer;
@@ -398,7 +404,7 @@ struct BgzfPipe {
         batch->n = off[n];
         const int nt = (int)std::min<size_t>((size_t)nthreads, n);
         std::atomic<size_t> next{0};
-        auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < n;) inflate_block(blocks[i], batch->p.get() + off[i]); };
+        auto work = [&]() { CpuScope cs(0); for (size_t i; (i = next.fetch_add(1)) < n;) inflate_block(blocks[i], batch->p.get() + off[i]); };
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(work);
         work();
@@ -1456,6 +1462,7 @@ int main(int argc, char** argv) {
         while (w.n < W) { if (!sr.next_raw(w.rd[w.n], &w.keep)) { w.last = true; break; } ++w.n; }
         const auto r2 = tnow();
         parallel_for(w.n, [&](size_t a, size_t b, int slot) {
+          CpuScope cs(1);
           std::unordered_map<std::string, int32_t>& dict = slot_dict[(size_t)slot];
           for (size_t k = a; k < b; ++k) {
             Read& r = w.rd[k];
@@ -1486,6 +1493,7 @@ int main(int argc, char** argv) {
         const std::chrono::steady_clock::time_point k0 = std::chrono::steady_clock::now();
         if (sw.on) px[3] += tsec(q0, k0);
         parallel_for(n, [&](size_t a, size_t b, int) {
+          CpuScope cs(2);
           for (size_t k = a; k < b; ++k) if (w.st[k].used) overlap(w.rd[k], w.st[k], w.snps.data() - w.snp_lo);
         });
         const std::chrono::steady_clock::time_point k1 = std::chrono::steady_clock::now();
@@ -1561,7 +1569,8 @@ int main(int argc, char** argv) {
   if (sw.on) {
     struct rusage ru;
     getrusage(RUSAGE_SELF, &ru);
-    notice("process CPU so far: %.3f s user + %.3f s system", ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec, ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec);
+    notice("process CPU so far: %.3f s user + %.3f s system; inside the parallel sections: inflate %.3f s, record parsing %.3f s, overlap %.3f s", ru.ru_utime.tv_sec + 1e-6 * ru.ru_utime.tv_usec, ru.ru_stime.tv_sec + 1e-6 * ru.ru_stime.tv_usec,
+           1e-9 * g_cpu_ns[0].load(), 1e-9 * g_cpu_ns[1].load(), 1e-9 * g_cpu_ns[2].load());
   }
   if (sw.on) notice("scan timing (%d threads, %s): total %.3f s = %.3g reads/s; alignment reader %.3f s, record parsing %.3f s, lock-step bookkeeping %.3f s, VCF reader (wait) %.3f s, overlap%s %.3f s, store batches %.3f s",
                     n_threads, windowed ? "windowed" : "read by read", scan_s, (double)sr.n_read / scan_s, sw.acc[0], sw.acc[3], sw.acc[4], sw.acc[1], windowed ? "" : " + store", sw.acc[2], sw.acc[5]);
