@@ -4424,7 +4424,10 @@ int launch_doublet(dmx_engine* e) {
     return launch_doublet_generic_w<true>(e);
   }
   // wide panels: the class kernel's LDS grows by 32 bytes per sample, the general A = 2 kernel's by 384 (64 KB at V = 128)
-  if (A != 2 || force_generic || V > (use_cls ? 1024 : 128)) {
+  // (FAST on the default grid reaches 256 soft-field samples: k_doublet_sym's slabs keep their LDS flat in V)
+  const bool sym_wide = e->mode == DMX_MODE_FAST && !use_cls && A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V > 128 && V <= 256 &&
+                        !getenv("DMX_NO_SYM") && !getenv("DMX_NO_SYM_WIDE");
+  if (A != 2 || force_generic || (V > (use_cls ? 1024 : 128) && !sym_wide)) {
     HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     if (int rc = launch_doublet_generic_w<false>(e)) return rc;
     HIP_TRY(hipGetLastError());
@@ -4493,7 +4496,7 @@ int launch_doublet(dmx_engine* e) {
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
                      e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);                                   \
   } while (0)
-  if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 128 && !getenv("DMX_NO_SYM")) {
+  if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && (V <= 128 || sym_wide) && !getenv("DMX_NO_SYM")) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do {                                                                                                                \
@@ -4544,24 +4547,25 @@ int launch_doublet(dmx_engine* e) {
     else if (V <= 48) DMX_K2S(256, 48, 8, false);
     else if (V <= 64) { if (V == 64) DMX_K2S(256, 64, 8, true); else DMX_K2S(256, 64, 8, false); }
     else {
-      // 64 < V <= 128: the entry list (V (V/2 + 1) + V, up to 8 448) in slabs of 9 entries per lane
+      // 64 < V <= 256: the entry list (V (V/2 + 1) + V, up to 33 280) in slabs of 9 entries per lane
       const unsigned ns = (unsigned)((V * (V / 2 + 1) + V + 256 * 9 - 1) / (256 * 9));
-#define DMX_K2SS(VMAX, FIX)                                                                                            \
+#define DMX_K2SS(VMAX, SUB, FIX)                                                                                       \
   do {                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1;                                                  \
-    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)2 * 8 * GSS_ * 4 + (size_t)8 * 3 * VUS_ * 8; \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, 8, FIX, 3, 9>),                \
+    constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)2 * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, SUB, FIX, 3, 9>),              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, 8, FIX, 3, 9, false>),         \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, SUB, FIX, 3, 9, false>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
     if (e->geno_safe)                                                                                                  \
-      hipLaunchKernelGGL((k_doublet_sym<256, VMAX, 8, FIX, 3, 9, false>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
+      hipLaunchKernelGGL((k_doublet_sym<256, VMAX, SUB, FIX, 3, 9, false>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
                          e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);      \
     else                                                                                                               \
-    hipLaunchKernelGGL((k_doublet_sym<256, VMAX, 8, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv,   \
+    hipLaunchKernelGGL((k_doublet_sym<256, VMAX, SUB, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
                        e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);        \
   } while (0)
-      if (V <= 96) DMX_K2SS(96, false); else if (V == 128) DMX_K2SS(128, true); else DMX_K2SS(128, false);
+      if (V <= 96) DMX_K2SS(96, 8, false); else if (V == 128) DMX_K2SS(128, 8, true); else if (V < 128) DMX_K2SS(128, 8, false);
+      else if (V <= 192) DMX_K2SS(192, 4, false); else DMX_K2SS(256, 4, false);        // (sub-tiles of 4 pairs: 40 / 53 KB of LDS per workgroup)
 #undef DMX_K2SS
     }
 #undef DMX_K2SV
@@ -4951,7 +4955,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   else {
     // worth it when an engine has more than ~0.15 s of kernels ahead of it (at ~6e11 evaluations/s; FAST evaluates the printed
     // entries only): the host then writes range r and stages r + 2 while the GPU computes r + 1
-    const bool sym = job->mode == DMX_MODE_FAST && A == 2 && job->alpha[0] == 0.0 && job->alpha[1] == 0.5 && V <= 128;
+    const bool sym = job->mode == DMX_MODE_FAST && A == 2 && job->alpha[0] == 0.0 && job->alpha[1] == 0.5 && V <= 256;
     const double evals = (double)(V + 1) + (doublet_ok ? (sym ? (double)V + 0.5 * V * (V + 1) : (double)nAB) : 0.0);
     if (doublet_ok && (double)pl.n_pairs * evals / ngpu > 0.15 * 6e11 && B / ngpu >= 8 * 1024) by_overlap = 4;
   }
