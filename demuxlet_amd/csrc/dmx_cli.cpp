@@ -320,6 +320,51 @@ static const bool g_cpu_on = getenv("DMX_CLI_TIMING") != nullptr;
 inline int64_t thread_cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000 + ts.tv_nsec; }
 struct CpuScope { int i; int64_t t0; explicit CpuScope(int i_) : i(i_), t0(g_cpu_on ? thread_cpu_ns() : 0) {} ~CpuScope() { if (g_cpu_on) g_cpu_ns[i] += thread_cpu_ns() - t0; } };
 
+// The host's worker threads, shared by every parallel section of the scan (BGZF inflate, record parsing, read x SNP overlap): a section
+// posts a job, the posting thread works on it too, and idle workers join the oldest job that still wants hands.  Several sections
+// run at the same time (the stages of the pipeline work on different windows); with one pool the process stays at n_threads busy
+// threads instead of creating ~1 800 short-lived ones per 2e6 reads.
+struct WorkerPool {
+  struct Job { std::function<void(int)> fn; int want = 0, taken = 0, done = 0; bool closed = false; };
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<std::shared_ptr<Job>> jobs;
+  int n_workers = 0;
+  static WorkerPool& get() { static WorkerPool* p = new WorkerPool(cli_threads() - 1); return *p; }   // (never destroyed: workers sleep until exit)
+  explicit WorkerPool(int n) : n_workers(std::max(0, n)) {
+    for (int i = 0; i < n_workers; ++i) std::thread([this] { loop(); }).detach();
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      std::shared_ptr<Job> j;
+      for (auto& q : jobs) if (!q->closed && q->taken < q->want) { j = q; break; }
+      if (!j) { cv_work.wait(lk); continue; }
+      const int slot = ++j->taken;               // the poster is slot 0
+      lk.unlock();
+      j->fn(slot);
+      lk.lock();
+      ++j->done;
+      cv_done.notify_all();
+    }
+  }
+  // fn(slot) on the calling thread (slot 0) and on up to `helpers` workers (slots 1..helpers); returns when all of them returned.
+  // fn is expected to pull its work items off a shared counter: a worker that joins late simply finds nothing left.
+  void run(int helpers, const std::function<void(int)>& fn) {
+    helpers = std::min(helpers, n_workers);
+    if (helpers <= 0) { fn(0); return; }
+    auto j = std::make_shared<Job>();
+    j->fn = fn; j->want = helpers;
+    { std::lock_guard<std::mutex> lk(mu); jobs.push_back(j); }
+    cv_work.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(mu);
+    j->closed = true;
+    for (auto it = jobs.begin(); it != jobs.end(); ++it) if (*it == j) { jobs.erase(it); break; }
+    cv_done.wait(lk, [&] { return j->done == j->taken; });
+  }
+};
+
 struct BgzfPipe {
   FILE* fp = nullptr;
   std::thread producer;
@@ -404,11 +449,7 @@ struct BgzfPipe {
         batch->n = off[n];
         const int nt = (int)std::min<size_t>((size_t)nthreads, n);
         std::atomic<size_t> next{0};
-        auto work = [&]() { CpuScope cs(0); for (size_t i; (i = next.fetch_add(1)) < n;) inflate_block(blocks[i], batch->p.get() + off[i]); };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work);
-        work();
-        for (std::thread& t : pool) t.join();
+        WorkerPool::get().run(nt - 1, [&](int) { CpuScope cs(0); for (size_t i; (i = next.fetch_add(1)) < n;) inflate_block(blocks[i], batch->p.get() + off[i]); });
         for (size_t i = 0; i < n; ++i) if (err.empty() && !blocks[i].err.empty()) { err = blocks[i].err; blocks[i].err.clear(); }
         { std::lock_guard<std::mutex> lk(io_mu); rb[bi].state = 0; }
         io_cv.notify_all();
@@ -886,7 +927,9 @@ struct VcfReader {
 struct Read {
   // One alignment.  The record's bytes stay where the reader put them (a reused buffer): sequence and qualities are
   // decoded per queried base (a read overlaps 0-2 SNPs), names and tags are views into the record.
-  std::string cb, ub;           // group / UMI tag values (copied: the store and the warnings want C strings)
+  std::string cb, ub;           // group / UMI tag values of a SAM line (not NUL-terminated there: copied) ...
+  const char* cb_p = ""; const char* ub_p = "";   // ... and where they are: in cb / ub (SAM) or inside the BAM record (NUL-terminated Z fields)
+  size_t cb_n = 0, ub_n = 0;
   bool has_cb = false, has_ub = false;
   int64_t endpos_c = 0;         // SamReader::endpos(*this), and the barcode as (worker slot, id in that slot's dictionary): filled by the
   int32_t cb_slot = -1, cb_lid = -1;   // parallel record parsing of the windowed scan, so that the in-order stage need not hash strings
@@ -1015,6 +1058,7 @@ struct SamReader {
       if (!t) break;
       q = t + 1;
     }
+    r.cb_p = r.cb.c_str(); r.cb_n = r.cb.size(); r.ub_p = r.ub.c_str(); r.ub_n = r.ub.size();
     return true;
   }
 
@@ -1081,8 +1125,8 @@ struct SamReader {
         if (!nul) fatal("[E:%s] corrupt BAM record: unterminated %c%c:%c aux field", __func__, t0, t1, ty);
         len = (size_t)((const char*)nul - s) + 1;
         if (ty == 'Z') {
-          if (gtag[0] && t0 == gtag[0] && t1 == gtag[1]) { r.cb = s; r.has_cb = true; }
-          if (utag[0] && t0 == utag[0] && t1 == utag[1]) { r.ub = s; r.has_ub = true; }
+          if (gtag[0] && t0 == gtag[0] && t1 == gtag[1]) { r.cb_p = s; r.cb_n = len - 1; r.has_cb = true; }
+          if (utag[0] && t0 == utag[0] && t1 == utag[1]) { r.ub_p = s; r.ub_n = len - 1; r.has_ub = true; }
         }
       } else if (ty == 'A' || ty == 'c' || ty == 'C') len = 1;
       else if (ty == 's' || ty == 'S') len = 2;
@@ -1332,7 +1376,7 @@ int main(int argc, char** argv) {
       ibcd = dmx_store_add_cell(scl, ".");
     } else {
       const char* sbcd = ".";
-      if (rd.has_cb) sbcd = rd.cb.c_str();
+      if (rd.has_cb) sbcd = rd.cb_p;
       else {
         if (n_warn_g < 10) notice("WARNING: Cannot find Droplet/Cell tag %s from %lld-th read %s at %s:%lld-%lld. Treating all of them as a single group", o.tag_group.c_str(), (long long)sr.n_read, rd.qname().c_str(), sr.targets[(size_t)rd.tid].c_str(), (long long)rd.pos, (long long)endpos);
         else if (n_warn_g == 10) notice("WARNING: Suppressing 10+ missing Droplet/Cell tag warnings...");
@@ -1357,7 +1401,7 @@ int main(int argc, char** argv) {
     // UMI (:272-293)
     st.umi_in_read = false;
     if (o.tag_umi.empty()) { char b[32]; snprintf(b, sizeof b, "%x", rand()); st.umi.assign("."); st.umi += b; }
-    else if (rd.has_ub) { if (windowed) st.umi_in_read = true; else st.umi = rd.ub; }
+    else if (rd.has_ub) { if (windowed) st.umi_in_read = true; else st.umi.assign(rd.ub_p, rd.ub_n); }
     else {
       st.umi.assign(".");
       if (n_warn_u < 10) notice("WARNING: Cannot find UMI tag %s from %lld-th read %s at %s:%lld-%lld. Treating all of them as a single UMI", o.tag_umi.c_str(), (long long)sr.n_read, rd.qname().c_str(), sr.targets[(size_t)rd.tid].c_str(), (long long)rd.pos, (long long)endpos);
@@ -1418,16 +1462,49 @@ int main(int argc, char** argv) {
       if (T <= 1) { fn(0, n, 0); return; }
       std::atomic<size_t> next{0};
       const size_t step = std::max<size_t>(256, n / (T * 8));
-      auto work = [&](int slot) { for (size_t a; (a = next.fetch_add(step)) < n;) fn(a, std::min(n, a + step), slot); };
-      std::vector<std::thread> th;
-      for (size_t t = 1; t < T; ++t) th.emplace_back(work, (int)t);
-      work(0);
-      for (std::thread& x : th) x.join();
+      WorkerPool::get().run((int)T - 1, [&](int slot) { for (size_t a; (a = next.fetch_add(step)) < n;) fn(a, std::min(n, a + step), slot); });
     };
     // barcode dictionaries of the parsing workers (slot -> barcode -> id in the slot) and, owned by the in-order stage, what each of
     // those ids is in the store: -1 not seen yet, -2 not in --group-list.  dmx_store_add_cell is then called once per (slot, barcode),
     // at the barcode's first read in BAM order as before.
-    std::vector<std::unordered_map<std::string, int32_t>> slot_dict((size_t)n_threads);
+    // (open addressing over the barcodes' bytes: one probe and one memcmp per read, no node to chase)
+    struct BcDict {
+      std::vector<uint32_t> slot;                // 0 = empty, else id + 1
+      std::vector<uint64_t> key_off;             // id -> offset of its bytes in pool
+      std::vector<uint32_t> key_len;
+      std::vector<uint64_t> key_hash;
+      std::string pool;
+      size_t mask = 0;
+      static uint64_t hash(const char* p, size_t n) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xFF51AFD7ED558CCDull);
+        while (n >= 8) { uint64_t w; memcpy(&w, p, 8); h = (h ^ w) * 0xC4CEB9FE1A85EC53ull; h ^= h >> 29; p += 8; n -= 8; }
+        uint64_t w = 0;
+        memcpy(&w, p, n);
+        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+        return h ^ (h >> 32);
+      }
+      void grow() {
+        const size_t cap = slot.empty() ? 1024 : slot.size() * 2;
+        slot.assign(cap, 0); mask = cap - 1;
+        for (size_t id = 0; id < key_off.size(); ++id) { size_t i = key_hash[id] & mask; while (slot[i]) i = (i + 1) & mask; slot[i] = (uint32_t)id + 1; }
+      }
+      int32_t intern(const char* p, size_t n) {
+        if (key_off.size() * 2 >= slot.size()) grow();
+        const uint64_t h = hash(p, n);
+        for (size_t i = h & mask;; i = (i + 1) & mask) {
+          const uint32_t v = slot[i];
+          if (!v) {
+            slot[i] = (uint32_t)key_off.size() + 1;
+            key_off.push_back(pool.size()); key_len.push_back((uint32_t)n); key_hash.push_back(h);
+            pool.append(p, n);
+            return (int32_t)key_off.size() - 1;
+          }
+          const size_t id = v - 1;
+          if (key_hash[id] == h && key_len[id] == n && memcmp(pool.data() + key_off[id], p, n) == 0) return (int32_t)id;
+        }
+      }
+    };
+    std::vector<BcDict> slot_dict((size_t)n_threads);
     std::vector<std::vector<int32_t>> slot_cell((size_t)n_threads);
     slot_cell_p = &slot_cell;
     // Three threads work on consecutive windows at the same time:
@@ -1463,16 +1540,14 @@ int main(int argc, char** argv) {
         const auto r2 = tnow();
         parallel_for(w.n, [&](size_t a, size_t b, int slot) {
           CpuScope cs(1);
-          std::unordered_map<std::string, int32_t>& dict = slot_dict[(size_t)slot];
+          BcDict& dict = slot_dict[(size_t)slot];
           for (size_t k = a; k < b; ++k) {
             Read& r = w.rd[k];
             sr.parse_raw(r);
             r.endpos_c = SamReader::endpos(r);
             r.cb_slot = -1;
             if (r.has_cb && !o.tag_group.empty()) {
-              auto it = dict.find(r.cb);
-              if (it == dict.end()) it = dict.emplace(r.cb, (int32_t)dict.size()).first;
-              r.cb_slot = slot; r.cb_lid = it->second;
+              r.cb_slot = slot; r.cb_lid = dict.intern(r.cb_p, r.cb_n);
             }
           }
         });
@@ -1503,9 +1578,10 @@ int main(int argc, char** argv) {
           const Staged& st = w.st[k];
           if (!st.used || st.hits.empty()) continue;
           const uint64_t off = b_pool.size();
-          const std::string& umi = st.umi_in_read ? w.rd[k].ub : st.umi;
-          b_pool.append(umi);
-          for (const Hit& h : st.hits) { b_snp.push_back(h.snp); b_cell.push_back(st.ibcd); b_off.push_back(off); b_len.push_back((uint32_t)umi.size()); b_al.push_back(h.allele); b_bq.push_back(h.bq); }
+          const char* umi_p = st.umi_in_read ? w.rd[k].ub_p : st.umi.data();
+          const size_t umi_n = st.umi_in_read ? w.rd[k].ub_n : st.umi.size();
+          b_pool.append(umi_p, umi_n);
+          for (const Hit& h : st.hits) { b_snp.push_back(h.snp); b_cell.push_back(st.ibcd); b_off.push_back(off); b_len.push_back((uint32_t)umi_n); b_al.push_back(h.allele); b_bq.push_back(h.bq); }
         }
         b_new.assign(b_snp.size(), 0);
         b_pool.push_back('\0');
