@@ -23,7 +23,7 @@ DMX_ENGINE_NO_CERTIFY = 1
 
 # every symbol include/dmx.h declares (tests/test_abi.py checks the header against this list and the .so against both)
 SYMBOLS = [
-    "dmx_abi_version", "dmx_last_error", "dmx_phred_tables", "dmx_geno_from_gt", "dmx_geno_from_pl", "dmx_geno_from_gp",
+    "dmx_abi_version", "dmx_last_error", "dmx_device_warm_up", "dmx_phred_tables", "dmx_geno_from_gt", "dmx_geno_from_pl", "dmx_geno_from_gp",
     "dmx_store_new", "dmx_store_free", "dmx_store_add_snp", "dmx_store_add_cell", "dmx_store_count_read",
     "dmx_store_add_read", "dmx_store_n_cells", "dmx_store_n_snps", "dmx_store_barcode", "dmx_store_freeze",
     "dmx_engine_create", "dmx_engine_destroy", "dmx_engine_set_stream", "dmx_engine_set_phred_tables",

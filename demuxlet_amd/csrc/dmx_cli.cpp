@@ -1289,6 +1289,11 @@ int main(int argc, char** argv) {
   const int n_threads = cli_threads();
   const bool windowed = n_threads > 1 && !getenv("DMX_SCAN_SEQUENTIAL");
   Stopwatch sw;
+  // the HIP context(s) the job will run on come up while the scan runs (0.12-0.13 s that dmx_demuxlet_run would otherwise wait for);
+  // a failure here is not reported: dmx_demuxlet_run meets the same condition and reports it
+  std::thread warm;
+  if (!o.pileup_only && !getenv("DMX_NO_WARM_UP")) warm = std::thread([&o] { dmx_device_warm_up(o.gpu, o.gpus); });
+  struct WarmGuard { std::thread& t; ~WarmGuard() { if (t.joinable()) t.join(); } } warm_guard{warm};
   const std::chrono::steady_clock::time_point scan_t0 = std::chrono::steady_clock::now();
 
   // variants in file order, parsed ahead by a producer thread in the windowed mode; each comes with the contig names its vr.read call registered

@@ -3861,6 +3861,23 @@ int upload(dmx_engine* e, const void* host, size_t count, void** slot, const T**
 
 }  // namespace
 
+namespace { __global__ void k_noop() {} }
+
+extern "C" int dmx_device_warm_up(int32_t device, int32_t n_gpus) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return set_error(DMX_ERR_NOGPU, "dmx_device_warm_up: no HIP device is visible (this library has no CPU fallback)");
+  if (device < 0 || device >= ndev) return set_error(DMX_ERR_ARG, "dmx_device_warm_up: device %d of %d", device, ndev);
+  for (int i = 0; i < std::max(1, std::min(n_gpus, ndev)); ++i) {
+    HIP_TRY(hipSetDevice((device + i) % ndev));
+    HIP_TRY(hipFree(nullptr));                   // (creates the primary context)
+    hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, nullptr);     // (loads this library's code object onto the device)
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  return DMX_OK;
+}
+
 extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out) {
   if (!cfg || !out) return set_error(DMX_ERR_ARG, "dmx_engine_create: null argument");
   if (cfg->n_samples < 1 || cfg->n_samples > 4094) return set_error(DMX_ERR_ARG, "dmx_engine_create: n_samples %d not in [1,4094]", cfg->n_samples);

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 4   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times (additions only: a caller of ABI 3 runs unchanged) */
+#define DMX_ABI_VERSION 5   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up (additions only: a caller of ABI 3 runs unchanged) */
 
 typedef enum {
   DMX_OK = 0,
@@ -293,6 +293,10 @@ typedef struct dmx_job_timing {
   int32_t n_ranges, n_engines, n_cells_grid_fetched, reserved;
 } dmx_job_timing;
 int dmx_demuxlet_run(const dmx_job*);
+/* Creates the HIP contexts of devices (device + i) mod (visible devices), i < n_gpus (n_gpus <= 0: one), and returns.  Optional: the first
+ * job of a process otherwise pays this (0.12-0.13 s) inside dmx_demuxlet_run; a caller that still has host work to do (the `demuxlet`
+ * binary: the BAM x VCF scan, cmd_cram_demuxlet.cpp:195-338) calls it on a thread of its own first.  Thread-safe. */
+int dmx_device_warm_up(int32_t device, int32_t n_gpus);
 
 #ifdef __cplusplus
 }
