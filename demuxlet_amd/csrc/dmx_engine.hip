@@ -2482,6 +2482,16 @@ __global__ void k_build_classes(const float* __restrict__ g, int32_t S, int32_t 
   atomicMax(max_cls, over ? kMaxCls + 1 : n);
 }
 
+// base + byte BYTE of w in ONE VALU instruction (SDWA operand select; the compiler emits v_bfe_u32 + v_add for the same expression)
+template <int BYTE> __device__ __forceinline__ uint32_t add_byte_of(uint32_t base, uint32_t w) {
+  uint32_t r;
+  if constexpr (BYTE == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(base), "v"(w));
+  else if constexpr (BYTE == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(base), "v"(w));
+  else if constexpr (BYTE == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(base), "v"(w));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(w));
+  return r;
+}
+
 // K2 over genotype classes (A = 2).  Same ownership and order as k_doublet_a2; per tile of 32 pairs:
 //   stage    headers, the pairs' class rows (4 x 3 float32) and per-sample class ids (V bytes) -> LDS
 //   phase 1  pG[n][3][3] per (pair, alpha) and the llks00 term, exactly as k_doublet_a2
@@ -2617,7 +2627,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
 #pragma unroll
       for (int i = 0; i < NRR; ++i) { const int e = tid + TPC * i; if (e < TP * 12) s_rows[e] = d_rows[i]; }
 #pragma unroll
-      for (int i = 0; i < NRI; ++i) { const int e = tid + TPC * i; if (e < TP * wpr) reinterpret_cast<uint32_t*>(s_ids)[e] = d_ids[i]; }
+      for (int i = 0; i < NRI; ++i) { const int e = tid + TPC * i; if (e < TP * wpr) reinterpret_cast<uint32_t*>(s_ids)[e] = d_ids[i] << 4; }   // (ids staged as byte offsets of 16-byte table cells)
       rd4_cur = d_rd4; g0_cur[0] = d_g0[0]; g0_cur[1] = d_g0[1]; g0_cur[2] = d_g0[2];
       publish_next();
       load_hdr(tbase + 2 * TP);
@@ -2642,7 +2652,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
         const uint8_t* src = ids + (size_t)s_snp[ti] * V + wq * 4;
         uint32_t wv = 0;
         for (int b = 0; b < 4; ++b) if (wq * 4 + b < V) wv |= (uint32_t)src[b] << (8 * b);
-        reinterpret_cast<uint32_t*>(s_ids)[ti * wpr + wq] = wv;
+        reinterpret_cast<uint32_t*>(s_ids)[ti * wpr + wq] = wv << 4;           // class id c (0..3) as c * 16: the byte offset of T[cj][c]
       }
     }
     }
@@ -2747,24 +2757,28 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
     if (owner) {
       for (int ti = 0; ti < tp; ++ti) {
         const uint8_t* idr = &s_ids[ti * VS];
-        const int cj = idr[j];
+        const int cj = idr[j] >> 4;
         const double* Tj = &s_T[ti * NT + cj * 8];
+        typedef double dmx_d2v __attribute__((ext_vector_type(2)));
+        using lds_c2 = const __attribute__((address_space(3))) dmx_d2v*;
+        const uint32_t tj_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)Tj;   // LDS byte address of T[cj][0]
         if (NK >= 4) {                            // class ids of the k-block, four per 32-bit LDS read (VS is padded to 4)
 #pragma unroll
           for (int kq = 0; kq < NK / 4; ++kq) {
             const uint32_t w4 = reinterpret_cast<const uint32_t*>(idr)[(kb * NK) / 4 + kq];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const double2 tv = *reinterpret_cast<const double2*>(&Tj[((w4 >> (8 * b)) & 3u) * 2]);
-              acc[kq * 4 + b][0] += tv.x;                                        // :683, alpha 0
-              acc[kq * 4 + b][1] += tv.y;                                        //       alpha 1
-            }
+            // address = row + byte b of the id word: one v_add_u32 with an SDWA byte select (the ids were staged as c * 16)
+            const dmx_d2v t0 = *(lds_c2)(uintptr_t)add_byte_of<0>(tj_a, w4), t1 = *(lds_c2)(uintptr_t)add_byte_of<1>(tj_a, w4),
+                          t2 = *(lds_c2)(uintptr_t)add_byte_of<2>(tj_a, w4), t3 = *(lds_c2)(uintptr_t)add_byte_of<3>(tj_a, w4);
+            acc[kq * 4 + 0][0] += t0.x; acc[kq * 4 + 0][1] += t0.y;             // :683, alpha 0 / alpha 1
+            acc[kq * 4 + 1][0] += t1.x; acc[kq * 4 + 1][1] += t1.y;
+            acc[kq * 4 + 2][0] += t2.x; acc[kq * 4 + 2][1] += t2.y;
+            acc[kq * 4 + 3][0] += t3.x; acc[kq * 4 + 3][1] += t3.y;
           }
         } else {
 #pragma unroll
           for (int kk = 0; kk < NK; ++kk) {
             const int k = min(kb * NK + kk, V - 1);
-            const double2 tv = *reinterpret_cast<const double2*>(&Tj[idr[k] * 2]);
+            const dmx_d2v tv = *(lds_c2)(uintptr_t)(tj_a + idr[k]);
             acc[kk][0] += tv.x;
             acc[kk][1] += tv.y;
           }
