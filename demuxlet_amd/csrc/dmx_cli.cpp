@@ -54,10 +54,15 @@ void warning(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
   fprintf(stderr, "\n");
 }
+std::thread g_warm_up;       // dmx_device_warm_up beside the scan (main): exit() must not run the HIP runtime's handlers under its feet
 [[noreturn]] void fatal(const char* fmt, ...) {
+  static std::atomic<bool> dying{false};
+  if (dying.exchange(true)) for (;;) std::this_thread::sleep_for(std::chrono::seconds(1));   // a second thread's error: the first one is on its way out
   fprintf(stderr, "\nFATAL ERROR - \n");
   va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap);
   fprintf(stderr, "\n\n");
+  fflush(stderr);
+  if (g_warm_up.joinable() && std::this_thread::get_id() != g_warm_up.get_id()) g_warm_up.join();
   exit(EXIT_FAILURE);      // the reference throws an uncaught exception here (Error.cpp:39): abnormal termination either way
 }
 
@@ -1291,9 +1296,8 @@ int main(int argc, char** argv) {
   Stopwatch sw;
   // the HIP context(s) the job will run on come up while the scan runs (0.12-0.13 s that dmx_demuxlet_run would otherwise wait for);
   // a failure here is not reported: dmx_demuxlet_run meets the same condition and reports it
-  std::thread warm;
-  if (!o.pileup_only && !getenv("DMX_NO_WARM_UP")) warm = std::thread([&o] { dmx_device_warm_up(o.gpu, o.gpus); });
-  struct WarmGuard { std::thread& t; ~WarmGuard() { if (t.joinable()) t.join(); } } warm_guard{warm};
+  if (!o.pileup_only && !getenv("DMX_NO_WARM_UP")) g_warm_up = std::thread([&o] { dmx_device_warm_up(o.gpu, o.gpus); });
+  struct WarmGuard { ~WarmGuard() { if (g_warm_up.joinable()) g_warm_up.join(); } } warm_guard;
   const std::chrono::steady_clock::time_point scan_t0 = std::chrono::steady_clock::now();
 
   // variants in file order, parsed ahead by a producer thread in the windowed mode; each comes with the contig names its vr.read call registered
