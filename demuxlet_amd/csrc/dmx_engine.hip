@@ -2498,7 +2498,11 @@ template <int BYTE> __device__ __forceinline__ uint32_t add_byte_of(uint32_t bas
 //   phase 1b the class table T[pair][cj][ck][n] = log(sum_lm row_cj[l] row_ck[m] pG[n][l][m]) — the very expression of
 //            :553,:677-683 on the very operands, once per distinct (cj, ck)
 //   phase 2  thread (j, k-block): acc[j][k][n] += T[pair][id_j][id_k][n], pairs in ascending SNP order
-template <int TPC, int NK, int MINW = 1>
+// UJ ("uniform j", panels of 33..64 samples): a wavefront owns a block of 16 samples j and its lanes are the samples k, so that the
+// class of j is the same for the whole wavefront at every pair.  A lane reads its COLUMN T[0..3][ck] of the pair's table into sixteen
+// consecutive registers and the row is chosen by VGPR-relative addressing (s_set_gpr_idx_on: the source register of the two v_add_f64
+// is offset by 4 cj dwords) — no look-up, no address arithmetic and no branch per (j, k): two FP64 adds and two scalar instructions.
+template <int TPC, int NK, int MINW = 1, bool UJ = false>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                           const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
                                                           const double* __restrict__ tabs, const double* __restrict__ alpha,
@@ -2553,11 +2557,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
   const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
   int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
 
+  static_assert(!UJ || (TPC == 256 && NK == 16 && MINW <= 2), "the uniform-j form: four wavefronts x 16 samples j, 64 lanes = samples k; registers v[232:247] are its column");
   const int KB = (V + NK - 1) / NK;
   const int JS = TPC / KB;                       // rows per workgroup; more rows => j-slabs over blockIdx.y (see k_doublet_a2)
   const int jl = tid / KB, kb = tid % KB;
   const int j = (int)blockIdx.y * JS + jl;
-  const bool owner = jl < JS && j < V;
+  const int uj_k = tid & 63, uj_jb = tid >> 6;   // UJ: lane = sample k, wavefront = samples j in [16 uj_jb, 16 uj_jb + 16)
+  const bool owner = UJ ? (uj_k < V && uj_jb * 16 < V) : (jl < JS && j < V);
   double acc[NK][A];
 #pragma unroll
   for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
@@ -2754,6 +2760,56 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
     }
     DMX_K2_SYNC();
     // ---- phase 2: one lookup and two adds per (j, k)
+    if (UJ) {
+      if (owner) {
+        typedef uint32_t dmx_u4 __attribute__((ext_vector_type(4)));
+        using lds_u4 = const __attribute__((address_space(3))) dmx_u4*;
+        const uint32_t t_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)s_T;
+        const uint32_t id_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t*)s_ids;
+        for (int ti = 0; ti < tp; ++ti) {
+          // the 16 classes of the wavefront's samples j (bytes c * 16, one broadcast read) into scalar registers
+          const dmx_u4 jw = *(lds_u4)(uintptr_t)(id_a + (uint32_t)(ti * VS + uj_jb * 16));
+          const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.y),
+                         w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.z), w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.w);
+          // this lane's column of the pair's table: T[cj][ck] for cj = 0..3 (rows 64 bytes apart), ck = the class of sample k
+          const uint32_t col = t_a + (uint32_t)(ti * NT * 8) + (uint32_t)s_ids[ti * VS + uj_k];
+          // One asm statement per pair: the column into v[232:247] (T[c] = v[232 + 4c : 235 + 4c]: alpha 0, alpha 1), then per j
+          // "index = 4 cj" (s_bfe_u32 takes bits 2..5 of the staged byte c * 16) and the two adds with SRC0 relative to it.
+#define DMX_UJ_STEP(A0, A1, W, B)                                                                              \
+          "s_bfe_u32 %[t], %[" W "], " B "\n\ts_set_gpr_idx_on %[t], 0x1\n\t"                                  \
+          "v_add_f64 %[" A0 "], v[232:233], %[" A0 "]\n\tv_add_f64 %[" A1 "], v[234:235], %[" A1 "]\n\t"
+          {
+            uint32_t tmp;
+            asm volatile(
+                "ds_read_b128 v[232:235], %[col]\n\tds_read_b128 v[236:239], %[col] offset:64\n\t"
+                "ds_read_b128 v[240:243], %[col] offset:128\n\tds_read_b128 v[244:247], %[col] offset:192\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                DMX_UJ_STEP("a0", "b0", "w0", "0x40002") DMX_UJ_STEP("a1", "b1", "w0", "0x4000a")
+                DMX_UJ_STEP("a2", "b2", "w0", "0x40012") DMX_UJ_STEP("a3", "b3", "w0", "0x4001a")
+                DMX_UJ_STEP("a4", "b4", "w1", "0x40002") DMX_UJ_STEP("a5", "b5", "w1", "0x4000a")
+                DMX_UJ_STEP("a6", "b6", "w1", "0x40012") DMX_UJ_STEP("a7", "b7", "w1", "0x4001a")
+                DMX_UJ_STEP("a8", "b8", "w2", "0x40002") DMX_UJ_STEP("a9", "b9", "w2", "0x4000a")
+                DMX_UJ_STEP("a10", "b10", "w2", "0x40012") DMX_UJ_STEP("a11", "b11", "w2", "0x4001a")
+                DMX_UJ_STEP("a12", "b12", "w3", "0x40002") DMX_UJ_STEP("a13", "b13", "w3", "0x4000a")
+                DMX_UJ_STEP("a14", "b14", "w3", "0x40012") DMX_UJ_STEP("a15", "b15", "w3", "0x4001a")
+                "s_set_gpr_idx_off"
+                : [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]), [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
+                  [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]), [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
+                  [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]), [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]),
+                  [a6] "+v"(acc[6][0]), [b6] "+v"(acc[6][1]), [a7] "+v"(acc[7][0]), [b7] "+v"(acc[7][1]),
+                  [a8] "+v"(acc[8][0]), [b8] "+v"(acc[8][1]), [a9] "+v"(acc[9][0]), [b9] "+v"(acc[9][1]),
+                  [a10] "+v"(acc[10][0]), [b10] "+v"(acc[10][1]), [a11] "+v"(acc[11][0]), [b11] "+v"(acc[11][1]),
+                  [a12] "+v"(acc[12][0]), [b12] "+v"(acc[12][1]), [a13] "+v"(acc[13][0]), [b13] "+v"(acc[13][1]),
+                  [a14] "+v"(acc[14][0]), [b14] "+v"(acc[14][1]), [a15] "+v"(acc[15][0]), [b15] "+v"(acc[15][1]),
+                  [t] "=&s"(tmp)
+                : [col] "v"(col), [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3)
+                : "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245",
+                  "v246", "v247", "m0", "scc", "memory");
+          }
+#undef DMX_UJ_STEP
+        }
+      }
+    } else
     if (owner) {
       for (int ti = 0; ti < tp; ++ti) {
         const uint8_t* idr = &s_ids[ti * VS];
@@ -2788,6 +2844,18 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
     DMX_K2_SYNC();
   }
   if (cell_ok) {
+    if (UJ) {
+      if (owner) {
+#pragma unroll
+        for (int jj = 0; jj < 16; ++jj) {
+          const int jx = uj_jb * 16 + jj;
+          if (jx < V) {
+            double* o = grid + (((size_t)cell * V + jx) * V + uj_k) * A;
+            o[0] = acc[jj][0]; o[1] = acc[jj][1];
+          }
+        }
+      }
+    } else
     if (owner) {
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
@@ -4507,6 +4575,7 @@ int launch_doublet(dmx_engine* e) {
     else if (V <= 32) DMX_K2C(256, 4);
     else if (getenv("DMX_CLS_MINW3")) DMX_K2C(256, 16, 3);    // kernel experiments only (36 spills: slower)
     else if (getenv("DMX_CLS_NK8")) { if (atoi(getenv("DMX_CLS_NK8")) == 3) DMX_K2C(256, 8, 3); else DMX_K2C(256, 8); }
+    else if (V <= 64 && !getenv("DMX_CLS_NO_UJ")) DMX_K2C(256, 16, 2, true);   // uniform-j form (a wavefront's 16 samples j share their class per pair)
     else DMX_K2C(256, 16);
 #undef DMX_K2C
     HIP_TRY(hipGetLastError());
