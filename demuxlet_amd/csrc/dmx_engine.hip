@@ -2510,6 +2510,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
                                                           double* __restrict__ grid, double* __restrict__ l00,
                                                           uint8_t* __restrict__ flagged) {
   constexpr int A = 2, TP = 32;
+  constexpr int ablate = DMX_ABLATE;             // profiling builds only (tools/build_variant.sh); 0 in the product
   constexpr int CPW = kThreads / TPC;
   constexpr int T00 = TP + 2;
   constexpr int NT = kMaxCls * kMaxCls * A;      // class-table entries per pair
@@ -2663,7 +2664,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
     }
     }
     // ---- phase 1 (identical to k_doublet_a2)
-    if (tid < 64) {
+    if (tid < 64 && !(ablate & 4096)) {
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
@@ -2742,7 +2743,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
       }
     }
     // ---- phase 1b: the class table
-    for (int e = tid; e < tp * NT; e += TPC) {
+    for (int e = tid; e < ((ablate & 2048) ? 0 : tp * NT); e += TPC) {
       const int ti = e / NT, cc = e % NT;
       const int cj = cc >> 3, ck = (cc >> 1) & 3, n = cc & 1;
       const float* rj = &s_rows[ti * 12 + cj * 3];
@@ -2761,7 +2762,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
     DMX_K2_SYNC();
     // ---- phase 2: one lookup and two adds per (j, k)
     if (UJ) {
-      if (owner) {
+      if (owner && !(ablate & 1024)) {
         typedef uint32_t dmx_u4 __attribute__((ext_vector_type(4)));
         using lds_u4 = const __attribute__((address_space(3))) dmx_u4*;
         const uint32_t t_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)s_T;
