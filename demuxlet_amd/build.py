@@ -41,7 +41,8 @@ CLI_SRC = CSRC / "dmx_cli.cpp"
 
 def build_cli(force: bool = False, verbose: bool = False) -> Path:
     """The `demuxlet` command-line front end (host C++ only; links libdmx.so and zlib)."""
-    if not force and CLI.exists() and CLI.stat().st_mtime >= max(CLI_SRC.stat().st_mtime, LIB.stat().st_mtime):
+    deps = [CLI_SRC, CSRC / "dmx_inflate.hpp", ROOT / "include" / "dmx.h", LIB]
+    if not force and CLI.exists() and CLI.stat().st_mtime >= max(p.stat().st_mtime for p in deps):
         return CLI
     cmd = [hipcc(), "-O2", "-std=c++17", "-Wall", "-x", "c++", f"-I{ROOT / 'include'}", str(CLI_SRC), "-o", str(CLI),
            f"-L{PKG}", "-ldmx", "-lz", "-Wl,-rpath,$ORIGIN"]
