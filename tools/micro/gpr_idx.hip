@@ -45,6 +45,15 @@ __global__ __launch_bounds__(256) void k_time(const double* in, double* out, int
                    "s_set_gpr_idx_off\n\t"
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [t] "=&s"(tmp) : [w] "s"(w), "v"(t0), "v"(t1)
                    : "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "m0", "scc");
+    else if (MODE == 3)   // the index written into M0 directly (its bits 15:12 carry the mode: the images come with 0x1000 set)
+      asm volatile("s_set_gpr_idx_on %[w], 0x1\n\t"
+                   "s_or_b32 m0, %[w], 0x1000\n\tv_add_f64 %0, v[200:201], %0\n\tv_add_f64 %1, v[202:203], %1\n\t"
+                   "s_or_b32 m0, %[w], 0x1000\n\tv_add_f64 %2, v[200:201], %2\n\tv_add_f64 %3, v[202:203], %3\n\t"
+                   "s_or_b32 m0, %[w], 0x1000\n\tv_add_f64 %4, v[200:201], %4\n\tv_add_f64 %5, v[202:203], %5\n\t"
+                   "s_or_b32 m0, %[w], 0x1000\n\tv_add_f64 %6, v[200:201], %6\n\tv_add_f64 %7, v[202:203], %7\n\t"
+                   "s_set_gpr_idx_off\n\t"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [t] "=&s"(tmp) : [w] "s"(w), "v"(t0), "v"(t1)
+                   : "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "m0", "scc");
     else
       asm volatile("s_set_gpr_idx_on %[w], 0x1\n\t"
                    "s_bfe_u32 %[t], %[w], 0x20000\n\ts_set_gpr_idx_idx %[t]\n\tv_add_f64 %0, v[200:201], %0\n\tv_add_f64 %1, v[202:203], %1\n\t"
@@ -89,9 +98,9 @@ int main() {
   printf("index mode selects the right registers: %s\n", bad ? "NO" : "yes");
   const int n = 200000;
   for (int w : {1, 2, 4}) {
-    const double c0 = run<0>(w, din, dout, n), c1 = run<1>(w, din, dout, n), c2 = run<2>(w, din, dout, n);
+    const double c0 = run<0>(w, din, dout, n), c1 = run<1>(w, din, dout, n), c2 = run<2>(w, din, dout, n), c3 = run<3>(w, din, dout, n);
     printf("%d wave(s)/SIMD: cycles per group {index change, two v_add_f64} — SIMD throughput / one wavefront's pace: adds alone %.1f / %.1f, with s_bfe + s_set_gpr_idx_on %.1f / %.1f, "
-           "with s_bfe + s_set_gpr_idx_idx %.1f / %.1f\n", w, c0, c0 * w, c1, c1 * w, c2, c2 * w);
+           "with s_bfe + s_set_gpr_idx_idx %.1f / %.1f, with one s_or_b32 into M0 %.1f / %.1f\n", w, c0, c0 * w, c1, c1 * w, c2, c2 * w, c3, c3 * w);
   }
   return bad != 0;
 }
