@@ -15,6 +15,7 @@ import os
 LIB_PATH = Path(os.environ.get("DMX_LIB", Path(__file__).resolve().parent / "libdmx.so"))   # DMX_LIB: kernel experiments only
 
 DMX_OK = 0
+DMX_ERR_ARG, DMX_ERR_HIP, DMX_ERR_STATE, DMX_ERR_IO, DMX_ERR_NOGPU, DMX_ERR_NOMEM = -1, -2, -3, -4, -5, -6   # dmx_status (include/dmx.h)
 DMX_MEM_HOST, DMX_MEM_DEVICE = 0, 1
 DMX_MODE_STRICT = 0
 DMX_MODE_FAST = 1
@@ -133,7 +134,7 @@ def load() -> C.CDLL:
     L.dmx_abi_version.restype = C.c_int
     L.dmx_last_error.restype = C.c_char_p
     sig = {
-        "dmx_phred_tables": [vp, vp], "dmx_geno_from_gt": [vp, i32, dbl, vp], "dmx_geno_from_pl": [vp, i32, vp],
+        "dmx_device_warm_up": [i32, i32], "dmx_phred_tables": [vp, vp], "dmx_geno_from_gt": [vp, i32, dbl, vp], "dmx_geno_from_pl": [vp, i32, vp],
         "dmx_geno_from_gp": [vp, i32, dbl, vp], "dmx_store_free": [vp], "dmx_store_add_snp": [vp],
         "dmx_store_add_cell": [vp, C.c_char_p], "dmx_store_count_read": [vp, i32],
         "dmx_store_add_read": [vp, i32, i32, C.c_char_p, i32, i32], "dmx_store_n_cells": [vp], "dmx_store_n_snps": [vp],

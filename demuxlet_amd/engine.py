@@ -15,6 +15,11 @@ from . import capi
 from .capi import check
 
 
+def device_warm_up(device: int = 0, n_gpus: int = 1) -> None:
+    """dmx_device_warm_up: HIP context(s) and this library's code object, ahead of the first job of the process."""
+    check(capi.load().dmx_device_warm_up(int(device), int(n_gpus)))
+
+
 def phred_tables():
     mat, err = np.zeros(256), np.zeros(256)
     check(capi.load().dmx_phred_tables(mat.ctypes.data, err.ctypes.data))

@@ -67,3 +67,16 @@ def test_product_never_touches_the_oracle():
             txt = p.read_text()
             assert "oracle_py" not in txt and "dmx_oracle" not in txt and "liboracle" not in txt, p
             assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), p
+
+
+def test_device_warm_up_without_a_gpu_reports_and_does_not_crash():
+    """dmx_device_warm_up (ABI 5) on a box without a HIP device: a negative status and a message, like every other entry point that
+    needs the GPU (this library has no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from demuxlet_amd import capi
+    lib = capi.load()
+    rc = lib.dmx_device_warm_up(0, 1)
+    assert rc < 0
+    assert b"no HIP device" in lib.dmx_last_error() or b"HIP" in lib.dmx_last_error()

@@ -824,3 +824,15 @@ def test_tie_order_certificate_agrees_with_the_host_arbiter(eng, oracle, tmp_pat
             for f in ("llk1", "llk2", "llk10", "llk20"):
                 assert abs(done[c][f] - want[f]) < 1e-9, (c, f)
     assert left <= max(1, resv.sum() // 20)
+
+
+def test_device_warm_up_on_the_gpu(eng):
+    """dmx_device_warm_up: OK for device 0 (any n_gpus: devices wrap around the visible ones), DMX_ERR_ARG for a device that is not there;
+    an engine created afterwards works as usual."""
+    from demuxlet_amd import capi
+    eng.device_warm_up(0, 1)
+    eng.device_warm_up(0, 3)
+    lib = capi.load()
+    assert lib.dmx_device_warm_up(4096, 1) == capi.DMX_ERR_ARG
+    e = eng.Engine(3, (0.0, 0.5), 0.5)
+    e.close()
