@@ -28,7 +28,7 @@ SYMBOLS = [
     "dmx_store_new", "dmx_store_free", "dmx_store_add_snp", "dmx_store_add_cell", "dmx_store_count_read",
     "dmx_store_add_read", "dmx_store_n_cells", "dmx_store_n_snps", "dmx_store_barcode", "dmx_store_freeze",
     "dmx_engine_create", "dmx_engine_destroy", "dmx_engine_set_stream", "dmx_engine_set_phred_tables",
-    "dmx_engine_set_genotypes", "dmx_engine_set_pileup", "dmx_engine_run_singlet", "dmx_engine_run_doublet",
+    "dmx_engine_set_genotypes", "dmx_engine_set_pileup", "dmx_engine_run_singlet", "dmx_engine_run_doublet", "dmx_engine_run",
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
     "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_write_doublet_summary", "dmx_debug_log_dd",
@@ -141,7 +141,7 @@ def load() -> C.CDLL:
         "dmx_store_barcode": [vp, i32], "dmx_store_freeze": [vp, vp], "dmx_engine_create": [vp, vp],
         "dmx_engine_destroy": [vp], "dmx_engine_set_stream": [vp, vp], "dmx_engine_set_phred_tables": [vp, vp, vp],
         "dmx_engine_set_genotypes": [vp, vp, i32, i32], "dmx_engine_set_pileup": [vp, vp], "dmx_engine_run_singlet": [vp],
-        "dmx_engine_run_doublet": [vp], "dmx_engine_sync": [vp], "dmx_engine_get_singlet": [vp, vp, vp],
+        "dmx_engine_run_doublet": [vp], "dmx_engine_run": [vp], "dmx_engine_sync": [vp], "dmx_engine_get_singlet": [vp, vp, vp],
         "dmx_engine_get_doublet": [vp, vp, vp, vp], "dmx_engine_device_view": [vp, vp],
         "dmx_engine_last_kernel_times": [vp, vp], "dmx_engine_algorithmic_bytes": [vp, vp],
         "dmx_write_single": [vp, C.c_char_p], "dmx_write_doublet": [vp, C.c_char_p], "dmx_demuxlet_run": [vp],

@@ -3867,6 +3867,8 @@ struct dmx_engine {
   double prior = 0.5;
   std::vector<double> alpha;
   hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t k1_stream = nullptr;               // dmx_engine_run: K1 beside K2 (lowest priority: it fills what K2's last round leaves free)
+  hipEvent_t ev_fork = nullptr, ev_k1_done = nullptr;
   double* d_lut = nullptr;
   double* d_alpha = nullptr;
   // genotypes
@@ -3981,6 +3983,13 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   e->alpha.assign(cfg->alpha, cfg->alpha + cfg->n_alpha);
   HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
+  {
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&e->k1_stream, hipStreamNonBlocking, least));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->ev_k1_done, hipEventDisableTiming));
+  }
   for (hipEvent_t& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
   for (auto& r : e->ring_s) for (hipEvent_t& ev : r) HIP_TRY(hipEventCreate(&ev));
   for (auto& r : e->ring_d) for (hipEvent_t& ev : r) HIP_TRY(hipEventCreate(&ev));
@@ -4018,6 +4027,9 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   for (auto& r : e->ring_s) for (hipEvent_t& ev : r) if (ev) (void)hipEventDestroy(ev);
   for (auto& r : e->ring_d) for (hipEvent_t& ev : r) if (ev) (void)hipEventDestroy(ev);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  if (e->k1_stream) (void)hipStreamDestroy(e->k1_stream);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_k1_done) (void)hipEventDestroy(e->ev_k1_done);
   delete e;
   return DMX_OK;
 }
@@ -4751,7 +4763,25 @@ extern "C" int dmx_engine_run_singlet(dmx_engine* e) {
   return DMX_OK;
 }
 
-extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
+namespace { int run_doublet_impl(dmx_engine* e, bool with_singlet); }
+
+extern "C" int dmx_engine_run_doublet(dmx_engine* e) { return run_doublet_impl(e, false); }
+
+// K1 and K2 -> K3 -> K3b of the staged pileup in one call.  K3 reads nothing of K1's, so K1 runs BESIDE K2 on a stream of the lowest
+// priority: K2's workgroups are dispatched first and K1 fills the slots K2 leaves free — above all during K2's last, partly filled
+// round (cfg3 FAST: 10 000 one-barcode wavefronts on 3 072 slots).  Fork and join are events on the engine's stream, so that for the
+// caller everything is ordered on that stream exactly as after run_singlet + run_doublet; the results are the same bits.
+extern "C" int dmx_engine_run(dmx_engine* e) {
+  if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_run: null engine");
+  if (e->V < 2 || e->A < 2 || getenv("DMX_NO_OVERLAP")) {
+    if (int rc = dmx_engine_run_singlet(e)) return rc;
+    return (e->V < 2 || e->A < 2) ? DMX_OK : dmx_engine_run_doublet(e);
+  }
+  return run_doublet_impl(e, true);
+}
+
+namespace {
+int run_doublet_impl(dmx_engine* e, bool with_singlet) {
   if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_run_doublet: null engine");
   if (!e->have_pileup || !e->d_g) return set_error(DMX_ERR_STATE, "dmx_engine_run_doublet: set genotypes and pileup first");
   if (e->V < 2 || e->A < 2) return set_error(DMX_ERR_ARG, "dmx_engine_run_doublet: needs >= 2 samples and >= 2 alphas (got %d, %d)", e->V, e->A);
@@ -4769,14 +4799,34 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
     HIP_TRY(hipMalloc((void**)&e->d_sing, std::max<size_t>(sizeof(double) * cap * e->V, 16)));
     e->grid_cap = (int32_t)cap;
   }
-  if (B == 0) { e->have_grid = true; return DMX_OK; }
+  if (B == 0) { e->have_grid = true; if (with_singlet) e->have_sing = true; return DMX_OK; }
   hipEvent_t* rd = e->ring_d[e->n_ring_d % dmx_engine::kRing];
+  if (with_singlet) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));       // (K1 must not start before what precedes this call on the stream)
   HIP_TRY(hipEventRecord(e->ev[4], e->stream));
   HIP_TRY(hipEventRecord(rd[0], e->stream));
   if (int rc = launch_doublet(e)) return rc;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(e->ev[5], e->stream));
   HIP_TRY(hipEventRecord(rd[1], e->stream));
+  if (with_singlet) {                            // K1, enqueued after K2, on the low-priority stream
+    hipStream_t main_stream = e->stream;
+    hipEvent_t* rs = e->ring_s[e->n_ring_s % dmx_engine::kRing];
+    HIP_TRY(hipStreamWaitEvent(e->k1_stream, e->ev_fork, 0));
+    e->stream = e->k1_stream;
+    int rc = DMX_OK;
+    hipError_t he = hipEventRecord(e->ev[2], e->stream);
+    if (he == hipSuccess) he = hipEventRecord(rs[0], e->stream);
+    if (he == hipSuccess) rc = launch_singlet(e);
+    if (he == hipSuccess && rc == DMX_OK) he = hipGetLastError();
+    if (he == hipSuccess && rc == DMX_OK) he = hipEventRecord(e->ev[3], e->stream);
+    if (he == hipSuccess && rc == DMX_OK) he = hipEventRecord(rs[1], e->stream);
+    if (he == hipSuccess && rc == DMX_OK) he = hipEventRecord(e->ev_k1_done, e->stream);
+    e->stream = main_stream;
+    if (rc != DMX_OK) return rc;
+    HIP_TRY(he);
+    ++e->n_ring_s;
+    e->timed[1] = true; e->have_sing = true;
+  }
   hipLaunchKernelGGL(k_reduce, dim3((unsigned)B), dim3(kThreads), 0, e->stream, e->d_grid, e->d_l00, e->pv.cell_pair_off,
                      e->d_alpha, e->V, e->A, e->prior, e->d_sum, e->d_sing);
   HIP_TRY(hipGetLastError());
@@ -4788,8 +4838,10 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) {
   e->ring_certified[e->n_ring_d % dmx_engine::kRing] = certify;
   ++e->n_ring_d;
   e->timed[2] = e->timed[3] = true; e->have_grid = true;
+  if (with_singlet) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_k1_done, 0));   // join: whatever follows on the stream sees K1's results
   return DMX_OK;
 }
+}  // namespace
 
 extern "C" int dmx_engine_sync(dmx_engine* e) {
   if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_sync: null engine");
@@ -5144,8 +5196,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     }
     dmx_engine* e = eng_of(r);
     if (int rc = dmx::engine_set_pileup_cells(e, &pl, sliced ? order.data() + x.lo : nullptr, nb)) return rc;
-    if (int rc = dmx_engine_run_singlet(e)) return rc;
-    if (doublet_ok) if (int rc = dmx_engine_run_doublet(e)) return rc;
+    if (doublet_ok) { if (int rc = dmx_engine_run(e)) return rc; }
+    else if (int rc = dmx_engine_run_singlet(e)) return rc;
     { std::lock_guard<std::mutex> lk(tm_mu); stage_s += secs(t0, clk::now()); }
     return DMX_OK;
   };

@@ -199,6 +199,7 @@ class Engine:
 
     def run_singlet(self) -> None: check(self._L.dmx_engine_run_singlet(self._h))
     def run_doublet(self) -> None: check(self._L.dmx_engine_run_doublet(self._h))
+    def run(self) -> None: check(self._L.dmx_engine_run(self._h))   # K1 beside K2 -> K3 -> K3b (dmx_engine_run)
     def sync(self) -> None: check(self._L.dmx_engine_sync(self._h))
 
     def get_singlet(self):

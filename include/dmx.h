@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 5   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up (additions only: a caller of ABI 3 runs unchanged) */
+#define DMX_ABI_VERSION 5   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up, dmx_engine_run (additions only: a caller of ABI 3 runs unchanged) */
 
 typedef enum {
   DMX_OK = 0,
@@ -173,6 +173,9 @@ int dmx_engine_set_pileup(dmx_engine*, const dmx_pileup*);
 int dmx_engine_run_singlet(dmx_engine*);
 /* K2 (+K3): llksAB[B][V][V][A], llks00[B][A] (:576-710) and the per-cell summaries (:713-734,:746-758,:799-828). */
 int dmx_engine_run_doublet(dmx_engine*);
+/* Both in one call (ABI 5): K1 runs beside K2 on a low-priority stream of the engine and fills the slots K2's last round leaves free; fork
+ * and join are events on the engine's stream (dmx_engine_set_stream), so the call orders like run_singlet + run_doublet.  Same bits. */
+int dmx_engine_run(dmx_engine*);
 int dmx_engine_sync(dmx_engine*);
 /* Device->host copies of the results (any pointer may be NULL). Synchronises. */
 int dmx_engine_get_singlet(dmx_engine*, double* llks, double* llk0s);

@@ -836,3 +836,35 @@ def test_device_warm_up_on_the_gpu(eng):
     assert lib.dmx_device_warm_up(4096, 1) == capi.DMX_ERR_ARG
     e = eng.Engine(3, (0.0, 0.5), 0.5)
     e.close()
+
+
+@pytest.mark.parametrize("V,field,dense,mode", [(8, "GT", True, "strict"), (12, "GP", False, "strict"), (32, "GP", True, "fast"), (64, "GT", False, "fast"),
+                                                  (48, "GT", True, "strict"), (5, "PL", False, "fast")])
+def test_run_is_singlet_and_doublet_in_one_call(eng, V, field, dense, mode):
+    """dmx_engine_run (K1 beside K2 on a low-priority stream, fork / join on the engine's stream): the same bits as run_singlet followed by
+    run_doublet, call after call, also when the two styles alternate on one engine."""
+    from demuxlet_amd import synth, capi
+    rng = np.random.default_rng(4400 + V)
+    S, B = 700, 40
+    raw = synth.make_raw_genotypes(rng, S, V)
+    if field == "GT":
+        g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    elif field == "GP":
+        g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+    else:
+        g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, raw.alleles)])
+    sp = synth.make_pileup(rng, raw.alleles, B, 1.0 if dense else 0.3, 1.5, dense_layout=dense, doublet_rate=0.3)
+    e = eng.Engine(V, (0.0, 0.5), 0.5, mode=capi.DMX_MODE_FAST if mode == "fast" else capi.DMX_MODE_STRICT)
+    e.set_genotypes(g); e.set_pileup(host_pileup(eng, sp))
+    e.run_singlet(); e.run_doublet()
+    want = (e.get_singlet(), e.get_doublet())
+    for _ in range(3):
+        e.run()
+        got = (e.get_singlet(), e.get_doublet())
+        for a, b in zip(want[0] + want[1], got[0] + got[1]):
+            assert np.array_equal(a, b) if a.dtype.names is None else a.tobytes() == b.tobytes()
+    e.run_singlet(); e.run_doublet()
+    again = (e.get_singlet(), e.get_doublet())
+    for a, b in zip(want[0] + want[1], again[0] + again[1]):
+        assert a.tobytes() == b.tobytes()
+    e.close()

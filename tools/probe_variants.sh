@@ -5,5 +5,5 @@ spec=$1; shift
 for v in "$@"; do
   [ "$v" = "-" ] && v=""
   env $v python bench.py --config $spec --only --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); k=d['fp64_valu']['kernel_ms']; print('cfg $spec | $v |', round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items() if not a.startswith('torch')})"
+import json,sys; d=json.loads(sys.stdin.read()); k=d['fp64_valu']['kernel_ms']; print('cfg $spec | $v |', round(d['ms_per_step'],2), {a: round(b,2) for a,b in k.items() if isinstance(b,(int,float)) and not isinstance(b,bool) and not a.startswith('torch')})"
 done
