@@ -381,12 +381,20 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
     # per-kernel times: the engine brackets every launch of K1, K2, K3 and K3b with HIP events on the stream it launches on
     # (dmx_engine_mean_kernel_times: mean over the timed launches, at most the last 16); torch's events on the same stream give
     # the K1 and K2 + K3 + K3b spans as a cross-check
+    if beside:
+        # K1 ran beside K2 in the timed steps (the product's way, dmx_engine_run): its event span is mostly waiting and K2's contains what
+        # K1 took from it.  The per-kernel figures below (and the roofline of the dominant kernel ALONE) come from two extra, untimed steps
+        # with the kernels one after the other.
+        eng.reset_kernel_times()
+        for _ in range(2):
+            eng.run_singlet(); eng.run_doublet()
+        torch.cuda.synchronize()
     km = eng.mean_kernel_times()
     k1_ms = float(km.singlet_ms)
     k2_only_ms = float(km.doublet_ms) if cfg["doublet"] else 0.0
     k3_ms, k3b_ms = (float(km.reduce_ms), float(km.certify_ms)) if cfg["doublet"] else (0.0, 0.0)
     k1_span_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
-    k2_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if cfg["doublet"] else 0.0      # K2 + K3 + K3b
+    k2_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if cfg["doublet"] else 0.0      # K2 + K3 + K3b (beside: K1 as well)
     gather_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs])) if cx.use_dist else 0.0
     out = None
     if rank == 0:
@@ -461,9 +469,10 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                           "kernel_ms": {"k_singlet": k1_ms, "k_doublet": k2_only_ms, "k_reduce": k3_ms, "k_certify": k3b_ms,
                                         "torch_events_k_singlet": k1_span_ms, "torch_events_k_doublet+k_reduce+k_certify": k2_ms,
                                         "k1_beside_k2": beside,
-                                        "note": ("K1 runs BESIDE K2 on a low-priority stream (dmx_engine_run): k_singlet is its event span, i.e. mostly the time it "
-                                                 "waited for slots K2 left free, and the torch span 'k_doublet+k_reduce+k_certify' covers K1 as well; "
-                                                 "DMX_NO_OVERLAP=1 runs them one after the other") if beside else "kernels one after the other"},
+                                        "note": ("the timed steps run K1 BESIDE K2 on a low-priority stream (dmx_engine_run, what dmx_demuxlet_run does): the torch "
+                                                 "span 'k_doublet+k_reduce+k_certify' of those steps covers K1 as well; k_singlet / k_doublet / k_reduce / k_certify are "
+                                                 "the engine's event times of two extra, untimed steps with the kernels one after the other (each kernel alone); "
+                                                 "DMX_NO_OVERLAP=1 times the steps that way too") if beside else "kernels one after the other"},
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }
         if world > 1 or cx.use_dist:
