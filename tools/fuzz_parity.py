@@ -69,10 +69,23 @@ for case in range(n_cases):
             bad_idx += int(summ[c][f] != want[f])
         bad_idx += int({int(summ[c]["j_best"]), int(summ[c]["k_best"])} != {int(want["j_best"]), int(want["k_best"])})   # K3b may order the pair
         want_ref = summary_from_grid(ref.llksAB[c], ref.llks00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)    # ... and the calls are the oracle's
-        bad_idx += int((summ[c]["i_sing1"], summ[c]["i_sing2"], summ[c]["n_best"]) != (want_ref["i_sing1"], want_ref["i_sing2"], want_ref["n_best"]))
-        bad_idx += int({int(summ[c]["j_best"]), int(summ[c]["k_best"])} != {int(want_ref["j_best"]), int(want_ref["k_best"])})
+        # ... unless K3 flagged the decision as a near-tie (another candidate within 1e-7): those go to the host arbiter, which evaluates
+        # them with the host's libm — a 1-ulp difference between dmx_log and libm may name either candidate here (seen: seed 9334, case 368:
+        # 7 SNPs, two samples with the same genotypes, all alphas of their doublet equal to the last bit)
+        if not (summ[c]["flags"] & 2):
+            bad_idx += int((summ[c]["i_sing1"], summ[c]["i_sing2"]) != (want_ref["i_sing1"], want_ref["i_sing2"]))
+        if not (summ[c]["flags"] & 1):
+            bad_idx += int(summ[c]["n_best"] != want_ref["n_best"])
+            bad_idx += int({int(summ[c]["j_best"]), int(summ[c]["k_best"])} != {int(want_ref["j_best"]), int(want_ref["k_best"])})
         if summ[c]["flags"] & 4:                                                             # certified: the oracle's order and bits
             bad_idx += int((summ[c]["j_best"], summ[c]["k_best"]) != (want_ref["j_best"], want_ref["k_best"])) + int(summ[c]["llk12"] != want_ref["llk12"])
+    if bad_idx and os.environ.get("DMX_FUZZ_VERBOSE"):
+        for c in np.nonzero(proc)[0][:8]:
+            want = summary_from_grid(grid[c], l00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)
+            want_ref = summary_from_grid(ref.llksAB[c], ref.llks00[c], alphas, 0.5, int(summ[c]["n_pairs"]), summ.dtype)
+            fields = ("i_sing1", "i_sing2", "j_best", "k_best", "n_best", "flags", "llk12", "sing_llk1", "sing_llk2")
+            print("  cell", c, "device", {f: summ[c][f] for f in fields}, "\n    from device grid", {f: want[f] for f in fields}, "\n    from oracle grid", {f: want_ref[f] for f in fields},
+                  "\n    max |grid - oracle| of the cell", np.abs(grid[c] - ref.llksAB[c]).max(), flush=True)
     worst_all = max(worst_all, d)
     print(f"case {case:3d}: V={V:3d} A={A} {field} dense={int(dense)} B={B:2d} S={S:3d} rbar={rbar:4.2f} alphas[0]={alphas[0]:.2f}: max|d|={d:.2e} idx_mismatch={bad_idx}", flush=True)
     if not (d < 1e-9) or bad_idx:
