@@ -14,6 +14,16 @@ nested records under "also", cfg3 in FAST mode, cfg2 (singlet-only), cfg5 (spars
 N > 1 line — ALL of cfg4 (100k barcodes x 100k SNPs x 64 samples, 1e10 covered pairs, 22.5 GB of pileup) on this one GPU in
 both modes, each timed the same way with fewer steps.  `--only` skips them.
 
+Output contract: stdout carries exactly ONE compact JSON line (< 6 KB: the driver's keys, `config`, `roofline`, `roofline_valu`,
+`cpu_baseline` and one short object per nested configuration under `also`; no prose).  The full record (every per-kernel time, the
+executed-flop figures, end-to-end stage seconds, sample descriptions) is written to `bench_full.json` beside this file (path in
+DMX_BENCH_FULL) and to stderr.
+
+`--gpus N` is what decides the number of ranks.  Launched plainly (`python bench.py --gpus N`, no WORLD_SIZE in the environment) with
+N > 1, this script checks that N GPUs are visible and re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1`; launched by torchrun, `--gpus` must equal WORLD_SIZE.  Every rank then checks that RCCL's
+world size is N and that the N ranks sit on N distinct devices; anything else exits non-zero with a message.
+
 N > 1: BASELINE.json configs[3] = cfg4 (100k barcodes x 100k SNPs x 64 samples, GT), STRONG scaling: the 100k barcodes are cut
 into N contiguous equal ranges (barcodes are independent, cmd_cram_demuxlet.cpp:576; dense pileup = equal work), rank r
 generates and owns range r, and every step ends with THE one collective of the job: the RCCL gather of the fixed-size
@@ -52,6 +62,7 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 T
 FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector peak (spec; half the 157.3 TF FP32 vector rate), FMA = 2 flop
 SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 VALU_PEAK_WAVE_INSTS = SIMDS * CLOCK_HZ / 4   # FP64 wave64 instructions/s: 16 FP64 lanes/clk per SIMD (= 78.6 TF / 128)
+LOG_FP64_INSTS = 11          # FP64 instructions of one dmx_log evaluation (csrc/dmx_log.hpp)
 METRIC = "cell-SNP-sample triples/sec (singlet+doublet llk); HBM GB/s vs roofline"
 
 
@@ -111,10 +122,10 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
     pairs_per_cell = max(1.0, dp.n_pairs / max(dp.n_cells, 1))
     n = int(max(1, min(dp.n_cells, round(target_s / (1e-9 * ns_per_pair * pairs_per_cell)))))
     t, pairs = execute(prepare(0, n))
+    # oracle/dmx_oracle.c, gcc -O2 -ffp-contract=off: a CSR walk of the reference's arithmetic — the reference's own std::map walk is
+    # slower (see reference_slice below), so this baseline is conservative
     out = dict(value=pairs * V / t, unit="cell-SNP-sample triples/s", cores=1, kind="port",
-               sample=f"first {n} barcodes of the same workload ({pairs} covered pairs), oracle/dmx_oracle.c "
-                      f"(gcc -O2 -ffp-contract=off; a CSR walk of the reference's arithmetic — the reference's own std::map walk "
-                      f"is slower, so this baseline is conservative), {t:.1f} s wall", seconds=t)
+               sample=f"first {n} barcodes of the same workload ({pairs} covered pairs), oracle/dmx_oracle.c on 1 thread, {t:.1f} s", seconds=t)
     if cfg["doublet"]:
         out["pair_evals_per_s"] = pairs * V * V * A / t
     ref = reference_slice_leg(dp, g, cfg)
@@ -243,6 +254,7 @@ def pmc_profile(cfgno, B, mode, dense):
             pj = json.loads(p.read_text())
             if pj.get("mode", "strict") != mode or not pj.get("barcodes_per_gpu"):
                 continue
+            pj["counts_file"] = f"profiles/{name}"
             if pj["barcodes_per_gpu"] == B:
                 return pj
             if dense:
@@ -379,23 +391,29 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
         total_pairs = float(dp.n_pairs)
 
     # per-kernel times: the engine brackets every launch of K1, K2, K3 and K3b with HIP events on the stream it launches on
-    # (dmx_engine_mean_kernel_times: mean over the timed launches, at most the last 16); torch's events on the same stream give
-    # the K1 and K2 + K3 + K3b spans as a cross-check
-    if beside:
-        # K1 ran beside K2 in the timed steps (the product's way, dmx_engine_run): its event span is mostly waiting and K2's contains what
-        # K1 took from it.  The per-kernel figures below (and the roofline of the dominant kernel ALONE) come from two extra, untimed steps
-        # with the kernels one after the other.
-        eng.reset_kernel_times()
-        for _ in range(2):
-            eng.run_singlet(); eng.run_doublet()
-        torch.cuda.synchronize()
+    # (dmx_engine_mean_kernel_times: mean over the TIMED launches, at most the last 16); torch's events on the same stream give
+    # the K1 and K2 + K3 + K3b spans as a cross-check.  The roofline of the dominant kernel uses these timed-launch means.
     km = eng.mean_kernel_times()
     k1_ms = float(km.singlet_ms)
     k2_only_ms = float(km.doublet_ms) if cfg["doublet"] else 0.0
     k3_ms, k3b_ms = (float(km.reduce_ms), float(km.certify_ms)) if cfg["doublet"] else (0.0, 0.0)
+    alone = None
+    if beside:
+        # K1 ran beside K2 in the timed steps (the product's way, dmx_engine_run): K1's own event span is mostly waiting and K2's
+        # contains what K1 took from it.  Two extra, untimed steps with the kernels one after the other give each kernel ALONE
+        # (full record only: `kernel_ms_alone`).
+        eng.reset_kernel_times()
+        for _ in range(2):
+            eng.run_singlet(); eng.run_doublet()
+        torch.cuda.synchronize()
+        ka = eng.mean_kernel_times()
+        alone = {"k_singlet": float(ka.singlet_ms), "k_doublet": float(ka.doublet_ms), "k_reduce": float(ka.reduce_ms), "k_certify": float(ka.certify_ms)}
+        k1_ms = alone["k_singlet"]                      # K1's timed-launch span is not a kernel time when it runs beside K2
     k1_span_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     k2_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) if cfg["doublet"] else 0.0      # K2 + K3 + K3b (beside: K1 as well)
     gather_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in evs])) if cx.use_dist else 0.0
+    # seconds of K1 + K2 + K3 + K3b per step: the torch span of the timed steps (beside: one span covers all four)
+    kernels_s = ((k1_span_ms if beside else k1_ms) + k2_ms) * 1e-3
     out = None
     if rank == 0:
         if cx.use_dist and gathered is not None:
@@ -404,33 +422,28 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
         ms_per_step = 1e3 * elapsed / steps
         dom_ms, dom_bytes, dom_name = (k2_only_ms, nbytes.doublet_bytes, "k_doublet") if cfg["doublet"] else (k1_ms, nbytes.singlet_bytes, "k_singlet")
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        traffic, valu = None, None
+        traffic, valu, counts_file = None, None, None
         pj = pmc_profile(cfgno, B, mode, cfg["delta"] >= 1.0)
         if pj:
-            traffic = pj.get("hbm_bytes_per_launch")
+            traffic, counts_file = pj.get("hbm_bytes_per_launch"), pj.get("counts_file")
             if pj.get("issue_cycles_per_launch"):
-                # issue-cycle roofline: every wave64 VALU instruction occupies its SIMD's issue port for 4 cycles (FP64 and
-                # transcendental) or 2 cycles (FP32 / int / convert / move: MI355X_MICROARCH.md "v_fma_f32 (wave64) 2 cyc");
+                # issue-cycle roofline (the binding one, SURVEY 8d / DESIGN 6): every wave64 VALU instruction holds its SIMD's issue
+                # port for 4 cycles (FP64, transcendental) or 2 (the rest) -> `frac`; `frac_measured_costs` prices the non-FP64
+                # instructions at their measured average cost in this kernel's loops (tools/micro/valu_rate.hip, tools/isa_mix.py);
                 # 1024 SIMDs x 2.4 GHz cycles are available per second.  Counts per launch from profiles/ PMC, time live.
                 rate = pj["issue_cycles_per_launch"] / (dom_ms * 1e-3)
                 valu = {"bound": "valu_issue", "achieved": rate, "peak": SIMDS * CLOCK_HZ, "unit": "SIMD issue cycles/s",
-                        "frac": rate / (SIMDS * CLOCK_HZ), "kernel": pj.get("kernel"), "counts_scaled_from_barcodes": pj.get("scaled_from_barcodes"),
+                        "frac": rate / (SIMDS * CLOCK_HZ), "kernel": pj.get("kernel"), "counts": counts_file,
+                        "counts_scaled_from_barcodes": pj.get("scaled_from_barcodes"),
                         "fp64_insts_per_launch": pj.get("fp64_insts_per_launch"), "other_valu_insts_per_launch": pj.get("other_valu_insts_per_launch"),
                         "upper_bound_all_insts_at_4_cycles": pj.get("valu_wave_insts_per_launch", 0) / (dom_ms * 1e-3) / VALU_PEAK_WAVE_INSTS,
                         "frac_measured_costs": (pj["issue_cycles_measured_costs_per_launch"] / (dom_ms * 1e-3) / (SIMDS * CLOCK_HZ)
                                                 if pj.get("issue_cycles_measured_costs_per_launch") else None),
-                        "cycles_per_other_valu_inst": pj.get("cycles_per_other_valu_inst"),
-                        "note": "the binding roofline of this path (SURVEY 8d): VALU issue. issue cycles = 4 x (FP64 + transcendental wave-"
-                                "instructions) + 2 x (all other VALU wave-instructions), per-type counts from profiles/ PMC.  frac_measured_costs prices "
-                                "the other instructions at their MEASURED average issue cost in this kernel's loops (tools/micro/valu_rate.hip: "
-                                "three-source integer ops, conversions, compares, v_mov_b64, DPP hold the port 4 cycles like FP64; tools/isa_mix.py) "
-                                "and is the better estimate; both are against the nominal 2.4 GHz"}
+                        "cycles_per_other_valu_inst": pj.get("cycles_per_other_valu_inst")}
             elif pj.get("valu_wave_insts_per_launch"):
-                rate = pj["valu_wave_insts_per_launch"] / (dom_ms * 1e-3)
+                rate = pj["valu_wave_insts_per_launch"] / (dom_ms * 1e-3)       # every VALU instruction charged 4 cycles: an upper bound
                 valu = {"bound": "valu_issue", "achieved": rate, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave-instructions/s",
-                        "frac": rate / VALU_PEAK_WAVE_INSTS, "kernel": pj.get("kernel"),
-                        "note": "UPPER bound on FP64-pipe utilisation: every VALU instruction charged 4 cycles (SQ_INSTS_VALU also counts "
-                                "2-cycle int/FP32/convert instructions); instruction count per launch from profiles/ PMC, time live"}
+                        "frac": rate / VALU_PEAK_WAVE_INSTS, "kernel": pj.get("kernel"), "counts": counts_file}
         logs = total_pairs * ((V + 1) + (V * V * A + A if cfg["doublet"] else 0))
         # GT inputs run the genotype-class kernels (log once per distinct class pair) and FAST evaluates the printed entries only:
         # both EXECUTE fewer logs / flops than the reference's count.  For them only executed figures are put against the machine
@@ -438,41 +451,38 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
         reduced = fast or cfg["field"] == "GT"
         executed = None
         if pj and pj.get("fp64_fma_per_launch") is not None:
+            # EXECUTED FP64 flop of the dominant kernel: PMC per-type wave-instruction counts x 64 lanes, FMA = 2, over its live event time
             ex_flop = 64.0 * (2 * pj["fp64_fma_per_launch"] + pj["fp64_mul_per_launch"] + pj["fp64_add_per_launch"] + pj.get("fp64_trans_per_launch", 0.0))
             executed = {"kernel": pj.get("kernel"), "fp64_flop_per_launch": ex_flop, "tflops": ex_flop / (dom_ms * 1e-3) / 1e12,
-                        "frac_of_peak": ex_flop / (dom_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                        "note": "EXECUTED FP64 flop of the dominant kernel (PMC per-type wave-instruction counts x 64 lanes, FMA = 2) over its live "
-                                "HIP-event time; STRICT forbids FMA in the nine-term sums, so <= 0.5 of peak is structural there"}
+                        "frac_of_peak": ex_flop / (dom_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}
         out = {
             "metric": METRIC,
             "value": triples * steps / elapsed, "unit": "triples/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["name"] + (" [DMX_MODE_FAST]" if fast else ""), "barcodes_total": B_total, "barcodes_per_gpu": B,
-                       "snps": S, "samples": V, "alphas": list(cfg["alphas"]),
+            "config": {"workload": cfg["name"] + (" [DMX_MODE_FAST]" if fast else ""), "tag": f"cfg{cfgno}/{mode}", "barcodes_total": B_total,
+                       "barcodes_per_gpu": B, "snps": S, "samples": V, "alphas": list(cfg["alphas"]),
                        "covered_pairs_per_gpu": dp.n_pairs, "reads_per_gpu": dp.n_reads, "mode": mode,
                        "sharding": (f"{B_total} barcodes cut into {world} contiguous ranges, one per GPU (strong scaling); "
                                     f"one RCCL gather of {max(counts)} x {record_matrix().shape[1] * 8} B records per rank per step")
                        if world > 1 else "single GPU"},
+            # HBM fraction as the metric asks (the path is VALU-issue bound, SURVEY 8d: see roofline_valu).  kernel_ms = mean HIP-event
+            # time of the dominant kernel over the TIMED launches (the engine's own events on the launch stream); traffic = PMC
+            # FETCH_SIZE x2 + WRITE_SIZE of one launch of this workload, from the committed pass named in `counts`
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
-                         "kernel_ms": dom_ms,
-                         "note": "VALU-issue/log-bound path (SURVEY §8d): HBM fraction is reported as the metric asks; see roofline_valu. "
-                                 "kernel_ms = mean HIP-event time of the dominant kernel ALONE over the timed launches (engine's own events on "
-                                 "the launch stream); traffic = PMC FETCH_SIZE x2 + WRITE_SIZE of one launch at this size (profiles/)"},
+                         "kernel_ms": dom_ms, "counts": counts_file},
             "roofline_valu": valu,
-            "fp64_valu": {"logical_log_terms_per_s": logs / world / (((k1_span_ms if beside else k1_ms) + k2_ms) * 1e-3),
-                          "logical_note": "the REFERENCE's count of log() evaluations for this workload (P*(V+1) + P*(V*V*A+A)) over K1 + K2 + K3 + K3b time"
-                                          + ("; this configuration executes fewer (genotype classes / FAST entry set)" if reduced else ""),
+            # logical = the REFERENCE's count of log() evaluations for this workload (P*(V+1) + P*(V*V*A+A)) over K1 + K2 + K3 + K3b time;
+            # GT inputs and FAST execute fewer (genotype classes / printed-entry set)
+            "fp64_valu": {"logical_log_terms_per_s": logs / world / kernels_s,
+                          "executes_fewer_logs_than_logical": reduced,
                           "executed": executed,
                           "kernel_ms": {"k_singlet": k1_ms, "k_doublet": k2_only_ms, "k_reduce": k3_ms, "k_certify": k3b_ms,
                                         "torch_events_k_singlet": k1_span_ms, "torch_events_k_doublet+k_reduce+k_certify": k2_ms,
-                                        "k1_beside_k2": beside,
-                                        "note": ("the timed steps run K1 BESIDE K2 on a low-priority stream (dmx_engine_run, what dmx_demuxlet_run does): the torch "
-                                                 "span 'k_doublet+k_reduce+k_certify' of those steps covers K1 as well; k_singlet / k_doublet / k_reduce / k_certify are "
-                                                 "the engine's event times of two extra, untimed steps with the kernels one after the other (each kernel alone); "
-                                                 "DMX_NO_OVERLAP=1 times the steps that way too") if beside else "kernels one after the other"},
+                                        "k1_beside_k2": beside},
+                          "kernel_ms_alone": alone,
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }
         if world > 1 or cx.use_dist:
@@ -492,21 +502,22 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                 engine.check(engine.capi.load().dmx_debug_log_rate(which, 4096, local, ctypes.byref(r)))
                 rates.append(r.value)
             out["log_microkernel"] = {"dmx_log_per_s": rates[0], "ocml_log_per_s": rates[1]}
-            # ALGORITHMIC FP64 rate against the 78.6 TF vector peak, log() costed as 1 op and as C_log ops, where
-            # C_log = (peak wave-instructions/s x 64 lanes) / measured dmx_log/s issue slots, 2 flop each.  Only where the kernels
-            # execute the reference's count (soft fields, STRICT): elsewhere these fractions would exceed 1 without meaning it.
+            # ALGORITHMIC FP64 rate against the 78.6 TF vector peak, log() costed as 1 op and as C_log flop.  C_log is
+            # what dmx_log executes per evaluation (csrc/dmx_log.hpp: LOG_FP64_INSTS FP64 instructions, each priced as an FMA = 2
+            # flop; the integer argument reduction is not FP64 work).  The microkernel's rate stays in the record as the device's
+            # log()/s ceiling, but it is latency-bound and is NOT used to price a log.  Only where the kernels
+            # execute the reference's count (soft fields, STRICT): elsewhere the fractions would exceed 1 without meaning it.
             rbar = dp.n_reads / max(dp.n_pairs, 1)
             ops1 = dp.n_pairs * ((rbar * 11 + 8 + V * 7 + 7) + ((rbar * A * 54 + A * 18 + V * V * A * 20 + A * 20) if cfg["doublet"] else 0))
-            c_log = VALU_PEAK_WAVE_INSTS * 64 / rates[0] * 2
-            secs = (k1_ms + k2_ms) * 1e-3
+            c_log = 2.0 * LOG_FP64_INSTS
             out["fp64_valu"]["c_log_flops"] = c_log
             if not reduced:
                 out["log_microkernel"]["path_logs_over_dmx_log_ceiling"] = out["fp64_valu"]["logical_log_terms_per_s"] / rates[0]
-                out["fp64_valu"].update({"algorithmic_tflops_log_as_1_op": ops1 / secs / 1e12,
-                                         "algorithmic_tflops_log_as_c_log": (ops1 + logs * (c_log - 1)) / secs / 1e12,
-                                         "frac_of_peak_log_as_c_log": (ops1 + logs * (c_log - 1)) / secs / 1e12 / FP64_VALU_PEAK_TFLOPS})
+                out["fp64_valu"].update({"algorithmic_tflops_log_as_1_op": ops1 / kernels_s / 1e12,
+                                         "algorithmic_tflops_log_as_c_log": (ops1 + logs / world * (c_log - 1)) / kernels_s / 1e12,
+                                         "frac_of_peak_log_as_c_log": (ops1 + logs / world * (c_log - 1)) / kernels_s / 1e12 / FP64_VALU_PEAK_TFLOPS})
             else:
-                out["fp64_valu"]["logical_tflops_log_as_1_op"] = ops1 / secs / 1e12
+                out["fp64_valu"]["logical_tflops_log_as_1_op"] = ops1 / kernels_s / 1e12
         if with_e2e and cfg["doublet"]:
             # The same workload through the one-call C-ABI entry (dmx_demuxlet_run: frozen host pileup -> H2D -> K1/K2/K3(+K3b) ->
             # tie arbiter -> .single/.sing2/.best), stage seconds from dmx_job_timing.  Outside the timed region; host -> device
@@ -541,13 +552,133 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
     return out
 
 
+def sig(x, n=6):
+    """floats to n significant digits (the stdout line is compact; the full record keeps every digit)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if np.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [sig(v, n) for v in x]
+    return x
+
+
+def pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+
+def compact_line(full):
+    """The ONE stdout line: the driver's keys + config + roofline + roofline_valu + cpu_baseline + a ~200-byte object per nested
+    configuration.  No prose.  Everything else is in the full record (bench_full.json, stderr)."""
+    line = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                       "dtype", "data", "pair_evals_per_s", "ranks_seen", "per_rank_ms_per_step", "gather_ms"))
+    line["vs_baseline"] = None
+    line["config"] = pick(full["config"], ("workload", "tag", "barcodes_total", "barcodes_per_gpu", "snps", "samples", "alphas",
+                                            "covered_pairs_per_gpu", "reads_per_gpu", "mode"))
+    line["config"]["sharding"] = f"{full['n_gpus']} contiguous barcode ranges + one RCCL gather per step" if full["n_gpus"] > 1 else "single GPU"
+    line["roofline"] = pick(full["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                                "kernel_ms", "counts"))
+    line["roofline"].setdefault("traffic", None)
+    if full.get("roofline_valu"):
+        line["roofline_valu"] = pick(full["roofline_valu"], ("bound", "frac", "frac_measured_costs", "kernel"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        c = pick(cb, ("value", "unit", "cores", "kind", "sample", "seconds", "gpu_over_cpu"))
+        if cb.get("reference_slice"):
+            c["reference_slice"] = pick(cb["reference_slice"], ("value", "cores", "seconds"))
+        if cb.get("all_cores"):
+            c["all_cores"] = pick(cb["all_cores"], ("value", "cores"))
+        line["cpu_baseline"] = c
+    if full.get("also"):
+        line["also"] = [dict(workload=a["config"]["tag"], barcodes=a["config"]["barcodes_total"], ms_per_step=a["ms_per_step"], value=a["value"],
+                             steps=a["steps"], kernel_ms=a["roofline"]["kernel_ms"], roofline_frac=a["roofline"]["frac"],
+                             roofline_valu_frac=(a.get("roofline_valu") or {}).get("frac"),
+                             roofline_valu_frac_measured=(a.get("roofline_valu") or {}).get("frac_measured_costs"),
+                             **pick(a, ("ranks_seen", "gather_ms")))
+                        for a in full["also"]]
+    e2e = full.get("end_to_end")
+    if e2e:
+        line["end_to_end"] = {m: pick(e2e[m], ("total_s", "stage_s", "wait_s", "write_s")) for m in ("strict", "fast") if m in e2e}
+        cli = e2e.get("from_bam_and_vcf") or {}
+        if "all_cores" in cli:
+            line["end_to_end"]["bam_vcf_scan_reads_per_s"] = cli["all_cores"].get("scan_reads_per_s")
+    line["full_record"] = full.get("full_record")
+    return sig(line)
+
+
+def free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def visible_gpus():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: check the devices, then become the launcher.  One process per GPU,
+    rendezvous on 127.0.0.1 (barcodes shard over the GPUs of ONE node, cmd_cram_demuxlet.cpp:576 — independent barcodes)."""
+    inject = bool(os.environ.get("DMX_BENCH_INJECT"))       # CPU test hook: gloo ranks with an injected compute, no devices needed
+    if not inject:
+        n = visible_gpus()
+        if args.gpus > n:
+            sys.exit(f"bench.py: {args.gpus} GPUs requested, {n} visible")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def run_injected(cx, cfg, steps, warmup):
+    """DMX_BENCH_INJECT=1 (tests/test_bench_dist_cpu.py): the N-rank bookkeeping of this script — launch, world-size checks, ranges,
+    padded gather, max-over-ranks timing, the compact line — on CPU tensors over gloo with a made-up record matrix instead of the
+    engine.  The line says so in `data`; it is never a measurement."""
+    torch, dist = cx.torch, cx.dist
+    world, rank, V, A = cx.world, cx.rank, cfg["V"], len(cfg["alphas"])
+    lo, hi = shard_range(cfg["B"], world, rank)
+    counts = [shard_range(cfg["B"], world, r)[1] - shard_range(cfg["B"], world, r)[0] for r in range(world)]
+    ncols = 2 * V + 1 + A + 24
+    rec = (torch.arange(lo, hi, dtype=torch.float64)[:, None] + 0.5 * torch.arange(ncols, dtype=torch.float64)[None, :]).contiguous()
+    gathered = None
+    for _ in range(warmup):
+        gathered = gather_records(torch, dist, rec, counts, rank, world)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gathered = gather_records(torch, dist, rec, counts, rank, world)
+    own = time.perf_counter() - t0
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_pairs = (hi - lo) * cfg["S"]
+    elapsed, total_pairs, per_rank = collect_timing(torch, dist, cx.dev, elapsed, own, n_pairs, steps, world)
+    if rank != 0:
+        return None
+    b = 0
+    for r in range(world):                                   # rank order == barcode order, padding rows zero
+        assert torch.equal(gathered[r][:counts[r], 0], torch.arange(b, b + counts[r], dtype=torch.float64))
+        assert (gathered[r][counts[r]:] == 0).all()
+        b += counts[r]
+    assert b == cfg["B"]
+    ms = 1e3 * elapsed / steps
+    return {"metric": METRIC, "value": total_pairs * V * steps / elapsed, "unit": "triples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "INJECTED records over gloo (DMX_BENCH_INJECT test hook: no GPU, no engine; not a measurement)",
+            "config": {"workload": cfg["name"], "tag": "cfg4/injected", "barcodes_total": cfg["B"], "barcodes_per_gpu": hi - lo, "snps": cfg["S"],
+                       "samples": V, "alphas": list(cfg["alphas"]), "mode": "injected"},
+            "roofline": {"bound": "hbm", "kernel": "none (injected)", "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0,
+                         "traffic": None, "kernel_ms": ms},
+            "ranks_seen": dist.get_world_size(), "per_rank_ms_per_step": per_rank, "gather_ms": ms}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(CONFIGS),
-                    help="0 = the driver's default: cfg3 (+ nested cfg3-fast/cfg2/cfg5 records) at N=1, cfg4 sharded at N>1")
+                    help="0 = the driver's default: cfg3 (+ nested cfg3-fast/cfg2/cfg5/cfg4-whole records) at N=1, cfg4 sharded at N>1")
     ap.add_argument("--cells", type=int, default=0, help="override the TOTAL barcode count (smaller = quicker run; not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--only", action="store_true", help="N=1: skip the nested records of the other configurations")
@@ -556,6 +687,16 @@ def main():
     ap.add_argument("--fast", action="store_true", help="DMX_MODE_FAST for the main record (opt-in, not the headline)")
     ap.add_argument("--alphas", default="", help="override the alpha grid, comma separated (experiments; not the headline)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+
+    # --gpus decides the number of ranks.  No launcher in the environment and N > 1: become the launcher (never returns).
+    # Under a launcher: its WORLD_SIZE must be what --gpus says.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            self_launch(args)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
 
     # stdout carries exactly one line, the JSON record.  Libraries that print banners from C (RCCL's version block is written
     # to fd 1 and flushed at exit, i.e. AFTER anything Python printed) are sent to stderr: fd 1 is re-pointed at fd 2 for the
@@ -566,28 +707,44 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from demuxlet_amd import build, engine, synth, synth_torch
 
     cx = Ctx()
-    cx.torch, cx.dist, cx.engine, cx.synth, cx.synth_torch = torch, dist, engine, synth, synth_torch
+    cx.torch, cx.dist = torch, dist
     cx.world = int(os.environ.get("WORLD_SIZE", "1"))
     cx.rank = int(os.environ.get("RANK", "0"))
     cx.local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
-    torch.cuda.set_device(cx.local)
-    cx.dev = torch.device("cuda", cx.local)
-    # DMX_BENCH_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (1-GPU boxes: exercises the gather)
+    inject = bool(os.environ.get("DMX_BENCH_INJECT"))
     cx.inputs = None
+    # DMX_BENCH_FORCE_DIST=1 runs the collective code path with a 1-rank RCCL group (1-GPU boxes: exercises the gather)
     cx.use_dist = cx.world > 1 or bool(os.environ.get("DMX_BENCH_FORCE_DIST"))
-    if cx.use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
-    if cx.rank == 0:
-        build.build()
-    if cx.use_dist:
-        dist.barrier()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if inject:
+        cx.dev = torch.device("cpu")
+        dist.init_process_group(backend="gloo", rank=cx.rank, world_size=cx.world)
+    else:
+        ndev = visible_gpus()
+        if ndev == 0:
+            sys.exit("bench.py needs a GPU (the engine has no CPU fallback)")
+        if cx.world > ndev or cx.local >= ndev:
+            sys.exit(f"bench.py: {cx.world} GPUs requested, {ndev} visible")
+        torch.cuda.set_device(cx.local)
+        cx.dev = torch.device("cuda", cx.local)
+        if cx.use_dist:
+            dist.init_process_group(backend="nccl", device_id=cx.dev, rank=cx.rank, world_size=cx.world)
+    if cx.use_dist or inject:
+        # the group must be what --gpus asked for, one rank per DISTINCT device
+        if dist.get_world_size() != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        if not inject:
+            pr = torch.cuda.get_device_properties(cx.local)
+            ids = [None] * cx.world
+            dist.all_gather_object(ids, (cx.local, getattr(pr, "pci_domain_id", None), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None)))
+            cx.devices = ids
+            if len({i[0] for i in ids}) != cx.world:
+                sys.exit(f"bench.py: {cx.world} ranks on {len({i[0] for i in ids})} distinct local devices")
+            if all(i[2] is not None for i in ids) and len({i[1:] for i in ids}) != cx.world and cx.rank == 0:
+                sys.stderr.write(f"bench.py: WARNING: ranks report non-distinct PCI ids: {ids}\n")
 
     default_run = args.config == 0
     cfgno = args.config or (3 if cx.world == 1 else 4)
@@ -604,34 +761,54 @@ def main():
         cfg["name"] += f" [override: V={cfg['V']}, field={cfg['field']}, alphas={list(cfg['alphas'])}]"
     if args.cells:
         cfg["name"] += f" [override: {args.cells} barcodes]"
-    single = cx.world == 1 and not cx.use_dist
-    out = run_config(cx, cfgno, cfg, "fast" if args.fast else "strict", args.steps, args.warmup,
-                     with_cpu=single and not args.no_cpu_baseline, with_log=single, with_e2e=single and default_run and not args.only)
-    if single and default_run and not args.only:
-        # nested records of the same run: the other single-GPU BASELINE configurations and the opt-in mode, fewer steps each
-        also = []
-        k, w = max(2, min(args.steps, 5)), min(args.warmup, 1)
-        keys = ("value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu", "fp64_valu", "pair_evals_per_s")
-        # cfg4 WHOLE on this one GPU (2 steps each: a STRICT pass is ~10 s) is the N = 1 point of the strong-scaling curve whose
-        # N > 1 points the driver measures with `--gpus N` (same workload, same code path minus the gather)
-        for no, mode, kk in ((3, "fast", k), (2, "strict", k), (5, "strict", k), (5, "fast", k), (4, "strict", 2), (4, "fast", 2)):
-            c = dict(CONFIGS[no])
-            if args.cells:
-                c["B"] = min(c["B"], args.cells)
-                c["name"] += f" [override: {c['B']} barcodes]"
-            r = run_config(cx, no, c, mode, kk, w, with_cpu=False, with_log=False)
-            also.append({key: r[key] for key in keys if key in r})
-        out["also"] = also
-    if cx.world > 1 and default_run and not args.only:
-        # the sharded job once more in the opt-in FAST mode (every rank takes part: it ends with the same gather)
-        r = run_config(cx, cfgno, cfg, "fast", max(2, min(args.steps, 5)), min(args.warmup, 1), with_cpu=False, with_log=False)
+
+    if inject:
+        out = run_injected(cx, cfg, args.steps, args.warmup)
+    else:
+        from demuxlet_amd import build, engine, synth, synth_torch
+        cx.engine, cx.synth, cx.synth_torch = engine, synth, synth_torch
         if cx.rank == 0:
-            out["also"] = [{key: r[key] for key in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu", "fp64_valu",
-                                                    "pair_evals_per_s", "ranks_seen", "per_rank_ms_per_step", "gather_ms") if key in r}]
-    cx.inputs = None
+            build.build()
+        if cx.use_dist:
+            dist.barrier()
+        single = cx.world == 1 and not cx.use_dist
+        out = run_config(cx, cfgno, cfg, "fast" if args.fast else "strict", args.steps, args.warmup,
+                         with_cpu=single and not args.no_cpu_baseline, with_log=single, with_e2e=single and default_run and not args.only)
+        keys = ("value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu", "fp64_valu", "pair_evals_per_s",
+                "ranks_seen", "per_rank_ms_per_step", "gather_ms")
+        if single and default_run and not args.only:
+            # nested records of the same run: the other single-GPU BASELINE configurations and the opt-in mode, fewer steps each
+            also = []
+            k, w = max(2, min(args.steps, 5)), min(args.warmup, 1)
+            # cfg4 WHOLE on this one GPU (2 steps each: a STRICT pass is ~7 s) is the N = 1 point of the strong-scaling curve whose
+            # N > 1 points the driver measures with `--gpus N` (same workload, same code path minus the gather)
+            for no, mode, kk in ((3, "fast", k), (2, "strict", k), (5, "strict", k), (5, "fast", k), (4, "strict", 2), (4, "fast", 2)):
+                c = dict(CONFIGS[no])
+                if args.cells:
+                    c["B"] = min(c["B"], args.cells)
+                    c["name"] += f" [override: {c['B']} barcodes]"
+                r = run_config(cx, no, c, mode, kk, w, with_cpu=False, with_log=False)
+                also.append({key: r[key] for key in keys if key in r})
+            out["also"] = also
+        if cx.world > 1 and default_run and not args.only:
+            # the sharded job once more in the opt-in FAST mode (every rank takes part: it ends with the same gather)
+            r = run_config(cx, cfgno, cfg, "fast", max(2, min(args.steps, 5)), min(args.warmup, 1), with_cpu=False, with_log=False)
+            if cx.rank == 0:
+                out["also"] = [{key: r[key] for key in keys if key in r}]
+        cx.inputs = None
     if cx.rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if cx.use_dist:
+        full_path = Path(os.environ.get("DMX_BENCH_FULL", str(ROOT / "bench_full.json")))
+        out["full_record"] = full_path.name
+        try:
+            full_path.write_text(json.dumps(out, indent=1) + "\n")
+        except OSError as ex:
+            out["full_record"] = f"not written: {ex!r}"
+        sys.stderr.write("bench.py full record: " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+        line = json.dumps(compact_line(out), separators=(",", ":"))
+        assert len(line) < 6144, len(line)
+        os.write(json_fd, (line + "\n").encode())
+    if cx.use_dist or inject:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -63,7 +63,11 @@ std::thread g_warm_up;       // dmx_device_warm_up beside the scan (main): exit(
   fprintf(stderr, "\n\n");
   fflush(stderr);
   if (g_warm_up.joinable() && std::this_thread::get_id() != g_warm_up.get_id()) g_warm_up.join();
-  exit(EXIT_FAILURE);      // the reference throws an uncaught exception here (Error.cpp:39): abnormal termination either way
+  // the reference throws an uncaught exception here (Error.cpp:39): abnormal termination either way.  _exit, not exit: pool workers, the
+  // reader, the sink, the BGZF producer and the feed thread may all be running, and exit() would run static destructors and the HIP
+  // runtime's atexit handlers under their feet
+  fflush(stdout);
+  _exit(EXIT_FAILURE);
 }
 
 // ---- f4: options --------------------------------------------------------------------------------------------------
@@ -404,6 +408,7 @@ struct BgzfPipe {
     memset(b.raw.data() + rest, 0, 56);
     b.data_off = 0; b.data_len = rest - 8;
     memcpy(&b.crc, &b.raw[rest - 8], 4); memcpy(&b.isize, &b.raw[rest - 4], 4);
+    if (b.isize > 65536) { error = "BGZF block with ISIZE > 64 KiB"; return false; }   // SAM spec 4.1; ISIZE sizes the batch allocation
     return true;
   }
   static void inflate_block(Block& b, uint8_t* out) {            // into the block's place in its batch (ISIZE bytes)
@@ -1338,7 +1343,8 @@ int main(int argc, char** argv) {
     v = std::move(f.v);
     return true;
   };
-  for (const auto& kv : vr.contig_rid) contig_seen.insert(kv);  // (the first record, read above, may have registered its contig)
+  // (contig_seen was copied from vr.contig_rid above, after the first record was read and BEFORE the feed thread started: from here on
+  // the feed thread owns vr — contigs reach this thread only through Fed::new_contigs)
 
   std::vector<std::vector<int32_t>>* slot_cell_p = nullptr;     // (windowed scan: see slot_cell below)
   struct Hit { int32_t snp; uint8_t allele, bq; };

@@ -48,7 +48,8 @@ inline bool build(const uint8_t* len, int n, int root, uint32_t* tab, int cap, b
   count[0] = 0;
   int left = 1, used = 0;
   for (int l = 1; l <= 15; ++l) { left = left * 2 - count[l]; if (left < 0) return false; used += count[l]; }
-  if (left > 0 && !(allow_incomplete && used <= 1)) return false;
+  // zlib (inftrees.c) accepts an incomplete set only with no code at all or ONE code of length 1; anything else goes to zlib, which rejects it
+  if (left > 0 && !(allow_incomplete && (used == 0 || (used == 1 && count[1] == 1)))) return false;
   uint32_t next[16]; uint32_t code = 0;
   for (int l = 1; l <= 15; ++l) { code = (code + (uint32_t)count[l - 1]) << 1; next[l] = code; }
   const uint32_t rmask = (1u << root) - 1u;

@@ -98,6 +98,34 @@ int main() {
             }
           }
         }
+  // Hand-made dynamic blocks whose distance code is INCOMPLETE: one code of length L.  zlib (inftrees.c) takes L = 1 only; so must we
+  // (the builder used to take any single code).  Stream: 'a', <length 3, distance 1>, end of block -> "aaaa".
+  for (int L = 1; L <= 3; ++L) {
+    std::vector<uint8_t> z(64 + 64, 0);
+    size_t bitpos = 0;
+    auto put = [&](uint32_t v, int nb) { for (int i = 0; i < nb; ++i, ++bitpos) if ((v >> i) & 1u) z[bitpos >> 3] |= (uint8_t)(1u << (bitpos & 7)); };   // LSB first (header fields, extra bits)
+    auto code = [&](uint32_t c, int nb) { for (int i = nb - 1; i >= 0; --i, ++bitpos) if ((c >> i) & 1u) z[bitpos >> 3] |= (uint8_t)(1u << (bitpos & 7)); }; // Huffman codes: MSB first
+    put(1, 1); put(2, 2);                 // BFINAL, BTYPE = dynamic
+    put(258 - 257, 5); put(0, 5); put(18 - 4, 4);
+    static const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    int cl_len[19] = {0};
+    cl_len[18] = 1; cl_len[1] = 2; cl_len[2] = 2; cl_len[3] = 0;
+    // code-length code: 18 -> 0, 1 -> 10, 2 -> 11; L = 3 needs symbol 3 as well: 18 -> 0, 1 -> 10, 2 -> 110, 3 -> 111
+    if (L == 3) { cl_len[2] = 3; cl_len[3] = 3; }
+    for (int i = 0; i < 18; ++i) put((uint32_t)cl_len[order[i]], 3);
+    auto zeros = [&](int n) { code(0, 1); put((uint32_t)(n - 11), 7); };                       // symbol 18: 11..138 zeros
+    auto lenv = [&](int v) { if (v == 1) code(2, 2); else if (v == 2) code(L == 3 ? 6 : 3, L == 3 ? 3 : 2); else code(7, 3); };
+    zeros(97); lenv(1); zeros(138); zeros(20); lenv(2); lenv(2);                               // 'a': 1 bit, 256 and 257: 2 bits
+    lenv(L);                                                                                     // the one distance code
+    code(0, 1); code(3, 2); code(0, L); code(2, 2);                                             // 'a', length 3, distance 1, end of block
+    const size_t zl = (bitpos + 7) / 8;
+    std::vector<uint8_t> mine_out(4, 0xEE), zo;
+    const bool mine = dmxz::inflate_raw(z.data(), zl, mine_out.data(), 4);
+    const bool theirs = zlib_inflate(z.data(), zl, zo, 4);
+    if (theirs != (L == 1)) { ++n_bad; fprintf(stderr, "hand-made incomplete distance code L=%d: zlib says %d (the test's stream is wrong)\n", L, (int)theirs); }
+    if (mine != theirs || (mine && memcmp(mine_out.data(), "aaaa", 4) != 0)) { ++n_bad; fprintf(stderr, "incomplete distance code L=%d: ours %d, zlib %d\n", L, (int)mine, (int)theirs); }
+    else ++n_ok;
+  }
   // CRC
   for (size_t n : {(size_t)0, (size_t)1, (size_t)15, (size_t)63, (size_t)64, (size_t)65, (size_t)79, (size_t)80, (size_t)1000, (size_t)65536, (size_t)100003}) {
     const std::vector<uint8_t> d = make_data(0, n + 3);

@@ -9,12 +9,13 @@ import numpy as np
 BASES = "ACGT"
 
 
-def make_vcf(rng, contigs, n_per_contig, samples, path, with_noise=True):
+def make_vcf(rng, contigs, n_per_contig, samples, path, with_noise=True, contig_lines=True):
     """Returns the list of records written (dicts) in file order."""
     recs = []
     lines = ["##fileformat=VCFv4.2"]
     for name, length in contigs:
-        lines.append(f"##contig=<ID={name},length={length}>")
+        if contig_lines:                           # without them a VCF teaches its contigs record by record (bcf_filtered_reader / htslib)
+            lines.append(f"##contig=<ID={name},length={length}>")
     lines += ['##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">', '##FORMAT=<ID=PL,Number=G,Type=Integer,Description="PL">',
               '##FORMAT=<ID=GP,Number=G,Type=Float,Description="GP">']
     lines.append("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(samples))

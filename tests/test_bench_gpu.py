@@ -17,7 +17,12 @@ def run_bench(*extra):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-500:]          # C-level banners (RCCL, ...) must not reach stdout
-    return json.loads(lines[0])
+    assert len(lines[0]) < 6144, len(lines[0])       # the driver could not parse a 27 KB line
+    assert "note" not in lines[0]                    # no prose on stdout
+    d = json.loads(lines[0])
+    full = json.loads((ROOT / d["full_record"]).read_text())      # the full record lies beside bench.py
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and "fp64_valu" in full
+    return d
 
 
 def test_bench_line_singlet():
@@ -48,10 +53,12 @@ def test_bench_default_line_is_cfg3_with_nested_records():
     d = run_bench("--cells", "64", "--no-cpu-baseline")
     assert d["config"]["workload"].startswith("cfg3") and d["config"]["mode"] == "strict" and d["pair_evals_per_s"] > 0
     assert d["roofline"]["kernel"] == "k_doublet" and d["scaling"] == "weak"
-    names = [(a["config"]["workload"][:4], a["config"]["mode"]) for a in d["also"]]
-    assert ("cfg3", "fast") in names and ("cfg2", "strict") in names and ("cfg5", "strict") in names
+    names = [a["workload"] for a in d["also"]]
+    assert names == ["cfg3/fast", "cfg2/strict", "cfg5/strict", "cfg5/fast", "cfg4/strict", "cfg4/fast"]
     for a in d["also"]:
-        assert a["value"] > 0 and a["roofline"]["achieved"] > 0
+        assert a["value"] > 0 and a["roofline_frac"] > 0 and a["kernel_ms"] > 0 and a["ms_per_step"] >= a["kernel_ms"] * 0.999
+    assert d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.001 and d["roofline"]["counts"].startswith("profiles/pmc_cfg3_strict")
+    assert d["roofline_valu"]["kernel"].startswith("k_doublet")
 
 
 def test_bench_sharded_path_with_a_one_rank_group():
@@ -64,3 +71,21 @@ def test_bench_sharded_path_with_a_one_rank_group():
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     assert d["ranks_seen"] == 1 and len(d["per_rank_ms_per_step"]) == 1 and d["gather_ms"] >= 0
     assert d["config"]["workload"].startswith("cfg4") and d["config"]["barcodes_total"] == 96
+
+
+def test_bench_gpus_n_without_a_launcher():
+    """`python bench.py --gpus N` (no torchrun): more ranks than visible devices fails loudly before anything is launched; with enough
+    devices it starts N ranks itself and the line says so (the N >= 2 leg needs a multi-GPU box)."""
+    import os
+    import torch
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n + 1), "--cells", "96"], capture_output=True, text=True, cwd=ROOT,
+                       timeout=600, env=env)
+    assert r.returncode != 0 and f"{n + 1} GPUs requested, {n} visible" in r.stderr and r.stdout.strip() == ""
+    if n >= 2:
+        r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cells", "192", "--only"],
+                           capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+        assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["config"]["barcodes_per_gpu"] == 96

@@ -432,3 +432,27 @@ def test_windowed_scan_equals_the_read_by_read_scan(cli, tmp_path, fmt, field, e
     for got in outs[1:]:
         assert got[0] == outs[0][0]
         assert got[1] == outs[0][1]
+
+
+@pytest.mark.parametrize("fmt", ["bam", "sam"])
+def test_windowed_scan_with_a_vcf_that_has_no_contig_lines(cli, tmp_path, fmt):
+    """a VCF without ##contig lines registers its contigs record by record — in the windowed scan on the feed thread,
+    which parses ahead of the reads.  The scanning thread must learn them only through the records it consumes (a read on a contig the
+    VCF has not reached yet is skipped, cmd_cram_demuxlet.cpp:198-200): same pileup, counters and messages as read by read on one
+    thread, run after run."""
+    rng = np.random.default_rng(977)
+    contigs = [("1", 20000), ("2", 15000), ("X", 12000), ("7", 9000)]
+    recs = sv.make_vcf(rng, contigs, 120, SAMPLES, tmp_path / "v.vcf.gz", with_noise=True, contig_lines=False)
+    bcs = [f"BC{i:02d}-1" for i in range(24)]
+    sv.make_reads(rng, contigs, recs, 6000, bcs, tmp_path / "r.sam", tmp_path / "r.bam")
+    outs = []
+    runs = [{"DMX_THREADS": "1"}] + [{"DMX_THREADS": "4", "DMX_SCAN_WINDOW": "53"}] * 4 + [{"DMX_THREADS": "6"}] * 3 + [{"DMX_THREADS": "3", "DMX_SCAN_SEQUENTIAL": "1"}]
+    for i, env_extra in enumerate(runs):
+        r = subprocess.run([cli, "--sam", f"r.{fmt}", "--vcf", "v.vcf.gz", "--field", "GT", "--out", f"o{i}", "--pileup-only"],
+                           capture_output=True, text=True, cwd=tmp_path, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stderr[-400:]
+        totals = [ln.split("] - ", 1)[1] for ln in r.stderr.splitlines() if "Total number" in ln or "Finished reading" in ln]
+        outs.append(((tmp_path / f"o{i}.pileup.txt").read_bytes(), totals))
+    assert len(outs[0][1]) >= 10 and b"PAIR" in outs[0][0]
+    for got in outs[1:]:
+        assert got[0] == outs[0][0] and got[1] == outs[0][1]
