@@ -579,6 +579,9 @@ def compact_line(full):
     line["roofline"] = pick(full["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
                                                 "kernel_ms", "counts"))
     line["roofline"].setdefault("traffic", None)
+    alone = (full.get("fp64_valu") or {}).get("kernel_ms_alone")
+    if alone:                                   # the dominant kernel with nothing beside it (two extra untimed steps)
+        line["roofline"]["kernel_ms_alone"] = alone.get(full["roofline"]["kernel"])
     if full.get("roofline_valu"):
         line["roofline_valu"] = pick(full["roofline_valu"], ("bound", "frac", "frac_measured_costs", "kernel"))
     cb = full.get("cpu_baseline")

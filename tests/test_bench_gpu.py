@@ -34,7 +34,7 @@ def test_bench_line_singlet():
     assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 * r["frac"] and r["achieved"] > 0      # (the line carries 6 significant digits)
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 10 * c["value"] and d["ms_per_step"] > 0
