@@ -31,7 +31,7 @@ SYMBOLS = [
     "dmx_engine_set_genotypes", "dmx_engine_set_pileup", "dmx_engine_run_singlet", "dmx_engine_run_doublet", "dmx_engine_run",
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
-    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_write_doublet_summary", "dmx_debug_log_dd",
+    "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_engine_get_cell_grids", "dmx_write_doublet_summary", "dmx_debug_log_dd",
     "dmx_resolve_tie_order", "dmx_engine_mean_kernel_times", "dmx_store_add_batch",
 ]
 
@@ -96,7 +96,7 @@ class FinalInput(C.Structure):
                 ("write_pair", C.c_int32), ("barcodes", C.c_void_p), ("sample_ids", C.c_void_p),
                 ("rd_totl", C.c_void_p), ("rd_pass", C.c_void_p), ("rd_uniq", C.c_void_p), ("n_snp", C.c_void_p),
                 ("llks", C.c_void_p), ("llk0s", C.c_void_p), ("llksAB", C.c_void_p), ("llks00", C.c_void_p),
-                ("tie_pileup", C.c_void_p), ("tie_g", C.c_void_p), ("tie_tol", C.c_double)]
+                ("tie_pileup", C.c_void_p), ("tie_g", C.c_void_p), ("tie_tol", C.c_double), ("cell_grid", C.c_void_p)]
 
 
 class Job(C.Structure):
@@ -149,6 +149,7 @@ def load() -> C.CDLL:
         "dmx_engine_get_sing": [vp, vp], "dmx_write_doublet_summary": [vp, vp, vp, C.c_char_p],
         "dmx_debug_device_div": [vp, vp, vp, C.c_int64, i32],
         "dmx_debug_log_rate": [i32, i32, i32, vp],
+        "dmx_engine_get_cell_grids": [vp, vp, i32, vp],
         "dmx_debug_log_dd": [vp, vp, vp, vp, vp, C.c_int64],
         "dmx_resolve_tie_order": [vp, C.c_int64],
         "dmx_engine_mean_kernel_times": [vp, i32, vp],

@@ -4883,6 +4883,19 @@ extern "C" int dmx_engine_get_sing(dmx_engine* e, double* sing) {
   return DMX_OK;
 }
 
+extern "C" int dmx_engine_get_cell_grids(dmx_engine* e, const int32_t* cells, int32_t n, double* out) {
+  if (!e || n < 0 || (n && (!cells || !out))) return set_error(DMX_ERR_ARG, "dmx_engine_get_cell_grids: bad arguments");
+  if (!e->have_grid) return set_error(DMX_ERR_STATE, "dmx_engine_get_cell_grids: run_doublet has not been called");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t nAB = (size_t)e->V * e->V * e->A;
+  for (int32_t i = 0; i < n; ++i) {
+    if (cells[i] < 0 || cells[i] >= e->pv.B) return set_error(DMX_ERR_ARG, "dmx_engine_get_cell_grids: cell %d out of range (0..%d)", cells[i], e->pv.B - 1);
+    HIP_TRY(hipMemcpyAsync(out + (size_t)i * nAB, e->d_grid + (size_t)cells[i] * nAB, sizeof(double) * nAB, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return DMX_OK;
+}
+
 extern "C" int dmx_engine_device_view(dmx_engine* e, dmx_device_view* out) {
   if (!e || !out) return set_error(DMX_ERR_ARG, "dmx_engine_device_view: null argument");
   out->llks = e->d_llks; out->llk0s = e->d_llk0s; out->llksAB = e->d_grid; out->llks00 = e->d_l00; out->summary = e->d_sum;

@@ -1011,7 +1011,7 @@ extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double
   if (!out_prefix || !sing || !summary || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: null sing/summary/llks00/alpha/prefix");
   if (in->write_pair) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: .pair rows need the full grid (use dmx_write_doublet)");
   dmx::DoubletSource src{};
-  src.sing = sing; src.summary = summary;
+  src.sing = sing; src.summary = summary; src.cell_grid = in->cell_grid;
   return dmx::write_doublet_core(in, src, out_prefix, false, "dmx_write_doublet_summary");
 }
 
@@ -1089,9 +1089,26 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
       resolved = *smp;
       if (dmx::resolve_tie_order(&resolved)) smp = &resolved;
     }
+    constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
+    bool host_grid = false;
+    if (!grid && smp && (smp->flags & kNear) && smp->n_pairs > 0 && arbiter) {
+      // A near-tie beyond the (j,k)/(k,j) mirror — another sample pair (duplicate samples), another alpha, a third singlet — and
+      // nothing but the record: which candidates sit within tol is not in the record, so the barcode's whole grid is evaluated
+      // here, in the reference's operation order with the host libm (:595-684).  Flagged barcodes are the shallow ones (a handful
+      // of covered SNPs) unless the panel itself is degenerate; a caller with the engine at hand passes the grids instead
+      // (dmx_final_input.cell_grid, dmx_engine_get_cell_grids).
+      reqs.clear();
+      for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) for (int32_t a = 0; a < A; ++a) reqs.push_back({j, k, a, 0.0});
+      dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), src.tie_cell ? src.tie_cell[c] : c, reqs);
+      scratch.resize(ng);
+      for (size_t q = 0; q < ng; ++q) scratch[q] = reqs[q].value;
+      grid = scratch.data();
+      host_grid = true;
+    }
     if (grid) {
-      constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
-      if (smp && (smp->flags & DMX_CELL_ORDER_CERTIFIED) && !(smp->flags & kNear)) {
+      if (host_grid) {
+        // every entry is already the reference's
+      } else if (smp && (smp->flags & DMX_CELL_ORDER_CERTIFIED) && !(smp->flags & kNear)) {
         // the device certified both accumulators of the best alpha = 0.5 pair (K3b) and K3 saw no other near-tie: the two
         // entries the arbiter would re-evaluate are known, bit for bit
         const dmx_cell_summary& sm = *smp;

@@ -7,6 +7,12 @@ its own GPU.  The one collective is the gather of the fixed-size per-cell record
 (backend "nccl") on GPUs, over gloo in the CPU tests.  `--write-pair` grids are never gathered: every rank formats its
 own barcode range and the text shards concatenate in rank order.
 
+Barcodes whose record carries a near-tie flag (DMX_CELL_NEAR_DOUBLET / _NEAR_SINGLET: another sample pair, another alpha or a third
+singlet within 1e-7 of a decision — duplicate samples in the panel, a handful of covered SNPs) cannot be decided from the record
+alone: the reference's strict-< scans (cmd_cram_demuxlet.cpp:746-758,:799-814) need the contenders' exact values.  Their grids
+(V*V*A doubles each) ride along in the SAME gather as extra rows behind the records (`near_grids`): rank 0 hands them to the
+writer, whose tie arbiter re-evaluates the contenders with the host libm exactly as the single-process path does.
+
 torch.distributed is plumbing here; nothing numerical happens in this module."""
 from __future__ import annotations
 
@@ -68,6 +74,8 @@ class CellRecords:
     sing: np.ndarray        # [n][V]      llksAB[j][0][0]
     llks00: np.ndarray      # [n][A]
     summary: np.ndarray     # [n] capi.SUMMARY_DTYPE
+    near_cells: Optional[np.ndarray] = None   # [m] shard-local ids of the near-tie-flagged cells (engine.near_tie_cells)
+    near_grids: Optional[np.ndarray] = None   # [m][V][V][A] their grids (Engine.get_cell_grids)
 
     def as_matrix(self) -> np.ndarray:
         """One float64 row per cell (the summary struct is reinterpreted as 8-byte words)."""
@@ -116,7 +124,35 @@ def run_sharded(pl: HostPileup, barcodes: Sequence[str], n_samples: int, n_alpha
     ranges = balanced_ranges(cell_cost(pl.n_snp_per_cell[order], n_samples, n_alpha), world)
     lo, hi = ranges[rank]
     rec = compute(slice_pileup(pl, order[lo:hi]))
-    m = gather_records(rec.as_matrix(), [b - a for a, b in ranges], device=device)
+    m = rec.as_matrix()
+    # the flagged cells' grids travel as extra rows of the same matrix: [shard-local id, grid entries ..., zero padding] cut into rows of
+    # the record width; every rank announces how many such rows it appends (a tiny all_gather of one integer, no data-path collective)
+    W = m.shape[1]
+    nAB = n_samples * n_samples * n_alpha
+    rows_per_grid = -(-(1 + nAB) // W)
+    n_near = 0 if rec.near_cells is None else len(rec.near_cells)
+    if n_near:
+        extra = np.zeros((n_near, rows_per_grid * W), dtype=np.float64)
+        extra[:, 0] = rec.near_cells
+        extra[:, 1:1 + nAB] = np.asarray(rec.near_grids, dtype=np.float64).reshape(n_near, nAB)
+        m = np.concatenate([m, extra.reshape(n_near * rows_per_grid, W)], axis=0)
+    import torch
+    mine = torch.tensor([n_near], dtype=torch.int64, device=device)
+    allc = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    near_counts = [int(x.item()) for x in allc]
+    base = [b - a for a, b in ranges]
+    full = gather_records(m, [base[r] + near_counts[r] * rows_per_grid for r in range(world)], device=device)
     if rank != 0:
         return None
-    return order, CellRecords.from_matrix(m, n_samples, n_alpha, summary_dtype)
+    recs, cells, grids, off = [], [], [], 0
+    for r in range(world):
+        recs.append(full[off:off + base[r]])
+        ex = full[off + base[r]:off + base[r] + near_counts[r] * rows_per_grid].reshape(near_counts[r], rows_per_grid * W)
+        cells.append(ex[:, 0].astype(np.int64) + ranges[r][0])            # -> index into the sorted-barcode order
+        grids.append(ex[:, 1:1 + nAB].reshape(near_counts[r], n_samples, n_samples, n_alpha))
+        off += base[r] + near_counts[r] * rows_per_grid
+    out = CellRecords.from_matrix(np.concatenate(recs, axis=0), n_samples, n_alpha, summary_dtype)
+    out.near_cells = np.concatenate(cells) if cells else np.zeros(0, np.int64)
+    out.near_grids = np.concatenate(grids, axis=0) if grids else np.zeros((0, n_samples, n_samples, n_alpha))
+    return order, out

@@ -221,6 +221,14 @@ class Engine:
         check(self._L.dmx_engine_get_sing(self._h, sing.ctypes.data))
         return sing
 
+    def get_cell_grids(self, cells) -> np.ndarray:
+        """llksAB[V][V][A] of the given cells (dmx_engine_get_cell_grids): the grids of the barcodes K3 flagged as near-ties are what a
+        records-only consumer (write_doublet_summary, the multi-GPU gather) needs besides the records."""
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        out = np.zeros((len(cells), self.V, self.V, self.A), dtype=np.float64)
+        check(self._L.dmx_engine_get_cell_grids(self._h, cells.ctypes.data, len(cells), out.ctypes.data))
+        return out
+
     def device_view(self) -> capi.DeviceView:
         v = capi.DeviceView()
         check(self._L.dmx_engine_device_view(self._h, C.byref(v)))
@@ -269,7 +277,7 @@ class FinalArgs:
 
 
 def _final_struct(fa: FinalArgs, llks=None, llk0s=None, grid=None, l00=None, tie_pileup: Optional[HostPileup] = None,
-                  tie_g: Optional[np.ndarray] = None):
+                  tie_g: Optional[np.ndarray] = None, cell_grids=None):
     keep = []
     alphas = np.ascontiguousarray(fa.alphas, dtype=np.float64)
     bc, k1 = _cstrs(fa.barcodes)
@@ -295,7 +303,16 @@ def _final_struct(fa: FinalArgs, llks=None, llk0s=None, grid=None, l00=None, tie
                           fa.min_total, fa.min_uniq, fa.min_snp, int(fa.write_pair), C.cast(bc, C.c_void_p),
                           C.cast(sm, C.c_void_p), arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
                           arrs[3].ctypes.data, p(llks), p(llk0s), p(grid), p(l00), tp,
-                          tie_g.ctypes.data if tie_pileup is not None else None, 0.0)
+                          tie_g.ctypes.data if tie_pileup is not None else None, 0.0, None)
+    if cell_grids:                                   # {cell id: llksAB[V][V][A]} of the near-tie-flagged barcodes
+        ptrs = (C.c_void_p * len(fa.barcodes))()
+        for c, gr in cell_grids.items():
+            gr = np.ascontiguousarray(gr, dtype=np.float64)
+            assert gr.size == len(fa.sample_ids) ** 2 * len(alphas)
+            keep.append(gr)
+            ptrs[int(c)] = gr.ctypes.data
+        keep.append(ptrs)
+        fin.cell_grid = C.cast(ptrs, C.c_void_p)
     return fin, keep
 
 
@@ -310,10 +327,18 @@ def write_doublet(fa: FinalArgs, grid, l00, out_prefix: str, tie_pileup: Optiona
     check(capi.load().dmx_write_doublet(C.byref(fin), out_prefix.encode()))
 
 
+def near_tie_cells(summary: np.ndarray) -> np.ndarray:
+    """ids of the covered cells whose K3 record carries DMX_CELL_NEAR_DOUBLET / _NEAR_SINGLET: a decision of theirs sits within 1e-7 of
+    an alternative other than the alpha = 0.5 mirror, and the writers decide it from the cell's grid (Engine.get_cell_grids)."""
+    return np.flatnonzero(((summary["flags"] & (capi.DMX_CELL_NEAR_DOUBLET | capi.DMX_CELL_NEAR_SINGLET)) != 0) & (summary["n_pairs"] > 0)).astype(np.int32)
+
+
 def write_doublet_summary(fa: FinalArgs, sing, l00, summary, out_prefix: str, tie_pileup: Optional[HostPileup] = None,
-                          tie_g: Optional[np.ndarray] = None) -> None:
-    """.sing2/.best from the per-cell records (K3 summaries) instead of the grid — what a multi-GPU run gathers."""
-    fin, keep = _final_struct(fa, l00=l00, tie_pileup=tie_pileup, tie_g=tie_g)
+                          tie_g: Optional[np.ndarray] = None, cell_grids=None) -> None:
+    """.sing2/.best from the per-cell records (K3 summaries) instead of the grid — what a multi-GPU run gathers.  `cell_grids`
+    {cell id: llksAB[V][V][A]} carries the grids of the near-tie-flagged barcodes (near_tie_cells); without them and with the tie
+    pileup such a barcode's grid is re-evaluated on the host."""
+    fin, keep = _final_struct(fa, l00=l00, tie_pileup=tie_pileup, tie_g=tie_g, cell_grids=cell_grids)
     sing = np.ascontiguousarray(sing, dtype=np.float64)
     summary = np.ascontiguousarray(summary, dtype=capi.SUMMARY_DTYPE)
     check(capi.load().dmx_write_doublet_summary(C.byref(fin), sing.ctypes.data, summary.ctypes.data, out_prefix.encode()))

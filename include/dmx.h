@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 5   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up, dmx_engine_run (additions only: a caller of ABI 3 runs unchanged) */
+#define DMX_ABI_VERSION 6   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up, dmx_engine_run; 6: dmx_engine_get_cell_grids, dmx_final_input.cell_grid (a trailing field: zero-initialised structs of ABI 5 callers mean "none") */
 
 typedef enum {
   DMX_OK = 0,
@@ -183,6 +183,9 @@ int dmx_engine_get_doublet(dmx_engine*, double* llksAB, double* llks00, dmx_cell
 /* sing[B][V] = llksAB[c][j][0][0], the singlet column of the grid (what .sing2 prints, :746-770) — lets a caller skip
  * the V*V*A grid entirely when --write-pair is off. */
 int dmx_engine_get_sing(dmx_engine*, double* sing);
+/* llksAB[V][V][A] of the n cells cells[0..n) (ids of the staged pileup) -> out[n][V][V][A]: the grids of the barcodes whose K3 record
+ * carries a near-tie flag are all that a records-only consumer (dmx_write_doublet_summary, a multi-GPU gather) needs besides the records. */
+int dmx_engine_get_cell_grids(dmx_engine*, const int32_t* cells, int32_t n, double* out);
 
 /* Device views for zero-copy hand-off (torch tensors over them, RCCL gather of the per-cell records). */
 typedef struct {
@@ -227,6 +230,10 @@ typedef struct {
   const dmx_pileup* tie_pileup;    /* NULL = no arbiter */
   const float*  tie_g;             /* [n_snps][V][3] */
   double  tie_tol;                 /* 0 = default 1e-7 */
+  /* dmx_write_doublet_summary only: [n_cells] pointers to single cells' llksAB[V][V][A] (NULL entries = none, NULL array = none).
+   * A barcode whose K3 record carries DMX_CELL_NEAR_DOUBLET / _NEAR_SINGLET is decided from its grid (dmx_engine_get_cell_grids
+   * fetches exactly those), with the tie arbiter re-evaluating the contenders as dmx_write_doublet does. */
+  const double* const* cell_grid;
 } dmx_final_input;
 
 int dmx_write_single(const dmx_final_input*, const char* path);                    /* <out>.single */
@@ -234,7 +241,11 @@ int dmx_write_doublet(const dmx_final_input*, const char* out_prefix);          
 /* The same <out>.sing2 and <out>.best from the per-cell records of the device-side reduction (dmx_engine_get_sing,
  * dmx_engine_get_doublet's summary and llks00) instead of the full grid: what a multi-GPU run gathers to rank 0.
  * in->llksAB is ignored; in->write_pair must be 0 (the .pair rows need the grid).  With in->tie_pileup the order of
- * the two samples of an alpha = 0.5 best doublet is arbitrated exactly. */
+ * the two samples of an alpha = 0.5 best doublet is arbitrated exactly.  Barcodes K3 flagged as near-ties
+ * (another sample pair, another alpha or another singlet within 1e-7 of a decision: duplicate samples, a handful of covered SNPs)
+ * need more than their record: pass their grids in in->cell_grid; without a grid but with in->tie_pileup the barcode's WHOLE grid is
+ * re-evaluated on the host in the reference's operation order (exact, pairs x V x V x A host log() calls for that barcode); with
+ * neither, the device's own choice among the near-tied candidates is printed (each within 1e-7 of the reference's best). */
 int dmx_write_doublet_summary(const dmx_final_input*, const double* sing, const dmx_cell_summary* summary, const char* out_prefix);
 /* For consumers of the K3 records themselves: turn every DMX_CELL_ORDER_RESOLVABLE record among summary[0..n) into a certified one
  * by asking this host's libm for the one or two log() values the device left open (the writers above do the same internally).

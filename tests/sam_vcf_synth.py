@@ -57,9 +57,12 @@ def make_vcf(rng, contigs, n_per_contig, samples, path, with_noise=True, contig_
 
 def make_reads(rng, contigs, recs, n_reads, barcodes, path_sam, path_bam=None):
     """Coordinate-sorted reads, many of them placed over variants; returns the parsed read dicts (after writing)."""
+    import bisect
     by_chrom = {}
     for r in recs:
         by_chrom.setdefault(r["chrom"], []).append(r)
+    pos_of = {c: [v["pos"] for v in vs] for c, vs in by_chrom.items()}        # (file order = ascending position inside a contig)
+    assert all(p == sorted(p) for p in pos_of.values())
     reads = []
     tid_of = {c[0]: i for i, c in enumerate(contigs)}
     for _ in range(n_reads):
@@ -79,8 +82,9 @@ def make_reads(rng, contigs, recs, n_reads, barcodes, path_sam, path_bam=None):
         cpos, rpos = start, 0
         for op, n in cig:
             if op == "M":
-                for v in by_chrom.get(cname, []):
-                    if cpos <= v["pos"] < cpos + n and rng.random() < 0.9:
+                vs, ps = by_chrom.get(cname, []), pos_of.get(cname, [])
+                for v in vs[bisect.bisect_left(ps, cpos):bisect.bisect_left(ps, cpos + n)]:     # the variants under this block, in file order
+                    if rng.random() < 0.9:
                         seq[rpos + v["pos"] - cpos] = (v["ref"][0] if rng.random() < 0.5 else v["alt"][0])
                 cpos += n; rpos += n
             elif op in "DN":

@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.dmx_abi_version() == 5
+    assert lib.dmx_abi_version() == 6
 
 
 def test_code_object_is_gfx950_only():

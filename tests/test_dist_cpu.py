@@ -63,6 +63,49 @@ def test_summary_writer_reproduces_reference_files(oracle, name, tmp_path):
     assert (tmp_path / "o.sing2").read_bytes() == gd.files["sing2"]
 
 
+@pytest.mark.parametrize("name", ["gt_v4_a2_pair", "pl_v12_a6_pair", "gt_v3_alpha_quirk", "gp_v8_a2_minsnp"])
+def test_summary_writer_near_tie_records(oracle, name, tmp_path):
+    """A record flagged DMX_CELL_NEAR_* is not decided from the record: (a) with the barcode's grid in
+    dmx_final_input.cell_grid the reference's scans run on it; (b) without a grid but with the tie pileup the barcode's whole grid is
+    re-evaluated on the host in the reference's operation order.  Either way a record whose own decisions are WRONG (as a device
+    that lost a last-bit tie to libm would produce) still gives the reference's files, byte for byte."""
+    from demuxlet_amd import build, capi, engine
+    build.build()
+    gd = Golden(name)
+    st = build_store(engine, gd.problem(oracle))
+    pl = st.freeze()
+    assert st.barcodes() == gd.ref_barcodes
+    cnt = gd.z["ref_counters"]
+    B, V = len(gd.ref_barcodes), len(gd.sample_ids)
+    grid, l00 = gd.z["ref_llksAB"], gd.z["ref_llks00"]
+    summ = np.zeros(B, dtype=capi.SUMMARY_DTYPE)
+    for c in range(B):
+        if gd.z["ref_processed"][c]:
+            summ[c] = summary_from_grid(grid[c], l00[c], gd.alphas, gd.doublet_prior, cnt[c, 3], capi.SUMMARY_DTYPE)
+    covered = np.flatnonzero(summ["n_pairs"] > 0)
+    bad = summ.copy()
+    for c in covered:                                   # sabotage every decision of the record and flag it
+        bad[c]["flags"] = capi.DMX_CELL_NEAR_DOUBLET | capi.DMX_CELL_NEAR_SINGLET
+        bad[c]["j_best"], bad[c]["k_best"] = (int(summ[c]["k_best"]) + 1) % V, int(summ[c]["j_best"])
+        bad[c]["n_best"] = 1 + int(summ[c]["n_best"]) % (len(gd.alphas) - 1)
+        bad[c]["i_sing1"], bad[c]["i_sing2"] = int(summ[c]["i_sing2"]), int(summ[c]["i_sing1"])
+        bad[c]["llk12"] += 0.25; bad[c]["max_llk"] += 0.125; bad[c]["sum_double"] *= 1.5
+    fa = engine.FinalArgs(gd.ref_barcodes, gd.sample_ids, gd.alphas, gd.doublet_prior, cnt[:, 0], cnt[:, 1], cnt[:, 2], cnt[:, 3],
+                          gd.min_total, gd.min_uniq, gd.min_snp, False)
+    sing = np.ascontiguousarray(grid[:, :, 0, 0]) + 0.5         # the singlet column of the records is not to be trusted either
+    assert list(engine.near_tie_cells(bad)) == list(covered)
+    # (a) grids handed over (here the reference's own; on a GPU box Engine.get_cell_grids)
+    engine.write_doublet_summary(fa, sing, l00, bad, str(tmp_path / "a"), cell_grids={int(c): grid[c] for c in covered})
+    # (b) no grids: the host re-evaluates the flagged barcodes from the pileup
+    engine.write_doublet_summary(fa, sing, l00, bad, str(tmp_path / "b"), tie_pileup=pl, tie_g=gd.g)
+    for pre in ("a", "b"):
+        assert (tmp_path / f"{pre}.best").read_bytes() == gd.files["best"], pre
+        assert (tmp_path / f"{pre}.sing2").read_bytes() == gd.files["sing2"], pre
+    # and with neither, the sabotaged record is what gets printed (nothing silently recomputes)
+    engine.write_doublet_summary(fa, sing, l00, bad, str(tmp_path / "c"))
+    assert (tmp_path / "c.best").read_bytes() != gd.files["best"]
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -92,7 +135,13 @@ def _worker(rank, world, port, name, outdir):
         for c in range(shard.n_cells):
             if shard.n_snp_per_cell[c] > 0:
                 summ[c] = summary_from_grid(r.llksAB[c], r.llks00[c], gd.alphas, gd.doublet_prior, shard.n_snp_per_cell[c], capi.SUMMARY_DTYPE)
-        return ddist.CellRecords(r.llks, r.llk0s, np.ascontiguousarray(r.llksAB[:, :, 0, 0]), r.llks00, summ)
+        # every third covered cell plays a near-tie: its record is flagged and sabotaged, its grid rides along in the gather
+        near = np.flatnonzero(summ["n_pairs"] > 0)[::3].astype(np.int32)
+        for c in near:
+            summ[c]["flags"] |= capi.DMX_CELL_NEAR_DOUBLET
+            summ[c]["j_best"], summ[c]["k_best"] = int(summ[c]["k_best"]), (int(summ[c]["j_best"]) + 1) % V
+            summ[c]["llk12"] -= 3.0
+        return ddist.CellRecords(r.llks, r.llk0s, np.ascontiguousarray(r.llksAB[:, :, 0, 0]), r.llks00, summ, near, r.llksAB[near])
 
     res = ddist.run_sharded(pl, barcodes, V, A, compute, capi.SUMMARY_DTYPE)
     if rank == 0:
@@ -101,7 +150,10 @@ def _worker(rank, world, port, name, outdir):
         fa = engine.FinalArgs(barcodes, gd.sample_ids, gd.alphas, gd.doublet_prior, pl.rd_totl, pl.rd_pass, pl.rd_uniq,
                               pl.n_snp_per_cell, gd.min_total, gd.min_uniq, gd.min_snp, False)
         engine.write_single(fa, rec.llks[inv], rec.llk0s[inv], os.path.join(outdir, "o.single"))
-        engine.write_doublet_summary(fa, rec.sing[inv], rec.llks00[inv], rec.summary[inv], os.path.join(outdir, "o"))
+        assert len(rec.near_cells) > 0 and rec.near_grids.shape == (len(rec.near_cells), V, V, A)
+        grids = {int(order[i]): gr for i, gr in zip(rec.near_cells, rec.near_grids)}      # sorted position -> cell id
+        assert set(grids) == set(int(c) for c in engine.near_tie_cells(rec.summary[inv]))
+        engine.write_doublet_summary(fa, rec.sing[inv], rec.llks00[inv], rec.summary[inv], os.path.join(outdir, "o"), cell_grids=grids)
     dist.barrier()
     dist.destroy_process_group()
 

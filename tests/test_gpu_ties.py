@@ -96,12 +96,20 @@ def run_both_paths(eng, oracle, tmp_path, g, pl, alphas, mode, what, min_fetched
     llks, llk0s = e.get_singlet()
     _, l00, summ = e.get_doublet(want_grid=False)
     sing = e.get_sing()
+    near_ids = eng.near_tie_cells(summ)
+    near_grids = e.get_cell_grids(near_ids)          # what a rank adds to the gather for its flagged barcodes (demuxlet_amd/dist.py)
     e.close()
     fa = eng.FinalArgs(bcs, sms, alphas, 0.5, pl.rd_totl, pl.rd_pass, pl.rd_uniq, pl.n_snp_per_cell)
     eng.write_single(fa, llks, llk0s, str(tmp_path / "rec.single"))
-    eng.write_doublet_summary(fa, sing, l00, summ, str(tmp_path / "rec"), tie_pileup=pl, tie_g=g)
-    for suf in ("single", "sing2", "best"):
-        assert_same_file(tmp_path / f"rec.{suf}", tmp_path / f"ref.{suf}", f"{what}, records path")
+    assert_same_file(tmp_path / "rec.single", tmp_path / "ref.single", f"{what}, records path")
+    # (a) records + the flagged barcodes' device grids + the arbiter: what rank 0 of a multi-GPU job does
+    eng.write_doublet_summary(fa, sing, l00, summ, str(tmp_path / "rec"), tie_pileup=pl, tie_g=g,
+                              cell_grids={int(c): gr for c, gr in zip(near_ids, near_grids)})
+    # (b) records + the arbiter only: the flagged barcodes' grids are re-evaluated on the host
+    eng.write_doublet_summary(fa, sing, l00, summ, str(tmp_path / "rech"), tie_pileup=pl, tie_g=g)
+    for pre in ("rec", "rech"):
+        for suf in ("sing2", "best"):
+            assert_same_file(tmp_path / f"{pre}.{suf}", tmp_path / f"ref.{suf}", f"{what}, records path ({'device grids' if pre == 'rec' else 'host grids'})")
     covered = int((summ["n_pairs"] > 0).sum())
     near = int(((summ["flags"] & (capi.DMX_CELL_NEAR_DOUBLET | capi.DMX_CELL_NEAR_SINGLET)) != 0).sum())
     print(f"{what}: {covered} covered barcodes, {near} flagged near-tie by K3, grid fetched for {fetched} "
