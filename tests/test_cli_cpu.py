@@ -67,7 +67,8 @@ def check_dump_against_scan(oracle, dump, snps, events, gts, recs, sm_cols, fiel
         if field == "GT":
             exp = oracle.geno_from_gt(np.array(a), gt_error)
         elif field == "PL":
-            pl = [[(np.iinfo(np.int32).min if x == "." else int(x)) for x in (recs[i]["fields"][c].split(":")[1].split(",") + [".", ".", "."])[:3]] for c in sm_cols]
+            k = recs[i]["fmt"].index("PL") if "fmt" in recs[i] else 1            # (the synthetic VCFs are GT:PL:GP)
+            pl = [[(np.iinfo(np.int32).min if x == "." else int(x)) for x in ((recs[i]["fields"][c].split(":") + ["."] * 8)[k].split(",") + [".", ".", "."])[:3]] for c in sm_cols]
             exp = oracle.geno_from_pl(np.array(pl))
         else:
             gp = [[(np.nan if x == "." else float(x)) for x in (recs[i]["fields"][c].split(":")[2].split(",") + [".", ".", "."])[:3]] for c in sm_cols]
@@ -456,3 +457,44 @@ def test_windowed_scan_with_a_vcf_that_has_no_contig_lines(cli, tmp_path, fmt):
     assert len(outs[0][1]) >= 10 and b"PAIR" in outs[0][0]
     for got in outs[1:]:
         assert got[0] == outs[0][0] and got[1] == outs[0][1]
+
+
+def test_tutorial_vcf_at_full_size_plumbing(cli, oracle, tmp_path):
+    """BASELINE config 1's VCF at its size on the host side: all 54 424 records of the tutorial file (a data fixture), reads over all of
+    its 24 contigs.  --field GT: the pileup and the genotype matrix are the restatement's, incl. the 25 259 records whose second sample
+    is missing (Hardy-Weinberg fallback, bcf_filtered_reader.cpp:381-388).  --field PL: 16 584 records carry no PL and the reference is
+    fatal at the first one the scan reaches (cmd_cram_demuxlet.cpp:211-212) — same message here; on the 37 840 records that do carry PL
+    the matrix is the 10-iteration EM of :244-320 on the file's own values."""
+    import gzip
+    vcf = ROOT / "tests" / "golden" / "tutorial_jurkat_293T_exons_only.vcf.gz"
+    recs, contigs = [], []
+    for line in gzip.open(vcf, "rt"):
+        if line.startswith("##contig=<ID="):
+            name = line[13:].split(",")[0].rstrip(">\n")
+            contigs.append((name, int(line.split("length=")[1].split(">")[0].split(",")[0]) if "length=" in line else 250000000))
+        elif not line.startswith("#"):
+            t = line.rstrip("\n").split("\t")
+            recs.append(dict(chrom=t[0], pos=int(t[1]) - 1, ref=t[3], alt=t[4], fields=t[9:], fmt=t[8].split(":")))
+    assert len(recs) == 54424
+    used = [c for c in contigs if c[0] in {r["chrom"] for r in recs}]
+    rng = np.random.default_rng(2025)
+    reads = sv.make_reads(rng, used, recs, 40000, [f"CELL{i:03d}-1" for i in range(100)], tmp_path / "r.sam", tmp_path / "r.bam")
+    samples = ["jurkat", "293T_RTG"]
+    subprocess.run([cli, "--sam", str(tmp_path / "r.bam"), "--vcf", str(vcf), "--field", "GT", "--out", str(tmp_path / "o"), "--pileup-only"],
+                   check=True, stderr=subprocess.DEVNULL)
+    dump = parse_dump(str(tmp_path / "o.pileup.txt"))
+    snps, events, gts, sm_cols = sv.scan(reads, recs, used, samples)
+    assert len(snps) > 50000 and sum(1 for a in gts if any(x < 0 for x in a[1])) == 25259
+    check_dump_against_scan(oracle, dump, snps, events, gts, recs, sm_cols, "GT")
+    first_without = next(r for r in recs if "PL" not in r["fmt"])
+    r = subprocess.run([cli, "--sam", str(tmp_path / "r.bam"), "--vcf", str(vcf), "--field", "PL", "--out", str(tmp_path / "x"), "--pileup-only"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and f"Cannot parse posterior probability at {first_without['chrom']}:{first_without['pos'] + 1}" in r.stderr
+    with gzip.open(tmp_path / "pl.vcf.gz", "wt") as f:
+        f.writelines(l for l in gzip.open(vcf, "rt") if l.startswith("#") or "PL" in l.split("\t")[8].split(":"))
+    recs_pl = [r for r in recs if "PL" in r["fmt"]]
+    assert len(recs_pl) == 37840
+    subprocess.run([cli, "--sam", str(tmp_path / "r.bam"), "--vcf", str(tmp_path / "pl.vcf.gz"), "--field", "PL", "--out", str(tmp_path / "p"), "--pileup-only"],
+                   check=True, stderr=subprocess.DEVNULL)
+    snps2, events2, gts2, sm2 = sv.scan(reads, recs_pl, used, samples)
+    check_dump_against_scan(oracle, parse_dump(str(tmp_path / "p.pileup.txt")), snps2, events2, gts2, recs_pl, sm2, "PL")

@@ -192,12 +192,52 @@ def test_cfg4_whole_job_on_one_gpu(mods, tmp_path):
     check_engine(mods, dp, g, cfg, cells, want, fast=False)
     check_engine(mods, dp, g, cfg, cells, want, fast=True)
 
-    # ---- product level: one dmx_demuxlet_run call over the frozen host pileup, FAST, --write-pair
+    # ---- product level: dmx_demuxlet_run calls over the frozen host pileup
     t0 = time.perf_counter()
     pl = engine.HostPileup(B, S, po, ro, None, dp.pair_nrd.cpu().numpy(), dp.reads.cpu().numpy(), counters, counters, counters)
     del dp
     torch.cuda.empty_cache()
     print(f"pileup to host memory in {time.perf_counter() - t0:.1f} s")
+    want_bc = {barcodes[c] for c in cells}
+
+    def compare_sampled(out, sufs):
+        n_num = n_diff = 0
+        for suf in sufs:
+            got = rows_of(f"{out}.{suf}", want_bc)
+            ref = []
+            for c in cells:
+                ref += open(tmp_path / f"r{c}.{suf}").read().splitlines()[1:]
+            ref.sort(key=lambda ln: ln.split("\t", 1)[0])                       # stable: rows of a barcode keep their order
+            assert len(got) == len(ref), (suf, len(got), len(ref))
+            for a, b in zip(got, ref):
+                fa, fb = a.split("\t"), b.split("\t")
+                assert len(fa) == len(fb)
+                for x, y in zip(fa, fb):
+                    try:
+                        fx, fy = float(x), float(y)
+                    except ValueError:
+                        assert x == y, (suf, a, b)
+                        continue
+                    n_num += 1
+                    if x != y:
+                        n_diff += 1
+                        assert abs(fx - fy) <= 1e-3 * max(1e-3, abs(fy)) + 1.01e-4, (suf, a, b)
+        return n_num, n_diff
+
+    # (1) STRICT, the default of every front end, without --write-pair: the records path (K3 records + sing, no grid off the device)
+    outs = str(tmp_path / "s")
+    tm = engine.demuxlet_run(pl, g, sm, cfg["alphas"], outs, write_pair=False, arbiter=True, barcodes=barcodes, timing=True, mode=capi.DMX_MODE_STRICT)
+    print("cfg4 whole through dmx_demuxlet_run (STRICT, records path):", {k: round(v, 3) if isinstance(v, float) else v for k, v in tm.items()})
+    assert tm["n_ranges"] >= 2 and not os.path.exists(outs + ".pair")
+    best_keys = [ln.split("\t", 1)[0] for ln in open(outs + ".best").read().splitlines()[1:]]
+    assert best_keys == sorted(barcodes)
+    n_num, n_diff = compare_sampled(outs, ("single", "sing2", "best"))
+    print(f"STRICT: sampled barcodes' rows of .single/.sing2/.best: {n_num} printed numbers, {n_diff} differ from the oracle's")
+    assert n_num > 700 and n_diff == 0            # GT inputs in STRICT mode reproduce the oracle's accumulators bit for bit (engine level: max |d| = 0)
+    for suf in ("single", "sing2", "best"):
+        os.remove(f"{outs}.{suf}")
+
+    # (2) FAST with --write-pair: the whole grid through the writers
     out = str(tmp_path / "o")
     tm = engine.demuxlet_run(pl, g, sm, cfg["alphas"], out, write_pair=True, arbiter=True, barcodes=barcodes, timing=True,
                              mode=capi.DMX_MODE_FAST)
@@ -216,27 +256,9 @@ def test_cfg4_whole_job_on_one_gpu(mods, tmp_path):
     best_keys = [ln.split("\t", 1)[0] for ln in open(out + ".best").read().splitlines()[1:]]
     assert best_keys == sorted(barcodes)
 
-    want_bc = {barcodes[c] for c in cells}
-    n_num = n_diff = 0
-    for suf in ("single", "sing2", "best", "pair"):
-        got = rows_of(f"{out}.{suf}", want_bc)
-        ref = []
-        for c in cells:
-            ref += open(tmp_path / f"r{c}.{suf}").read().splitlines()[1:]
-        ref.sort(key=lambda ln: ln.split("\t", 1)[0])                       # stable: rows of a barcode keep their order
-        assert len(got) == len(ref), (suf, len(got), len(ref))
-        for a, b in zip(got, ref):
-            fa, fb = a.split("\t"), b.split("\t")
-            assert len(fa) == len(fb)
-            for x, y in zip(fa, fb):
-                try:
-                    fx, fy = float(x), float(y)
-                except ValueError:
-                    assert x == y, (suf, a, b)
-                    continue
-                n_num += 1
-                if x != y:
-                    n_diff += 1
-                    assert abs(fx - fy) <= 1e-3 * max(1e-3, abs(fy)) + 1.01e-4, (suf, a, b)
-    print(f"sampled barcodes' rows of all four files: {n_num} printed numbers, {n_diff} differ from the oracle's in the last digit")
-    assert n_diff <= max(2, n_num // 100000)
+    n_num, n_diff = compare_sampled(out, ("single", "sing2", "best", "pair"))
+    print(f"FAST: sampled barcodes' rows of all four files: {n_num} printed numbers, {n_diff} differ from the oracle's in the last digit")
+    # FAST's contract is |d| <= 1e-9 on a log-likelihood (measured 5.8e-11 here), not the oracle's digits: a printed %.4f / %.5f digit
+    # flips when the value lies within that distance of a rounding boundary — about 1e-6 per number, 0.04 expected over these 42 912.
+    # One flip is tolerated; two would be a regression.  (STRICT above is held to zero.)
+    assert n_diff <= 1
