@@ -2781,7 +2781,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
           "v_add_f64 %[" A0 "], v[232:233], %[" A0 "]\n\tv_add_f64 %[" A1 "], v[234:235], %[" A1 "]\n\t"
           {
             uint32_t tmp;
+            uint32_t m0_keep;                         // s_set_gpr_idx_on writes M0: saved and restored inside the statement (the
+                                                      // compiler may keep an LDS-DMA base or a movrel index live in it)
             asm volatile(
+                "s_mov_b32 %[m0k], m0\n\t"
                 "ds_read_b128 v[232:235], %[col]\n\tds_read_b128 v[236:239], %[col] offset:64\n\t"
                 "ds_read_b128 v[240:243], %[col] offset:128\n\tds_read_b128 v[244:247], %[col] offset:192\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
@@ -2793,7 +2796,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
                 DMX_UJ_STEP("a10", "b10", "w2", "0x40012") DMX_UJ_STEP("a11", "b11", "w2", "0x4001a")
                 DMX_UJ_STEP("a12", "b12", "w3", "0x40002") DMX_UJ_STEP("a13", "b13", "w3", "0x4000a")
                 DMX_UJ_STEP("a14", "b14", "w3", "0x40012") DMX_UJ_STEP("a15", "b15", "w3", "0x4001a")
-                "s_set_gpr_idx_off"
+                "s_set_gpr_idx_off\n\ts_mov_b32 m0, %[m0k]"
                 : [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]), [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
                   [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]), [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
                   [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]), [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]),
@@ -2802,10 +2805,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
                   [a10] "+v"(acc[10][0]), [b10] "+v"(acc[10][1]), [a11] "+v"(acc[11][0]), [b11] "+v"(acc[11][1]),
                   [a12] "+v"(acc[12][0]), [b12] "+v"(acc[12][1]), [a13] "+v"(acc[13][0]), [b13] "+v"(acc[13][1]),
                   [a14] "+v"(acc[14][0]), [b14] "+v"(acc[14][1]), [a15] "+v"(acc[15][0]), [b15] "+v"(acc[15][1]),
-                  [t] "=&s"(tmp)
+                  [t] "=&s"(tmp), [m0k] "=&s"(m0_keep)
                 : [col] "v"(col), [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3)
                 : "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245",
-                  "v246", "v247", "m0", "scc", "memory");
+                  "v246", "v247", "scc", "memory");
           }
 #undef DMX_UJ_STEP
         }
@@ -2871,6 +2874,393 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
     if (!ok) flag_cell(flagged, cell);
   }
 #undef DMX_K2_SYNC
+}
+
+// K2 over genotype classes, STRICT, A = 2, panels of 33..64 samples: PRODUCER / CONSUMER form of k_doublet_cls's uniform-j kernel (round 4).
+// In k_doublet_cls a tile has four workgroup barriers and phase 1 runs on one of the barcode's four wavefronts while the other three
+// wait (43 % of the wave time parked, rocprofv3 r03).  Here the four wavefronts of a barcode's workgroup have two roles:
+//   wavefront 0 (producer)   tile t + 1: headers, class rows and ids (requested a tile ahead, in registers) -> LDS, phase 1 (pG, the
+//                            llks00 terms and their ordered sum), phase 1b (the class table) into one half of a double buffer
+//                            {T, ids, classes of the wavefronts' samples j}; then phase 2 of tile t for the LAST 4 samples j;
+//   wavefronts 1..3 (consumers)  tile t: phase 2 of the uniform-j form for 20 samples j each — lanes = samples k, the pair's table
+//                            column in sixteen consecutive registers, the row chosen by VGPR-relative addressing (see k_doublet_cls);
+// ONE s_barrier per tile.  4 / 20 / 20 / 20 roughly balances the wavefronts' issue cycles (production costs about 12 samples' worth of
+// phase 2; 7 / 19 / 19 / 19 would be even, but 14 accumulators beside phase 1 spill at 168 registers), so the four SIMDs of a CU stay evenly loaded whichever wavefronts share them.  The consumers never touch global memory
+// inside the loop and need no register of phases 1 / 1b, the producer only 8 accumulators: 168 registers, 3 wavefronts per SIMD
+// (k_doublet_cls<256,16,uniform-j>: 256 registers, 2 per SIMD), so a SIMD has two other barcodes to issue for while one waits.
+// Same operands, same operations, same order of additions as k_doublet_cls: bit-identical (tests).  cmd_cram_demuxlet.cpp:594-710.
+#ifndef DMX_PC_J0
+#define DMX_PC_J0 4          // kernel experiments: 7 (with 19 per consumer), 1 (21), 10 (18)
+#endif
+constexpr int kPcJ0 = DMX_PC_J0, kPcJ = (64 - DMX_PC_J0) / 3;
+static_assert(kPcJ0 + 3 * kPcJ == 64 && kPcJ0 <= 8 && kPcJ <= 20 && kPcJ >= 19, "k_doublet_clsp: 4 / 20 / 20 / 20 or 7 / 19 / 19 / 19");              // samples j of wavefront 0 (the last ones) and of wavefronts 1..3
+template <int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, int nrd_width, const float* __restrict__ rows,
+                                                                const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
+                                                                const double* __restrict__ tabs, const double* __restrict__ alpha,
+                                                                const int32_t* __restrict__ sched, int32_t V, int32_t VS,
+                                                                double* __restrict__ grid, double* __restrict__ l00,
+                                                                uint8_t* __restrict__ flagged) {
+  constexpr int A = 2, TP = 32;
+  constexpr int T00 = TP + 2;
+  constexpr int NT = kMaxCls * kMaxCls * A;      // class-table entries per pair
+  constexpr int JW = 5;                          // words of class bytes per (pair, wavefront): up to 20 samples j
+  constexpr int VSC = 64;                        // id row stride in the LDS (bytes): compile-time for panels of up to 64 samples
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  __shared__ double s_tab[kTab];
+  __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha
+  const double* s_log = s_tab + kLut;
+  const int t = threadIdx.x;
+  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  if (t < 18) {
+    const int n = t / 9, l = (t % 9) / 3, m = t % 3;
+    const double p = 0.5 * l + (m - l) * 0.5 * alpha[n];
+    s_w[n][t % 9] = p;
+    s_w[n][9 + t % 9] = 1.0 - p;
+  }
+  // double-buffered (what phase 2 reads): the class table, the ids (as c * 16) and the wavefronts' class words;
+  // producer-private: pG, the llks00 terms, headers (current and next), rows
+  double* s_Tb = (double*)s_raw;                                  // [2][TP][4][4][2]
+  uint8_t* s_idb = (uint8_t*)(s_Tb + 2 * TP * NT);                // [2][TP][VSC]
+  uint32_t* s_jwb = (uint32_t*)(s_idb + 2 * (size_t)TP * VSC);     // [2][TP][4][JW + 3]   (VSC is a multiple of 16; 8 words per (pair, wavefront))
+  double* s_pG = (double*)(s_jwb + 2 * TP * 4 * 8);               // [TP][2][9]
+  double* s_t00 = s_pG + TP * 18;                                 // [2][T00]
+  int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                   // [TP]
+  int64_t* s_off2 = s_off + TP;                                   // [TP]  header of the NEXT tile
+  int32_t* s_snp = (int32_t*)(s_off2 + TP);                       // [TP]
+  int32_t* s_snp2 = s_snp + TP;
+  uint32_t* s_cnt = (uint32_t*)(s_snp2 + TP);                     // [TP]
+  uint32_t* s_cnt2 = s_cnt + TP;
+  float* s_rows = (float*)(s_cnt2 + TP);                          // [TP][4][3]
+  __syncthreads();
+
+  const int32_t cell = sched[blockIdx.x];
+  const int64_t p_beg = pv.cell_pair_off[cell];
+  const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
+  constexpr int wpr = VSC / 4;                   // id words per pair
+  (void)VS;
+  const int wave = t >> 6, lane = t & 63;        // lane = sample k in phase 2
+  const int j0 = wave == 0 ? 3 * kPcJ : (wave - 1) * kPcJ;       // first sample j of this wavefront
+  typedef uint32_t dmx_u4 __attribute__((ext_vector_type(4)));
+  using lds_u4 = const __attribute__((address_space(3))) dmx_u4*;
+  using lds_u1 = const __attribute__((address_space(3))) uint32_t*;
+
+  // phase 2 of one pair for NJ samples j (one asm statement; see k_doublet_cls).  Column registers v[152:167]: the top of the 168-register budget.
+#define DMX_UJP_STEP(A0, A1, W, B)                                                                                \
+  "s_bfe_u32 %[t], %[" W "], " B "\n\ts_set_gpr_idx_on %[t], 0x1\n\t"                                             \
+  "v_add_f64 %[" A0 "], v[152:153], %[" A0 "]\n\tv_add_f64 %[" A1 "], v[154:155], %[" A1 "]\n\t"
+#define DMX_UJP_HEAD                                                                                              \
+  "s_mov_b32 %[m0k], m0\n\t"                                                                                      \
+  "ds_read_b128 v[152:155], %[col]\n\tds_read_b128 v[156:159], %[col] offset:64\n\t"                              \
+  "ds_read_b128 v[160:163], %[col] offset:128\n\tds_read_b128 v[164:167], %[col] offset:192\n\t"                  \
+  "s_waitcnt lgkmcnt(0)\n\t"
+#define DMX_UJP_TAIL "s_set_gpr_idx_off\n\ts_mov_b32 m0, %[m0k]"
+#define DMX_UJP_CLOB "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "scc", "memory"
+
+  if (wave == 0) {
+    // ================================================= producer =================================================
+    const int ti1 = lane >> 1, n1 = lane & 1;
+    int64_t rd_base = pv.cell_read_off[cell];
+    double acc00 = 0.0;
+    bool ok = true;
+    double acc[kPcJ0][A];
+#pragma unroll
+    for (int kk = 0; kk < kPcJ0; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
+    const bool owner = lane < V && j0 < V;
+    constexpr int NRR = 6, NRI = 8;              // per-lane registers of a tile's rows / id words: half a pair's 12 floats / 16 id words
+    uint32_t hd_n = 0u; int32_t hd_s = 0;        // header loads in flight (lanes < TP)
+    uint32_t pn = 0u; int32_t psn = 0; int64_t poff = 0;
+    float d_rows[NRR]; uint32_t d_ids[NRI]; uint32_t d_rd4 = 0u; double d_g0[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NRR; ++i) d_rows[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NRI; ++i) d_ids[i] = 0u;
+    auto load_hdr = [&](int64_t first) {
+      hd_n = 0u; hd_s = 0;
+      const int64_t nx = first + lane;
+      if (lane < TP && nx < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + nx, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + nx] : (int32_t)nx; }
+    };
+    auto publish_next = [&]() {                  // hd_* (arrived) -> the prepared header of the next tile, into LDS
+      pn = hd_n; psn = hd_s;
+      const uint32_t incl = seg_scan_incl<32>(pn);
+      poff = rd_base + (int64_t)(incl - pn);
+      rd_base += (int64_t)__shfl(incl, 31);
+      if (lane < TP) { s_cnt2[lane] = pn; s_off2[lane] = poff; s_snp2[lane] = psn; }
+    };
+    auto request_next = [&]() {                  // the published tile's rows, ids, leading read bytes and gp0 -> registers
+      // lane (pair ti1, half n1): six consecutive floats of the pair's class rows and eight consecutive id words — one base address each
+      const int32_t snp = s_snp2[ti1];
+      const float* rsrc = rows + (size_t)snp * 12 + n1 * 6;
+#pragma unroll
+      for (int i = 0; i < NRR; ++i) d_rows[i] = rsrc[i];
+      const uint8_t* isrc = ids + (size_t)snp * V + n1 * 32;
+#pragma unroll
+      for (int i = 0; i < NRI; ++i) {
+        // one (possibly unaligned) 4-byte load per word: gfx950 global loads take any alignment; a row's last word is masked to its V
+        // bytes (the bytes beyond belong to the next SNP's row; d_ids is allocated with 16 bytes of slack)
+        const int k0 = n1 * 32 + 4 * i;
+        uint32_t wv = 0;
+        if (k0 < V) {
+          __builtin_memcpy(&wv, isrc + 4 * i, 4);
+          const int nb = V - k0;
+          if (nb < 4) wv &= (1u << (8 * nb)) - 1u;
+        }
+        d_ids[i] = wv;
+      }
+      d_rd4 = load_rd4(pv, s_off2[ti1], s_cnt2[ti1]);
+      const double* g0 = gp0 + (size_t)snp * 3;
+      d_g0[0] = g0[0]; d_g0[1] = g0[1]; d_g0[2] = g0[2];
+    };
+    auto build = [&](int64_t tbase, int b) {     // tile [tbase, tbase + TP) -> buffer b
+      const int tp = (int)min((int64_t)TP, np - tbase);
+      double* s_T = s_Tb + (size_t)b * TP * NT;
+      uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
+      uint32_t* s_jw = s_jwb + (size_t)b * TP * 4 * 8;
+      if (lane < TP) { s_cnt[lane] = pn; s_off[lane] = poff; s_snp[lane] = psn; }
+#pragma unroll
+      for (int i = 0; i < NRR; ++i) s_rows[ti1 * 12 + n1 * 6 + i] = d_rows[i];
+#pragma unroll
+      for (int i = 0; i < NRI; ++i) reinterpret_cast<uint32_t*>(s_ids)[ti1 * wpr + n1 * 8 + i] = d_ids[i] << 4;   // class id c as c * 16
+      const uint32_t rd4 = d_rd4;
+      const double qq[3] = {d_g0[0], d_g0[1], d_g0[2]};
+      publish_next();
+      load_hdr(tbase + 2 * TP);
+      DMX_WAVE_LDS_ORDER();
+      // the class bytes of every wavefront's samples j, five words per (pair, wavefront)
+      for (int e = lane; e < TP * 4 * JW; e += 64) {
+        const int ti = e / (4 * JW), w = (e / JW) & 3, m = e % JW;
+        const int jb = (w == 0 ? 3 * kPcJ : (w - 1) * kPcJ) + 4 * m, nj = w == 0 ? kPcJ0 : kPcJ;
+        uint32_t wv = 0;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) if (4 * m + bb < nj && jb + bb < V) wv |= (uint32_t)s_ids[ti * VSC + jb + bb] << (8 * bb);
+        s_jw[(ti * 4 + w) * 8 + m] = wv;
+      }
+      // ---- phase 1 (identical to k_doublet_a2 / k_doublet_cls)
+      {
+        const bool on = ti1 < tp;
+        const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+        const int64_t off = on ? s_off[ti1] : 0;
+        double pG[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) pG[i] = 1.0;
+        for (uint32_t r = 0; __any(r < cnt); ++r) {
+          const bool live = r < cnt;
+          const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
+          const uint32_t bq = byte & 127u;
+          const bool alt = (byte >> 7) != 0;
+          const double pR = alt ? s_tab[128 + bq] : s_tab[bq];
+          const double pA = alt ? s_tab[bq] : s_tab[128 + bq];
+          double mx = 0.0;
+          if (live) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+              pG[i] *= (pR * s_w[n1][9 + i] + pA * s_w[n1][i]);
+              mx = fmax(mx, pG[i]);
+            }
+          }
+          {
+            const double o = shfl_xor1(mx);
+            mx = fmax(mx, o);
+          }
+          if (live) {
+            if (cnt <= kSafeReads) {
+              const double y = rcp_refined(mx);
+#pragma unroll
+              for (int i = 0; i < 9; ++i) pG[i] = div_by(pG[i], mx, y);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 9; ++i) pG[i] /= mx;
+            }
+          }
+        }
+        double mx = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+          pG[i] += 1e-6;
+          mx = fmax(mx, pG[i]);
+        }
+        {
+          const double o = shfl_xor1(mx);
+          mx = fmax(mx, o);
+        }
+        if (on) {
+          const double y = rcp_refined(mx);
+          double sum = 0.0;
+#pragma unroll
+          for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              const double v = div_by(pG[l * 3 + m], mx, y);
+              s_pG[(ti1 * 2 + n1) * 9 + l * 3 + m] = v;
+              sum += ((qq[l] * qq[m]) * v);
+            }
+          ok &= __builtin_amdgcn_class(sum, 0x100);
+          s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);
+        }
+      }
+      DMX_WAVE_LDS_ORDER();
+      request_next();                                              // (after phase 1: its registers are free again; phase 1b, this wavefront's
+                                                                   //  phase 2 and the barrier cover the loads' latency)
+      if (lane < 2) {                                              // llks00[n] += the tile's terms, ascending SNP order (:688-704)
+        const double* row = &s_t00[lane * T00];
+        if (tp == TP) {
+          double2 v[TP / 2];
+#pragma unroll
+          for (int i = 0; i < TP / 2; ++i) v[i] = *reinterpret_cast<const double2*>(&row[2 * i]);
+#pragma unroll
+          for (int i = 0; i < TP / 2; ++i) { acc00 += v[i].x; acc00 += v[i].y; }
+        } else {
+          for (int i = 0; i < tp; ++i) acc00 += row[i];
+        }
+      }
+      // ---- phase 1b: the class table (16 entries per lane)
+      for (int e = lane; e < tp * NT; e += 64) {
+        const int ti = e / NT, cc = e % NT;
+        const int cj = cc >> 3, ck = (cc >> 1) & 3, n = cc & 1;
+        const float* rj = &s_rows[ti * 12 + cj * 3];
+        const float* rk = &s_rows[ti * 12 + ck * 3];
+        const double* P = &s_pG[(ti * 2 + n) * 9];
+        const double aj[3] = {(double)rj[0], (double)rj[1], (double)rj[2]};
+        const double bk[3] = {(double)rk[0], (double)rk[1], (double)rk[2]};
+        double sum = 0.0;                                                          // :674
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) sum += ((aj[l] * bk[m]) * P[l * 3 + m]);     // :553, :677-679
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        s_T[ti * NT + cc] = dmx_log_fast(sum, s_log);                              // the :683 term
+      }
+      DMX_WAVE_LDS_ORDER();                                        // (pG, t00, rows and the headers are rewritten by the next build)
+    };
+    auto consume = [&](int64_t tbase, int b) {   // phase 2 of tile [tbase, ..) for this wavefront's 4 samples j
+      const int tp = (int)min((int64_t)TP, np - tbase);
+      if (!owner) return;
+      const uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
+      const uint32_t t_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
+      const uint32_t jw_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)(s_jwb + (size_t)b * TP * 4 * 8);
+      for (int ti = 0; ti < tp; ++ti) {
+        const uint32_t ja = jw_a + (uint32_t)((ti * 4 + 0) * 32);
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(lds_u1)(uintptr_t)ja),
+                       w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(lds_u1)(uintptr_t)(ja + 4));
+        const uint32_t col = t_a + (uint32_t)(ti * NT * 8) + (uint32_t)s_ids[ti * VSC + lane];
+        uint32_t tmp, m0_keep;
+        asm volatile(DMX_UJP_HEAD
+            DMX_UJP_STEP("a0", "b0", "w0", "0x40002") DMX_UJP_STEP("a1", "b1", "w0", "0x4000a")
+            DMX_UJP_STEP("a2", "b2", "w0", "0x40012") DMX_UJP_STEP("a3", "b3", "w0", "0x4001a")
+#if DMX_PC_J0 == 7
+            DMX_UJP_STEP("a4", "b4", "w1", "0x40002") DMX_UJP_STEP("a5", "b5", "w1", "0x4000a") DMX_UJP_STEP("a6", "b6", "w1", "0x40012")
+#endif
+            DMX_UJP_TAIL
+            : [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]), [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
+              [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]), [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
+#if DMX_PC_J0 == 7
+              [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]), [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]), [a6] "+v"(acc[6][0]), [b6] "+v"(acc[6][1]),
+#endif
+              [t] "=&s"(tmp), [m0k] "=&s"(m0_keep)
+            : [col] "v"(col), [w0] "s"(w0), [w1] "s"(w1)
+            : DMX_UJP_CLOB);
+      }
+    };
+    if (np > 0) {
+      load_hdr(0);
+      publish_next();
+      load_hdr(TP);
+      DMX_WAVE_LDS_ORDER();
+      request_next();
+      DMX_WAVE_LDS_ORDER();                        // (the next tile's header may be overwritten from here on)
+    }
+    int b = 1;                                     // the round before the first tile only builds tile 0 (into buffer 0)
+    for (int64_t tbase = -TP; tbase < np; tbase += TP, b ^= 1) {
+      if (tbase + TP < np) build(tbase + TP, b ^ 1);
+      if (tbase >= 0) consume(tbase, b);
+      __syncthreads();
+    }
+    if (owner) {
+#pragma unroll
+      for (int jj = 0; jj < kPcJ0; ++jj) {
+        const int jx = j0 + jj;
+        if (jx < V) {
+          double* o = grid + (((size_t)cell * V + jx) * V + lane) * A;
+          o[0] = acc[jj][0]; o[1] = acc[jj][1];
+        }
+      }
+    }
+    if (lane < 2) l00[(size_t)cell * A + lane] = acc00;
+    if (!ok) flag_cell(flagged, cell);
+  } else {
+    // ================================================= consumers ================================================
+    const bool owner = lane < V && j0 < V;
+    double acc[kPcJ][A];
+#pragma unroll
+    for (int kk = 0; kk < kPcJ; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
+    int b = 1;
+    for (int64_t tbase = -TP; tbase < np; tbase += TP, b ^= 1) {
+      const int tp = tbase < 0 ? 0 : (int)min((int64_t)TP, np - tbase);
+      if (owner) {
+        const uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
+        const uint32_t t_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
+        const uint32_t jw_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)(s_jwb + (size_t)b * TP * 4 * 8);
+        for (int ti = 0; ti < tp; ++ti) {
+          // the classes of the wavefront's 20 samples j (bytes c * 16; broadcast reads) into scalar registers
+          const uint32_t ja = jw_a + (uint32_t)((ti * 4 + wave) * 32);
+          const dmx_u4 jw = *(lds_u4)(uintptr_t)ja;
+          const uint32_t j4 = *(lds_u1)(uintptr_t)(ja + 16);
+          const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.y),
+                         w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.z), w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.w),
+                         w4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j4);
+          // this lane's column of the pair's table: T[cj][ck] for cj = 0..3 (rows 64 bytes apart), ck = the class of sample k
+          const uint32_t col = t_a + (uint32_t)(ti * NT * 8) + (uint32_t)s_ids[ti * VSC + lane];
+          uint32_t tmp, m0_keep;
+          asm volatile(DMX_UJP_HEAD
+              DMX_UJP_STEP("a0", "b0", "w0", "0x40002") DMX_UJP_STEP("a1", "b1", "w0", "0x4000a")
+              DMX_UJP_STEP("a2", "b2", "w0", "0x40012") DMX_UJP_STEP("a3", "b3", "w0", "0x4001a")
+              DMX_UJP_STEP("a4", "b4", "w1", "0x40002") DMX_UJP_STEP("a5", "b5", "w1", "0x4000a")
+              DMX_UJP_STEP("a6", "b6", "w1", "0x40012") DMX_UJP_STEP("a7", "b7", "w1", "0x4001a")
+              DMX_UJP_STEP("a8", "b8", "w2", "0x40002") DMX_UJP_STEP("a9", "b9", "w2", "0x4000a")
+              DMX_UJP_STEP("a10", "b10", "w2", "0x40012") DMX_UJP_STEP("a11", "b11", "w2", "0x4001a")
+              DMX_UJP_STEP("a12", "b12", "w3", "0x40002") DMX_UJP_STEP("a13", "b13", "w3", "0x4000a")
+              DMX_UJP_STEP("a14", "b14", "w3", "0x40012") DMX_UJP_STEP("a15", "b15", "w3", "0x4001a")
+              DMX_UJP_STEP("a16", "b16", "w4", "0x40002") DMX_UJP_STEP("a17", "b17", "w4", "0x4000a")
+              DMX_UJP_STEP("a18", "b18", "w4", "0x40012")
+#if DMX_PC_J0 == 4
+              DMX_UJP_STEP("a19", "b19", "w4", "0x4001a")
+#endif
+              DMX_UJP_TAIL
+              : [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]), [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
+                [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]), [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
+                [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]), [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]),
+                [a6] "+v"(acc[6][0]), [b6] "+v"(acc[6][1]), [a7] "+v"(acc[7][0]), [b7] "+v"(acc[7][1]),
+                [a8] "+v"(acc[8][0]), [b8] "+v"(acc[8][1]), [a9] "+v"(acc[9][0]), [b9] "+v"(acc[9][1]),
+                [a10] "+v"(acc[10][0]), [b10] "+v"(acc[10][1]), [a11] "+v"(acc[11][0]), [b11] "+v"(acc[11][1]),
+                [a12] "+v"(acc[12][0]), [b12] "+v"(acc[12][1]), [a13] "+v"(acc[13][0]), [b13] "+v"(acc[13][1]),
+                [a14] "+v"(acc[14][0]), [b14] "+v"(acc[14][1]), [a15] "+v"(acc[15][0]), [b15] "+v"(acc[15][1]),
+                [a16] "+v"(acc[16][0]), [b16] "+v"(acc[16][1]), [a17] "+v"(acc[17][0]), [b17] "+v"(acc[17][1]),
+                [a18] "+v"(acc[18][0]), [b18] "+v"(acc[18][1]),
+#if DMX_PC_J0 == 4
+                [a19] "+v"(acc[19][0]), [b19] "+v"(acc[19][1]),
+#endif
+                [t] "=&s"(tmp), [m0k] "=&s"(m0_keep)
+              : [col] "v"(col), [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3), [w4] "s"(w4)
+              : DMX_UJP_CLOB);
+        }
+      }
+      __syncthreads();
+    }
+    if (owner) {
+#pragma unroll
+      for (int jj = 0; jj < kPcJ; ++jj) {
+        const int jx = j0 + jj;
+        if (jx < V) {
+          double* o = grid + (((size_t)cell * V + jx) * V + lane) * A;
+          o[0] = acc[jj][0]; o[1] = acc[jj][1];
+        }
+      }
+    }
+  }
+#undef DMX_UJP_STEP
+#undef DMX_UJP_HEAD
+#undef DMX_UJP_TAIL
+#undef DMX_UJP_CLOB
 }
 
 // K2 over genotype classes, FAST mode, alpha grid {0, 0.5}: k_doublet_sym's entry set (singlet column + one evaluation per
@@ -4588,6 +4978,13 @@ int launch_doublet(dmx_engine* e) {
     else if (V <= 32) DMX_K2C(256, 4);
     else if (getenv("DMX_CLS_MINW3")) DMX_K2C(256, 16, 3);    // kernel experiments only (36 spills: slower)
     else if (getenv("DMX_CLS_NK8")) { if (atoi(getenv("DMX_CLS_NK8")) == 3) DMX_K2C(256, 8, 3); else DMX_K2C(256, 8); }
+    else if (V <= 64 && !getenv("DMX_CLS_NO_PROD") && !getenv("DMX_CLS_NO_UJ")) {
+      // producer / consumer form (round 4): one barrier per tile, wavefront 0 builds the next tile's class table, 3 wavefronts per SIMD
+      const size_t lds = (size_t)2 * 32 * 32 * 8 + (size_t)2 * 32 * 64 + (size_t)2 * 32 * 4 * 8 * 4 + (size_t)32 * 18 * 8 + 2 * 34 * 8 + 2 * 32 * (8 + 4 + 4) +
+                         (size_t)32 * 12 * 4;
+      hipLaunchKernelGGL((k_doublet_clsp<3>), dim3((unsigned)B), dim3(kThreads), lds, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0,
+                         e->d_lut, e->d_alpha, e->d_sched, V, VS, e->d_grid, e->d_l00, e->d_flag);
+    }
     else if (V <= 64 && !getenv("DMX_CLS_NO_UJ")) DMX_K2C(256, 16, 2, true);   // uniform-j form (a wavefront's 16 samples j share their class per pair)
     else DMX_K2C(256, 16);
 #undef DMX_K2C
