@@ -529,13 +529,24 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
             bcs = [f"BC{i:07d}-1" for i in range(B)]
             sms = [f"SM{j:02d}" for j in range(V)]
             e2e = {"what": "dmx_demuxlet_run on this workload from a frozen HOST pileup (no --write-pair, tie arbiter on, 1 GPU): wall seconds per stage"}
-            with tempfile.TemporaryDirectory() as td:
+            with tempfile.TemporaryDirectory() as td_dir:
                 for name, md in (("strict", engine.capi.DMX_MODE_STRICT), ("fast", engine.capi.DMX_MODE_FAST)):
-                    tm = engine.demuxlet_run(hp, g, sms, cfg["alphas"], os.path.join(td, name), barcodes=bcs, timing=True, mode=md)
+                    tm = engine.demuxlet_run(hp, g, sms, cfg["alphas"], os.path.join(td_dir, name), barcodes=bcs, timing=True, mode=md)
                     tm.pop("reserved", None)
                     tm["arbiter_format_write_frac"] = tm["write_s"] / tm["total_s"]
                     tm["triples_per_s"] = dp.n_pairs * V / tm["total_s"]
                     e2e[name] = tm
+                    # the same job from the DEVICE-resident pileup (dmx_pileup.memory = DMX_MEM_DEVICE: no host slicing, no H2D of the CSR;
+                    # only the per-cell counters and the barcodes are host memory); same files, byte for byte
+                    ds = dp.as_struct()
+                    ds.rd_totl = ds.rd_pass = ds.rd_uniq = nreads.ctypes.data
+                    td = engine.demuxlet_run(ds, g, sms, cfg["alphas"], os.path.join(td_dir, name + "_dev"), barcodes=bcs, timing=True, mode=md)
+                    td.pop("reserved", None)
+                    td["triples_per_s"] = dp.n_pairs * V / td["total_s"]
+                    td["files_identical_to_the_host_run"] = all(
+                        open(os.path.join(td_dir, f"{name}.{suf}"), "rb").read() == open(os.path.join(td_dir, f"{name}_dev.{suf}"), "rb").read()
+                        for suf in ("single", "sing2", "best"))
+                    e2e[name + "_device_pileup"] = td
             try:
                 e2e["from_bam_and_vcf"] = cli_leg()
             except Exception as ex:                      # the leg is a side record: never let it take the bench line down
@@ -601,7 +612,8 @@ def compact_line(full):
                         for a in full["also"]]
     e2e = full.get("end_to_end")
     if e2e:
-        line["end_to_end"] = {m: pick(e2e[m], ("total_s", "stage_s", "wait_s", "write_s")) for m in ("strict", "fast") if m in e2e}
+        line["end_to_end"] = {m: pick(e2e[m], ("total_s", "stage_s", "wait_s", "write_s", "files_identical_to_the_host_run"))
+                              for m in ("strict", "fast", "strict_device_pileup", "fast_device_pileup") if m in e2e}
         cli = e2e.get("from_bam_and_vcf") or {}
         if "all_cores" in cli:
             line["end_to_end"]["bam_vcf_scan_reads_per_s"] = cli["all_cores"].get("scan_reads_per_s")

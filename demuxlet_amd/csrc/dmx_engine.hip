@@ -4266,8 +4266,8 @@ struct dmx_engine {
   float* d_rows = nullptr; uint8_t* d_ids = nullptr; uint32_t* d_idw = nullptr; uint32_t* d_idd = nullptr; int32_t nwd2 = 0; int32_t n_classes = 0;   // genotype classes (0 = not usable)
   // pileup
   PileupView pv{}; int32_t nrd_width = 1; int64_t P = 0, R = 0; bool have_pileup = false;
-  void* own[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // device copies of a host pileup (grow-only: a job's ranges reuse them)
-  size_t own_cap[5] = {0, 0, 0, 0, 0};
+  void* own[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device copies of a host pileup (grow-only: a job's ranges reuse them); [5]: gather sources
+  size_t own_cap[6] = {0, 0, 0, 0, 0, 0};
   int32_t* d_sched = nullptr; size_t sched_cap = 0;
   int32_t* d_bad = nullptr;                                          // set by k_check_snp_ids
   bool have_gT = false;                                              // d_gT / d_g0T hold the current genotype matrix
@@ -4292,7 +4292,7 @@ struct dmx_engine {
 namespace {
 
 int free_pileup(dmx_engine* e) {
-  for (int i = 0; i < 5; ++i) { if (e->own[i]) (void)hipFree(e->own[i]); e->own[i] = nullptr; e->own_cap[i] = 0; }
+  for (int i = 0; i < 6; ++i) { if (e->own[i]) (void)hipFree(e->own[i]); e->own[i] = nullptr; e->own_cap[i] = 0; }
   if (e->d_sched) (void)hipFree(e->d_sched);
   e->d_sched = nullptr; e->sched_cap = 0;
   e->have_pileup = false;
@@ -4566,6 +4566,98 @@ struct StageWriter {
 
 // Cells cells[0..nb) of the host pileup `pl` (NULL = all of them, in order) become cells 0..nb-1 of the engine: the CSR is
 // re-based on the fly while it streams to the device, runs of consecutive cells move as one piece.
+// A range of a DEVICE-resident pileup whose cells are not consecutive: the cells' pieces of the three big arrays are copied to the
+// engine's own buffers on the device (one workgroup per cell; src = the cells' first pair / first read byte in the caller's arrays).
+__global__ __launch_bounds__(256) void k_gather_cells(const int64_t* __restrict__ src_pair, const int64_t* __restrict__ src_read,
+                                                      const int64_t* __restrict__ dst_pair_off, const int64_t* __restrict__ dst_read_off,
+                                                      const int32_t* __restrict__ pair_snp, const uint8_t* __restrict__ pair_nrd, int w,
+                                                      const uint8_t* __restrict__ reads, int32_t* __restrict__ o_snp,
+                                                      uint8_t* __restrict__ o_nrd, uint8_t* __restrict__ o_reads) {
+  const int k = blockIdx.x;
+  const int64_t sp = src_pair[k], sr = src_read[k], dp = dst_pair_off[k], dr = dst_read_off[k];
+  const int64_t np = dst_pair_off[k + 1] - dp, nr = dst_read_off[k + 1] - dr;
+  if (pair_snp) for (int64_t i = threadIdx.x; i < np; i += blockDim.x) o_snp[dp + i] = pair_snp[sp + i];
+  for (int64_t i = threadIdx.x; i < np * w; i += blockDim.x) o_nrd[dp * w + i] = pair_nrd[sp * w + i];
+  for (int64_t i = threadIdx.x; i < nr; i += blockDim.x) o_reads[dr + i] = reads[sr + i];
+}
+
+// dmx_engine_set_pileup for cells cells[0..nb) (NULL: all) of a DEVICE-resident pileup; h_po / h_ro = host copies of its two offset
+// arrays.  Consecutive cells are a VIEW of the caller's arrays (nothing is copied: the kernels index the big arrays with the absolute
+// offsets they read from cell_pair_off / cell_read_off); anything else is gathered on the device.
+int set_pileup_cells_device(dmx_engine* e, const dmx_pileup* pl, const int64_t* h_po, const int64_t* h_ro, const int32_t* cells, int32_t nb,
+                            const char* who) {
+  const int32_t B = nb;
+  const bool dense = !pl->pair_snp && pl->n_pairs > 0;
+  bool consecutive = true;
+  for (int32_t k = 0; k < B; ++k) {
+    const int32_t c = cells ? cells[k] : k;
+    if (c < 0 || c >= pl->n_cells) return set_error(DMX_ERR_ARG, "%s: cell %d of %d", who, c, pl->n_cells);
+    if (h_po[c + 1] < h_po[c] || h_ro[c + 1] < h_ro[c]) return set_error(DMX_ERR_ARG, "%s: cell_pair_off / cell_read_off not monotone at %d", who, c);
+    if (h_po[c] < 0 || h_po[c + 1] > pl->n_pairs || h_ro[c] < 0 || h_ro[c + 1] > pl->n_reads) return set_error(DMX_ERR_ARG, "%s: offsets of cell %d leave the arrays", who, c);
+    if (dense && h_po[c + 1] - h_po[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "%s: dense layout needs n_snps pairs per cell (cell %d)", who, c);
+    if (cells && k && cells[k] != cells[k - 1] + 1) consecutive = false;
+  }
+  std::vector<int64_t> h_off((size_t)B + 1, 0), h_roff((size_t)B + 1, 0);
+  for (int32_t k = 0; k < B; ++k) {
+    const int32_t c = cells ? cells[k] : k;
+    h_off[(size_t)k + 1] = h_off[(size_t)k] + (h_po[c + 1] - h_po[c]);
+    h_roff[(size_t)k + 1] = h_roff[(size_t)k] + (h_ro[c + 1] - h_ro[c]);
+  }
+  const int64_t P = h_off[(size_t)B], R = h_roff[(size_t)B];
+  if (consecutive) {
+    const int32_t c0 = B ? (cells ? cells[0] : 0) : 0;
+    e->pv.cell_pair_off = pl->cell_pair_off + c0; e->pv.cell_read_off = pl->cell_read_off + c0;
+    e->pv.pair_snp = pl->pair_snp; e->pv.pair_nrd = pl->pair_nrd; e->pv.reads = pl->reads;
+    if (!pl->pair_snp && P == 0) {               // no pairs at all: never the dense layout (NULL would select it)
+      if (int rc = ensure_dev(&e->own[2], &e->own_cap[2], 16)) return rc;
+      e->pv.pair_snp = (const int32_t*)e->own[2];
+    }
+    e->pv.R = pl->n_reads;                       // (the bound of the caller's read array: offsets are absolute in a view)
+  } else {
+    const size_t w = (size_t)pl->nrd_width;
+    if (int rc = ensure_dev(&e->own[0], &e->own_cap[0], sizeof(int64_t) * ((size_t)B + 1))) return rc;
+    if (int rc = ensure_dev(&e->own[1], &e->own_cap[1], sizeof(int64_t) * ((size_t)B + 1))) return rc;
+    if (int rc = ensure_dev(&e->own[2], &e->own_cap[2], dense ? 16 : sizeof(int32_t) * (size_t)P + 16)) return rc;
+    if (int rc = ensure_dev(&e->own[3], &e->own_cap[3], (size_t)P * w + 4)) return rc;
+    if (int rc = ensure_dev(&e->own[4], &e->own_cap[4], (size_t)R + 4)) return rc;
+    if (int rc = ensure_dev(&e->own[5], &e->own_cap[5], sizeof(int64_t) * 2 * (size_t)std::max(B, 1))) return rc;
+    std::vector<int64_t> src((size_t)2 * std::max(B, 1));
+    for (int32_t k = 0; k < B; ++k) { src[(size_t)k] = h_po[cells[k]]; src[(size_t)B + k] = h_ro[cells[k]]; }
+    HIP_TRY(hipMemcpyAsync(e->own[0], h_off.data(), sizeof(int64_t) * ((size_t)B + 1), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->own[1], h_roff.data(), sizeof(int64_t) * ((size_t)B + 1), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->own[5], src.data(), sizeof(int64_t) * 2 * (size_t)B, hipMemcpyHostToDevice, e->stream));
+    if (B) {
+      hipLaunchKernelGGL(k_gather_cells, dim3((unsigned)B), dim3(256), 0, e->stream, (const int64_t*)e->own[5], (const int64_t*)e->own[5] + B,
+                         (const int64_t*)e->own[0], (const int64_t*)e->own[1], dense ? nullptr : pl->pair_snp, (const uint8_t*)pl->pair_nrd, (int)w,
+                         pl->reads, (int32_t*)e->own[2], (uint8_t*)e->own[3], (uint8_t*)e->own[4]);
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));     // (h_off, h_roff, src go away)
+    e->pv.cell_pair_off = (const int64_t*)e->own[0]; e->pv.cell_read_off = (const int64_t*)e->own[1];
+    e->pv.pair_snp = (dense && P > 0) ? nullptr : (const int32_t*)e->own[2];
+    e->pv.pair_nrd = (const uint8_t*)e->own[3]; e->pv.reads = (const uint8_t*)e->own[4];
+    e->pv.R = R;
+  }
+  if (e->pv.pair_snp && P > 0) {                  // what the kernels will index the genotype matrix with (a view checks its own pairs only)
+    if (!e->d_bad) HIP_TRY(hipMalloc((void**)&e->d_bad, sizeof(int32_t)));
+    HIP_TRY(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), e->stream));
+    const int32_t* first = consecutive ? pl->pair_snp + h_po[B ? (cells ? cells[0] : 0) : 0] : e->pv.pair_snp;
+    hipLaunchKernelGGL(k_check_snp_ids, dim3(1024), dim3(256), 0, e->stream, first, P, e->S, e->d_bad);
+    HIP_TRY(hipGetLastError());
+  }
+  e->pv.B = B; e->pv.S = e->S; e->nrd_width = pl->nrd_width; e->P = P; e->R = R;
+  std::vector<int32_t> sched((size_t)B);
+  std::iota(sched.begin(), sched.end(), 0);
+  std::stable_sort(sched.begin(), sched.end(), [&](int32_t a, int32_t b) { return (h_off[a + 1] - h_off[a]) > (h_off[b + 1] - h_off[b]); });
+  if (int rc = ensure_dev((void**)&e->d_sched, &e->sched_cap, sizeof(int32_t) * (size_t)B)) return rc;
+  if (B) HIP_TRY(hipMemcpyAsync(e->d_sched, sched.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, e->stream));
+  int32_t bad = 0;
+  if (e->pv.pair_snp && P > 0) HIP_TRY(hipMemcpyAsync(&bad, e->d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (bad) return set_error(DMX_ERR_ARG, "%s: a pair_snp entry is outside [0, %d)", who, e->S);
+  return DMX_OK;
+}
+
 int set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, int32_t nb, const char* who) {
   const int32_t B = nb;
   std::vector<int64_t> h_off((size_t)B + 1, 0), h_roff((size_t)B + 1, 0);
@@ -4646,7 +4738,7 @@ extern "C" int dmx_engine_set_pileup(dmx_engine* e, const dmx_pileup* pl) {
   return dmx::engine_set_pileup_cells(e, pl, nullptr, pl->n_cells);
 }
 
-int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, int32_t nb) {
+int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, int32_t nb, const int64_t* host_po, const int64_t* host_ro) {
   if (pl->n_cells < 0 || pl->n_pairs < 0 || pl->n_reads < 0 || nb < 0) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: negative size");
   if (pl->nrd_width != 1 && pl->nrd_width != 2 && pl->nrd_width != 4) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: nrd_width %d", pl->nrd_width);
   if (!pl->cell_pair_off || !pl->cell_read_off || (pl->n_pairs && !pl->pair_nrd) || (pl->n_reads && !pl->reads))
@@ -4657,27 +4749,23 @@ int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int3
   e->have_pileup = false;
   const int32_t B = nb;
   if (pl->memory == DMX_MEM_DEVICE) {
-    if (cells) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: a cell subset needs a host pileup");
-    std::vector<int64_t> h_off((size_t)B + 1);
-    HIP_TRY(hipMemcpy(h_off.data(), pl->cell_pair_off, sizeof(int64_t) * ((size_t)B + 1), hipMemcpyDeviceToHost));
-    e->pv.cell_pair_off = pl->cell_pair_off; e->pv.cell_read_off = pl->cell_read_off; e->pv.pair_snp = pl->pair_snp;
-    e->pv.pair_nrd = pl->pair_nrd; e->pv.reads = pl->reads;
-    if (!pl->pair_snp && pl->n_pairs == 0) {     // no pairs at all: never the dense layout (NULL would select it)
-      if (int rc = ensure_dev(&e->own[2], &e->own_cap[2], 16)) return rc;
-      e->pv.pair_snp = (const int32_t*)e->own[2];
+    hipPointerAttribute_t at{};                   // the arrays must be visible to this engine's device
+    if (hipPointerGetAttributes(&at, pl->cell_pair_off) == hipSuccess && at.type == hipMemoryTypeDevice && at.device != e->device) {
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, e->device, at.device);
+      if (!can) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: the pileup lives on device %d, the engine on device %d (no peer access)", at.device, e->device);
     }
-    if (h_off[0] != 0 || h_off[(size_t)B] != pl->n_pairs) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off does not span n_pairs");
-    for (int32_t c = 0; c < B; ++c) {
-      if (h_off[c + 1] < h_off[c]) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off not monotone at %d", c);
-      if (!e->pv.pair_snp && h_off[c + 1] - h_off[c] != pl->n_snps) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: dense layout needs n_snps pairs per cell (cell %d)", c);
+    (void)hipGetLastError();
+    const int64_t *h_po = host_po, *h_ro = host_ro;
+    std::vector<int64_t> po_buf, ro_buf;
+    if (!h_po || !h_ro) {
+      po_buf.resize((size_t)pl->n_cells + 1); ro_buf.resize((size_t)pl->n_cells + 1);
+      HIP_TRY(hipMemcpy(po_buf.data(), pl->cell_pair_off, sizeof(int64_t) * ((size_t)pl->n_cells + 1), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(ro_buf.data(), pl->cell_read_off, sizeof(int64_t) * ((size_t)pl->n_cells + 1), hipMemcpyDeviceToHost));
+      h_po = po_buf.data(); h_ro = ro_buf.data();
     }
-    e->pv.B = B; e->pv.S = e->S; e->pv.R = pl->n_reads; e->nrd_width = pl->nrd_width; e->P = pl->n_pairs; e->R = pl->n_reads;
-    std::vector<int32_t> sched((size_t)B);
-    std::iota(sched.begin(), sched.end(), 0);
-    std::stable_sort(sched.begin(), sched.end(), [&](int32_t a, int32_t b) { return (h_off[a + 1] - h_off[a]) > (h_off[b + 1] - h_off[b]); });
-    if (int rc = ensure_dev((void**)&e->d_sched, &e->sched_cap, sizeof(int32_t) * (size_t)B)) return rc;
-    if (B) HIP_TRY(hipMemcpyAsync(e->d_sched, sched.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!cells && (h_po[0] != 0 || h_po[(size_t)B] != pl->n_pairs)) return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off does not span n_pairs");
+    if (int rc = set_pileup_cells_device(e, pl, h_po, h_ro, cells, nb, "dmx_engine_set_pileup")) return rc;
   } else {
     if (!cells && (pl->cell_pair_off[0] != 0 || pl->cell_pair_off[(size_t)B] != pl->n_pairs))
       return set_error(DMX_ERR_ARG, "dmx_engine_set_pileup: cell_pair_off does not span n_pairs");
@@ -5471,12 +5559,33 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   if (job->store) { if (int rc = dmx_store_freeze(job->store, &pl)) return rc; }
   else {
     pl = *job->pileup;
-    if (pl.memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup must be host memory");
+    if (pl.memory != DMX_MEM_HOST && pl.memory != DMX_MEM_DEVICE) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup.memory %d", pl.memory);
     if (!pl.rd_totl || !pl.rd_pass || !pl.rd_uniq) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup needs the per-cell read counters");
     // everything this function itself indexes before the engine's own checks run
     if (pl.n_cells < 0 || pl.n_snps < 0 || pl.n_pairs < 0 || pl.n_reads < 0) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup has a negative size");
     if (!pl.cell_pair_off || !pl.cell_read_off) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup needs cell_pair_off and cell_read_off");
     for (int32_t c = 0; c < pl.n_cells; ++c) if (!job->barcodes[c]) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: barcodes[%d] is null", c);
+  }
+  // A DEVICE-resident pileup (dmx_pileup.memory == DMX_MEM_DEVICE: the five arrays live in the HBM of job->device; counters and barcodes are
+  // host memory as always): nothing is sliced or copied on the host.  Its two offset arrays come to the host once (range cuts, N.SNP);
+  // a range of consecutive cells is a view of the caller's arrays, any other range is gathered on the device; the few barcodes the tie
+  // arbiter has to re-evaluate (near-tie flags, an open tie-order certificate) have their pieces of the pileup fetched when their range is written.
+  const bool dev_pl = pl.memory == DMX_MEM_DEVICE;
+  const dmx_pileup pl_dev = pl;                    // what the engines are given
+  std::vector<int64_t> h_po, h_ro;
+  if (dev_pl) {
+    if (job->n_gpus > 1) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: a device-resident pileup lives on one GPU (n_gpus = %d)", job->n_gpus);
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return set_error(DMX_ERR_NOGPU, "dmx_demuxlet_run: no HIP device is visible (this library has no CPU fallback)");
+    HIP_TRY(hipSetDevice(job->device % nd));
+    h_po.resize((size_t)pl.n_cells + 1); h_ro.resize((size_t)pl.n_cells + 1);
+    HIP_TRY(hipMemcpy(h_po.data(), pl.cell_pair_off, sizeof(int64_t) * ((size_t)pl.n_cells + 1), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h_ro.data(), pl.cell_read_off, sizeof(int64_t) * ((size_t)pl.n_cells + 1), hipMemcpyDeviceToHost));
+    if (h_po[0] != 0 || h_po[(size_t)pl.n_cells] != pl.n_pairs || h_ro[0] != 0 || h_ro[(size_t)pl.n_cells] != pl.n_reads)
+      return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup's offset arrays do not span n_pairs / n_reads");
+    for (int32_t c = 0; c < pl.n_cells; ++c)
+      if (h_po[(size_t)c + 1] < h_po[(size_t)c] || h_ro[(size_t)c + 1] < h_ro[(size_t)c]) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: job->pileup's offsets are not monotone at cell %d", c);
+    pl.cell_pair_off = h_po.data(); pl.cell_read_off = h_ro.data();      // the host logic below reads offsets only; the big arrays stay device pointers
   }
   if (job->n_samples < 1 || job->n_alpha < 1) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: n_samples %d, n_alpha %d", job->n_samples, job->n_alpha);
   for (int32_t j = 0; j < job->n_samples; ++j) if (!job->sample_ids[j]) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: sample_ids[%d] is null", j);
@@ -5554,6 +5663,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     std::vector<dmx_cell_summary> summ;
     std::vector<std::vector<double>> flagged_grid;
     std::vector<const double*> cell_grid;
+    // device-resident pileups: the host pieces of the barcodes the tie arbiter may have to walk (tie_cell[k] = index here, -1 = not staged)
+    std::vector<int32_t> tie_cell, t_snp; std::vector<int64_t> t_po, t_ro; std::vector<uint8_t> t_nrd, t_reads;
     int32_t lo = 0, hi = 0;
     void release() { *this = Range(); }
   };
@@ -5605,7 +5716,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
       }
     }
     dmx_engine* e = eng_of(r);
-    if (int rc = dmx::engine_set_pileup_cells(e, &pl, sliced ? order.data() + x.lo : nullptr, nb)) return rc;
+    if (dev_pl) { if (int rc = dmx::engine_set_pileup_cells(e, &pl_dev, sliced ? order.data() + x.lo : nullptr, nb, h_po.data(), h_ro.data())) return rc; }
+    else if (int rc = dmx::engine_set_pileup_cells(e, &pl, sliced ? order.data() + x.lo : nullptr, nb)) return rc;
     if (doublet_ok) { if (int rc = dmx_engine_run(e)) return rc; }
     else if (int rc = dmx_engine_run_singlet(e)) return rc;
     { std::lock_guard<std::mutex> lk(tm_mu); stage_s += secs(t0, clk::now()); }
@@ -5643,6 +5755,40 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
         }
       }
     }
+    if (dev_pl && doublet_ok && job->arbiter) {
+      // which barcodes can the writers' arbiter touch?  Those with a near-tie flag, and those whose best doublet sits at alpha = 0.5
+      // without a (resolved) tie-order certificate (dmx::write_doublet_core).  Their pairs and read bytes come to the host now.
+      constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
+      const size_t w = (size_t)pl.nrd_width;
+      x.tie_cell.assign(nb1, -1);
+      x.t_po.assign(1, 0); x.t_ro.assign(1, 0);
+      std::vector<int32_t> need;
+      for (size_t k = 0; k < nb; ++k) {
+        dmx_cell_summary sm = x.summ[k];
+        if (sm.n_pairs <= 0) continue;
+        if (sm.flags & DMX_CELL_ORDER_RESOLVABLE) (void)dmx::resolve_tie_order(&sm);
+        const bool open_order = sm.n_best >= 0 && sm.n_best < A && job->alpha[sm.n_best] == 0.5 && !(sm.flags & DMX_CELL_ORDER_CERTIFIED);
+        if (!(sm.flags & kNear) && !open_order) continue;
+        const int32_t c = sliced ? order[(size_t)x.lo + k] : (int32_t)k;
+        x.tie_cell[k] = (int32_t)need.size();
+        need.push_back(c);
+        x.t_po.push_back(x.t_po.back() + (pl.cell_pair_off[c + 1] - pl.cell_pair_off[c]));
+        x.t_ro.push_back(x.t_ro.back() + (pl.cell_read_off[c + 1] - pl.cell_read_off[c]));
+      }
+      x.t_nrd.resize((size_t)x.t_po.back() * w + 4); x.t_reads.resize((size_t)x.t_ro.back() + 4);
+      if (pl.pair_snp) x.t_snp.resize((size_t)x.t_po.back() + 1);
+      HIP_TRY(hipSetDevice(e->device));
+      for (size_t i = 0; i < need.size(); ++i) {
+        const int32_t c = need[i];
+        const int64_t p0 = pl.cell_pair_off[c], np_ = pl.cell_pair_off[c + 1] - p0, r0 = pl.cell_read_off[c], nr_ = pl.cell_read_off[c + 1] - r0;
+        if (np_ > 0) {
+          if (pl.pair_snp) HIP_TRY(hipMemcpyAsync(x.t_snp.data() + x.t_po[i], pl.pair_snp + p0, sizeof(int32_t) * (size_t)np_, hipMemcpyDeviceToHost, e->stream));
+          HIP_TRY(hipMemcpyAsync(x.t_nrd.data() + (size_t)x.t_po[i] * w, (const uint8_t*)pl.pair_nrd + (size_t)p0 * w, (size_t)np_ * w, hipMemcpyDeviceToHost, e->stream));
+        }
+        if (nr_ > 0) HIP_TRY(hipMemcpyAsync(x.t_reads.data() + x.t_ro[i], pl.reads + r0, (size_t)nr_, hipMemcpyDeviceToHost, e->stream));
+      }
+      HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     dmx_kernel_times kt{};
     (void)dmx_engine_last_kernel_times(e, &kt);
     { std::lock_guard<std::mutex> lk(tm_mu); wait_s += secs(t0, clk::now()); kernel_ms += kt.singlet_ms + kt.doublet_ms + kt.reduce_ms; n_fetched += fetched; }
@@ -5662,9 +5808,16 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     if (int rc = dmx::write_single_impl(&fin, (pre + ".single").c_str(), r > 0)) return rc;
     if (doublet_ok) {
       fin.llks00 = x.l00.data();
-      if (job->arbiter) { fin.tie_pileup = &pl; fin.tie_g = job->g; }
+      dmx_pileup tie{};                          // device-resident pileups: the staged pieces of this range's arbiter barcodes
+      if (job->arbiter && dev_pl) {
+        tie.n_cells = (int32_t)x.t_po.size() - 1; tie.n_snps = pl.n_snps; tie.n_pairs = x.t_po.back(); tie.n_reads = x.t_ro.back();
+        tie.cell_pair_off = x.t_po.data(); tie.cell_read_off = x.t_ro.data(); tie.pair_snp = pl.pair_snp ? x.t_snp.data() : nullptr;
+        tie.pair_nrd = x.t_nrd.data(); tie.nrd_width = pl.nrd_width; tie.memory = DMX_MEM_HOST; tie.reads = x.t_reads.data();
+        fin.tie_pileup = &tie; fin.tie_g = job->g;
+      } else if (job->arbiter) { fin.tie_pileup = &pl; fin.tie_g = job->g; }
       dmx::DoubletSource src{};
-      if (sliced) src.tie_cell = order.data() + x.lo;
+      if (dev_pl) { if (job->arbiter) src.tie_cell = x.tie_cell.data(); }
+      else if (sliced) src.tie_cell = order.data() + x.lo;
       if (job->write_pair) { fin.llksAB = x.grid.data(); src.grid_all = x.grid.data(); src.summary = x.summ.data(); }
       else { src.sing = x.sing.data(); src.summary = x.summ.data(); src.cell_grid = x.cell_grid.data(); }
       if (int rc = dmx::write_doublet_core(&fin, src, job->out_prefix, r > 0, "dmx_demuxlet_run")) return rc;

@@ -1063,11 +1063,14 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
   // the arbiter walks a cell's whole pileup: keep chunks small enough that every host thread gets work
   const size_t per_chunk = arbiter ? std::max<size_t>(1, std::min<size_t>(16384 / rows_per_cell, (cells.size() + 4 * (size_t)host_threads() - 1) / (4 * (size_t)host_threads())))
                                    : std::max<size_t>(1, 16384 / rows_per_cell);
-  return format_in_order(cells.size(), per_chunk, files, [&](size_t first, size_t last, Chunk& ck) {
+  std::atomic<int32_t> tie_missing{-1};           // a barcode the arbiter needed although src.tie_cell says its pileup is not staged
+  const int frc = format_in_order(cells.size(), per_chunk, files, [&](size_t first, size_t last, Chunk& ck) {
   std::vector<double> scratch;
   std::vector<dmx::GridReq> reqs;
   for (size_t q = first; q < last; ++q) {
     const int32_t c = cells[q];
+    const int32_t tc = src.tie_cell ? src.tie_cell[c] : c;      // the cell's index in in->tie_pileup
+    // (tc < 0: the caller did not stage this barcode's pileup — legitimate only if the arbiter has nothing to do for it; checked below)
     const double* grid = src.grid_all ? src.grid_all + (size_t)c * ng : (src.cell_grid ? src.cell_grid[c] : nullptr);
     const double* l00 = in->llks00 + (size_t)c * A;
     const char* bc = in->barcodes[c];
@@ -1091,7 +1094,8 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
     }
     constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
     bool host_grid = false;
-    if (!grid && smp && (smp->flags & kNear) && smp->n_pairs > 0 && arbiter) {
+    if (!grid && smp && (smp->flags & kNear) && smp->n_pairs > 0 && arbiter && tc < 0) tie_missing = c;
+    else if (!grid && smp && (smp->flags & kNear) && smp->n_pairs > 0 && arbiter) {
       // A near-tie beyond the (j,k)/(k,j) mirror — another sample pair (duplicate samples), another alpha, a third singlet — and
       // nothing but the record: which candidates sit within tol is not in the record, so the barcode's whole grid is evaluated
       // here, in the reference's operation order with the host libm (:595-684).  Flagged barcodes are the shallow ones (a handful
@@ -1099,7 +1103,7 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
       // (dmx_final_input.cell_grid, dmx_engine_get_cell_grids).
       reqs.clear();
       for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) for (int32_t a = 0; a < A; ++a) reqs.push_back({j, k, a, 0.0});
-      dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), src.tie_cell ? src.tie_cell[c] : c, reqs);
+      dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), tc, reqs);
       scratch.resize(ng);
       for (size_t q = 0; q < ng; ++q) scratch[q] = reqs[q].value;
       grid = scratch.data();
@@ -1132,8 +1136,9 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
         for (int32_t j = 0; j < V; ++j) for (int32_t k = 0; k < V; ++k) if (j != k) for (int32_t a = 1; a < A; ++a)
           if (grid[((size_t)j * V + k) * A + a] >= mab - tol) reqs.push_back({j, k, a, 0.0});
         if (reqs.size() - nd0 == 1) reqs.pop_back();
-        if (!reqs.empty()) {
-          dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), src.tie_cell ? src.tie_cell[c] : c, reqs);
+        if (!reqs.empty() && tc < 0) tie_missing = c;
+        else if (!reqs.empty()) {
+          dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), tc, reqs);
           scratch.assign(grid, grid + ng);
           for (const dmx::GridReq& r : reqs) scratch[((size_t)r.j * V + r.k) * A + r.n] = r.value;
           grid = scratch.data();
@@ -1162,12 +1167,13 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
       i_sing1 = sm.i_sing1; i_sing2 = sm.i_sing2; jb = sm.j_best; kb = sm.k_best; nb = sm.n_best;
       sing1 = sg[i_sing1]; sing2v = sg[i_sing2];
       l12 = sm.llk12; l1 = sm.llk1; l2 = sm.llk2; l10 = sm.llk10; l20 = sm.llk20;
-      if (arbiter && in->alpha[nb] == 0.5 && !(sm.flags & DMX_CELL_ORDER_CERTIFIED)) {
+      if (arbiter && in->alpha[nb] == 0.5 && !(sm.flags & DMX_CELL_ORDER_CERTIFIED) && tc < 0) tie_missing = c;
+      else if (arbiter && in->alpha[nb] == 0.5 && !(sm.flags & DMX_CELL_ORDER_CERTIFIED)) {
         // (j,k) and (k,j) are one doublet at alpha = 0.5 and differ only by rounding: re-evaluate both in the
         // reference's operation order and let its strict-< scan decide, which visits the smaller first index first.
         const int32_t a = std::min(jb, kb), b = std::max(jb, kb);
         reqs.assign({{a, b, nb, 0.0}, {b, a, nb, 0.0}});
-        dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), src.tie_cell ? src.tie_cell[c] : c, reqs);
+        dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), tc, reqs);
         const bool swap_to_ba = reqs[0].value < reqs[1].value;
         const int32_t nj = swap_to_ba ? b : a, nk = swap_to_ba ? a : b;
         if (nj != jb) { std::swap(l1, l2); std::swap(l10, l20); }
@@ -1221,4 +1227,7 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
             in->sample_ids[kb], in->alpha[nb], l12, l1, l2, l10, l20, l00b, post_dbl, post_sng);
   }
   });
+  if (frc == DMX_OK && tie_missing.load() >= 0)
+    return set_error(DMX_ERR_STATE, "%s: the tie arbiter needed barcode %s, whose pileup was not staged", who, in->barcodes[tie_missing.load()]);
+  return frc;
 }

@@ -63,10 +63,11 @@ struct DoubletSource {
   const double* const* cell_grid = nullptr;      // [n_cells] -> [V][V][A] or NULL
   const double* sing = nullptr;                  // [n_cells][V]
   const dmx_cell_summary* summary = nullptr;     // [n_cells]
-  const int32_t* tie_cell = nullptr;             // [n_cells] -> the cell's index in in->tie_pileup (NULL: the same index)
+  const int32_t* tie_cell = nullptr;             // [n_cells] -> the cell's index in in->tie_pileup (NULL: the same index; -1: not staged there)
 };
 // dmx_engine_set_pileup for cells cells[0..nb) of a HOST pileup (NULL: all, in order), re-based while it streams to the device
-int engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, int32_t nb);
+// (a DEVICE pileup: host_po / host_ro = host copies of its offset arrays when the caller has them, else they are fetched)
+int engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, int32_t nb, const int64_t* host_po = nullptr, const int64_t* host_ro = nullptr);
 // true when the host libm's log() stays inside dmx_log_bracket()'s brackets on a fixed sample of arguments (checked once)
 bool libm_log_within_brackets();
 bool resolve_tie_order(dmx_cell_summary* r);   // DMX_CELL_ORDER_RESOLVABLE -> certified, by the host libm's log()

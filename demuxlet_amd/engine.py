@@ -355,14 +355,17 @@ def demuxlet_run(store, g: np.ndarray, sample_ids: Sequence[str], alphas: Sequen
                  doublet_prior: float = 0.5, min_total: int = 0, min_uniq: int = 0, min_snp: int = 0,
                  write_pair: bool = False, device: int = 0, arbiter: bool = True, n_gpus: int = 1, mode: int = capi.DMX_MODE_STRICT,
                  barcodes: Optional[Sequence[str]] = None, timing: bool = False):
-    """cmd_cram_demuxlet.cpp:390-881 in one call (dmx_demuxlet_run).  `store` is a Store, or a frozen HostPileup together with
-    `barcodes` (dmx_job.pileup).  With timing=True returns the stage seconds (dmx_job_timing) as a dict."""
+    """cmd_cram_demuxlet.cpp:390-881 in one call (dmx_demuxlet_run).  `store` is a Store, or a frozen pileup — a HostPileup or a
+    capi.Pileup struct (device-resident arrays: memory = DMX_MEM_DEVICE, one GPU) — together with `barcodes` (dmx_job.pileup).
+    With timing=True returns the stage seconds (dmx_job_timing) as a dict."""
     g = np.ascontiguousarray(g, dtype=np.float32)
     al = np.ascontiguousarray(alphas, dtype=np.float64)
     sm, keep = _cstrs(sample_ids)
     tm = capi.JobTiming()
-    if isinstance(store, HostPileup):
-        st = store.as_struct()
+    if isinstance(store, (HostPileup, capi.Pileup)):
+        # a frozen pileup: host arrays (HostPileup) or a dmx_pileup struct as it is — DMX_MEM_DEVICE: the five arrays in HBM, the
+        # rd_* counters host memory (the caller keeps whatever the pointers refer to alive)
+        st = store.as_struct() if isinstance(store, HostPileup) else store
         bc, keep_b = _cstrs(barcodes)
         job = capi.Job(None, g.ctypes.data, g.shape[1], C.cast(sm, C.c_void_p), len(al), al.ctypes.data, doublet_prior,
                        min_total, min_uniq, min_snp, int(write_pair), out_prefix.encode(), device, int(arbiter), n_gpus, mode,

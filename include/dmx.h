@@ -289,8 +289,11 @@ typedef struct {
                                       (cmd_cram_demuxlet.cpp:576): no collective. */
   int32_t      mode;               /* DMX_MODE_STRICT (0: the default of this struct, of the Python binding and of the `demuxlet`
                                       binary) or DMX_MODE_FAST (`demuxlet --fast`) */
-  /* Optional (ABI 2): a pileup that is already frozen (host memory, sparse or dense layout) instead of `store` (then NULL), with
-   * its barcodes by cell id — what a caller that builds the CSR itself hands over (tools/e2e_bench.cpp, the benchmarks). */
+  /* Optional (ABI 2): a pileup that is already frozen (sparse or dense layout) instead of `store` (then NULL), with its barcodes by
+   * cell id — what a caller that builds the CSR itself hands over (tools/e2e_bench.cpp, the benchmarks).  memory = DMX_MEM_HOST, or
+   * (ABI 6) DMX_MEM_DEVICE: the five arrays live in the HBM of `device` (n_gpus <= 1), the rd_* counters stay host memory.  Nothing is
+   * then sliced or copied on the host: a range of consecutive cells is a view of the caller's arrays, any other range is gathered
+   * on the device, and the barcodes the tie arbiter walks (near-tie flags, an open tie-order certificate) have their pieces fetched. */
   const dmx_pileup*  pileup;
   const char* const* barcodes;
   /* Optional (ABI 2): wall-clock seconds of the stages of this call, written on return (NULL = not wanted). */

@@ -871,3 +871,64 @@ def test_run_is_singlet_and_doublet_in_one_call(eng, V, field, dense, mode):
     for a, b in zip(want[0] + want[1], again[0] + again[1]):
         assert a.tobytes() == b.tobytes()
     e.close()
+
+
+@pytest.mark.parametrize("V,field,dense,mode,sorted_ids", [(8, "GT", True, "strict", True), (12, "GP", False, "strict", False), (33, "GT", False, "fast", False),
+                                                           (16, "PL", False, "fast", True), (5, "GT", False, "strict", False)])
+def test_demuxlet_run_from_a_device_resident_pileup(eng, oracle, tmp_path, monkeypatch, V, field, dense, mode, sorted_ids):
+    """dmx_job.pileup with memory = DMX_MEM_DEVICE: the five pileup arrays live in HBM, nothing is sliced or copied on
+    the host; ranges of consecutive barcodes are views of the caller's arrays, others are gathered on the device, and the barcodes the tie
+    arbiter has to walk get their pieces fetched.  Byte-identical files to the same job from the host pileup — one range and many
+    (DMX_RANGE_BYTES), with and without --write-pair — and those are the oracle's."""
+    import torch
+    from demuxlet_amd import synth, capi
+    rng = np.random.default_rng(4100 + V)
+    S, B = 500, 300
+    raw = synth.make_raw_genotypes(rng, S, V)
+    if V == 5:                                     # duplicate samples: near-tie flags, barcodes whose grids AND pileup pieces are fetched
+        raw.alleles[:, 1] = raw.alleles[:, 0]; raw.alleles[:, 3] = raw.alleles[:, 2]
+    if field == "GT":
+        g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    elif field == "GP":
+        g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+    else:
+        g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, raw.alleles)])
+    sp = synth.make_pileup(rng, raw.alleles, B, 1.0 if dense else (0.03 if V == 5 else 0.3), 1.5, dense_layout=dense, doublet_rate=0.4)
+    pl = host_pileup(eng, sp)
+    bcs = [f"BC{i:05d}-1" for i in range(B)] if sorted_ids else [f"BC{(i * 7919) % 100003:06d}-1" for i in range(B)]
+    sms = [f"S{j:02d}" for j in range(V)]
+    md = capi.DMX_MODE_FAST if mode == "fast" else capi.DMX_MODE_STRICT
+    dev = torch.device("cuda", 0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(getattr(pl, k))).to(dev) for k in ("cell_pair_off", "cell_read_off", "pair_nrd", "reads")}
+    t_snp = torch.from_numpy(np.ascontiguousarray(pl.pair_snp)).to(dev) if pl.pair_snp is not None else None
+    hs = pl.as_struct()                            # (normalises the host arrays; the counters below stay host memory)
+    ds = capi.Pileup(B, S, hs.n_pairs, hs.n_reads, t["cell_pair_off"].data_ptr(), t["cell_read_off"].data_ptr(),
+                     t_snp.data_ptr() if t_snp is not None else None, t["pair_nrd"].data_ptr(), pl.pair_nrd.dtype.itemsize, capi.DMX_MEM_DEVICE,
+                     t["reads"].data_ptr(), pl.rd_totl.ctypes.data, pl.rd_pass.ctypes.data, pl.rd_uniq.ctypes.data)
+    ref = oracle_from_pileup_files(oracle, sp, g, (0.0, 0.5), bcs, sms, tmp_path / "orc")
+    for tag, rb, wp in (("one", None, False), ("many", "6000", False), ("pair", "30000", True)):
+        if rb: monkeypatch.setenv("DMX_RANGE_BYTES", rb)
+        else: monkeypatch.delenv("DMX_RANGE_BYTES", raising=False)
+        th = eng.demuxlet_run(pl, g, sms, (0.0, 0.5), str(tmp_path / f"h_{tag}"), write_pair=wp, barcodes=bcs, mode=md, timing=True)
+        td = eng.demuxlet_run(ds, g, sms, (0.0, 0.5), str(tmp_path / f"d_{tag}"), write_pair=wp, barcodes=bcs, mode=md, timing=True)
+        assert td["n_ranges"] == th["n_ranges"] and (rb is None or td["n_ranges"] > 2)
+        assert td["n_cells_grid_fetched"] == th["n_cells_grid_fetched"]
+        for suf in ("single", "sing2", "best") + (("pair",) if wp else ()):
+            a, b = (tmp_path / f"d_{tag}.{suf}").read_bytes(), (tmp_path / f"h_{tag}.{suf}").read_bytes()
+            assert a == b, (tag, suf)
+            if mode == "strict":
+                assert a == (tmp_path / f"orc.{suf}").read_bytes(), (tag, suf)
+    if V == 5:
+        assert th["n_cells_grid_fetched"] > 10
+    # n_gpus > 1 is refused for a device-resident pileup
+    with pytest.raises(Exception, match="one GPU"):
+        eng.demuxlet_run(ds, g, sms, (0.0, 0.5), str(tmp_path / "x"), barcodes=bcs, n_gpus=2)
+
+
+def oracle_from_pileup_files(oracle, sp, g, alphas, barcodes, sample_ids, prefix):
+    al = (sp.reads >> 7).astype(np.uint32)
+    words = (al << 24) | ((sp.reads & 0x7F).astype(np.uint32) << 16) | 1
+    pair_snp = sp.pair_snp if sp.pair_snp is not None else np.tile(np.arange(sp.n_snps, dtype=np.int32), sp.n_cells)
+    csr = oracle.Csr(list(barcodes), sp.cell_pair_off, pair_snp, np.concatenate([[0], np.cumsum(sp.pair_nrd.astype(np.int64))]), words.astype(np.uint32),
+                     sp.rd_totl, sp.rd_pass, sp.rd_uniq)
+    return oracle.run_csr(csr, list(sample_ids), g, oracle.Params(tuple(alphas), 0.5, 0, 0, 0, True), str(prefix))
