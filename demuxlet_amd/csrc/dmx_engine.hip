@@ -5697,6 +5697,10 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   }
   tm.setup_s = secs(t_setup, clk::now());
   std::mutex tm_mu;
+  const bool trace = getenv("DMX_E2E_TRACE") != nullptr;     // per-range timeline on stderr (seconds since the call began)
+  auto mark = [&](const char* what, int r, clk::time_point t0) {
+    if (trace) fprintf(stderr, "[dmx_demuxlet_run] %-6s range %d: %.4f -> %.4f s\n", what, r, secs(t_begin, t0), secs(t_begin, clk::now()));
+  };
   double stage_s = 0, wait_s = 0, write_s = 0, kernel_ms = 0;
   int32_t n_fetched = 0;
 
@@ -5721,6 +5725,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     if (doublet_ok) { if (int rc = dmx_engine_run(e)) return rc; }
     else if (int rc = dmx_engine_run_singlet(e)) return rc;
     { std::lock_guard<std::mutex> lk(tm_mu); stage_s += secs(t0, clk::now()); }
+    mark("launch", r, t0);
     return DMX_OK;
   };
   auto fetch = [&](int r) -> int {               // results of range r to the host (waits for its kernels)
@@ -5792,6 +5797,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     dmx_kernel_times kt{};
     (void)dmx_engine_last_kernel_times(e, &kt);
     { std::lock_guard<std::mutex> lk(tm_mu); wait_s += secs(t0, clk::now()); kernel_ms += kt.singlet_ms + kt.doublet_ms + kt.reduce_ms; n_fetched += fetched; }
+    mark("fetch", r, t0);
+    if (trace) fprintf(stderr, "[dmx_demuxlet_run]        range %d kernels: K1 %.1f ms, K2 %.1f ms, K3+K3b %.1f ms\n", r, kt.singlet_ms, kt.doublet_ms, kt.reduce_ms);
     return DMX_OK;
   };
   const std::string pre(job->out_prefix);
@@ -5824,6 +5831,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     }
     x.release();
     { std::lock_guard<std::mutex> lk(tm_mu); write_s += secs(t0, clk::now()); }
+    mark("write", r, t0);
     return DMX_OK;
   };
 

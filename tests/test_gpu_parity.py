@@ -913,13 +913,15 @@ def test_demuxlet_run_from_a_device_resident_pileup(eng, oracle, tmp_path, monke
         td = eng.demuxlet_run(ds, g, sms, (0.0, 0.5), str(tmp_path / f"d_{tag}"), write_pair=wp, barcodes=bcs, mode=md, timing=True)
         assert td["n_ranges"] == th["n_ranges"] and (rb is None or td["n_ranges"] > 2)
         assert td["n_cells_grid_fetched"] == th["n_cells_grid_fetched"]
+        if tag == "one":
+            fetched_one = th["n_cells_grid_fetched"]
         for suf in ("single", "sing2", "best") + (("pair",) if wp else ()):
             a, b = (tmp_path / f"d_{tag}.{suf}").read_bytes(), (tmp_path / f"h_{tag}.{suf}").read_bytes()
             assert a == b, (tag, suf)
             if mode == "strict":
                 assert a == (tmp_path / f"orc.{suf}").read_bytes(), (tag, suf)
     if V == 5:
-        assert th["n_cells_grid_fetched"] > 10
+        assert fetched_one > 10
     # n_gpus > 1 is refused for a device-resident pileup
     with pytest.raises(Exception, match="one GPU"):
         eng.demuxlet_run(ds, g, sms, (0.0, 0.5), str(tmp_path / "x"), barcodes=bcs, n_gpus=2)
