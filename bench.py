@@ -62,7 +62,8 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 T
 FP64_VALU_PEAK_TFLOPS = 78.6  # FP64 vector peak (spec; half the 157.3 TF FP32 vector rate), FMA = 2 flop
 SIMDS, CLOCK_HZ = 256 * 4, 2.4e9
 VALU_PEAK_WAVE_INSTS = SIMDS * CLOCK_HZ / 4   # FP64 wave64 instructions/s: 16 FP64 lanes/clk per SIMD (= 78.6 TF / 128)
-LOG_FP64_INSTS = 11          # FP64 instructions of one dmx_log evaluation (csrc/dmx_log.hpp)
+LOG_FP64_INSTS = 10          # FP64 instructions of one evaluation of the doublet kernels' log (dmx_log2, csrc/dmx_log.hpp; the singlet
+                             # kernels' 128-bin dmx_log has 11)
 METRIC = "cell-SNP-sample triples/sec (singlet+doublet llk); HBM GB/s vs roofline"
 
 

@@ -76,7 +76,14 @@ constexpr int kPair = 128 * 128 * 4;                    // then dmx::PairTables:
 constexpr int kTriple = dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes * 4;   // then dmx::TripleTables: third | final3
 constexpr int kTabAll = kTabK1 + 2 * kPair + 2 * kTriple;
 constexpr int kTabLogLo = kTabAll;                      // then dmx_log_dd's second-order table (128 doubles)
-constexpr int kTabTotal = kTabAll + 128;
+constexpr int kTabLog2 = kTabAll + 128;                 // then dmx_log2's 256-bin {invc, logc} table (the doublet kernels' log, round 4)
+constexpr int kTabTotal = kTabLog2 + DMX_LOG2_TABLE_DOUBLES;
+constexpr int kTab2 = kLut + DMX_LOG2_TABLE_DOUBLES;    // a doublet kernel's LDS table: read LUT | dmx_log2 table
+// stage a doublet kernel's tables: the read LUT from the head of the device buffer, dmx_log2's table from its tail
+__device__ __forceinline__ void stage_k2_tables(double* s_tab, const double* __restrict__ tabs, int t, int nthreads) {
+  for (int i = t; i < kLut; i += nthreads) s_tab[i] = tabs[i];
+  for (int i = t; i < DMX_LOG2_TABLE_DOUBLES; i += nthreads) s_tab[kLut + i] = tabs[kTabLog2 + i];
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void k_gp0(const float* __restrict__ g, int32_t S, int32_t V, double* __restrict__ gp0) {
@@ -930,14 +937,14 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
   // flagged at all (flag_cell also raises the launch-wide word in front of the array): nothing to fix costs ~2 us instead of a
   // dispatch of B workgroups.  The first pass (FIXUP = false) is launched with one workgroup per cell: one trip through the loop.
   if (FIXUP && !flags_any(flagged)) return;
-  __shared__ double s_lut[kTab];
+  __shared__ double s_lut[kTab2];
   __shared__ double s_pG[kThreads * 9];
   __shared__ int32_t s_snp[32];
   __shared__ uint32_t s_cnt[32];
   __shared__ int64_t s_off[32];
 
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_lut[i] = lut[i];
+  stage_k2_tables(s_lut, lut, t, kThreads);
   const double* s_log = s_lut + kLut;
   for (int32_t bx = (int32_t)blockIdx.x; bx < pv.B; bx += (int32_t)gridDim.x) {
   if (FIXUP && !flagged[sched[bx]]) continue;
@@ -1089,7 +1096,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 #pragma unroll
           for (int m = 0; m < 3; ++m) sum += ((a[l] * b[m]) * P[l * 3 + m]);   // :553 then :677-679, l-major
         if (!FIXUP) ok &= __builtin_amdgcn_class(sum, 0x100);
-        acc[i] += FIXUP ? log(sum) : dmx_log_fast(sum, s_log);                     // :683 / :709
+        acc[i] += FIXUP ? log(sum) : dmx_log2_fast(sum, s_log);                     // :683 / :709
       }
     }
     __syncthreads();
@@ -1136,12 +1143,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
   constexpr int T00 = TP + 2;
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha: [n][0..8] = p (ALT), [n][9..17] = 1 - p; in LDS so
                                                  // that they occupy registers only while phase 1 runs (36 VGPRs otherwise)
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 18) {
     const int n = t / 9, l = (t % 9) / 3, m = t % 3;
     const double p = 0.5 * l + (m - l) * 0.5 * alpha[n];
@@ -1274,7 +1281,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
             sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
           }
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);                    // :708-709 term
       }
     }
     DMX_K2_SYNC();
@@ -1319,8 +1326,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
               s1 += (gp * P1[l * 3 + m]);                                     // alpha 1
             }
           if (CHK) ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-          acc[kk][0] += dmx_log_fast_pinned(s0, s_log, lk);                   // :683
-          acc[kk][1] += dmx_log_fast_pinned(s1, s_log, lk);
+          acc[kk][0] += dmx_log2_fast_pinned(s0, s_log, lk);                   // :683
+          acc[kk][1] += dmx_log2_fast_pinned(s1, s_log, lk);
         }
       }
     }
@@ -1357,10 +1364,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
   constexpr int T00 = TP + 2;
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;         // cell slot inside the workgroup, thread inside the cell
@@ -1502,7 +1509,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
           }
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);                    // :708-709 term
       }
     }
     DMX_K2_SYNC();
@@ -1545,8 +1552,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             const double s0 = __builtin_fma(a2, x[2], __builtin_fma(a1, x[1], a0 * x[0]));
             const double s1 = __builtin_fma(a2, y[2], __builtin_fma(a1, y[1], a0 * y[0]));
             ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-            acc[kk][0] += dmx_log_fast_pinned(s0, s_log, lk);
-            acc[kk][1] += dmx_log_fast_pinned(s1, s_log, lk);
+            acc[kk][0] += dmx_log2_fast_pinned(s0, s_log, lk);
+            acc[kk][1] += dmx_log2_fast_pinned(s1, s_log, lk);
           }
         }
       }
@@ -1583,8 +1590,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             const double s0 = __builtin_fma(a2, x2, __builtin_fma(a1, x01.y, a0 * x01.x));
             const double s1 = __builtin_fma(a2, y2, __builtin_fma(a1, y01.y, a0 * y01.x));
             ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-            acc[kk][0] += dmx_log_fast_pinned(s0, s_log, lk);
-            acc[kk][1] += dmx_log_fast_pinned(s1, s_log, lk);
+            acc[kk][0] += dmx_log2_fast_pinned(s0, s_log, lk);
+            acc[kk][1] += dmx_log2_fast_pinned(s1, s_log, lk);
           }
         }
       }
@@ -1648,11 +1655,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   constexpr int GSS = (3 * VMAX + 3) & ~3;       // genotype row stride (floats)
 #define DMX_K2_SYNC() do { if (TPC <= 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][10];                  // mixing weights of :613 per alpha and distinct value: [n][0..4] = p (ALT), [n][5..9] = 1 - p
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 10) {
     // alpha 0: p = 0.5 l does not depend on m -> slots 0..2 hold l = 0..2 (slots 3, 4 repeat l = 2); alpha 0.5: p = 0.25 (l + m)
     // -> slot = l + m.  Same operands, same operations as the nine entries of the reference: the values are bit-identical.
@@ -1829,7 +1836,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
             sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
           }
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);                    // :708-709 term
         if (n1) {
 #pragma unroll
           for (int i = 0; i < 5; ++i) s_q1[ti1 * 6 + i] = q[i];
@@ -1909,7 +1916,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
                          x2 = DMX_LDS_NOMERGE ? lds_read_f64(&up[2 * VUS + ek[i]]) : up[2 * VUS + ek[i]];
             const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
             if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100);
-            acc[i] += dmx_log_fast_pinned(sj, s_log, lk);
+            acc[i] += dmx_log2_fast_pinned(sj, s_log, lk);
           }
         }
       }
@@ -1956,10 +1963,10 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
   constexpr int T00 = TP + 2;
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;
@@ -2101,7 +2108,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
             sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
           }
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);                    // :708-709 term
       }
     }
     DMX_K2_SYNC();
@@ -2136,8 +2143,8 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
                   s1 += (gp * P1v[l * 3 + m]);
                 }
               ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-              acc[kk][2 * ap] += dmx_log_fast(s0, s_log);                     // :683
-              acc[kk][2 * ap + 1] += dmx_log_fast(s1, s_log);
+              acc[kk][2 * ap] += dmx_log2_fast(s0, s_log);                     // :683
+              acc[kk][2 * ap + 1] += dmx_log2_fast(s1, s_log);
             }
           } else {                                 // the last alpha of an odd-sized grid
             double P0[9];
@@ -2153,7 +2160,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
 #pragma unroll
                 for (int m = 0; m < 3; ++m) s0 += ((aj[l] * bk[m]) * P0[l * 3 + m]);
               ok &= __builtin_amdgcn_class(s0, 0x100);
-              acc[kk][2 * ap] += dmx_log_fast(s0, s_log);
+              acc[kk][2 * ap] += dmx_log2_fast(s0, s_log);
             }
           }
         }
@@ -2199,10 +2206,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_anf(PileupView pv, i
   constexpr int T00 = TP + 2;
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;
@@ -2350,7 +2357,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_anf(PileupView pv, i
             sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
           }
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);                    // :708-709 term
       }
     }
     DMX_K2_SYNC();
@@ -2395,7 +2402,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_anf(PileupView pv, i
               const double x0 = lds_read_f64(&up[o]), x1 = lds_read_f64(&up[o + VU]), x2 = lds_read_f64(&up[o + 2 * VU]);
               const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
               if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100) || kb * NK + kk >= V;
-              acc[kk][n - 1] += dmx_log_fast_pinned(sj, s_log, lk);
+              acc[kk][n - 1] += dmx_log2_fast_pinned(sj, s_log, lk);
             }
             __builtin_amdgcn_sched_barrier(0);     // one alpha's NK evaluations in flight at a time (register budget)
           }
@@ -2403,7 +2410,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_anf(PileupView pv, i
             const double* u0 = s_u + (size_t)pi * NU + (A - 1) * 3 * VU;
             const double sj = __builtin_fma(a2, u0[2], __builtin_fma(a1, u0[1], a0 * u0[0]));
             ok &= __builtin_amdgcn_class(sj, 0x100);
-            accS += dmx_log_fast_pinned(sj, s_log, lk);
+            accS += dmx_log2_fast_pinned(sj, s_log, lk);
           }
         }
       }
@@ -2516,11 +2523,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
   constexpr int NT = kMaxCls * kMaxCls * A;      // class-table entries per pair
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha (see k_doublet_a2): registers only while phase 1 runs
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 18) {
     const int n = t / 9, l = (t % 9) / 3, m = t % 3;
     const double p = 0.5 * l + (m - l) * 0.5 * alpha[n];
@@ -2726,7 +2733,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
             sum += ((qq[l] * qq[m]) * v);
           }
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);
       }
     }
     DMX_K2_SYNC();
@@ -2757,7 +2764,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
 #pragma unroll
         for (int m = 0; m < 3; ++m) sum += ((aj[l] * bk[m]) * P[l * 3 + m]);     // :553, :677-679
       ok &= __builtin_amdgcn_class(sum, 0x100);
-      s_T[ti * NT + cc] = dmx_log_fast(sum, s_log);                              // the :683 term
+      s_T[ti * NT + cc] = dmx_log2_fast(sum, s_log);                              // the :683 term
     }
     DMX_K2_SYNC();
     // ---- phase 2: one lookup and two adds per (j, k)
@@ -2907,11 +2914,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   constexpr int JW = 5;                          // words of class bytes per (pair, wavefront): up to 20 samples j
   constexpr int VSC = 64;                        // id row stride in the LDS (bytes): compile-time for panels of up to 64 samples
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 18) {
     const int n = t / 9, l = (t % 9) / 3, m = t % 3;
     const double p = 0.5 * l + (m - l) * 0.5 * alpha[n];
@@ -3095,7 +3102,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
               sum += ((qq[l] * qq[m]) * v);
             }
           ok &= __builtin_amdgcn_class(sum, 0x100);
-          s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);
+          s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);
         }
       }
       DMX_WAVE_LDS_ORDER();
@@ -3128,7 +3135,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
 #pragma unroll
           for (int m = 0; m < 3; ++m) sum += ((aj[l] * bk[m]) * P[l * 3 + m]);     // :553, :677-679
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_T[ti * NT + cc] = dmx_log_fast(sum, s_log);                              // the :683 term
+        s_T[ti * NT + cc] = dmx_log2_fast(sum, s_log);                              // the :683 term
       }
       DMX_WAVE_LDS_ORDER();                                        // (pG, t00, rows and the headers are rewritten by the next build)
     };
@@ -3289,11 +3296,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
   constexpr int NRW = (2 * NED + 30) / 32 + 1;    // words a lane's window can span
   constexpr int NT = 32;                          // class-table doubles per pair: [cj][8]: ck = 0..3 | singlet | pad
   extern __shared__ __attribute__((aligned(64))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][10];                  // mixing weights per alpha and distinct value (see k_doublet_sym)
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 10) {
     const int n = t / 5, q = t % 5;
     const int l = n ? (q > 2 ? 2 : q) : min(q, 2), m = n ? q - l : 0;
@@ -3483,7 +3490,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
             sum += ((qq[l] * qq[m]) * v);                                    // :555, :702-705
           }
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);
         if (n1) {
 #pragma unroll
           for (int i = 0; i < 5; ++i) s_q1[ti1 * 6 + i] = qv[i];
@@ -3537,7 +3544,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
         }
         const double sum = __builtin_fma(a2, u2, __builtin_fma(a1, u1, a0 * u0));
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        const double lv = dmx_log_fast(sum, s_log);
+        const double lv = dmx_log2_fast(sum, s_log);
         if (c < 10) { s_T[pi * NT + cj * 8 + ck] = lv; s_T[pi * NT + ck * 8 + cj] = lv; }
         else s_T[pi * NT + cj * 8 + 4] = lv;
       }
@@ -3628,10 +3635,10 @@ __global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nr
   constexpr int NT = kMaxCls * kMaxCls * AP;     // class-table entries per pair
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-  __shared__ double s_tab[kTab];
+  __shared__ double s_tab[kTab2];
   const double* s_log = s_tab + kLut;
   const int t = threadIdx.x;
-  for (int i = t; i < kTab; i += kThreads) s_tab[i] = tabs[i];
+  stage_k2_tables(s_tab, tabs, t, kThreads);
   __syncthreads();
 
   const int cw = t / TPC, tid = t % TPC;
@@ -3777,7 +3784,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nr
             sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
           }
         ok &= __builtin_amdgcn_class(sum, 0x100);
-        s_t00[n1 * T00 + ti1] = dmx_log_fast(sum, s_log);                    // :708-709 term
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);                    // :708-709 term
       }
     }
     DMX_K2_SYNC();
@@ -3801,7 +3808,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nr
 #pragma unroll
         for (int m = 0; m < 3; ++m) sum += ((aj[l] * bk[m]) * P[l * 3 + m]);     // :553, :677-679
       ok &= __builtin_amdgcn_class(sum, 0x100);
-      s_T[ti * NT + cc] = dmx_log_fast(sum, s_log);                              // the :683 term
+      s_T[ti * NT + cc] = dmx_log2_fast(sum, s_log);                              // the :683 term
     }
     DMX_K2_SYNC();
     // ---- phase 2
@@ -4386,6 +4393,7 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipMalloc((void**)&e->d_lut, sizeof(double) * kTabTotal));
   HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabLogLo, dmx_log_table_lo_host, sizeof(double) * 128, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_lut + kTabLog2, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
   e->certify = !(cfg->flags & DMX_ENGINE_NO_CERTIFY) && !getenv("DMX_NO_CERTIFY") && dmx::libm_log_within_brackets();
   HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
   HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
@@ -5442,11 +5450,15 @@ extern "C" int dmx_engine_algorithmic_bytes(dmx_engine* e, dmx_kernel_bytes* out
 
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
+template <int WHICH>   // 0: dmx_log (128 bins; the singlet kernels), 2: dmx_log2 (256 bins; the doublet kernels)
 __global__ void k_debug_log(const double* __restrict__ x, double* __restrict__ y, int64_t n, const double* __restrict__ tab) {
-  __shared__ double s_log[DMX_LOG_TABLE_DOUBLES];
-  dmx_log_stage(s_log, tab, threadIdx.x, blockDim.x);
+  __shared__ double s_log[DMX_LOG2_TABLE_DOUBLES];
+  for (int i = threadIdx.x; i < (WHICH == 2 ? DMX_LOG2_TABLE_DOUBLES : DMX_LOG_TABLE_DOUBLES); i += blockDim.x) s_log[i] = tab[i];
   __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = dmx_log(x[i], s_log);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = WHICH == 2 ? dmx_log2_fast(x[i], s_log) : dmx_log_fast(x[i], s_log);
+    y[i] = dmx_log_is_special(x[i]) ? log(x[i]) : v;
+  }
 }
 }  // namespace
 
@@ -5460,11 +5472,11 @@ __global__ void k_debug_div(const double* __restrict__ a, const double* __restri
 namespace {
 // log() ceiling of the device: every lane evaluates `iters` logs of register-resident arguments spread over (0.01, 1] (the
 // range likelihood terms live in), four independent streams per lane so the issue rate, not the latency, is measured.
-// WHICH = 0: dmx_log (what the kernels use), 1: ocml log().
+// WHICH = 0: dmx_log (the singlet kernels), 1: ocml log(), 2: dmx_log2 (the doublet kernels).
 template <int WHICH>
 __global__ __launch_bounds__(256) void k_log_rate(int iters, const double* __restrict__ tab, double* __restrict__ sink) {
-  __shared__ double s_log[DMX_LOG_TABLE_DOUBLES];
-  dmx_log_stage(s_log, tab, threadIdx.x, blockDim.x);
+  __shared__ double s_log[DMX_LOG2_TABLE_DOUBLES];
+  for (int i = threadIdx.x; i < (WHICH == 2 ? DMX_LOG2_TABLE_DOUBLES : DMX_LOG_TABLE_DOUBLES); i += blockDim.x) s_log[i] = tab[i];
   __syncthreads();
   const double x0 = 0.01 + 0.9 * ((threadIdx.x * 37 + blockIdx.x * 11) % 1024) / 1024.0;
   double x[4] = {x0, x0 * 0.75, x0 * 0.5, x0 * 0.31}, acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -5472,7 +5484,7 @@ __global__ __launch_bounds__(256) void k_log_rate(int iters, const double* __res
   for (int i = 0; i < iters; i += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      acc[u] += WHICH == 0 ? dmx_log(x[u], s_log) : log(x[u]);
+      acc[u] += WHICH == 0 ? dmx_log(x[u], s_log) : (WHICH == 2 ? dmx_log2_fast(x[u], s_log) : log(x[u]));
       x[u] += dx;
     }
   }
@@ -5481,15 +5493,16 @@ __global__ __launch_bounds__(256) void k_log_rate(int iters, const double* __res
 }  // namespace
 
 extern "C" int dmx_debug_log_rate(int32_t which, int32_t iters, int32_t device, double* logs_per_second) {
-  if ((which != 0 && which != 1) || iters < 4 || !logs_per_second) return set_error(DMX_ERR_ARG, "dmx_debug_log_rate: bad arguments");
+  if (which < 0 || which > 2 || iters < 4 || !logs_per_second) return set_error(DMX_ERR_ARG, "dmx_debug_log_rate: bad arguments");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return set_error(DMX_ERR_NOGPU, "dmx_debug_log_rate: no such HIP device");
   HIP_TRY(hipSetDevice(device));
   const int blocks = 256 * 8, threads = 256;                  // 8 workgroups (32 wavefronts) per CU
   double *dt = nullptr, *ds = nullptr;
-  HIP_TRY(hipMalloc((void**)&dt, sizeof(double) * DMX_LOG_TABLE_DOUBLES));
+  HIP_TRY(hipMalloc((void**)&dt, sizeof(double) * DMX_LOG2_TABLE_DOUBLES));
   HIP_TRY(hipMalloc((void**)&ds, sizeof(double) * (size_t)blocks * threads));
-  HIP_TRY(hipMemcpy(dt, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  if (which == 2) HIP_TRY(hipMemcpy(dt, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemcpy(dt, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
   iters &= ~3;
@@ -5497,6 +5510,7 @@ extern "C" int dmx_debug_log_rate(int32_t which, int32_t iters, int32_t device, 
   for (int rep = 0; rep < 4; ++rep) {                          // first pass warms up; keep the fastest
     HIP_TRY(hipEventRecord(e0, 0));
     if (which == 0) hipLaunchKernelGGL((k_log_rate<0>), dim3(blocks), dim3(threads), 0, 0, iters, dt, ds);
+    else if (which == 2) hipLaunchKernelGGL((k_log_rate<2>), dim3(blocks), dim3(threads), 0, 0, iters, dt, ds);
     else            hipLaunchKernelGGL((k_log_rate<1>), dim3(blocks), dim3(threads), 0, 0, iters, dt, ds);
     HIP_TRY(hipEventRecord(e1, 0));
     HIP_TRY(hipEventSynchronize(e1));
@@ -5528,7 +5542,8 @@ extern "C" int dmx_debug_device_div(const double* a, const double* b, double* q,
   return DMX_OK;
 }
 
-extern "C" int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device) {
+namespace {
+int debug_device_log(int which, const double* x, double* y, int64_t n, int32_t device) {
   if (!x || !y || n < 0) return set_error(DMX_ERR_ARG, "dmx_debug_device_log: bad arguments");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return set_error(DMX_ERR_NOGPU, "dmx_debug_device_log: no such HIP device");
@@ -5536,15 +5551,20 @@ extern "C" int dmx_debug_device_log(const double* x, double* y, int64_t n, int32
   double *dx = nullptr, *dy = nullptr, *dt = nullptr;
   HIP_TRY(hipMalloc((void**)&dx, std::max<size_t>(sizeof(double) * (size_t)n, 16)));
   HIP_TRY(hipMalloc((void**)&dy, std::max<size_t>(sizeof(double) * (size_t)n, 16)));
-  HIP_TRY(hipMalloc((void**)&dt, sizeof(double) * DMX_LOG_TABLE_DOUBLES));
+  HIP_TRY(hipMalloc((void**)&dt, sizeof(double) * DMX_LOG2_TABLE_DOUBLES));
   HIP_TRY(hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(dt, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_debug_log, dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
+  if (which == 2) HIP_TRY(hipMemcpy(dt, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemcpy(dt, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  if (which == 2) hipLaunchKernelGGL((k_debug_log<2>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
+  else hipLaunchKernelGGL((k_debug_log<0>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(y, dy, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
   (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dt);
   return DMX_OK;
 }
+}  // namespace
+extern "C" int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(0, x, y, n, device); }
+extern "C" int dmx_debug_device_log2(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(2, x, y, n, device); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // cmd_cram_demuxlet.cpp:390-881 in one call: store (or a frozen pileup) + genotype matrix in, four text files out.

@@ -255,9 +255,10 @@ int dmx_resolve_tie_order(dmx_cell_summary* summary, int64_t n);
 /* Diagnostics: evaluate the device's log() replacement (dmx_log, csrc/dmx_log.hpp) on n host doubles. Used by the tests
  * to show the device function performs exactly the IEEE operation sequence whose accuracy is measured on the host. */
 int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device);
+int dmx_debug_device_log2(const double* x, double* y, int64_t n, int32_t device);   /* dmx_log2: the doublet kernels' log (256 bins, ABI 6) */
 /* Diagnostics: the device's log() ceiling, measured by a register-resident microkernel (no memory traffic): which = 0 the
  * kernels' dmx_log, which = 1 ocml's log().  bench.py reports both next to the kernels' achieved log rate. */
-int dmx_debug_log_rate(int32_t which, int32_t iters, int32_t device, double* logs_per_second);
+int dmx_debug_log_rate(int32_t which, int32_t iters, int32_t device, double* logs_per_second);   /* which: 0 dmx_log, 1 ocml log(), 2 dmx_log2 */
 /* Diagnostics: q[i] = a[i] / b[i] through the kernels' shared-reciprocal division (must equal IEEE division bit for bit
  * for 2^-700 < a,b < 2^700). */
 int dmx_debug_device_div(const double* a, const double* b, double* q, int64_t n, int32_t device);

@@ -3,3 +3,4 @@
 #include "dmx_log.hpp"
 extern "C" void dmx_log_emul_n(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = dmx_log_host_emul(x[i]); }
 extern "C" void dmx_log_lite_emul_n(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = dmx_log_comp_host_emul(x[i]); }   // the compensated form kept for the record
+extern "C" void dmx_log2_emul_n(const double* x, double* y, long n) { for (long i = 0; i < n; ++i) y[i] = dmx_log2_host_emul(x[i]); }   // the K2 kernels' log (256 bins)
