@@ -78,11 +78,13 @@ constexpr int kTabAll = kTabK1 + 2 * kPair + 2 * kTriple;
 constexpr int kTabLogLo = kTabAll;                      // then dmx_log_dd's second-order table (128 doubles)
 constexpr int kTabLog2 = kTabAll + 128;                 // then dmx_log2's 256-bin {invc, logc} table (the doublet kernels' log, round 4)
 constexpr int kTabTotal = kTabLog2 + DMX_LOG2_TABLE_DOUBLES;
-constexpr int kTab2 = kLut + DMX_LOG2_TABLE_DOUBLES;    // a doublet kernel's LDS table: read LUT | dmx_log2 table
+constexpr int kLut2 = 2 * 128;                           // the doublet kernels read mat | err/3 only (the third LUT part is the singlet kernels')
+constexpr int kTab2 = kLut2 + DMX_LOG2_TABLE_DOUBLES;   // a doublet kernel's LDS table: read LUT (2 KB) | dmx_log2 table (4 KB) = 1 KB more than
+                                                        // rounds 1-3's 3 + 2 KB: k_doublet_a2<64,4> keeps its three workgroups per CU (3 x 53.4 KB)
 // stage a doublet kernel's tables: the read LUT from the head of the device buffer, dmx_log2's table from its tail
 __device__ __forceinline__ void stage_k2_tables(double* s_tab, const double* __restrict__ tabs, int t, int nthreads) {
-  for (int i = t; i < kLut; i += nthreads) s_tab[i] = tabs[i];
-  for (int i = t; i < DMX_LOG2_TABLE_DOUBLES; i += nthreads) s_tab[kLut + i] = tabs[kTabLog2 + i];
+  for (int i = t; i < kLut2; i += nthreads) s_tab[i] = tabs[i];
+  for (int i = t; i < DMX_LOG2_TABLE_DOUBLES; i += nthreads) s_tab[kLut2 + i] = tabs[kTabLog2 + i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -945,7 +947,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 
   const int t = threadIdx.x;
   stage_k2_tables(s_lut, lut, t, kThreads);
-  const double* s_log = s_lut + kLut;
+  const double* s_log = s_lut + kLut2;
   for (int32_t bx = (int32_t)blockIdx.x; bx < pv.B; bx += (int32_t)gridDim.x) {
   if (FIXUP && !flagged[sched[bx]]) continue;
   const int32_t cell = sched[bx];
@@ -1146,7 +1148,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
   __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha: [n][0..8] = p (ALT), [n][9..17] = 1 - p; in LDS so
                                                  // that they occupy registers only while phase 1 runs (36 VGPRs otherwise)
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 18) {
@@ -1365,7 +1367,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   __syncthreads();
@@ -1657,7 +1659,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][10];                  // mixing weights of :613 per alpha and distinct value: [n][0..4] = p (ALT), [n][5..9] = 1 - p
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 10) {
@@ -1964,7 +1966,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_an(PileupView pv, int nrd_
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   __syncthreads();
@@ -2207,7 +2209,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_anf(PileupView pv, i
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   __syncthreads();
@@ -2525,7 +2527,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha (see k_doublet_a2): registers only while phase 1 runs
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 18) {
@@ -2916,7 +2918,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][18];                  // mixing weights of :613 per alpha
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 18) {
@@ -3298,7 +3300,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsym(PileupView pv,
   extern __shared__ __attribute__((aligned(64))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][10];                  // mixing weights per alpha and distinct value (see k_doublet_sym)
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   if (t < 10) {
@@ -3636,7 +3638,7 @@ __global__ __launch_bounds__(kThreads) void k_doublet_clsn(PileupView pv, int nr
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
-  const double* s_log = s_tab + kLut;
+  const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
   __syncthreads();
