@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: the round's full-size profiles of every BASELINE configuration and mode (tools/profile_round.sh each), ~15 min.
-TAG=${1:-r03}
+TAG=${1:-r04}
 STEPS=5 tools/profile_round.sh $TAG 3
 STEPS=5 tools/profile_round.sh $TAG 3 "--fast"
 STEPS=5 tools/profile_round.sh $TAG 2
