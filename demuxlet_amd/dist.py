@@ -113,6 +113,42 @@ def gather_records(local: np.ndarray, counts: Sequence[int], device=None, dst: i
     return np.concatenate([outs[r][:counts[r]].cpu().numpy() for r in range(world)], axis=0)
 
 
+def engine_compute(g: np.ndarray, alphas: Sequence[float], doublet_prior: float = 0.5, device: int = 0, mode: int = 0):
+    """The `compute` of run_sharded on a GPU: one engine on `device`, the shard staged, K1 beside K2 -> K3 -> K3b, and what leaves the device
+    is the fixed-size record per barcode plus the grids of the barcodes K3 flagged as near-ties (cmd_cram_demuxlet.cpp:412-461, :576-734)."""
+    from . import engine as eng
+
+    def compute(shard: HostPileup) -> CellRecords:
+        e = eng.Engine(g.shape[1], alphas, doublet_prior, device=device, mode=mode)
+        try:
+            e.set_genotypes(g)
+            e.set_pileup(shard)
+            e.run()
+            llks, llk0s = e.get_singlet()
+            _, l00, summ = e.get_doublet(want_grid=False)
+            sing = e.get_sing()
+            near = eng.near_tie_cells(summ)
+            grids = e.get_cell_grids(near)
+        finally:
+            e.close()
+        return CellRecords(llks, llk0s, sing, l00, summ, near, grids)
+    return compute
+
+
+def write_from_records(order: np.ndarray, rec: CellRecords, pl: HostPileup, barcodes: Sequence[str], sample_ids: Sequence[str], alphas: Sequence[float],
+                       out_prefix: str, g: Optional[np.ndarray] = None, doublet_prior: float = 0.5, min_total: int = 0, min_uniq: int = 0, min_snp: int = 0):
+    """Rank 0 after run_sharded: .single / .sing2 / .best from the gathered records (sorted-barcode order -> cell ids), the flagged barcodes'
+    grids handed to the writer; with `g` the tie arbiter walks the host pileup for the orders the device left open (:799-814)."""
+    from . import engine as eng
+    inv = np.empty_like(order)
+    inv[order] = np.arange(len(order))
+    fa = eng.FinalArgs(barcodes, sample_ids, alphas, doublet_prior, pl.rd_totl, pl.rd_pass, pl.rd_uniq, pl.n_snp_per_cell, min_total, min_uniq, min_snp, False)
+    eng.write_single(fa, rec.llks[inv], rec.llk0s[inv], out_prefix + ".single")
+    grids = {int(order[i]): gr for i, gr in zip(rec.near_cells, rec.near_grids)} if rec.near_cells is not None else None
+    eng.write_doublet_summary(fa, rec.sing[inv], rec.llks00[inv], rec.summary[inv], out_prefix, tie_pileup=pl if g is not None else None, tie_g=g,
+                              cell_grids=grids)
+
+
 def run_sharded(pl: HostPileup, barcodes: Sequence[str], n_samples: int, n_alpha: int,
                 compute: Callable[[HostPileup], CellRecords], summary_dtype, device=None):
     """Shard -> compute (one engine per rank) -> gather.  Returns on rank 0 (order, CellRecords over ALL cells in

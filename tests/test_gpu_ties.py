@@ -164,3 +164,45 @@ def test_every_sample_duplicated(eng, oracle, tmp_path):
             d = tmp_path / f"{V}{field}"
             d.mkdir()
             run_both_paths(eng, oracle, d, g, pl, (0.0, 0.5), "strict", f"all-duplicated V={V} {field}", min_fetched_frac=0.5)
+
+
+def _dist_worker(rank, world, port, seed, V, field, outdir):
+    import os
+    import sys
+    sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+    import torch
+    import torch.distributed as dist
+    from demuxlet_amd import capi, engine
+    from demuxlet_amd import dist as ddist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    g, pl = tie_problem(engine, seed, V, field, 200)
+    bcs = [f"BC{(i * 7919) % 100003:06d}-1" for i in range(pl.n_cells)]
+    sms = [f"SM{j:02d}" for j in range(V)]
+    res = ddist.run_sharded(pl, bcs, V, 2, ddist.engine_compute(g, (0.0, 0.5), device=rank), capi.SUMMARY_DTYPE, device=torch.device("cuda", rank))
+    if rank == 0:
+        order, rec = res
+        assert len(rec.near_cells) > 10
+        ddist.write_from_records(order, rec, pl, bcs, sms, (0.0, 0.5), os.path.join(outdir, "o"), g=g)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("V,field", [(8, "GT"), (33, "GP")])
+def test_sharded_run_over_rccl_with_the_engine(eng, oracle, tmp_path, V, field):
+    """demuxlet_amd/dist.py end to end on the GPU(s) of this box: one process per GPU (all there are, at most 8; on a 1-GPU box a 1-rank RCCL
+    group), the real engine per rank, ONE gather of the records with the near-tie-flagged barcodes' grids riding along, rank 0 writes
+    — the tie-heavy problem's files are the oracle's byte for byte (cmd_cram_demuxlet.cpp:576: barcodes are independent)."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    world = max(1, min(8, torch.cuda.device_count()))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    seed = 7300 + V
+    mp.spawn(_dist_worker, args=(world, port, seed, V, field, str(tmp_path)), nprocs=world, join=True)
+    g, pl = tie_problem(eng, seed, V, field, 200)
+    bcs = [f"BC{(i * 7919) % 100003:06d}-1" for i in range(pl.n_cells)]
+    oracle_files(oracle, pl, g, (0.0, 0.5), bcs, [f"SM{j:02d}" for j in range(V)], tmp_path / "ref")
+    for suf in ("single", "sing2", "best"):
+        assert_same_file(tmp_path / f"o.{suf}", tmp_path / f"ref.{suf}", f"dist.py over RCCL, world {world}, V={V} {field}")
