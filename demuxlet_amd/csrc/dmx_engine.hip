@@ -520,7 +520,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
 // scratch[class id of (snp, k)] into the chain buffer — the very double k_singlet would have computed for sample k
 // (same operands, same operations), so the sums that follow are bit-identical.  4+1 logs per pair instead of V+1.
 template <int CW, int KC>
-__global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows,
+__global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows, int chk,
                                                              const uint32_t* __restrict__ idw, const double* __restrict__ gp0,
                                                              const double* __restrict__ tabs,
                                                              const int32_t* __restrict__ sched, int32_t V,
@@ -626,8 +626,10 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
       const double x2 = G0 * (double)r1.z + G1 * (double)r1.w + G2 * (double)r2.x;     // class 2
       const double x3 = G0 * (double)r2.y + G1 * (double)r2.z + G2 * (double)r2.w;     // class 3
       const double x4 = G0 * q0 + G1 * q1 + G2 * q2;                                    // llk0      (:459)
-      const bool fast_ok = __builtin_amdgcn_class(x0, 0x100) && __builtin_amdgcn_class(x1, 0x100) && __builtin_amdgcn_class(x2, 0x100) &&
-                           __builtin_amdgcn_class(x3, 0x100) && __builtin_amdgcn_class(x4, 0x100);
+      // chk == 0: k_check_geno proved every row finite, non-negative, with an entry >= 1e-30, and GL >= 1e-6 / (1 + 3e-6) (:452): every
+      // argument is a positive normal number and the class test cannot fire (what the K2 kernels' CHK = false variants rely on)
+      const bool fast_ok = !chk || (__builtin_amdgcn_class(x0, 0x100) && __builtin_amdgcn_class(x1, 0x100) && __builtin_amdgcn_class(x2, 0x100) &&
+                                    __builtin_amdgcn_class(x3, 0x100) && __builtin_amdgcn_class(x4, 0x100));
       double* t0 = &term[(c * NC + KC) * TS + ti];   // the llk0 chain's slot of this pair
       if (__builtin_expect(fast_ok, 1)) {
         scr[0] = dmx_log_fast(x0, s_log); scr[64] = dmx_log_fast(x1, s_log); scr[128] = dmx_log_fast(x2, s_log);
@@ -4852,7 +4854,8 @@ int launch_singlet(dmx_engine* e) {
     const size_t dynb = sizeof(double) * (size_t)(kThreads / 64) * nchc * CW * (KC + 1);
     if (dynb <= 16 * 1024) {
       const dim3 blk(kThreads), grd((unsigned)((B + (kThreads / 64) * CW - 1) / ((kThreads / 64) * CW)));
-#define DMX_K1C(CC, KK) hipLaunchKernelGGL((k_singlet_cls<CC, KK>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, \
+      const int chk = e->geno_safe ? 0 : 1;       // (DMX_FORCE_CHECK=1 keeps the test: bit-identical, tests/test_gpu_parity.py)
+#define DMX_K1C(CC, KK) hipLaunchKernelGGL((k_singlet_cls<CC, KK>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, chk, \
                                            e->d_idw, e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
       if (KC == 4) { if (CW == 4) DMX_K1C(4, 4); else if (CW == 2) DMX_K1C(2, 4); else DMX_K1C(1, 4); }
       else         { if (CW == 4) DMX_K1C(4, 8); else if (CW == 2) DMX_K1C(2, 8); else DMX_K1C(1, 8); }

@@ -674,7 +674,7 @@ def test_every_launch_geometry_gives_the_same_bits(eng, oracle, V, field, dense,
     sp = synth.make_pileup(rng, al, B, 1.0 if dense else 0.3, 2.0, dense_layout=dense, doublet_rate=0.3)
     pl = host_pileup(eng, sp)
     for k in ("DMX_K1_CW", "DMX_K1_WIDE_V", "DMX_K2_GENERIC", "DMX_NO_CLASSES", "DMX_NO_K1_CLASSES", "DMX_K1_BLOCK_BYTES", "DMX_K1_NO_BLOCKS",
-              "DMX_FORCE_CHECK", "DMX_CLS_NO_UJ"):
+              "DMX_FORCE_CHECK", "DMX_CLS_NO_UJ", "DMX_CLS_NO_PROD"):
         monkeypatch.delenv(k, raising=False)
     base = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
     ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
@@ -689,7 +689,9 @@ def test_every_launch_geometry_gives_the_same_bits(eng, oracle, V, field, dense,
                 # the per-term argument-class test kept although this panel is provably safe (k_check_geno)
                 {"DMX_FORCE_CHECK": "1"}, {"DMX_FORCE_CHECK": "1", "DMX_NO_CLASSES": "1"},
                 # the class K2 of 33..64-sample GT panels in its look-up form instead of the uniform-j form (VGPR-relative row selection)
-                {"DMX_CLS_NO_UJ": "1"}]
+                {"DMX_CLS_NO_UJ": "1"},
+                # ... and in the round-3 uniform-j form instead of the producer / consumer kernel (k_doublet_clsp)
+                {"DMX_CLS_NO_PROD": "1"}]
     for env in variants:
         for k, v in env.items():
             monkeypatch.setenv(k, v)
