@@ -248,6 +248,12 @@ __device__ __forceinline__ uint32_t load_rd4(const PileupView& pv, int64_t off, 
 // The value of the neighbouring lane (lane ^ 1: the other alpha of the same pair in phase 1) by DPP quad permutation [1,0,3,2] —
 // two VALU moves instead of the two LDS-crossbar operations (ds_bpermute) that __shfl_xor becomes, in the middle of phase 1's
 // dependent chain (products -> maximum -> neighbour's maximum -> reciprocal -> quotients).
+// Both lanes of an (even, odd) pair get the ODD lane's value (quad permutation [1,1,3,3]): one DPP move per word, no select.
+__device__ __forceinline__ double shfl_odd(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xF5, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xF5, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double shfl_xor1(double x) {
   const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, true);
   const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, true);
@@ -4063,7 +4069,8 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
 #pragma unroll
   for (int i = 0; i < NV; ++i) v[i] = div_by(pG[i], mx, y);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) { const double o = shfl_xor1(v[i]); v[i] = n1 ? v[i] : o; }
+  for (int i = 0; i < NV; ++i) v[i] = shfl_odd(v[i]);     // (the alpha = 0.5 lane is the odd one: n1 == lane & 1)
+  (void)n1;
 }
 
 // K3b — the tie-order certificate (DESIGN.md "Ties").  At alpha = 0.5 the reference's llksAB[j][k] and llksAB[k][j] are one number
@@ -4076,7 +4083,7 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
 // both operands).  When lower == upper for both, they ARE the reference's values and the order is decided here — for any such
 // libm; the host tie arbiter (which calls the host's log()) is left with the barcodes where a bracket stayed open, about one in
 // ten.  Requires A = 2 (phase 1 is k_doublet_a2's) and no other doublet entry within 1e-7 of the best (K3's flag).
-template <int MINW>
+template <int MINW, bool FIVE>   // FIVE: alpha[0] == 0 (the default grid): five distinct phase-1 values per lane instead of nine
 __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                       const float* __restrict__ gT,
                                                       const double* __restrict__ tabs, const double* __restrict__ alpha,
@@ -4108,7 +4115,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
   const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
   int64_t rd_base = pv.cell_read_off[cell];
   const int ti1 = tid >> 1, n1 = tid & 1;
-  const bool five = alpha[0] == 0.0;             // the default grid {0, 0.5}: five distinct values per lane instead of nine
+  constexpr bool five = FIVE;
   double wA5[5], wR5[5];
   {
 #pragma unroll
@@ -4130,8 +4137,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
   bool clean[2] = {true, true};
   if (tid < 4) s_ev[cw][tid] = 0.0;               // [ab: log argument, lower candidate | ba: ...] of the open event
   const size_t S = (size_t)pv.S;
-  const float* const colA = gT ? gT + (size_t)(ia * 3) * S : g + (size_t)ia * 3;
-  const float* const colB = gT ? gT + (size_t)(ib * 3) * S : g + (size_t)ib * 3;
+  // lane n1 = 0 accumulates llksAB[a][b], lane 1 llksAB[b][a]: the lane's FIRST sample (rows l of :675-681) is a resp. b, its second b resp. a —
+  // chosen here, once, by the column pointers instead of per product by selects
+  const float* const colA = gT ? gT + (size_t)((n1 ? ib : ia) * 3) * S : g + (size_t)(n1 ? ib : ia) * 3;
+  const float* const colB = gT ? gT + (size_t)((n1 ? ia : ib) * 3) * S : g + (size_t)(n1 ? ia : ib) * 3;
   const size_t estride = gT ? S : 1, sstride = gT ? 1 : (size_t)V * 3;
   uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
   if (tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
@@ -4163,7 +4172,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
       const float fa0 = colA[so], fa1 = colA[so + estride], fa2 = colA[so + 2 * estride];
       const float fb0 = colB[so], fb1 = colB[so + estride], fb2 = colB[so + 2 * estride];
       double v[9];                                 // pG[1][l][m] of the pair (five: v[l + m])
-      if (five) {
+      if constexpr (five) {
         double v5[5];
         certify_pair_values<5>(pv, cnt, off, rd4, s_tab, wA5, wR5, n1, v5);
 #pragma unroll
@@ -4190,8 +4199,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
         for (int l = 0; l < 3; ++l)
 #pragma unroll
           for (int m = 0; m < 3; ++m) {
-            const double gp = n1 ? (bk[l] * aj[m]) : (aj[l] * bk[m]);       // lane 0: llksAB[a][b], lane 1: llksAB[b][a]   (:553)
-            sx += (gp * v[l * 3 + m]);                                       // :677-679
+            sx += ((aj[l] * bk[m]) * v[l * 3 + m]);                          // :553, :677-679 (aj = this lane's first sample, see colA)
           }
         ok &= __builtin_amdgcn_class(sx, 0x100);
         double lo1, hi1;
@@ -5234,10 +5242,13 @@ int launch_certify(dmx_engine* e) {
   const int32_t B = e->pv.B;
   const float* gT = (!e->pv.pair_snp && e->have_gT && !getenv("DMX_CERTIFY_NO_GT")) ? e->d_gT : nullptr;   // dense pileups: SNP-minor columns
   if (getenv("DMX_CERTIFY_MINW3"))                // kernel experiments only
-    hipLaunchKernelGGL(k_certify<3>, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
+    hipLaunchKernelGGL((k_certify<3, false>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
+                       e->d_alpha, e->V, e->d_sum);
+  else if (e->alpha[0] == 0.0)
+    hipLaunchKernelGGL((k_certify<4, true>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
                        e->d_alpha, e->V, e->d_sum);
   else
-    hipLaunchKernelGGL(k_certify<4>, dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
+    hipLaunchKernelGGL((k_certify<4, false>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
                        e->d_alpha, e->V, e->d_sum);
   HIP_TRY(hipGetLastError());
   return DMX_OK;
