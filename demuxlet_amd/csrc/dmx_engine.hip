@@ -123,6 +123,7 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
 // peak of the FAST kernels, whose accumulators have to stay in registers across it.
 __device__ __attribute__((noinline)) double div_slow(double a, double b) { return a / b; }
 
+constexpr int kPark = 12;              // doubles of parked k_certify state per barcode: 4 chains | 4 event words | clean[2] | ok | pad
 constexpr uint32_t kSafeReads = 15;   // each read scales a likelihood by >= err(127)/3 > 2^-44: 15 reads stay above 2^-700
 
 // ---- genotype likelihoods of a (cell, SNP) pair (cmd_cram_demuxlet.cpp:427-452) -----------------------------------------
@@ -4087,7 +4088,12 @@ template <int MINW, bool FIVE>   // FIVE: alpha[0] == 0 (the default grid): five
 __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                       const float* __restrict__ gT,
                                                       const double* __restrict__ tabs, const double* __restrict__ alpha,
-                                                      int32_t V, dmx_cell_summary* __restrict__ summ) {
+                                                      int32_t V, dmx_cell_summary* __restrict__ summ,
+                                                      const int64_t* __restrict__ blk, int32_t blk_i, int32_t nblk, double* __restrict__ park) {
+  // blk != nullptr (round 4): this launch covers SNP block blk_i of nblk only — sparse pileups whose genotype matrix does not fit an XCD's L2
+  // gather two pieces of a V*12-byte row per pair, and walking the SNP axis block by block (launch_certify; the table is k_snp_blocks',
+  // shared with sparse K1) keeps the rows a launch touches L2-resident.  Between launches a barcode's state — the four chains, the open
+  // events, the two clean flags, the class-test flag — is parked in park[cell][kPark]; the chains add the same terms in the same order.
   constexpr int TP = 32, T00 = TP + 2, TPC = 64, CPW = kThreads / TPC;
   __shared__ double s_tab[kTab];
   __shared__ double s_lo[128];
@@ -4111,9 +4117,14 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
   if (sm_np <= 0 || sm_j < 0 || sm_k < 0 || sm_n != 1 || alpha[1] != 0.5 || (sm_fl & DMX_CELL_NEAR_DOUBLET)) return;
   const int32_t ia = min(sm_j, sm_k), ib = max(sm_j, sm_k);
   int64_t* s_off = s_offs[cw]; int32_t* s_snp = s_snps[cw]; uint32_t* s_cnt = s_cnts[cw];
-  const int64_t p_beg = pv.cell_pair_off[cell];
-  const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
-  int64_t rd_base = pv.cell_read_off[cell];
+  // (blk_i = first table block of this launch | blocks per launch << 16: a launch may cover several of K1's blocks)
+  const int32_t b0 = blk_i & 0xFFFF, bs = max(1, blk_i >> 16), b1 = min(b0 + bs, nblk);
+  const int64_t* bt = blk ? blk + ((size_t)cell * (nblk + 1) + b0) * 2 : nullptr;
+  const int64_t p_beg = blk ? bt[0] : pv.cell_pair_off[cell];
+  const int64_t np = (blk ? bt[2 * (b1 - b0)] : pv.cell_pair_off[cell + 1]) - p_beg;
+  int64_t rd_base = blk ? bt[1] : pv.cell_read_off[cell];
+  const bool resume = blk && b0 > 0, last_launch = !blk || b1 == nblk;
+  double* const pk = park ? park + (size_t)cell * kPark : nullptr;
   const int ti1 = tid >> 1, n1 = tid & 1;
   constexpr bool five = FIVE;
   double wA5[5], wR5[5];
@@ -4126,16 +4137,16 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
       wR5[q] = 1.0 - p;
     }
   }
-  bool ok = true;
+  bool ok = resume ? pk[10] != 0.0 : true;
   // Lanes 0..3 own the four chains: (a,b) low, (a,b) high, (b,a) low, (b,a) high = the accumulator had every ambiguous log() come
   // out low / high.  While low == high an accumulator is known.  A step that splits them is an EVENT (its log() argument and
   // lower candidate are kept); from there on each of the two paths has to stay unambiguous by itself (clean): then the
   // reference's value is the low path if its libm returned the lower candidate at the event and the high path otherwise,
   // whatever it returned elsewhere.  The chains are serial (one add per pair); the event / clean tests of a tile's 32 steps
   // run lane-parallel on the chains' prefixes.
-  double acc = 0.0;
-  bool clean[2] = {true, true};
-  if (tid < 4) s_ev[cw][tid] = 0.0;               // [ab: log argument, lower candidate | ba: ...] of the open event
+  double acc = (resume && tid < 4) ? pk[tid] : 0.0;
+  bool clean[2] = {resume ? pk[8] != 0.0 : true, resume ? pk[9] != 0.0 : true};
+  if (tid < 4) s_ev[cw][tid] = resume ? pk[4 + tid] : 0.0;   // [ab: log argument, lower candidate | ba: ...] of the open event
   const size_t S = (size_t)pv.S;
   // lane n1 = 0 accumulates llksAB[a][b], lane 1 llksAB[b][a]: the lane's FIRST sample (rows l of :675-681) is a resp. b, its second b resp. a —
   // chosen here, once, by the column pointers instead of per product by selects
@@ -4244,6 +4255,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
     DMX_WAVE_LDS_ORDER();
   }
   const bool all_ok = __all(ok ? 1 : 0) != 0;
+  if (!last_launch) {                             // park the barcode's state for the next SNP block
+    DMX_WAVE_LDS_ORDER();
+    if (tid < 4) { pk[tid] = acc; pk[4 + tid] = s_ev[cw][tid]; }
+    if (tid == 0) { pk[8] = clean[0] ? 1.0 : 0.0; pk[9] = clean[1] ? 1.0 : 0.0; pk[10] = all_ok ? 1.0 : 0.0; }
+    return;
+  }
   const double ab_lo = __shfl(acc, 0), ab_hi = __shfl(acc, 1), ba_lo = __shfl(acc, 2), ba_hi = __shfl(acc, 3);
   if (tid == 0 && all_ok && !(ab_lo == ab_hi && ba_lo == ba_hi) && (ab_lo == ab_hi || clean[0]) && (ba_lo == ba_hi || clean[1])) {
     dmx_cell_summary* r = summ + cell;
@@ -4290,6 +4307,7 @@ struct dmx_engine {
   int32_t* d_sched = nullptr; size_t sched_cap = 0;
   int32_t* d_bad = nullptr;                                          // set by k_check_snp_ids
   bool have_gT = false;                                              // d_gT / d_g0T hold the current genotype matrix
+  double* d_park = nullptr; size_t park_cap = 0;   // k_certify's per-barcode state between the launches of its SNP-blocked walk
   int64_t* d_blk = nullptr; size_t blk_cap = 0; int32_t blk_shift = 0, blk_n = 0;   // k_snp_blocks table of the staged (sparse) pileup; blk_n = 0: none
   bool geno_safe = false;                                            // every genotype row finite, non-negative, max >= 2^-400 (k_check_geno)
   // host -> device staging of the big pileup arrays: two pinned chunks filled by host threads while the other one is in flight
@@ -4432,6 +4450,7 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_alpha) (void)hipFree(e->d_alpha);
   if (e->d_bad) (void)hipFree(e->d_bad);
   if (e->d_blk) (void)hipFree(e->d_blk);
+  if (e->d_park) (void)hipFree(e->d_park);
   for (int i = 0; i < 2; ++i) { if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]); if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]); }
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& r : e->ring_s) for (hipEvent_t& ev : r) if (ev) (void)hipEventDestroy(ev);
@@ -5240,16 +5259,31 @@ int launch_doublet(dmx_engine* e) {
 namespace {
 int launch_certify(dmx_engine* e) {
   const int32_t B = e->pv.B;
+  // sparse pileups over a matrix beyond the L2: one launch per SNP block (the table of the blocked K1 walk), state parked in between
+  // — OFF by default: measured at cfg5 it cuts K3b's L2-side traffic (profiles/r04_certify_blocks.txt) but costs time (10.15 against 9.28 ms: the kernel is
+  // bound by its own instruction stream, and 25 launches with their partial tiles cost more than the L2 hits save); DMX_CERTIFY_BLOCKS=1 turns it on,
+  // and forced small blocks (DMX_K1_BLOCK_BYTES) always use it so that the tests cover the parked-state path
+  const int64_t* blk = (e->pv.pair_snp && e->blk_n > 1 && (getenv("DMX_CERTIFY_BLOCKS") || getenv("DMX_K1_BLOCK_BYTES"))) ? e->d_blk : nullptr;
+  const int bstride = (blk && getenv("DMX_CERTIFY_BLOCK_STRIDE")) ? std::max(1, atoi(getenv("DMX_CERTIFY_BLOCK_STRIDE"))) : 1;   // table blocks per launch
+  const int n_launch = blk ? (e->blk_n + bstride - 1) / bstride : 1;
+  double* park = nullptr;
+  if (blk) {
+    if (int rc = ensure_dev((void**)&e->d_park, &e->park_cap, sizeof(double) * kPark * (size_t)std::max(B, 1))) return rc;
+    park = e->d_park;
+  }
   const float* gT = (!e->pv.pair_snp && e->have_gT && !getenv("DMX_CERTIFY_NO_GT")) ? e->d_gT : nullptr;   // dense pileups: SNP-minor columns
   if (getenv("DMX_CERTIFY_MINW3"))                // kernel experiments only
-    hipLaunchKernelGGL((k_certify<3, false>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
-                       e->d_alpha, e->V, e->d_sum);
+    for (int bi = 0; bi < n_launch; ++bi)
+      hipLaunchKernelGGL((k_certify<3, false>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
+                         e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park);
   else if (e->alpha[0] == 0.0)
-    hipLaunchKernelGGL((k_certify<4, true>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
-                       e->d_alpha, e->V, e->d_sum);
+    for (int bi = 0; bi < n_launch; ++bi)
+      hipLaunchKernelGGL((k_certify<4, true>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
+                         e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park);
   else
-    hipLaunchKernelGGL((k_certify<4, false>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
-                       e->d_alpha, e->V, e->d_sum);
+    for (int bi = 0; bi < n_launch; ++bi)
+      hipLaunchKernelGGL((k_certify<4, false>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
+                         e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park);
   HIP_TRY(hipGetLastError());
   return DMX_OK;
 }
