@@ -876,7 +876,8 @@ def test_run_is_singlet_and_doublet_in_one_call(eng, V, field, dense, mode):
 
 
 @pytest.mark.parametrize("V,field,dense,mode,sorted_ids", [(8, "GT", True, "strict", True), (12, "GP", False, "strict", False), (33, "GT", False, "fast", False),
-                                                           (16, "PL", False, "fast", True), (5, "GT", False, "strict", False)])
+                                                           (16, "PL", False, "fast", True), (5, "GT", False, "strict", False),
+                                                           (9, "GP", False, "strict", False), (6, "GT", False, "strict", True)])   # V = 9, 6: a three-alpha grid
 def test_demuxlet_run_from_a_device_resident_pileup(eng, oracle, tmp_path, monkeypatch, V, field, dense, mode, sorted_ids):
     """dmx_job.pileup with memory = DMX_MEM_DEVICE: the five pileup arrays live in HBM, nothing is sliced or copied on
     the host; ranges of consecutive barcodes are views of the caller's arrays, others are gathered on the device, and the barcodes the tie
@@ -886,6 +887,7 @@ def test_demuxlet_run_from_a_device_resident_pileup(eng, oracle, tmp_path, monke
     from demuxlet_amd import synth, capi
     rng = np.random.default_rng(4100 + V)
     S, B = 500, 300
+    alphas = (0.0, 0.25, 0.5) if V in (9, 6) else (0.0, 0.5)       # A = 3: no device certificate, every alpha-0.5 best doublet goes to the arbiter
     raw = synth.make_raw_genotypes(rng, S, V)
     if V == 5:                                     # duplicate samples: near-tie flags, barcodes whose grids AND pileup pieces are fetched
         raw.alleles[:, 1] = raw.alleles[:, 0]; raw.alleles[:, 3] = raw.alleles[:, 2]
@@ -907,12 +909,12 @@ def test_demuxlet_run_from_a_device_resident_pileup(eng, oracle, tmp_path, monke
     ds = capi.Pileup(B, S, hs.n_pairs, hs.n_reads, t["cell_pair_off"].data_ptr(), t["cell_read_off"].data_ptr(),
                      t_snp.data_ptr() if t_snp is not None else None, t["pair_nrd"].data_ptr(), pl.pair_nrd.dtype.itemsize, capi.DMX_MEM_DEVICE,
                      t["reads"].data_ptr(), pl.rd_totl.ctypes.data, pl.rd_pass.ctypes.data, pl.rd_uniq.ctypes.data)
-    ref = oracle_from_pileup_files(oracle, sp, g, (0.0, 0.5), bcs, sms, tmp_path / "orc")
+    ref = oracle_from_pileup_files(oracle, sp, g, alphas, bcs, sms, tmp_path / "orc")
     for tag, rb, wp in (("one", None, False), ("many", "6000", False), ("pair", "30000", True)):
         if rb: monkeypatch.setenv("DMX_RANGE_BYTES", rb)
         else: monkeypatch.delenv("DMX_RANGE_BYTES", raising=False)
-        th = eng.demuxlet_run(pl, g, sms, (0.0, 0.5), str(tmp_path / f"h_{tag}"), write_pair=wp, barcodes=bcs, mode=md, timing=True)
-        td = eng.demuxlet_run(ds, g, sms, (0.0, 0.5), str(tmp_path / f"d_{tag}"), write_pair=wp, barcodes=bcs, mode=md, timing=True)
+        th = eng.demuxlet_run(pl, g, sms, alphas, str(tmp_path / f"h_{tag}"), write_pair=wp, barcodes=bcs, mode=md, timing=True)
+        td = eng.demuxlet_run(ds, g, sms, alphas, str(tmp_path / f"d_{tag}"), write_pair=wp, barcodes=bcs, mode=md, timing=True)
         assert td["n_ranges"] == th["n_ranges"] and (rb is None or td["n_ranges"] > 2)
         assert td["n_cells_grid_fetched"] == th["n_cells_grid_fetched"]
         if tag == "one":
@@ -926,7 +928,7 @@ def test_demuxlet_run_from_a_device_resident_pileup(eng, oracle, tmp_path, monke
         assert fetched_one > 10
     # n_gpus > 1 is refused for a device-resident pileup
     with pytest.raises(Exception, match="one GPU"):
-        eng.demuxlet_run(ds, g, sms, (0.0, 0.5), str(tmp_path / "x"), barcodes=bcs, n_gpus=2)
+        eng.demuxlet_run(ds, g, sms, alphas, str(tmp_path / "x"), barcodes=bcs, n_gpus=2)
 
 
 def oracle_from_pileup_files(oracle, sp, g, alphas, barcodes, sample_ids, prefix):
