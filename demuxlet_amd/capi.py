@@ -110,7 +110,7 @@ class Job(C.Structure):
 class JobTiming(C.Structure):
     _fields_ = [("freeze_s", C.c_double), ("setup_s", C.c_double), ("stage_s", C.c_double), ("wait_s", C.c_double),
                 ("write_s", C.c_double), ("total_s", C.c_double), ("kernel_ms", C.c_double),
-                ("n_ranges", C.c_int32), ("n_engines", C.c_int32), ("n_cells_grid_fetched", C.c_int32), ("reserved", C.c_int32)]
+                ("n_ranges", C.c_int32), ("n_engines", C.c_int32), ("n_cells_grid_fetched", C.c_int32), ("n_cells_single", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

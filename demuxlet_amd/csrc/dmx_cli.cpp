@@ -1718,7 +1718,13 @@ int main(int argc, char** argv) {
   job.n_alpha = (int32_t)o.alpha.size(); job.alpha = o.alpha.data(); job.doublet_prior = o.doublet_prior;
   job.min_total = o.min_total; job.min_uniq = o.min_uniq; job.min_snp = o.min_snp; job.write_pair = o.write_pair;
   job.out_prefix = o.out.c_str(); job.device = o.gpu; job.arbiter = o.no_arbiter ? 0 : 1; job.n_gpus = o.gpus; job.mode = (o.fast && !o.strict) ? DMX_MODE_FAST : DMX_MODE_STRICT;
+  dmx_job_timing jt;
+  memset(&jt, 0, sizeof jt);
+  job.timing = &jt;
   if (dmx_demuxlet_run(&job) != DMX_OK) fatal("[E:%s] %s", __func__, dmx_last_error());
+  // the hot path's own notices (:468, :524; the per-1000-droplets / per-100-cells progress lines in between belong to loops that do not exist here)
+  notice("Identifying best-matching individual..");
+  notice("Finished processing %d droplets total", jt.n_cells_single);
   notice("Finished writing output files");                                                                 // :876
   dmx_store_free(scl);
   return 0;

@@ -5950,6 +5950,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   wr.close();
   if (wr.rc) return set_error(wr.rc, "%s", wr.msg.c_str());
   tm.stage_s = stage_s; tm.wait_s = wait_s; tm.write_s = write_s; tm.kernel_ms = kernel_ms; tm.n_cells_grid_fetched = n_fetched;
+  for (int32_t c = 0; c < B; ++c)                  // the droplets the reference counts at :480-524
+    if (pl.rd_totl[c] >= job->min_total && pl.rd_uniq[c] >= job->min_uniq && nsnp[(size_t)c] >= job->min_snp) ++tm.n_cells_single;
   tm.total_s = secs(t_begin, clk::now());
   if (job->timing) *job->timing = tm;
   if (getenv("DMX_E2E_TIMING"))

@@ -308,7 +308,8 @@ typedef struct dmx_job_timing {
   double write_s;                  /* tie arbiter + row formatting + file writes (all ranges) */
   double total_s;
   double kernel_ms;                /* sum over ranges of the K1 + K2 + K3 HIP-event times (device time, all engines) */
-  int32_t n_ranges, n_engines, n_cells_grid_fetched, reserved;
+  int32_t n_ranges, n_engines, n_cells_grid_fetched;
+  int32_t n_cells_single;          /* barcodes that passed --min-total / --min-uniq / --min-snp: the droplets of cmd_cram_demuxlet.cpp:480-524 (ABI 6; was `reserved`) */
 } dmx_job_timing;
 int dmx_demuxlet_run(const dmx_job*);
 /* Creates the HIP contexts of devices (device + i) mod (visible devices), i < n_gpus (n_gpus <= 0: one), and returns.  Optional: the first

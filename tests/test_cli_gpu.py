@@ -86,6 +86,12 @@ def test_nan_likelihoods_do_not_crash(tmp_path):
     assert r.returncode == 0, r.stderr[-500:]
     for suf in ("single", "sing2", "best", "pair"):
         assert (tmp_path / f"o.{suf}").stat().st_size > 100
+    # the hot path's own notices (cmd_cram_demuxlet.cpp:406,:468,:524,:876), in the reference's order, with its droplet count
+    n_drop = (len((tmp_path / "o.single").read_text().splitlines()) - 1) // len(SAMPLES)
+    msgs = [ln.split("] - ", 1)[1] for ln in r.stderr.splitlines() if ln.startswith("NOTICE")]
+    tail = [m for m in msgs if m.startswith(("Starting to identify", "Identifying best", "Finished processing", "Finished writing"))]
+    assert tail == ["Starting to identify best matching individual IDs", "Identifying best-matching individual..",
+                    f"Finished processing {n_drop} droplets total", "Finished writing output files"], tail
 
 
 def test_cfg1_tutorial_vcf_through_the_binary_on_the_gpu(oracle, tmp_path):
