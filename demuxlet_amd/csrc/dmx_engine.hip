@@ -4084,7 +4084,8 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
 // both operands).  When lower == upper for both, they ARE the reference's values and the order is decided here — for any such
 // libm; the host tie arbiter (which calls the host's log()) is left with the barcodes where a bracket stayed open, about one in
 // ten.  Requires A = 2 (phase 1 is k_doublet_a2's) and no other doublet entry within 1e-7 of the best (K3's flag).
-template <int MINW, bool FIVE>   // FIVE: alpha[0] == 0 (the default grid): five distinct phase-1 values per lane instead of nine
+template <int MINW, bool FIVE, bool DENSE = false>   // FIVE: alpha[0] == 0 (the default grid): five distinct phase-1 values per lane instead of nine;
+                                                     // DENSE: gT != NULL (SNP-minor columns) — compile-time strides, so the sparse form's three row entries are one load
 __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                       const float* __restrict__ gT,
                                                       const double* __restrict__ tabs, const double* __restrict__ alpha,
@@ -4150,9 +4151,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
   const size_t S = (size_t)pv.S;
   // lane n1 = 0 accumulates llksAB[a][b], lane 1 llksAB[b][a]: the lane's FIRST sample (rows l of :675-681) is a resp. b, its second b resp. a —
   // chosen here, once, by the column pointers instead of per product by selects
-  const float* const colA = gT ? gT + (size_t)((n1 ? ib : ia) * 3) * S : g + (size_t)(n1 ? ib : ia) * 3;
-  const float* const colB = gT ? gT + (size_t)((n1 ? ia : ib) * 3) * S : g + (size_t)(n1 ? ia : ib) * 3;
-  const size_t estride = gT ? S : 1, sstride = gT ? 1 : (size_t)V * 3;
+  const float* const colA = DENSE ? gT + (size_t)((n1 ? ib : ia) * 3) * S : g + (size_t)(n1 ? ib : ia) * 3;
+  const float* const colB = DENSE ? gT + (size_t)((n1 ? ia : ib) * 3) * S : g + (size_t)(n1 ? ia : ib) * 3;
+  const size_t estride = DENSE ? S : 1, sstride = DENSE ? 1 : (size_t)V * 3;
   uint32_t hd_n = 0u; int32_t hd_s = 0;          // header (stored reads, SNP id) of this lane's pair in the NEXT tile
   if (tid < TP && tid < np) { hd_n = load_nrd(pv.pair_nrd, p_beg + tid, nrd_width); hd_s = pv.pair_snp ? pv.pair_snp[p_beg + tid] : (int32_t)tid; }
   for (int64_t tbase = 0; tbase < np; tbase += TP) {
@@ -5272,18 +5273,15 @@ int launch_certify(dmx_engine* e) {
     park = e->d_park;
   }
   const float* gT = (!e->pv.pair_snp && e->have_gT && !getenv("DMX_CERTIFY_NO_GT")) ? e->d_gT : nullptr;   // dense pileups: SNP-minor columns
-  if (getenv("DMX_CERTIFY_MINW3"))                // kernel experiments only
-    for (int bi = 0; bi < n_launch; ++bi)
-      hipLaunchKernelGGL((k_certify<3, false>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
-                         e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park);
-  else if (e->alpha[0] == 0.0)
-    for (int bi = 0; bi < n_launch; ++bi)
-      hipLaunchKernelGGL((k_certify<4, true>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
-                         e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park);
-  else
-    for (int bi = 0; bi < n_launch; ++bi)
-      hipLaunchKernelGGL((k_certify<4, false>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, e->d_lut,
-                         e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park);
+#define DMX_K3B(MINW_, FIVE_, DENSE_)                                                                                  \
+  for (int bi = 0; bi < n_launch; ++bi)                                                                                 \
+    hipLaunchKernelGGL((k_certify<MINW_, FIVE_, DENSE_>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, \
+                       e->d_lut, e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park)
+  const bool five = e->alpha[0] == 0.0;
+  if (getenv("DMX_CERTIFY_MINW3")) { if (gT) DMX_K3B(3, false, true); else DMX_K3B(3, false, false); }      // kernel experiments only
+  else if (gT) { if (five) DMX_K3B(4, true, true); else DMX_K3B(4, false, true); }
+  else { if (five) DMX_K3B(4, true, false); else DMX_K3B(4, false, false); }
+#undef DMX_K3B
   HIP_TRY(hipGetLastError());
   return DMX_OK;
 }
