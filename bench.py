@@ -12,7 +12,7 @@ N = 1 (the driver's headline line): BASELINE.json configs[2] = cfg3, the heavies
 exercises the whole metric (singlet + doublet), in STRICT mode (the reference's operation order).  The same run appends, as
 nested records under "also", cfg3 in FAST mode, cfg2 (singlet-only), cfg5 (sparse PL) and — the strong-scaling base of the
 N > 1 line — ALL of cfg4 (100k barcodes x 100k SNPs x 64 samples, 1e10 covered pairs, 22.5 GB of pileup) on this one GPU in
-both modes, each timed the same way with fewer steps.  `--only` skips them.
+both modes, and cfg4's 12 500-barcode shard (one GPU's share of the 8-GPU run), each timed the same way with fewer steps.  `--only` skips them.
 
 Output contract: stdout carries exactly ONE compact JSON line (< 6 KB: the driver's keys, `config`, `roofline`, `roofline_valu`,
 `cpu_baseline` and one short object per nested configuration under `also`; no prose).  The full record (every per-kernel time, the
@@ -798,12 +798,19 @@ def main():
             k, w = max(2, min(args.steps, 5)), min(args.warmup, 1)
             # cfg4 WHOLE on this one GPU (2 steps each: a STRICT pass is ~7 s) is the N = 1 point of the strong-scaling curve whose
             # N > 1 points the driver measures with `--gpus N` (same workload, same code path minus the gather)
-            for no, mode, kk in ((3, "fast", k), (2, "strict", k), (5, "strict", k), (5, "fast", k), (4, "strict", 2), (4, "fast", 2)):
+            # ... and its 12 500-barcode shard, one GPU's share of the 8-GPU run: what a perfectly scaling N = 8 step costs (plus the gather)
+            for no, mode, kk, shard in ((3, "fast", k, 0), (2, "strict", k, 0), (5, "strict", k, 0), (5, "fast", k, 0), (4, "strict", 2, 0), (4, "fast", 2, 0),
+                                        (4, "strict", 3, 12_500)):
                 c = dict(CONFIGS[no])
+                if shard:
+                    c["B"] = shard
+                    c["name"] += f" [one of 8 shards: {shard} barcodes]"
                 if args.cells:
                     c["B"] = min(c["B"], args.cells)
                     c["name"] += f" [override: {c['B']} barcodes]"
                 r = run_config(cx, no, c, mode, kk, w, with_cpu=False, with_log=False)
+                if shard:
+                    r["config"]["tag"] = f"cfg{no}-shard/{mode}"
                 also.append({key: r[key] for key in keys if key in r})
             out["also"] = also
         if cx.world > 1 and default_run and not args.only:

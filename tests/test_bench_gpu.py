@@ -54,7 +54,7 @@ def test_bench_default_line_is_cfg3_with_nested_records():
     assert d["config"]["workload"].startswith("cfg3") and d["config"]["mode"] == "strict" and d["pair_evals_per_s"] > 0
     assert d["roofline"]["kernel"] == "k_doublet" and d["scaling"] == "weak"
     names = [a["workload"] for a in d["also"]]
-    assert names == ["cfg3/fast", "cfg2/strict", "cfg5/strict", "cfg5/fast", "cfg4/strict", "cfg4/fast"]
+    assert names == ["cfg3/fast", "cfg2/strict", "cfg5/strict", "cfg5/fast", "cfg4/strict", "cfg4/fast", "cfg4-shard/strict"]
     for a in d["also"]:
         assert a["value"] > 0 and a["roofline_frac"] > 0 and a["kernel_ms"] > 0 and a["ms_per_step"] >= a["kernel_ms"] * 0.999
     assert d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.001 and d["roofline"]["counts"].startswith("profiles/pmc_cfg3_strict")
