@@ -5312,9 +5312,22 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) { return run_doublet_impl(e
 // priority: K2's workgroups are dispatched first and K1 fills the slots K2 leaves free — above all during K2's last, partly filled
 // round (cfg3 FAST: 10 000 one-barcode wavefronts on 3 072 slots).  Fork and join are events on the engine's stream, so that for the
 // caller everything is ordered on that stream exactly as after run_singlet + run_doublet; the results are the same bits.
+namespace {
+// the doublet kernel launch_doublet will pick is k_doublet_clsp (GT classes, STRICT grid of two alphas, 33..64 samples)
+bool k2_will_be_clsp(const dmx_engine* e) {
+  const bool use_cls = e->n_classes > 0 && !getenv("DMX_NO_CLASSES");
+  const bool fast_sym = e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && e->V <= 64 && !getenv("DMX_NO_SYM");
+  return use_cls && e->A == 2 && !fast_sym && e->V > 32 && e->V <= 64 && !getenv("DMX_K2_GENERIC") && !getenv("DMX_CLS_NO_PROD") && !getenv("DMX_CLS_NO_UJ") &&
+         !getenv("DMX_CLS_MINW3") && !getenv("DMX_CLS_NK8");
+}
+}  // namespace
+
 extern "C" int dmx_engine_run(dmx_engine* e) {
   if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_run: null engine");
-  if (e->V < 2 || e->A < 2 || getenv("DMX_NO_OVERLAP")) {
+  // K1 beside K2 pays where K2 leaves slots free.  k_doublet_clsp does not (three wavefronts per SIMD, all of them issuing): measured on
+  // the cfg4 shard 838.5 ms with K1 beside it against 828.5 ms one after the other, so there K1 simply goes first.  (DMX_FORCE_OVERLAP=1: beside anyway.)
+  const bool serial = getenv("DMX_NO_OVERLAP") || (e->have_pileup && k2_will_be_clsp(e) && !getenv("DMX_FORCE_OVERLAP"));
+  if (e->V < 2 || e->A < 2 || serial) {
     if (int rc = dmx_engine_run_singlet(e)) return rc;
     return (e->V < 2 || e->A < 2) ? DMX_OK : dmx_engine_run_doublet(e);
   }
