@@ -2902,16 +2902,16 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
 //                            {T, ids, classes of the wavefronts' samples j}; then phase 2 of tile t for the LAST 4 samples j;
 //   wavefronts 1..3 (consumers)  tile t: phase 2 of the uniform-j form for 20 samples j each — lanes = samples k, the pair's table
 //                            column in sixteen consecutive registers, the row chosen by VGPR-relative addressing (see k_doublet_cls);
-// ONE s_barrier per tile.  4 / 20 / 20 / 20 roughly balances the wavefronts' issue cycles (production costs about 12 samples' worth of
+// ONE s_barrier per tile.  Phase 2 of a tile is ONE software-pipelined asm statement per wavefront (DMX_PJ_* below): while a pair's
+// additions issue out of one set of column registers, the next pair's column is read into a second set and the class words of the pair
+// after it into v[130:135] — no LDS round trip on the additions' path.  A wavefront's class words are simply its twenty bytes of the
+// pair's id row (c * 16 per sample; 0 beyond V), five aligned words.  4 / 20 / 20 / 20 roughly balances the wavefronts' issue cycles (production costs about 12 samples' worth of
 // phase 2; 7 / 19 / 19 / 19 would be even, but 14 accumulators beside phase 1 spill at 168 registers), so the four SIMDs of a CU stay evenly loaded whichever wavefronts share them.  The consumers never touch global memory
 // inside the loop and need no register of phases 1 / 1b, the producer only 8 accumulators: 168 registers, 3 wavefronts per SIMD
 // (k_doublet_cls<256,16,uniform-j>: 256 registers, 2 per SIMD), so a SIMD has two other barcodes to issue for while one waits.
 // Same operands, same operations, same order of additions as k_doublet_cls: bit-identical (tests).  cmd_cram_demuxlet.cpp:594-710.
-#ifndef DMX_PC_J0
-#define DMX_PC_J0 4          // kernel experiments: 7 (with 19 per consumer), 1 (21), 10 (18)
-#endif
-constexpr int kPcJ0 = DMX_PC_J0, kPcJ = (64 - DMX_PC_J0) / 3;
-static_assert(kPcJ0 + 3 * kPcJ == 64 && kPcJ0 <= 8 && kPcJ <= 20 && kPcJ >= 19, "k_doublet_clsp: 4 / 20 / 20 / 20 or 7 / 19 / 19 / 19");              // samples j of wavefront 0 (the last ones) and of wavefronts 1..3
+constexpr int kPcJ0 = 4, kPcJ = (64 - kPcJ0) / 3;             // samples j of wavefront 0 (the last ones) and of wavefronts 1..3
+static_assert(kPcJ0 + 3 * kPcJ == 64 && kPcJ % 4 == 0, "k_doublet_clsp: 4 / 20 / 20 / 20 (a wavefront's class bytes are whole words of the id row)");
 template <int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                                 const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
@@ -2922,7 +2922,6 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   constexpr int A = 2, TP = 32;
   constexpr int T00 = TP + 2;
   constexpr int NT = kMaxCls * kMaxCls * A;      // class-table entries per pair
-  constexpr int JW = 5;                          // words of class bytes per (pair, wavefront): up to 20 samples j
   constexpr int VSC = 64;                        // id row stride in the LDS (bytes): compile-time for panels of up to 64 samples
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
@@ -2936,12 +2935,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
     s_w[n][t % 9] = p;
     s_w[n][9 + t % 9] = 1.0 - p;
   }
-  // double-buffered (what phase 2 reads): the class table, the ids (as c * 16) and the wavefronts' class words;
+  // double-buffered (what phase 2 reads): the class table and the ids (as c * 16);
   // producer-private: pG, the llks00 terms, headers (current and next), rows
   double* s_Tb = (double*)s_raw;                                  // [2][TP][4][4][2]
   uint8_t* s_idb = (uint8_t*)(s_Tb + 2 * TP * NT);                // [2][TP][VSC]
-  uint32_t* s_jwb = (uint32_t*)(s_idb + 2 * (size_t)TP * VSC);     // [2][TP][4][JW + 3]   (VSC is a multiple of 16; 8 words per (pair, wavefront))
-  double* s_pG = (double*)(s_jwb + 2 * TP * 4 * 8);               // [TP][2][9]
+  double* s_pG = (double*)(s_idb + 2 * (size_t)TP * VSC);         // [TP][2][9]
   double* s_t00 = s_pG + TP * 18;                                 // [2][T00]
   int64_t* s_off = (int64_t*)(s_t00 + 2 * T00);                   // [TP]
   int64_t* s_off2 = s_off + TP;                                   // [TP]  header of the NEXT tile
@@ -2959,21 +2957,55 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   (void)VS;
   const int wave = t >> 6, lane = t & 63;        // lane = sample k in phase 2
   const int j0 = wave == 0 ? 3 * kPcJ : (wave - 1) * kPcJ;       // first sample j of this wavefront
-  typedef uint32_t dmx_u4 __attribute__((ext_vector_type(4)));
-  using lds_u4 = const __attribute__((address_space(3))) dmx_u4*;
-  using lds_u1 = const __attribute__((address_space(3))) uint32_t*;
+  using lds_u8 = const __attribute__((address_space(3))) uint8_t*;
 
-  // phase 2 of one pair for NJ samples j (one asm statement; see k_doublet_cls).  Column registers v[152:167]: the top of the 168-register budget.
-#define DMX_UJP_STEP(A0, A1, W, B)                                                                                \
+  // Phase 2 of one tile for a wavefront's samples j, one asm statement.  Per (pair, sample j): the class of j (wave-uniform) picks the row
+  // of the lane's column by VGPR-relative addressing (see k_doublet_cls), then one addition per alpha.  Column sets X = v[152:167] and
+  // Y = v[136:151] (the top of the 168-register budget), class words of the pair being requested in v[130:134], its id byte in v135;
+  // two sets of class words in scalar registers (wa*, wb*).  Invariant at the top of a pair: its column requested, then the next pair's
+  // words and id byte (NW LDS operations younger): s_waitcnt lgkmcnt(NW) is enough (LDS operations return in order).  The pairs beyond
+  // the tile that the last rounds request read LDS inside the workgroup's allocation (the id byte is masked to a class's 0x30, so the
+  // column reads stay 16-byte aligned) and are drained before the statement ends.  DS instructions of gfx9+ do not use M0, so the
+  // indexing state left in it is harmless; M0 is restored at the end.
+#define DMX_PJ_STEP(C0, C1, A0, A1, W, B)                                                                         \
   "s_bfe_u32 %[t], %[" W "], " B "\n\ts_set_gpr_idx_on %[t], 0x1\n\t"                                             \
-  "v_add_f64 %[" A0 "], v[152:153], %[" A0 "]\n\tv_add_f64 %[" A1 "], v[154:155], %[" A1 "]\n\t"
-#define DMX_UJP_HEAD                                                                                              \
-  "s_mov_b32 %[m0k], m0\n\t"                                                                                      \
-  "ds_read_b128 v[152:155], %[col]\n\tds_read_b128 v[156:159], %[col] offset:64\n\t"                              \
-  "ds_read_b128 v[160:163], %[col] offset:128\n\tds_read_b128 v[164:167], %[col] offset:192\n\t"                  \
-  "s_waitcnt lgkmcnt(0)\n\t"
-#define DMX_UJP_TAIL "s_set_gpr_idx_off\n\ts_mov_b32 m0, %[m0k]"
-#define DMX_UJP_CLOB "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "scc", "memory"
+  "v_add_f64 %[" A0 "], " C0 ", %[" A0 "]\n\tv_add_f64 %[" A1 "], " C1 ", %[" A1 "]\n\t"
+#define DMX_PJ_FIRST4(C0, C1, P)                                                                                  \
+  DMX_PJ_STEP(C0, C1, "a0", "b0", P "0", "0x40002") DMX_PJ_STEP(C0, C1, "a1", "b1", P "0", "0x4000a")               \
+  DMX_PJ_STEP(C0, C1, "a2", "b2", P "0", "0x40012") DMX_PJ_STEP(C0, C1, "a3", "b3", P "0", "0x4001a")
+#define DMX_PJ_REST16(C0, C1, P)                                                                                  \
+  DMX_PJ_STEP(C0, C1, "a4", "b4", P "1", "0x40002") DMX_PJ_STEP(C0, C1, "a5", "b5", P "1", "0x4000a")               \
+  DMX_PJ_STEP(C0, C1, "a6", "b6", P "1", "0x40012") DMX_PJ_STEP(C0, C1, "a7", "b7", P "1", "0x4001a")               \
+  DMX_PJ_STEP(C0, C1, "a8", "b8", P "2", "0x40002") DMX_PJ_STEP(C0, C1, "a9", "b9", P "2", "0x4000a")               \
+  DMX_PJ_STEP(C0, C1, "a10", "b10", P "2", "0x40012") DMX_PJ_STEP(C0, C1, "a11", "b11", P "2", "0x4001a")           \
+  DMX_PJ_STEP(C0, C1, "a12", "b12", P "3", "0x40002") DMX_PJ_STEP(C0, C1, "a13", "b13", P "3", "0x4000a")           \
+  DMX_PJ_STEP(C0, C1, "a14", "b14", P "3", "0x40012") DMX_PJ_STEP(C0, C1, "a15", "b15", P "3", "0x4001a")           \
+  DMX_PJ_STEP(C0, C1, "a16", "b16", P "4", "0x40002") DMX_PJ_STEP(C0, C1, "a17", "b17", P "4", "0x4000a")           \
+  DMX_PJ_STEP(C0, C1, "a18", "b18", P "4", "0x40012") DMX_PJ_STEP(C0, C1, "a19", "b19", P "4", "0x4001a")
+  // the next pair: wait for its words / id byte, request its column into the set N0..N3 and move its words into a scalar set (RFL);
+  // then request the words of the pair after it (WORDS).  pj: the wavefront's words in the id row, pi: the lane's id byte, pt: the table.
+#define DMX_PJ_MID(N0, N1, N2, N3, RFL, WORDS)                                                                     \
+  "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\t"                                                                 \
+  "v_and_b32 %[colv], 0x30, v135\n\tv_add_u32 %[colv], %[pt], %[colv]\n\t"                                         \
+  "ds_read_b128 " N0 ", %[colv]\n\tds_read_b128 " N1 ", %[colv] offset:64\n\t"                                     \
+  "ds_read_b128 " N2 ", %[colv] offset:128\n\tds_read_b128 " N3 ", %[colv] offset:192\n\t"                         \
+  RFL                                                                                                             \
+  "v_add_u32 %[pj], 64, %[pj]\n\tv_add_u32 %[pi], 64, %[pi]\n\tv_add_u32 %[pt], 0x100, %[pt]\n\t"                   \
+  WORDS
+#define DMX_PJ_MIDX(RFL, WORDS) DMX_PJ_MID("v[152:155]", "v[156:159]", "v[160:163]", "v[164:167]", RFL, WORDS)
+#define DMX_PJ_MIDY(RFL, WORDS) DMX_PJ_MID("v[136:139]", "v[140:143]", "v[144:147]", "v[148:151]", RFL, WORDS)
+#define DMX_PJ_WORDS5 "ds_read2_b32 v[130:131], %[pj] offset1:1\n\tds_read2_b32 v[132:133], %[pj] offset0:2 offset1:3\n\t" \
+                      "ds_read_b32 v134, %[pj] offset:16\n\tds_read_u8 v135, %[pi]\n\t"
+#define DMX_PJ_WORDS1 "ds_read_b32 v130, %[pj]\n\tds_read_u8 v135, %[pi]\n\t"
+#define DMX_PJ_RFL5(Q)                                                                                            \
+  "v_readfirstlane_b32 %[" Q "0], v130\n\tv_readfirstlane_b32 %[" Q "1], v131\n\tv_readfirstlane_b32 %[" Q "2], v132\n\t" \
+  "v_readfirstlane_b32 %[" Q "3], v133\n\tv_readfirstlane_b32 %[" Q "4], v134\n\t"
+#define DMX_PJ_RFL1(Q) "v_readfirstlane_b32 %[" Q "0], v130\n\t"
+#define DMX_PJ_NEXT(LBL) "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_ge_u32 %[ti], %[tp]\n\ts_cbranch_scc1 " LBL "\n\t"
+#define DMX_PJ_END "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %[m0k]"
+#define DMX_PJ_CLOB "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", \
+                    "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", \
+                    "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "scc", "memory"
 
   if (wave == 0) {
     // ================================================= producer =================================================
@@ -3033,7 +3065,6 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
       const int tp = (int)min((int64_t)TP, np - tbase);
       double* s_T = s_Tb + (size_t)b * TP * NT;
       uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
-      uint32_t* s_jw = s_jwb + (size_t)b * TP * 4 * 8;
       if (lane < TP) { s_cnt[lane] = pn; s_off[lane] = poff; s_snp[lane] = psn; }
 #pragma unroll
       for (int i = 0; i < NRR; ++i) s_rows[ti1 * 12 + n1 * 6 + i] = d_rows[i];
@@ -3044,15 +3075,6 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
       publish_next();
       load_hdr(tbase + 2 * TP);
       DMX_WAVE_LDS_ORDER();
-      // the class bytes of every wavefront's samples j, five words per (pair, wavefront)
-      for (int e = lane; e < TP * 4 * JW; e += 64) {
-        const int ti = e / (4 * JW), w = (e / JW) & 3, m = e % JW;
-        const int jb = (w == 0 ? 3 * kPcJ : (w - 1) * kPcJ) + 4 * m, nj = w == 0 ? kPcJ0 : kPcJ;
-        uint32_t wv = 0;
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) if (4 * m + bb < nj && jb + bb < V) wv |= (uint32_t)s_ids[ti * VSC + jb + bb] << (8 * bb);
-        s_jw[(ti * 4 + w) * 8 + m] = wv;
-      }
       // ---- phase 1 (identical to k_doublet_a2 / k_doublet_cls)
       {
         const bool on = ti1 < tp;
@@ -3154,30 +3176,28 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
       const int tp = (int)min((int64_t)TP, np - tbase);
       if (!owner) return;
       const uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
-      const uint32_t t_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
-      const uint32_t jw_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)(s_jwb + (size_t)b * TP * 4 * 8);
-      for (int ti = 0; ti < tp; ++ti) {
-        const uint32_t ja = jw_a + (uint32_t)((ti * 4 + 0) * 32);
-        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(lds_u1)(uintptr_t)ja),
-                       w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(lds_u1)(uintptr_t)(ja + 4));
-        const uint32_t col = t_a + (uint32_t)(ti * NT * 8) + (uint32_t)s_ids[ti * VSC + lane];
-        uint32_t tmp, m0_keep;
-        asm volatile(DMX_UJP_HEAD
-            DMX_UJP_STEP("a0", "b0", "w0", "0x40002") DMX_UJP_STEP("a1", "b1", "w0", "0x4000a")
-            DMX_UJP_STEP("a2", "b2", "w0", "0x40012") DMX_UJP_STEP("a3", "b3", "w0", "0x4001a")
-#if DMX_PC_J0 == 7
-            DMX_UJP_STEP("a4", "b4", "w1", "0x40002") DMX_UJP_STEP("a5", "b5", "w1", "0x4000a") DMX_UJP_STEP("a6", "b6", "w1", "0x40012")
-#endif
-            DMX_UJP_TAIL
-            : [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]), [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
+      uint32_t pi = (uint32_t)(uintptr_t)(lds_u8)(s_ids + lane), pj = (uint32_t)(uintptr_t)(lds_u8)(s_ids + 3 * kPcJ);
+      uint32_t pt = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
+      uint32_t tmp, m0_keep, colv, ti_c, wa0, wb0;
+      // a pair is four additions long here, so the requests go FIRST in a round (the column a pair ahead, the words two ahead)
+      asm volatile("s_mov_b32 %[m0k], m0\n\t" DMX_PJ_WORDS1
+          DMX_PJ_MIDX(DMX_PJ_RFL1("wa"), DMX_PJ_WORDS1)
+          "s_mov_b32 %[ti], 0\n"
+          "L_pjp_%=:\n\t"
+          DMX_PJ_MIDY(DMX_PJ_RFL1("wb"), DMX_PJ_WORDS1)
+          DMX_PJ_FIRST4("v[152:153]", "v[154:155]", "wa")
+          DMX_PJ_NEXT("L_pjq_%=")
+          DMX_PJ_MIDX(DMX_PJ_RFL1("wa"), DMX_PJ_WORDS1)
+          DMX_PJ_FIRST4("v[136:137]", "v[138:139]", "wb")
+          "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_lt_u32 %[ti], %[tp]\n\ts_cbranch_scc1 L_pjp_%=\n"
+          "L_pjq_%=:\n\t"
+          DMX_PJ_END
+          : [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]), [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
               [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]), [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
-#if DMX_PC_J0 == 7
-              [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]), [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]), [a6] "+v"(acc[6][0]), [b6] "+v"(acc[6][1]),
-#endif
-              [t] "=&s"(tmp), [m0k] "=&s"(m0_keep)
-            : [col] "v"(col), [w0] "s"(w0), [w1] "s"(w1)
-            : DMX_UJP_CLOB);
-      }
+            [pj] "+v"(pj), [pi] "+v"(pi), [pt] "+v"(pt), [colv] "=&v"(colv),
+            [t] "=&s"(tmp), [m0k] "=&s"(m0_keep), [ti] "=&s"(ti_c), [wa0] "=&s"(wa0), [wb0] "=&s"(wb0)
+          : [tp] "s"(tp)
+          : DMX_PJ_CLOB);
     };
     if (np > 0) {
       load_hdr(0);
@@ -3214,53 +3234,44 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
     int b = 1;
     for (int64_t tbase = -TP; tbase < np; tbase += TP, b ^= 1) {
       const int tp = tbase < 0 ? 0 : (int)min((int64_t)TP, np - tbase);
-      if (owner) {
+      if (owner && tp > 0) {
         const uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
-        const uint32_t t_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
-        const uint32_t jw_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)(s_jwb + (size_t)b * TP * 4 * 8);
-        for (int ti = 0; ti < tp; ++ti) {
-          // the classes of the wavefront's 20 samples j (bytes c * 16; broadcast reads) into scalar registers
-          const uint32_t ja = jw_a + (uint32_t)((ti * 4 + wave) * 32);
-          const dmx_u4 jw = *(lds_u4)(uintptr_t)ja;
-          const uint32_t j4 = *(lds_u1)(uintptr_t)(ja + 16);
-          const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.x), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.y),
-                         w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.z), w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)jw.w),
-                         w4 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j4);
-          // this lane's column of the pair's table: T[cj][ck] for cj = 0..3 (rows 64 bytes apart), ck = the class of sample k
-          const uint32_t col = t_a + (uint32_t)(ti * NT * 8) + (uint32_t)s_ids[ti * VSC + lane];
-          uint32_t tmp, m0_keep;
-          asm volatile(DMX_UJP_HEAD
-              DMX_UJP_STEP("a0", "b0", "w0", "0x40002") DMX_UJP_STEP("a1", "b1", "w0", "0x4000a")
-              DMX_UJP_STEP("a2", "b2", "w0", "0x40012") DMX_UJP_STEP("a3", "b3", "w0", "0x4001a")
-              DMX_UJP_STEP("a4", "b4", "w1", "0x40002") DMX_UJP_STEP("a5", "b5", "w1", "0x4000a")
-              DMX_UJP_STEP("a6", "b6", "w1", "0x40012") DMX_UJP_STEP("a7", "b7", "w1", "0x4001a")
-              DMX_UJP_STEP("a8", "b8", "w2", "0x40002") DMX_UJP_STEP("a9", "b9", "w2", "0x4000a")
-              DMX_UJP_STEP("a10", "b10", "w2", "0x40012") DMX_UJP_STEP("a11", "b11", "w2", "0x4001a")
-              DMX_UJP_STEP("a12", "b12", "w3", "0x40002") DMX_UJP_STEP("a13", "b13", "w3", "0x4000a")
-              DMX_UJP_STEP("a14", "b14", "w3", "0x40012") DMX_UJP_STEP("a15", "b15", "w3", "0x4001a")
-              DMX_UJP_STEP("a16", "b16", "w4", "0x40002") DMX_UJP_STEP("a17", "b17", "w4", "0x4000a")
-              DMX_UJP_STEP("a18", "b18", "w4", "0x40012")
-#if DMX_PC_J0 == 4
-              DMX_UJP_STEP("a19", "b19", "w4", "0x4001a")
-#endif
-              DMX_UJP_TAIL
-              : [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]), [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
-                [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]), [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
-                [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]), [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]),
-                [a6] "+v"(acc[6][0]), [b6] "+v"(acc[6][1]), [a7] "+v"(acc[7][0]), [b7] "+v"(acc[7][1]),
-                [a8] "+v"(acc[8][0]), [b8] "+v"(acc[8][1]), [a9] "+v"(acc[9][0]), [b9] "+v"(acc[9][1]),
-                [a10] "+v"(acc[10][0]), [b10] "+v"(acc[10][1]), [a11] "+v"(acc[11][0]), [b11] "+v"(acc[11][1]),
-                [a12] "+v"(acc[12][0]), [b12] "+v"(acc[12][1]), [a13] "+v"(acc[13][0]), [b13] "+v"(acc[13][1]),
-                [a14] "+v"(acc[14][0]), [b14] "+v"(acc[14][1]), [a15] "+v"(acc[15][0]), [b15] "+v"(acc[15][1]),
-                [a16] "+v"(acc[16][0]), [b16] "+v"(acc[16][1]), [a17] "+v"(acc[17][0]), [b17] "+v"(acc[17][1]),
-                [a18] "+v"(acc[18][0]), [b18] "+v"(acc[18][1]),
-#if DMX_PC_J0 == 4
-                [a19] "+v"(acc[19][0]), [b19] "+v"(acc[19][1]),
-#endif
-                [t] "=&s"(tmp), [m0k] "=&s"(m0_keep)
-              : [col] "v"(col), [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [w3] "s"(w3), [w4] "s"(w4)
-              : DMX_UJP_CLOB);
-        }
+        uint32_t pi = (uint32_t)(uintptr_t)(lds_u8)(s_ids + lane), pj = (uint32_t)(uintptr_t)(lds_u8)(s_ids + j0);
+        uint32_t pt = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
+        uint32_t tmp, m0_keep, colv, ti_c, wa0, wa1, wa2, wa3, wa4, wb0, wb1, wb2, wb3, wb4;
+        asm volatile("s_mov_b32 %[m0k], m0\n\t" DMX_PJ_WORDS5
+            DMX_PJ_MIDX(DMX_PJ_RFL5("wa"), DMX_PJ_WORDS5)
+            "s_mov_b32 %[ti], 0\n"
+            "L_pjc_%=:\n\t"
+            "s_waitcnt lgkmcnt(4)\n\t"
+            DMX_PJ_FIRST4("v[152:153]", "v[154:155]", "wa")
+            DMX_PJ_MIDY(DMX_PJ_RFL5("wb"), DMX_PJ_WORDS5)
+            DMX_PJ_REST16("v[152:153]", "v[154:155]", "wa")
+            DMX_PJ_NEXT("L_pjd_%=")
+            "s_waitcnt lgkmcnt(4)\n\t"
+            DMX_PJ_FIRST4("v[136:137]", "v[138:139]", "wb")
+            DMX_PJ_MIDX(DMX_PJ_RFL5("wa"), DMX_PJ_WORDS5)
+            DMX_PJ_REST16("v[136:137]", "v[138:139]", "wb")
+            "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_lt_u32 %[ti], %[tp]\n\ts_cbranch_scc1 L_pjc_%=\n"
+            "L_pjd_%=:\n\t"
+            DMX_PJ_END
+            :
+                [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]),                [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
+                [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]),                [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
+                [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]),                [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]),
+                [a6] "+v"(acc[6][0]), [b6] "+v"(acc[6][1]),                [a7] "+v"(acc[7][0]), [b7] "+v"(acc[7][1]),
+                [a8] "+v"(acc[8][0]), [b8] "+v"(acc[8][1]),                [a9] "+v"(acc[9][0]), [b9] "+v"(acc[9][1]),
+                [a10] "+v"(acc[10][0]), [b10] "+v"(acc[10][1]),                [a11] "+v"(acc[11][0]), [b11] "+v"(acc[11][1]),
+                [a12] "+v"(acc[12][0]), [b12] "+v"(acc[12][1]),                [a13] "+v"(acc[13][0]), [b13] "+v"(acc[13][1]),
+                [a14] "+v"(acc[14][0]), [b14] "+v"(acc[14][1]),                [a15] "+v"(acc[15][0]), [b15] "+v"(acc[15][1]),
+                [a16] "+v"(acc[16][0]), [b16] "+v"(acc[16][1]),                [a17] "+v"(acc[17][0]), [b17] "+v"(acc[17][1]),
+                [a18] "+v"(acc[18][0]), [b18] "+v"(acc[18][1]),                [a19] "+v"(acc[19][0]), [b19] "+v"(acc[19][1]),
+                [pj] "+v"(pj), [pi] "+v"(pi), [pt] "+v"(pt), [colv] "=&v"(colv),
+                [t] "=&s"(tmp), [m0k] "=&s"(m0_keep), [ti] "=&s"(ti_c),
+                [wa0] "=&s"(wa0), [wa1] "=&s"(wa1), [wa2] "=&s"(wa2), [wa3] "=&s"(wa3), [wa4] "=&s"(wa4),
+                [wb0] "=&s"(wb0), [wb1] "=&s"(wb1), [wb2] "=&s"(wb2), [wb3] "=&s"(wb3), [wb4] "=&s"(wb4)
+            : [tp] "s"(tp)
+            : DMX_PJ_CLOB);
       }
       __syncthreads();
     }
@@ -3275,10 +3286,19 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
       }
     }
   }
-#undef DMX_UJP_STEP
-#undef DMX_UJP_HEAD
-#undef DMX_UJP_TAIL
-#undef DMX_UJP_CLOB
+#undef DMX_PJ_STEP
+#undef DMX_PJ_FIRST4
+#undef DMX_PJ_REST16
+#undef DMX_PJ_MID
+#undef DMX_PJ_MIDX
+#undef DMX_PJ_MIDY
+#undef DMX_PJ_WORDS5
+#undef DMX_PJ_WORDS1
+#undef DMX_PJ_RFL5
+#undef DMX_PJ_RFL1
+#undef DMX_PJ_NEXT
+#undef DMX_PJ_END
+#undef DMX_PJ_CLOB
 }
 
 // K2 over genotype classes, FAST mode, alpha grid {0, 0.5}: k_doublet_sym's entry set (singlet column + one evaluation per
@@ -5109,7 +5129,7 @@ int launch_doublet(dmx_engine* e) {
     else if (getenv("DMX_CLS_NK8")) { if (atoi(getenv("DMX_CLS_NK8")) == 3) DMX_K2C(256, 8, 3); else DMX_K2C(256, 8); }
     else if (V <= 64 && !getenv("DMX_CLS_NO_PROD") && !getenv("DMX_CLS_NO_UJ")) {
       // producer / consumer form (round 4): one barrier per tile, wavefront 0 builds the next tile's class table, 3 wavefronts per SIMD
-      const size_t lds = (size_t)2 * 32 * 32 * 8 + (size_t)2 * 32 * 64 + (size_t)2 * 32 * 4 * 8 * 4 + (size_t)32 * 18 * 8 + 2 * 34 * 8 + 2 * 32 * (8 + 4 + 4) +
+      const size_t lds = (size_t)2 * 32 * 32 * 8 + (size_t)2 * 32 * 64 + (size_t)32 * 18 * 8 + 2 * 34 * 8 + 2 * 32 * (8 + 4 + 4) +
                          (size_t)32 * 12 * 4;
       hipLaunchKernelGGL((k_doublet_clsp<3>), dim3((unsigned)B), dim3(kThreads), lds, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0,
                          e->d_lut, e->d_alpha, e->d_sched, V, VS, e->d_grid, e->d_l00, e->d_flag);
