@@ -2910,8 +2910,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
 // inside the loop and need no register of phases 1 / 1b, the producer only 8 accumulators: 168 registers, 3 wavefronts per SIMD
 // (k_doublet_cls<256,16,uniform-j>: 256 registers, 2 per SIMD), so a SIMD has two other barcodes to issue for while one waits.
 // Same operands, same operations, same order of additions as k_doublet_cls: bit-identical (tests).  cmd_cram_demuxlet.cpp:594-710.
-constexpr int kPcJ0 = 4, kPcJ = (64 - kPcJ0) / 3;             // samples j of wavefront 0 (the last ones) and of wavefronts 1..3
-static_assert(kPcJ0 + 3 * kPcJ == 64 && kPcJ % 4 == 0, "k_doublet_clsp: 4 / 20 / 20 / 20 (a wavefront's class bytes are whole words of the id row)");
+#ifndef DMX_CLSP_SPLIT
+#define DMX_CLSP_SPLIT 1     // samples j per wavefront 0..3: 1 = 0 / 24 / 20 / 20 (the producer only produces), 0 = 4 / 20 / 20 / 20
+#endif
+constexpr int kPcJ0 = DMX_CLSP_SPLIT ? 0 : 4, kPcJ = 20, kPcJ1 = 64 - kPcJ0 - 2 * kPcJ;   // wavefront 0 (the LAST samples), wavefronts 2..3, wavefront 1
+static_assert(kPcJ1 % 4 == 0 && kPcJ % 4 == 0 && (kPcJ1 == 20 || kPcJ1 == 24), "k_doublet_clsp: a wavefront's class bytes are whole words of the id row");
 template <int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                                 const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
@@ -2956,7 +2959,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   constexpr int wpr = VSC / 4;                   // id words per pair
   (void)VS;
   const int wave = t >> 6, lane = t & 63;        // lane = sample k in phase 2
-  const int j0 = wave == 0 ? 3 * kPcJ : (wave - 1) * kPcJ;       // first sample j of this wavefront
+  const int j0 = wave == 0 ? 64 - kPcJ0 : wave == 1 ? 0 : kPcJ1 + (wave - 2) * kPcJ;       // first sample j of this wavefront
   using lds_u8 = const __attribute__((address_space(3))) uint8_t*;
 
   // Phase 2 of one tile for a wavefront's samples j, one asm statement.  Per (pair, sample j): the class of j (wave-uniform) picks the row
@@ -2994,16 +2997,32 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   WORDS
 #define DMX_PJ_MIDX(RFL, WORDS) DMX_PJ_MID("v[152:155]", "v[156:159]", "v[160:163]", "v[164:167]", RFL, WORDS)
 #define DMX_PJ_MIDY(RFL, WORDS) DMX_PJ_MID("v[136:139]", "v[140:143]", "v[144:147]", "v[148:151]", RFL, WORDS)
-#define DMX_PJ_WORDS5 "ds_read2_b32 v[130:131], %[pj] offset1:1\n\tds_read2_b32 v[132:133], %[pj] offset0:2 offset1:3\n\t" \
-                      "ds_read_b32 v134, %[pj] offset:16\n\tds_read_u8 v135, %[pi]\n\t"
-#define DMX_PJ_WORDS1 "ds_read_b32 v130, %[pj]\n\tds_read_u8 v135, %[pi]\n\t"
+#define DMX_PJ_WORDS5 "ds_read2_b32 v[128:129], %[pj] offset1:1\n\tds_read2_b32 v[130:131], %[pj] offset0:2 offset1:3\n\t" \
+                      "ds_read_b32 v132, %[pj] offset:16\n\tds_read_u8 v135, %[pi]\n\t"
+#define DMX_PJ_WORDS6 "ds_read2_b32 v[128:129], %[pj] offset1:1\n\tds_read2_b32 v[130:131], %[pj] offset0:2 offset1:3\n\t" \
+                      "ds_read2_b32 v[132:133], %[pj] offset0:4 offset1:5\n\tds_read_u8 v135, %[pi]\n\t"
+#define DMX_PJ_WORDS1 "ds_read_b32 v128, %[pj]\n\tds_read_u8 v135, %[pi]\n\t"
 #define DMX_PJ_RFL5(Q)                                                                                            \
-  "v_readfirstlane_b32 %[" Q "0], v130\n\tv_readfirstlane_b32 %[" Q "1], v131\n\tv_readfirstlane_b32 %[" Q "2], v132\n\t" \
-  "v_readfirstlane_b32 %[" Q "3], v133\n\tv_readfirstlane_b32 %[" Q "4], v134\n\t"
-#define DMX_PJ_RFL1(Q) "v_readfirstlane_b32 %[" Q "0], v130\n\t"
+  "v_readfirstlane_b32 %[" Q "0], v128\n\tv_readfirstlane_b32 %[" Q "1], v129\n\tv_readfirstlane_b32 %[" Q "2], v130\n\t" \
+  "v_readfirstlane_b32 %[" Q "3], v131\n\tv_readfirstlane_b32 %[" Q "4], v132\n\t"
+#define DMX_PJ_RFL6(Q) DMX_PJ_RFL5(Q) "v_readfirstlane_b32 %[" Q "5], v133\n\t"
+#define DMX_PJ_RFL1(Q) "v_readfirstlane_b32 %[" Q "0], v128\n\t"
+#define DMX_PJ_REST20(C0, C1, P) DMX_PJ_REST16(C0, C1, P)                                                          \
+  DMX_PJ_STEP(C0, C1, "a20", "b20", P "5", "0x40002") DMX_PJ_STEP(C0, C1, "a21", "b21", P "5", "0x4000a")           \
+  DMX_PJ_STEP(C0, C1, "a22", "b22", P "5", "0x40012") DMX_PJ_STEP(C0, C1, "a23", "b23", P "5", "0x4001a")
+  // a consumer's tile: WORDS / RFL(set) / REST for its 20 or 24 samples j
+#define DMX_PJ_CONSUMER(WORDS, RFL, REST)                                                                          \
+  "s_mov_b32 %[m0k], m0\n\t" WORDS DMX_PJ_MIDX(RFL("wa"), WORDS) "s_mov_b32 %[ti], 0\n"                            \
+  "L_pjc_%=:\n\t"                                                                                                 \
+  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4("v[152:153]", "v[154:155]", "wa") DMX_PJ_MIDY(RFL("wb"), WORDS)          \
+  REST("v[152:153]", "v[154:155]", "wa") DMX_PJ_NEXT("L_pjd_%=")                                                   \
+  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4("v[136:137]", "v[138:139]", "wb") DMX_PJ_MIDX(RFL("wa"), WORDS)          \
+  REST("v[136:137]", "v[138:139]", "wb")                                                                          \
+  "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_lt_u32 %[ti], %[tp]\n\ts_cbranch_scc1 L_pjc_%=\n"                           \
+  "L_pjd_%=:\n\t" DMX_PJ_END
 #define DMX_PJ_NEXT(LBL) "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_ge_u32 %[ti], %[tp]\n\ts_cbranch_scc1 " LBL "\n\t"
 #define DMX_PJ_END "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\ts_mov_b32 m0, %[m0k]"
-#define DMX_PJ_CLOB "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", \
+#define DMX_PJ_CLOB "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", \
                     "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", \
                     "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "scc", "memory"
 
@@ -3013,9 +3032,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
     int64_t rd_base = pv.cell_read_off[cell];
     double acc00 = 0.0;
     bool ok = true;
-    double acc[kPcJ0][A];
+    double acc[kPcJ0 ? kPcJ0 : 1][A];            // (4 / 20 / 20 / 20 only)
 #pragma unroll
-    for (int kk = 0; kk < kPcJ0; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
+    for (int kk = 0; kk < (kPcJ0 ? kPcJ0 : 1); ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
     const bool owner = lane < V && j0 < V;
     constexpr int NRR = 6, NRI = 8;              // per-lane registers of a tile's rows / id words: half a pair's 12 floats / 16 id words
     uint32_t hd_n = 0u; int32_t hd_s = 0;        // header loads in flight (lanes < TP)
@@ -3154,6 +3173,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
         }
       }
       // ---- phase 1b: the class table (16 entries per lane)
+#ifdef DMX_X_1B_UNROLL
+#pragma unroll DMX_X_1B_UNROLL
+#endif
       for (int e = lane; e < tp * NT; e += 64) {
         const int ti = e / NT, cc = e % NT;
         const int cj = cc >> 3, ck = (cc >> 1) & 3, n = cc & 1;
@@ -3174,9 +3196,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
     };
     auto consume = [&](int64_t tbase, int b) {   // phase 2 of tile [tbase, ..) for this wavefront's 4 samples j
       const int tp = (int)min((int64_t)TP, np - tbase);
-      if (!owner) return;
+      if (!owner || kPcJ0 == 0) return;
       const uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
-      uint32_t pi = (uint32_t)(uintptr_t)(lds_u8)(s_ids + lane), pj = (uint32_t)(uintptr_t)(lds_u8)(s_ids + 3 * kPcJ);
+      uint32_t pi = (uint32_t)(uintptr_t)(lds_u8)(s_ids + lane), pj = (uint32_t)(uintptr_t)(lds_u8)(s_ids + (64 - kPcJ0));
       uint32_t pt = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
       uint32_t tmp, m0_keep, colv, ti_c, wa0, wb0;
       // a pair is four additions long here, so the requests go FIRST in a round (the column a pair ahead, the words two ahead)
@@ -3228,9 +3250,11 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   } else {
     // ================================================= consumers ================================================
     const bool owner = lane < V && j0 < V;
-    double acc[kPcJ][A];
+    constexpr int NJM = kPcJ1 > kPcJ ? kPcJ1 : kPcJ;
+    const int nj = wave == 1 ? kPcJ1 : kPcJ;
+    double acc[NJM][A];
 #pragma unroll
-    for (int kk = 0; kk < kPcJ; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
+    for (int kk = 0; kk < NJM; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
     int b = 1;
     for (int64_t tbase = -TP; tbase < np; tbase += TP, b ^= 1) {
       const int tp = tbase < 0 ? 0 : (int)min((int64_t)TP, np - tbase);
@@ -3239,23 +3263,31 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
         uint32_t pi = (uint32_t)(uintptr_t)(lds_u8)(s_ids + lane), pj = (uint32_t)(uintptr_t)(lds_u8)(s_ids + j0);
         uint32_t pt = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
         uint32_t tmp, m0_keep, colv, ti_c, wa0, wa1, wa2, wa3, wa4, wb0, wb1, wb2, wb3, wb4;
-        asm volatile("s_mov_b32 %[m0k], m0\n\t" DMX_PJ_WORDS5
-            DMX_PJ_MIDX(DMX_PJ_RFL5("wa"), DMX_PJ_WORDS5)
-            "s_mov_b32 %[ti], 0\n"
-            "L_pjc_%=:\n\t"
-            "s_waitcnt lgkmcnt(4)\n\t"
-            DMX_PJ_FIRST4("v[152:153]", "v[154:155]", "wa")
-            DMX_PJ_MIDY(DMX_PJ_RFL5("wb"), DMX_PJ_WORDS5)
-            DMX_PJ_REST16("v[152:153]", "v[154:155]", "wa")
-            DMX_PJ_NEXT("L_pjd_%=")
-            "s_waitcnt lgkmcnt(4)\n\t"
-            DMX_PJ_FIRST4("v[136:137]", "v[138:139]", "wb")
-            DMX_PJ_MIDX(DMX_PJ_RFL5("wa"), DMX_PJ_WORDS5)
-            DMX_PJ_REST16("v[136:137]", "v[138:139]", "wb")
-            "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_lt_u32 %[ti], %[tp]\n\ts_cbranch_scc1 L_pjc_%=\n"
-            "L_pjd_%=:\n\t"
-            DMX_PJ_END
-            :
+        if (kPcJ1 == 24 && wave == 1) {
+          uint32_t wa5, wb5;
+          asm volatile(DMX_PJ_CONSUMER(DMX_PJ_WORDS6, DMX_PJ_RFL6, DMX_PJ_REST20)
+              :
+                [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]),                [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
+                [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]),                [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
+                [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]),                [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]),
+                [a6] "+v"(acc[6][0]), [b6] "+v"(acc[6][1]),                [a7] "+v"(acc[7][0]), [b7] "+v"(acc[7][1]),
+                [a8] "+v"(acc[8][0]), [b8] "+v"(acc[8][1]),                [a9] "+v"(acc[9][0]), [b9] "+v"(acc[9][1]),
+                [a10] "+v"(acc[10][0]), [b10] "+v"(acc[10][1]),                [a11] "+v"(acc[11][0]), [b11] "+v"(acc[11][1]),
+                [a12] "+v"(acc[12][0]), [b12] "+v"(acc[12][1]),                [a13] "+v"(acc[13][0]), [b13] "+v"(acc[13][1]),
+                [a14] "+v"(acc[14][0]), [b14] "+v"(acc[14][1]),                [a15] "+v"(acc[15][0]), [b15] "+v"(acc[15][1]),
+                [a16] "+v"(acc[16][0]), [b16] "+v"(acc[16][1]),                [a17] "+v"(acc[17][0]), [b17] "+v"(acc[17][1]),
+                [a18] "+v"(acc[18][0]), [b18] "+v"(acc[18][1]),                [a19] "+v"(acc[19][0]), [b19] "+v"(acc[19][1]),
+                [a20] "+v"(acc[20][0]), [b20] "+v"(acc[20][1]),                [a21] "+v"(acc[21][0]), [b21] "+v"(acc[21][1]),
+                [a22] "+v"(acc[22][0]), [b22] "+v"(acc[22][1]),                [a23] "+v"(acc[23][0]), [b23] "+v"(acc[23][1]),
+                [pj] "+v"(pj), [pi] "+v"(pi), [pt] "+v"(pt), [colv] "=&v"(colv),
+                [t] "=&s"(tmp), [m0k] "=&s"(m0_keep), [ti] "=&s"(ti_c),
+                [wa0] "=&s"(wa0), [wa1] "=&s"(wa1), [wa2] "=&s"(wa2), [wa3] "=&s"(wa3), [wa4] "=&s"(wa4), [wa5] "=&s"(wa5),
+                [wb0] "=&s"(wb0), [wb1] "=&s"(wb1), [wb2] "=&s"(wb2), [wb3] "=&s"(wb3), [wb4] "=&s"(wb4), [wb5] "=&s"(wb5)
+              : [tp] "s"(tp)
+              : DMX_PJ_CLOB);
+        } else {
+          asm volatile(DMX_PJ_CONSUMER(DMX_PJ_WORDS5, DMX_PJ_RFL5, DMX_PJ_REST16)
+              :
                 [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]),                [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
                 [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]),                [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
                 [a4] "+v"(acc[4][0]), [b4] "+v"(acc[4][1]),                [a5] "+v"(acc[5][0]), [b5] "+v"(acc[5][1]),
@@ -3270,16 +3302,17 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
                 [t] "=&s"(tmp), [m0k] "=&s"(m0_keep), [ti] "=&s"(ti_c),
                 [wa0] "=&s"(wa0), [wa1] "=&s"(wa1), [wa2] "=&s"(wa2), [wa3] "=&s"(wa3), [wa4] "=&s"(wa4),
                 [wb0] "=&s"(wb0), [wb1] "=&s"(wb1), [wb2] "=&s"(wb2), [wb3] "=&s"(wb3), [wb4] "=&s"(wb4)
-            : [tp] "s"(tp)
-            : DMX_PJ_CLOB);
+              : [tp] "s"(tp)
+              : DMX_PJ_CLOB);
+        }
       }
       __syncthreads();
     }
     if (owner) {
 #pragma unroll
-      for (int jj = 0; jj < kPcJ; ++jj) {
+      for (int jj = 0; jj < NJM; ++jj) {
         const int jx = j0 + jj;
-        if (jx < V) {
+        if (jj < nj && jx < V) {
           double* o = grid + (((size_t)cell * V + jx) * V + lane) * A;
           o[0] = acc[jj][0]; o[1] = acc[jj][1];
         }
@@ -3293,6 +3326,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
 #undef DMX_PJ_MIDX
 #undef DMX_PJ_MIDY
 #undef DMX_PJ_WORDS5
+#undef DMX_PJ_WORDS6
+#undef DMX_PJ_RFL6
+#undef DMX_PJ_REST20
+#undef DMX_PJ_CONSUMER
 #undef DMX_PJ_WORDS1
 #undef DMX_PJ_RFL5
 #undef DMX_PJ_RFL1
