@@ -2898,23 +2898,20 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
 // In k_doublet_cls a tile has four workgroup barriers and phase 1 runs on one of the barcode's four wavefronts while the other three
 // wait (43 % of the wave time parked, rocprofv3 r03).  Here the four wavefronts of a barcode's workgroup have two roles:
 //   wavefront 0 (producer)   tile t + 1: headers, class rows and ids (requested a tile ahead, in registers) -> LDS, phase 1 (pG, the
-//                            llks00 terms and their ordered sum), phase 1b (the class table) into one half of a double buffer
-//                            {T, ids, classes of the wavefronts' samples j}; then phase 2 of tile t for the LAST 4 samples j;
-//   wavefronts 1..3 (consumers)  tile t: phase 2 of the uniform-j form for 20 samples j each — lanes = samples k, the pair's table
+//                            llks00 terms and their ordered sum), phase 1b (the class table) into one half of a double buffer {T, ids};
+//   wavefronts 1..3 (consumers)  tile t: phase 2 of the uniform-j form for 24 / 20 / 20 samples j — lanes = samples k, the pair's table
 //                            column in sixteen consecutive registers, the row chosen by VGPR-relative addressing (see k_doublet_cls);
 // ONE s_barrier per tile.  Phase 2 of a tile is ONE software-pipelined asm statement per wavefront (DMX_PJ_* below): while a pair's
 // additions issue out of one set of column registers, the next pair's column is read into a second set and the class words of the pair
-// after it into v[130:135] — no LDS round trip on the additions' path.  A wavefront's class words are simply its twenty bytes of the
-// pair's id row (c * 16 per sample; 0 beyond V), five aligned words.  4 / 20 / 20 / 20 roughly balances the wavefronts' issue cycles (production costs about 12 samples' worth of
-// phase 2; 7 / 19 / 19 / 19 would be even, but 14 accumulators beside phase 1 spill at 168 registers), so the four SIMDs of a CU stay evenly loaded whichever wavefronts share them.  The consumers never touch global memory
-// inside the loop and need no register of phases 1 / 1b, the producer only 8 accumulators: 168 registers, 3 wavefronts per SIMD
+// after it into v[128:133] — no LDS round trip on the additions' path (the unpipelined loop of the round's first version had two per
+// pair, about as long as the additions themselves: 741 ms at the cfg4 shard, this form 486 ms).  A wavefront's class words are simply
+// its bytes of the pair's id row (class 0 beyond V): six or five aligned words.  Production (about 15 k cycles of one wavefront per tile,
+// mostly latency) is as long as a consumer's 32 x 24 samples; with the last four samples j also on the producer (4 / 20 / 20 / 20, the
+// first version) it was the critical path.  The consumers never touch global memory inside the loop: 168 registers, 3 wavefronts per SIMD
 // (k_doublet_cls<256,16,uniform-j>: 256 registers, 2 per SIMD), so a SIMD has two other barcodes to issue for while one waits.
 // Same operands, same operations, same order of additions as k_doublet_cls: bit-identical (tests).  cmd_cram_demuxlet.cpp:594-710.
-#ifndef DMX_CLSP_SPLIT
-#define DMX_CLSP_SPLIT 1     // samples j per wavefront 0..3: 1 = 0 / 24 / 20 / 20 (the producer only produces), 0 = 4 / 20 / 20 / 20
-#endif
-constexpr int kPcJ0 = DMX_CLSP_SPLIT ? 0 : 4, kPcJ = 20, kPcJ1 = 64 - kPcJ0 - 2 * kPcJ;   // wavefront 0 (the LAST samples), wavefronts 2..3, wavefront 1
-static_assert(kPcJ1 % 4 == 0 && kPcJ % 4 == 0 && (kPcJ1 == 20 || kPcJ1 == 24), "k_doublet_clsp: a wavefront's class bytes are whole words of the id row");
+constexpr int kPcJ1 = 24, kPcJ = 20;           // samples j of wavefront 1 and of wavefronts 2, 3
+static_assert(kPcJ1 + 2 * kPcJ == 64 && kPcJ1 % 4 == 0 && kPcJ % 4 == 0, "k_doublet_clsp: a wavefront's class bytes are whole words of the id row");
 template <int MINW>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                                 const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
@@ -2959,7 +2956,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   constexpr int wpr = VSC / 4;                   // id words per pair
   (void)VS;
   const int wave = t >> 6, lane = t & 63;        // lane = sample k in phase 2
-  const int j0 = wave == 0 ? 64 - kPcJ0 : wave == 1 ? 0 : kPcJ1 + (wave - 2) * kPcJ;       // first sample j of this wavefront
+  const int j0 = wave <= 1 ? 0 : kPcJ1 + (wave - 2) * kPcJ;      // first sample j of this (consumer) wavefront
   using lds_u8 = const __attribute__((address_space(3))) uint8_t*;
 
   // Phase 2 of one tile for a wavefront's samples j, one asm statement.  Per (pair, sample j): the class of j (wave-uniform) picks the row
@@ -2970,26 +2967,46 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   // the tile that the last rounds request read LDS inside the workgroup's allocation (the id byte is masked to a class's 0x30, so the
   // column reads stay 16-byte aligned) and are drained before the statement ends.  DS instructions of gfx9+ do not use M0, so the
   // indexing state left in it is harmless; M0 is restored at the end.
-#define DMX_PJ_STEP(C0, C1, A0, A1, W, B)                                                                         \
-  "s_bfe_u32 %[t], %[" W "], " B "\n\ts_set_gpr_idx_on %[t], 0x1\n\t"                                             \
-  "v_add_f64 %[" A0 "], " C0 ", %[" A0 "]\n\tv_add_f64 %[" A1 "], " C1 ", %[" A1 "]\n\t"
-#define DMX_PJ_FIRST4(C0, C1, P)                                                                                  \
-  DMX_PJ_STEP(C0, C1, "a0", "b0", P "0", "0x40002") DMX_PJ_STEP(C0, C1, "a1", "b1", P "0", "0x4000a")               \
-  DMX_PJ_STEP(C0, C1, "a2", "b2", P "0", "0x40012") DMX_PJ_STEP(C0, C1, "a3", "b3", P "0", "0x4001a")
+#ifndef DMX_CLSP_M0
+#define DMX_CLSP_M0 1        // 0: every sample j extracts its index (s_bfe_u32) and sets it (s_set_gpr_idx_on): kernel experiments
+#endif
+#define DMX_PJ_ADD2(C0, C1, A0, A1) "v_add_f64 %[" A0 "], " C0 ", %[" A0 "]\n\tv_add_f64 %[" A1 "], " C1 ", %[" A1 "]\n\t"
+#if DMX_CLSP_M0
+  // id bytes 0x10 | c << 2: a word of four, shifted right by whole bytes, IS the M0 of the indexing mode — M0[7:0] = 16 + 4 c (the column
+  // operands name the registers 16 below the set), M0[15:12] = the next byte's 0x1 = "index SRC0".  One scalar instruction per sample j
+  // for three of a word's four.
+#define DMX_PJ_XC0 "v[136:137]"
+#define DMX_PJ_XC1 "v[138:139]"
+#define DMX_PJ_YC0 "v[120:121]"
+#define DMX_PJ_YC1 "v[122:123]"
+#define DMX_PJ_WORD4(C0, C1, W, A0, B0, A1, B1, A2, B2, A3, B3)                                                     \
+  "s_set_gpr_idx_on %[" W "], 0x1\n\t" DMX_PJ_ADD2(C0, C1, A0, B0)                                                 \
+  "s_lshr_b32 m0, %[" W "], 8\n\t" DMX_PJ_ADD2(C0, C1, A1, B1)                                                     \
+  "s_lshr_b32 m0, %[" W "], 16\n\t" DMX_PJ_ADD2(C0, C1, A2, B2)                                                    \
+  "s_lshr_b32 %[t], %[" W "], 24\n\ts_set_gpr_idx_on %[t], 0x1\n\t" DMX_PJ_ADD2(C0, C1, A3, B3)
+#define DMX_PJ_COLADDR "v_and_b32 %[colv], 12, v135\n\tv_lshl_add_u32 %[colv], %[colv], 2, %[pt]\n\t"
+#else
+#define DMX_PJ_XC0 "v[152:153]"
+#define DMX_PJ_XC1 "v[154:155]"
+#define DMX_PJ_YC0 "v[136:137]"
+#define DMX_PJ_YC1 "v[138:139]"
+#define DMX_PJ_STEP(C0, C1, A0, A1, W, B) "s_bfe_u32 %[t], %[" W "], " B "\n\ts_set_gpr_idx_on %[t], 0x1\n\t" DMX_PJ_ADD2(C0, C1, A0, A1)
+#define DMX_PJ_WORD4(C0, C1, W, A0, B0, A1, B1, A2, B2, A3, B3)                                                     \
+  DMX_PJ_STEP(C0, C1, A0, B0, W, "0x40002") DMX_PJ_STEP(C0, C1, A1, B1, W, "0x4000a")                               \
+  DMX_PJ_STEP(C0, C1, A2, B2, W, "0x40012") DMX_PJ_STEP(C0, C1, A3, B3, W, "0x4001a")
+#define DMX_PJ_COLADDR "v_and_b32 %[colv], 0x30, v135\n\tv_add_u32 %[colv], %[pt], %[colv]\n\t"
+#endif
+#define DMX_PJ_FIRST4(C0, C1, P) DMX_PJ_WORD4(C0, C1, P "0", "a0", "b0", "a1", "b1", "a2", "b2", "a3", "b3")
 #define DMX_PJ_REST16(C0, C1, P)                                                                                  \
-  DMX_PJ_STEP(C0, C1, "a4", "b4", P "1", "0x40002") DMX_PJ_STEP(C0, C1, "a5", "b5", P "1", "0x4000a")               \
-  DMX_PJ_STEP(C0, C1, "a6", "b6", P "1", "0x40012") DMX_PJ_STEP(C0, C1, "a7", "b7", P "1", "0x4001a")               \
-  DMX_PJ_STEP(C0, C1, "a8", "b8", P "2", "0x40002") DMX_PJ_STEP(C0, C1, "a9", "b9", P "2", "0x4000a")               \
-  DMX_PJ_STEP(C0, C1, "a10", "b10", P "2", "0x40012") DMX_PJ_STEP(C0, C1, "a11", "b11", P "2", "0x4001a")           \
-  DMX_PJ_STEP(C0, C1, "a12", "b12", P "3", "0x40002") DMX_PJ_STEP(C0, C1, "a13", "b13", P "3", "0x4000a")           \
-  DMX_PJ_STEP(C0, C1, "a14", "b14", P "3", "0x40012") DMX_PJ_STEP(C0, C1, "a15", "b15", P "3", "0x4001a")           \
-  DMX_PJ_STEP(C0, C1, "a16", "b16", P "4", "0x40002") DMX_PJ_STEP(C0, C1, "a17", "b17", P "4", "0x4000a")           \
-  DMX_PJ_STEP(C0, C1, "a18", "b18", P "4", "0x40012") DMX_PJ_STEP(C0, C1, "a19", "b19", P "4", "0x4001a")
+  DMX_PJ_WORD4(C0, C1, P "1", "a4", "b4", "a5", "b5", "a6", "b6", "a7", "b7")                                       \
+  DMX_PJ_WORD4(C0, C1, P "2", "a8", "b8", "a9", "b9", "a10", "b10", "a11", "b11")                                   \
+  DMX_PJ_WORD4(C0, C1, P "3", "a12", "b12", "a13", "b13", "a14", "b14", "a15", "b15")                               \
+  DMX_PJ_WORD4(C0, C1, P "4", "a16", "b16", "a17", "b17", "a18", "b18", "a19", "b19")
   // the next pair: wait for its words / id byte, request its column into the set N0..N3 and move its words into a scalar set (RFL);
   // then request the words of the pair after it (WORDS).  pj: the wavefront's words in the id row, pi: the lane's id byte, pt: the table.
 #define DMX_PJ_MID(N0, N1, N2, N3, RFL, WORDS)                                                                     \
   "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\t"                                                                 \
-  "v_and_b32 %[colv], 0x30, v135\n\tv_add_u32 %[colv], %[pt], %[colv]\n\t"                                         \
+  DMX_PJ_COLADDR                                                                                                  \
   "ds_read_b128 " N0 ", %[colv]\n\tds_read_b128 " N1 ", %[colv] offset:64\n\t"                                     \
   "ds_read_b128 " N2 ", %[colv] offset:128\n\tds_read_b128 " N3 ", %[colv] offset:192\n\t"                         \
   RFL                                                                                                             \
@@ -3001,23 +3018,20 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
                       "ds_read_b32 v132, %[pj] offset:16\n\tds_read_u8 v135, %[pi]\n\t"
 #define DMX_PJ_WORDS6 "ds_read2_b32 v[128:129], %[pj] offset1:1\n\tds_read2_b32 v[130:131], %[pj] offset0:2 offset1:3\n\t" \
                       "ds_read2_b32 v[132:133], %[pj] offset0:4 offset1:5\n\tds_read_u8 v135, %[pi]\n\t"
-#define DMX_PJ_WORDS1 "ds_read_b32 v128, %[pj]\n\tds_read_u8 v135, %[pi]\n\t"
 #define DMX_PJ_RFL5(Q)                                                                                            \
   "v_readfirstlane_b32 %[" Q "0], v128\n\tv_readfirstlane_b32 %[" Q "1], v129\n\tv_readfirstlane_b32 %[" Q "2], v130\n\t" \
   "v_readfirstlane_b32 %[" Q "3], v131\n\tv_readfirstlane_b32 %[" Q "4], v132\n\t"
 #define DMX_PJ_RFL6(Q) DMX_PJ_RFL5(Q) "v_readfirstlane_b32 %[" Q "5], v133\n\t"
-#define DMX_PJ_RFL1(Q) "v_readfirstlane_b32 %[" Q "0], v128\n\t"
 #define DMX_PJ_REST20(C0, C1, P) DMX_PJ_REST16(C0, C1, P)                                                          \
-  DMX_PJ_STEP(C0, C1, "a20", "b20", P "5", "0x40002") DMX_PJ_STEP(C0, C1, "a21", "b21", P "5", "0x4000a")           \
-  DMX_PJ_STEP(C0, C1, "a22", "b22", P "5", "0x40012") DMX_PJ_STEP(C0, C1, "a23", "b23", P "5", "0x4001a")
+  DMX_PJ_WORD4(C0, C1, P "5", "a20", "b20", "a21", "b21", "a22", "b22", "a23", "b23")
   // a consumer's tile: WORDS / RFL(set) / REST for its 20 or 24 samples j
 #define DMX_PJ_CONSUMER(WORDS, RFL, REST)                                                                          \
   "s_mov_b32 %[m0k], m0\n\t" WORDS DMX_PJ_MIDX(RFL("wa"), WORDS) "s_mov_b32 %[ti], 0\n"                            \
   "L_pjc_%=:\n\t"                                                                                                 \
-  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4("v[152:153]", "v[154:155]", "wa") DMX_PJ_MIDY(RFL("wb"), WORDS)          \
-  REST("v[152:153]", "v[154:155]", "wa") DMX_PJ_NEXT("L_pjd_%=")                                                   \
-  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4("v[136:137]", "v[138:139]", "wb") DMX_PJ_MIDX(RFL("wa"), WORDS)          \
-  REST("v[136:137]", "v[138:139]", "wb")                                                                          \
+  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4(DMX_PJ_XC0, DMX_PJ_XC1, "wa") DMX_PJ_MIDY(RFL("wb"), WORDS)          \
+  REST(DMX_PJ_XC0, DMX_PJ_XC1, "wa") DMX_PJ_NEXT("L_pjd_%=")                                                   \
+  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4(DMX_PJ_YC0, DMX_PJ_YC1, "wb") DMX_PJ_MIDX(RFL("wa"), WORDS)          \
+  REST(DMX_PJ_YC0, DMX_PJ_YC1, "wb")                                                                          \
   "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_lt_u32 %[ti], %[tp]\n\ts_cbranch_scc1 L_pjc_%=\n"                           \
   "L_pjd_%=:\n\t" DMX_PJ_END
 #define DMX_PJ_NEXT(LBL) "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_ge_u32 %[ti], %[tp]\n\ts_cbranch_scc1 " LBL "\n\t"
@@ -3032,10 +3046,6 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
     int64_t rd_base = pv.cell_read_off[cell];
     double acc00 = 0.0;
     bool ok = true;
-    double acc[kPcJ0 ? kPcJ0 : 1][A];            // (4 / 20 / 20 / 20 only)
-#pragma unroll
-    for (int kk = 0; kk < (kPcJ0 ? kPcJ0 : 1); ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
-    const bool owner = lane < V && j0 < V;
     constexpr int NRR = 6, NRI = 8;              // per-lane registers of a tile's rows / id words: half a pair's 12 floats / 16 id words
     uint32_t hd_n = 0u; int32_t hd_s = 0;        // header loads in flight (lanes < TP)
     uint32_t pn = 0u; int32_t psn = 0; int64_t poff = 0;
@@ -3088,7 +3098,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
 #pragma unroll
       for (int i = 0; i < NRR; ++i) s_rows[ti1 * 12 + n1 * 6 + i] = d_rows[i];
 #pragma unroll
-      for (int i = 0; i < NRI; ++i) reinterpret_cast<uint32_t*>(s_ids)[ti1 * wpr + n1 * 8 + i] = d_ids[i] << 4;   // class id c as c * 16
+      for (int i = 0; i < NRI; ++i) reinterpret_cast<uint32_t*>(s_ids)[ti1 * wpr + n1 * 8 + i] =
+          DMX_CLSP_M0 ? (d_ids[i] << 2) | 0x10101010u : d_ids[i] << 4;   // class id c as c * 16 (DMX_CLSP_M0: 0x10 | c * 4)
       const uint32_t rd4 = d_rd4;
       const double qq[3] = {d_g0[0], d_g0[1], d_g0[2]};
       publish_next();
@@ -3173,9 +3184,6 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
         }
       }
       // ---- phase 1b: the class table (16 entries per lane)
-#ifdef DMX_X_1B_UNROLL
-#pragma unroll DMX_X_1B_UNROLL
-#endif
       for (int e = lane; e < tp * NT; e += 64) {
         const int ti = e / NT, cc = e % NT;
         const int cj = cc >> 3, ck = (cc >> 1) & 3, n = cc & 1;
@@ -3194,33 +3202,6 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
       }
       DMX_WAVE_LDS_ORDER();                                        // (pG, t00, rows and the headers are rewritten by the next build)
     };
-    auto consume = [&](int64_t tbase, int b) {   // phase 2 of tile [tbase, ..) for this wavefront's 4 samples j
-      const int tp = (int)min((int64_t)TP, np - tbase);
-      if (!owner || kPcJ0 == 0) return;
-      const uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
-      uint32_t pi = (uint32_t)(uintptr_t)(lds_u8)(s_ids + lane), pj = (uint32_t)(uintptr_t)(lds_u8)(s_ids + (64 - kPcJ0));
-      uint32_t pt = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
-      uint32_t tmp, m0_keep, colv, ti_c, wa0, wb0;
-      // a pair is four additions long here, so the requests go FIRST in a round (the column a pair ahead, the words two ahead)
-      asm volatile("s_mov_b32 %[m0k], m0\n\t" DMX_PJ_WORDS1
-          DMX_PJ_MIDX(DMX_PJ_RFL1("wa"), DMX_PJ_WORDS1)
-          "s_mov_b32 %[ti], 0\n"
-          "L_pjp_%=:\n\t"
-          DMX_PJ_MIDY(DMX_PJ_RFL1("wb"), DMX_PJ_WORDS1)
-          DMX_PJ_FIRST4("v[152:153]", "v[154:155]", "wa")
-          DMX_PJ_NEXT("L_pjq_%=")
-          DMX_PJ_MIDX(DMX_PJ_RFL1("wa"), DMX_PJ_WORDS1)
-          DMX_PJ_FIRST4("v[136:137]", "v[138:139]", "wb")
-          "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_lt_u32 %[ti], %[tp]\n\ts_cbranch_scc1 L_pjp_%=\n"
-          "L_pjq_%=:\n\t"
-          DMX_PJ_END
-          : [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]), [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
-              [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]), [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
-            [pj] "+v"(pj), [pi] "+v"(pi), [pt] "+v"(pt), [colv] "=&v"(colv),
-            [t] "=&s"(tmp), [m0k] "=&s"(m0_keep), [ti] "=&s"(ti_c), [wa0] "=&s"(wa0), [wb0] "=&s"(wb0)
-          : [tp] "s"(tp)
-          : DMX_PJ_CLOB);
-    };
     if (np > 0) {
       load_hdr(0);
       publish_next();
@@ -3232,25 +3213,14 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
     int b = 1;                                     // the round before the first tile only builds tile 0 (into buffer 0)
     for (int64_t tbase = -TP; tbase < np; tbase += TP, b ^= 1) {
       if (tbase + TP < np) build(tbase + TP, b ^ 1);
-      if (tbase >= 0) consume(tbase, b);
       __syncthreads();
-    }
-    if (owner) {
-#pragma unroll
-      for (int jj = 0; jj < kPcJ0; ++jj) {
-        const int jx = j0 + jj;
-        if (jx < V) {
-          double* o = grid + (((size_t)cell * V + jx) * V + lane) * A;
-          o[0] = acc[jj][0]; o[1] = acc[jj][1];
-        }
-      }
     }
     if (lane < 2) l00[(size_t)cell * A + lane] = acc00;
     if (!ok) flag_cell(flagged, cell);
   } else {
     // ================================================= consumers ================================================
     const bool owner = lane < V && j0 < V;
-    constexpr int NJM = kPcJ1 > kPcJ ? kPcJ1 : kPcJ;
+    constexpr int NJM = kPcJ1;
     const int nj = wave == 1 ? kPcJ1 : kPcJ;
     double acc[NJM][A];
 #pragma unroll
@@ -3263,7 +3233,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
         uint32_t pi = (uint32_t)(uintptr_t)(lds_u8)(s_ids + lane), pj = (uint32_t)(uintptr_t)(lds_u8)(s_ids + j0);
         uint32_t pt = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)(s_Tb + (size_t)b * TP * NT);
         uint32_t tmp, m0_keep, colv, ti_c, wa0, wa1, wa2, wa3, wa4, wb0, wb1, wb2, wb3, wb4;
-        if (kPcJ1 == 24 && wave == 1) {
+        if (wave == 1) {
           uint32_t wa5, wb5;
           asm volatile(DMX_PJ_CONSUMER(DMX_PJ_WORDS6, DMX_PJ_RFL6, DMX_PJ_REST20)
               :
@@ -3320,6 +3290,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
     }
   }
 #undef DMX_PJ_STEP
+#undef DMX_PJ_ADD2
+#undef DMX_PJ_WORD4
+#undef DMX_PJ_COLADDR
+#undef DMX_PJ_XC0
+#undef DMX_PJ_XC1
+#undef DMX_PJ_YC0
+#undef DMX_PJ_YC1
 #undef DMX_PJ_FIRST4
 #undef DMX_PJ_REST16
 #undef DMX_PJ_MID
@@ -3330,9 +3307,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
 #undef DMX_PJ_RFL6
 #undef DMX_PJ_REST20
 #undef DMX_PJ_CONSUMER
-#undef DMX_PJ_WORDS1
 #undef DMX_PJ_RFL5
-#undef DMX_PJ_RFL1
 #undef DMX_PJ_NEXT
 #undef DMX_PJ_END
 #undef DMX_PJ_CLOB
