@@ -2912,7 +2912,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_cls(PileupView pv, i
 // Same operands, same operations, same order of additions as k_doublet_cls: bit-identical (tests).  cmd_cram_demuxlet.cpp:594-710.
 constexpr int kPcJ1 = 24, kPcJ = 20;           // samples j of wavefront 1 and of wavefronts 2, 3
 static_assert(kPcJ1 + 2 * kPcJ == 64 && kPcJ1 % 4 == 0 && kPcJ % 4 == 0, "k_doublet_clsp: a wavefront's class bytes are whole words of the id row");
-template <int MINW>
+// FAST (DMX_MODE_FAST, alpha grid {0, 0.5}; round 4): the same kernel over the entries demuxlet prints or decides on.  The class table holds
+// alpha 0.5 only, ONE evaluation per unordered class pair (cj <= ck, mirrored: T is bitwise symmetric, so the accumulators of (j, k) and (k, j)
+// add identical terms and the grid comes out mirrored without an exchange), plus the four alpha-0 values T[cj][class of sample 0] of the
+// singlet column.  Phase 2 adds one value per (pair, j, k) instead of two (columns of 8 registers, index 16 + 2 c); the producer wavefront
+// (lanes = samples j) accumulates the singlet column [j][0][0], which the never-printed [j][k][0] repeat (as in k_doublet_sym / _clsym).
+// The values are STRICT's own (reference operation order) for the orientation evaluated.
+template <int MINW, bool FAST = false>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                                 const uint8_t* __restrict__ ids, const double* __restrict__ gp0,
                                                                 const double* __restrict__ tabs, const double* __restrict__ alpha,
@@ -2967,53 +2973,45 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   // the tile that the last rounds request read LDS inside the workgroup's allocation (the id byte is masked to a class's 0x30, so the
   // column reads stay 16-byte aligned) and are drained before the statement ends.  DS instructions of gfx9+ do not use M0, so the
   // indexing state left in it is harmless; M0 is restored at the end.
-#ifndef DMX_CLSP_M0
-#define DMX_CLSP_M0 1        // 0: every sample j extracts its index (s_bfe_u32) and sets it (s_set_gpr_idx_on): kernel experiments
-#endif
-#define DMX_PJ_ADD2(C0, C1, A0, A1) "v_add_f64 %[" A0 "], " C0 ", %[" A0 "]\n\tv_add_f64 %[" A1 "], " C1 ", %[" A1 "]\n\t"
-#if DMX_CLSP_M0
-  // id bytes 0x10 | c << 2: a word of four, shifted right by whole bytes, IS the M0 of the indexing mode — M0[7:0] = 16 + 4 c (the column
-  // operands name the registers 16 below the set), M0[15:12] = the next byte's 0x1 = "index SRC0".  One scalar instruction per sample j
-  // for three of a word's four.
-#define DMX_PJ_XC0 "v[136:137]"
-#define DMX_PJ_XC1 "v[138:139]"
-#define DMX_PJ_YC0 "v[120:121]"
-#define DMX_PJ_YC1 "v[122:123]"
-#define DMX_PJ_WORD4(C0, C1, W, A0, B0, A1, B1, A2, B2, A3, B3)                                                     \
-  "s_set_gpr_idx_on %[" W "], 0x1\n\t" DMX_PJ_ADD2(C0, C1, A0, B0)                                                 \
-  "s_lshr_b32 m0, %[" W "], 8\n\t" DMX_PJ_ADD2(C0, C1, A1, B1)                                                     \
-  "s_lshr_b32 m0, %[" W "], 16\n\t" DMX_PJ_ADD2(C0, C1, A2, B2)                                                    \
-  "s_lshr_b32 %[t], %[" W "], 24\n\ts_set_gpr_idx_on %[t], 0x1\n\t" DMX_PJ_ADD2(C0, C1, A3, B3)
-#define DMX_PJ_COLADDR "v_and_b32 %[colv], 12, v135\n\tv_lshl_add_u32 %[colv], %[colv], 2, %[pt]\n\t"
-#else
-#define DMX_PJ_XC0 "v[152:153]"
-#define DMX_PJ_XC1 "v[154:155]"
-#define DMX_PJ_YC0 "v[136:137]"
-#define DMX_PJ_YC1 "v[138:139]"
-#define DMX_PJ_STEP(C0, C1, A0, A1, W, B) "s_bfe_u32 %[t], %[" W "], " B "\n\ts_set_gpr_idx_on %[t], 0x1\n\t" DMX_PJ_ADD2(C0, C1, A0, A1)
-#define DMX_PJ_WORD4(C0, C1, W, A0, B0, A1, B1, A2, B2, A3, B3)                                                     \
-  DMX_PJ_STEP(C0, C1, A0, B0, W, "0x40002") DMX_PJ_STEP(C0, C1, A1, B1, W, "0x4000a")                               \
-  DMX_PJ_STEP(C0, C1, A2, B2, W, "0x40012") DMX_PJ_STEP(C0, C1, A3, B3, W, "0x4001a")
-#define DMX_PJ_COLADDR "v_and_b32 %[colv], 0x30, v135\n\tv_add_u32 %[colv], %[pt], %[colv]\n\t"
-#endif
-#define DMX_PJ_FIRST4(C0, C1, P) DMX_PJ_WORD4(C0, C1, P "0", "a0", "b0", "a1", "b1", "a2", "b2", "a3", "b3")
-#define DMX_PJ_REST16(C0, C1, P)                                                                                  \
-  DMX_PJ_WORD4(C0, C1, P "1", "a4", "b4", "a5", "b5", "a6", "b6", "a7", "b7")                                       \
-  DMX_PJ_WORD4(C0, C1, P "2", "a8", "b8", "a9", "b9", "a10", "b10", "a11", "b11")                                   \
-  DMX_PJ_WORD4(C0, C1, P "3", "a12", "b12", "a13", "b13", "a14", "b14", "a15", "b15")                               \
-  DMX_PJ_WORD4(C0, C1, P "4", "a16", "b16", "a17", "b17", "a18", "b18", "a19", "b19")
-  // the next pair: wait for its words / id byte, request its column into the set N0..N3 and move its words into a scalar set (RFL);
-  // then request the words of the pair after it (WORDS).  pj: the wavefront's words in the id row, pi: the lane's id byte, pt: the table.
-#define DMX_PJ_MID(N0, N1, N2, N3, RFL, WORDS)                                                                     \
-  "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\t"                                                                 \
-  DMX_PJ_COLADDR                                                                                                  \
-  "ds_read_b128 " N0 ", %[colv]\n\tds_read_b128 " N1 ", %[colv] offset:64\n\t"                                     \
-  "ds_read_b128 " N2 ", %[colv] offset:128\n\tds_read_b128 " N3 ", %[colv] offset:192\n\t"                         \
-  RFL                                                                                                             \
+  // The id bytes are 0x10 | c << 2 (FAST: 0x10 | c << 1): a word of four, shifted right by whole bytes, IS the M0 of the indexing mode —
+  // M0[7:0] = 16 + 4 c (16 + 2 c; the column operands name the registers 16 below the set), M0[15:12] = the next byte's 0x1 = "index
+  // SRC0".  One scalar instruction per sample j for three of a word's four (the hardware interlocks the M0 write against the indexed read).
+  // Macro arguments: M = ST (STRICT: two additions per sample j, 16-register columns) | FA (FAST: one, 8-register columns); SET = SX | SY.
+#define DMX_PJ_C0_SX "v[136:137]"
+#define DMX_PJ_C1_SX "v[138:139]"
+#define DMX_PJ_C0_SY "v[120:121]"
+#define DMX_PJ_C1_SY "v[122:123]"
+#define DMX_PJ_ADDS_ST(SET, A0, A1) "v_add_f64 %[" A0 "], " DMX_PJ_C0_##SET ", %[" A0 "]\n\tv_add_f64 %[" A1 "], " DMX_PJ_C1_##SET ", %[" A1 "]\n\t"
+#define DMX_PJ_ADDS_FA(SET, A0, A1) "v_add_f64 %[" A1 "], " DMX_PJ_C0_##SET ", %[" A1 "]\n\t"
+#define DMX_PJ_WORD4(M, SET, W, A0, B0, A1, B1, A2, B2, A3, B3)                                                     \
+  "s_set_gpr_idx_on %[" W "], 0x1\n\t" DMX_PJ_ADDS_##M(SET, A0, B0)                                                \
+  "s_lshr_b32 m0, %[" W "], 8\n\t" DMX_PJ_ADDS_##M(SET, A1, B1)                                                    \
+  "s_lshr_b32 m0, %[" W "], 16\n\t" DMX_PJ_ADDS_##M(SET, A2, B2)                                                   \
+  "s_lshr_b32 %[t], %[" W "], 24\n\ts_set_gpr_idx_on %[t], 0x1\n\t" DMX_PJ_ADDS_##M(SET, A3, B3)
+#define DMX_PJ_FIRST4(M, SET, P) DMX_PJ_WORD4(M, SET, P "0", "a0", "b0", "a1", "b1", "a2", "b2", "a3", "b3")
+#define DMX_PJ_REST16(M, SET, P)                                                                                  \
+  DMX_PJ_WORD4(M, SET, P "1", "a4", "b4", "a5", "b5", "a6", "b6", "a7", "b7")                                       \
+  DMX_PJ_WORD4(M, SET, P "2", "a8", "b8", "a9", "b9", "a10", "b10", "a11", "b11")                                   \
+  DMX_PJ_WORD4(M, SET, P "3", "a12", "b12", "a13", "b13", "a14", "b14", "a15", "b15")                               \
+  DMX_PJ_WORD4(M, SET, P "4", "a16", "b16", "a17", "b17", "a18", "b18", "a19", "b19")
+#define DMX_PJ_REST20(M, SET, P) DMX_PJ_REST16(M, SET, P)                                                          \
+  DMX_PJ_WORD4(M, SET, P "5", "a20", "b20", "a21", "b21", "a22", "b22", "a23", "b23")
+  // the lane's column of the pair's table: T[cj][ck][n] for cj = 0..3 (rows 64 bytes apart), ck = the class of sample k = lane
+#define DMX_PJ_COLADDR_ST "v_and_b32 %[colv], 12, v135\n\tv_lshl_add_u32 %[colv], %[colv], 2, %[pt]\n\t"
+#define DMX_PJ_COLADDR_FA "v_and_b32 %[colv], 6, v135\n\tv_lshl_add_u32 %[colv], %[colv], 3, %[pt]\n\t"
+#define DMX_PJ_READS_ST_SX "ds_read_b128 v[152:155], %[colv]\n\tds_read_b128 v[156:159], %[colv] offset:64\n\t"                                     \
+                           "ds_read_b128 v[160:163], %[colv] offset:128\n\tds_read_b128 v[164:167], %[colv] offset:192\n\t"
+#define DMX_PJ_READS_ST_SY "ds_read_b128 v[136:139], %[colv]\n\tds_read_b128 v[140:143], %[colv] offset:64\n\t"                                     \
+                           "ds_read_b128 v[144:147], %[colv] offset:128\n\tds_read_b128 v[148:151], %[colv] offset:192\n\t"
+  // (FAST: the alpha-0.5 halves only; offsets in 8-byte units)
+#define DMX_PJ_READS_FA_SX "ds_read2_b64 v[152:155], %[colv] offset0:1 offset1:9\n\tds_read2_b64 v[156:159], %[colv] offset0:17 offset1:25\n\t"
+#define DMX_PJ_READS_FA_SY "ds_read2_b64 v[136:139], %[colv] offset0:1 offset1:9\n\tds_read2_b64 v[140:143], %[colv] offset0:17 offset1:25\n\t"
+  // the next pair: wait for its words / id byte, request its column into the set and move its words into a scalar set (RFL); then
+  // request the words of the pair after it (WORDS).  pj: the wavefront's words in the id row, pi: the lane's id byte, pt: the table.
+#define DMX_PJ_MID(M, SET, RFL, WORDS)                                                                            \
+  "s_set_gpr_idx_off\n\ts_waitcnt lgkmcnt(0)\n\t" DMX_PJ_COLADDR_##M DMX_PJ_READS_##M##_##SET RFL                   \
   "v_add_u32 %[pj], 64, %[pj]\n\tv_add_u32 %[pi], 64, %[pi]\n\tv_add_u32 %[pt], 0x100, %[pt]\n\t"                   \
   WORDS
-#define DMX_PJ_MIDX(RFL, WORDS) DMX_PJ_MID("v[152:155]", "v[156:159]", "v[160:163]", "v[164:167]", RFL, WORDS)
-#define DMX_PJ_MIDY(RFL, WORDS) DMX_PJ_MID("v[136:139]", "v[140:143]", "v[144:147]", "v[148:151]", RFL, WORDS)
 #define DMX_PJ_WORDS5 "ds_read2_b32 v[128:129], %[pj] offset1:1\n\tds_read2_b32 v[130:131], %[pj] offset0:2 offset1:3\n\t" \
                       "ds_read_b32 v132, %[pj] offset:16\n\tds_read_u8 v135, %[pi]\n\t"
 #define DMX_PJ_WORDS6 "ds_read2_b32 v[128:129], %[pj] offset1:1\n\tds_read2_b32 v[130:131], %[pj] offset0:2 offset1:3\n\t" \
@@ -3022,16 +3020,15 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   "v_readfirstlane_b32 %[" Q "0], v128\n\tv_readfirstlane_b32 %[" Q "1], v129\n\tv_readfirstlane_b32 %[" Q "2], v130\n\t" \
   "v_readfirstlane_b32 %[" Q "3], v131\n\tv_readfirstlane_b32 %[" Q "4], v132\n\t"
 #define DMX_PJ_RFL6(Q) DMX_PJ_RFL5(Q) "v_readfirstlane_b32 %[" Q "5], v133\n\t"
-#define DMX_PJ_REST20(C0, C1, P) DMX_PJ_REST16(C0, C1, P)                                                          \
-  DMX_PJ_WORD4(C0, C1, P "5", "a20", "b20", "a21", "b21", "a22", "b22", "a23", "b23")
-  // a consumer's tile: WORDS / RFL(set) / REST for its 20 or 24 samples j
-#define DMX_PJ_CONSUMER(WORDS, RFL, REST)                                                                          \
-  "s_mov_b32 %[m0k], m0\n\t" WORDS DMX_PJ_MIDX(RFL("wa"), WORDS) "s_mov_b32 %[ti], 0\n"                            \
+  // a consumer's tile: WORDS / RFL(set) / REST for its 20 or 24 samples j.  At the top of a pair its column is requested and then the
+  // next pair's words and id byte, four LDS operations younger: s_waitcnt lgkmcnt(4) waits for exactly the column.
+#define DMX_PJ_CONSUMER(M, WORDS, RFL, REST)                                                                       \
+  "s_mov_b32 %[m0k], m0\n\t" WORDS DMX_PJ_MID(M, SX, RFL("wa"), WORDS) "s_mov_b32 %[ti], 0\n"                      \
   "L_pjc_%=:\n\t"                                                                                                 \
-  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4(DMX_PJ_XC0, DMX_PJ_XC1, "wa") DMX_PJ_MIDY(RFL("wb"), WORDS)          \
-  REST(DMX_PJ_XC0, DMX_PJ_XC1, "wa") DMX_PJ_NEXT("L_pjd_%=")                                                   \
-  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4(DMX_PJ_YC0, DMX_PJ_YC1, "wb") DMX_PJ_MIDX(RFL("wa"), WORDS)          \
-  REST(DMX_PJ_YC0, DMX_PJ_YC1, "wb")                                                                          \
+  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4(M, SX, "wa") DMX_PJ_MID(M, SY, RFL("wb"), WORDS)                        \
+  REST(M, SX, "wa") DMX_PJ_NEXT("L_pjd_%=")                                                                       \
+  "s_waitcnt lgkmcnt(4)\n\t" DMX_PJ_FIRST4(M, SY, "wb") DMX_PJ_MID(M, SX, RFL("wa"), WORDS)                        \
+  REST(M, SY, "wb")                                                                                               \
   "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_lt_u32 %[ti], %[tp]\n\ts_cbranch_scc1 L_pjc_%=\n"                           \
   "L_pjd_%=:\n\t" DMX_PJ_END
 #define DMX_PJ_NEXT(LBL) "s_add_u32 %[ti], %[ti], 1\n\ts_cmp_ge_u32 %[ti], %[tp]\n\ts_cbranch_scc1 " LBL "\n\t"
@@ -3040,11 +3037,41 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
                     "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", \
                     "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "scc", "memory"
 
+  // FAST, phase 1b: the class table of tile [tbase, ..) into buffer b2, by ALL FOUR wavefronts between two barriers of their own (14 of 16
+  // slots per pair, two per thread): in FAST the producer is the longer role (phase 2 is half of STRICT's), and its 1b was half of its time.
+  auto phase1b_fast = [&](int64_t tbase, int b2, bool& ok) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    double* s_T = s_Tb + (size_t)b2 * TP * NT;
+    const uint8_t* s_ids = s_idb + (size_t)b2 * TP * VSC;
+    const int q = t & 15;
+    // q < 10: the unordered class pairs (cj <= ck) at alpha 0.5; q = 10..13: (cj = q - 10, the class of sample 0) at alpha 0
+    const int cj = (0xE4E9500u >> (2 * q)) & 3, ckq = (0xFB9E4u >> (2 * q)) & 3, n = q < 10 ? 1 : 0;
+    if (q < 14)
+      for (int ti = t >> 4; ti < tp; ti += kThreads / 16) {
+        const int ck = q < 10 ? ckq : (s_ids[ti * VSC] >> 1) & 3;
+        const float* rj = &s_rows[ti * 12 + cj * 3];
+        const float* rk = &s_rows[ti * 12 + ck * 3];
+        const double* P = &s_pG[(ti * 2 + n) * 9];
+        const double aj[3] = {(double)rj[0], (double)rj[1], (double)rj[2]};
+        const double bk[3] = {(double)rk[0], (double)rk[1], (double)rk[2]};
+        double sum = 0.0;                                                          // :674
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) sum += ((aj[l] * bk[m]) * P[l * 3 + m]);     // :553, :677-679
+        ok &= __builtin_amdgcn_class(sum, 0x100);
+        const double val = dmx_log2_fast(sum, s_log);                              // the :683 term
+        s_T[ti * NT + (cj * 4 + ck) * 2 + n] = val;
+        if (q < 10) s_T[ti * NT + (ck * 4 + cj) * 2 + 1] = val;
+      }
+  };
+
   if (wave == 0) {
     // ================================================= producer =================================================
     const int ti1 = lane >> 1, n1 = lane & 1;
     int64_t rd_base = pv.cell_read_off[cell];
     double acc00 = 0.0;
+    [[maybe_unused]] double acc0 = 0.0;          // FAST: the singlet column entry of sample j = lane
     bool ok = true;
     constexpr int NRR = 6, NRI = 8;              // per-lane registers of a tile's rows / id words: half a pair's 12 floats / 16 id words
     uint32_t hd_n = 0u; int32_t hd_s = 0;        // header loads in flight (lanes < TP)
@@ -3099,7 +3126,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
       for (int i = 0; i < NRR; ++i) s_rows[ti1 * 12 + n1 * 6 + i] = d_rows[i];
 #pragma unroll
       for (int i = 0; i < NRI; ++i) reinterpret_cast<uint32_t*>(s_ids)[ti1 * wpr + n1 * 8 + i] =
-          DMX_CLSP_M0 ? (d_ids[i] << 2) | 0x10101010u : d_ids[i] << 4;   // class id c as c * 16 (DMX_CLSP_M0: 0x10 | c * 4)
+          (d_ids[i] << (FAST ? 1 : 2)) | 0x10101010u;                    // class id c as 0x10 | c << 2 (FAST: 0x10 | c << 1), see DMX_PJ_WORD4
       const uint32_t rd4 = d_rd4;
       const double qq[3] = {d_g0[0], d_g0[1], d_g0[2]};
       publish_next();
@@ -3183,7 +3210,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
           for (int i = 0; i < tp; ++i) acc00 += row[i];
         }
       }
-      // ---- phase 1b: the class table (16 entries per lane)
+      // ---- phase 1b: the class table (16 entries per lane; FAST: 14 of 16 slots per pair, 8 per lane)
+      if constexpr (!FAST)
       for (int e = lane; e < tp * NT; e += 64) {
         const int ti = e / NT, cc = e % NT;
         const int cj = cc >> 3, ck = (cc >> 1) & 3, n = cc & 1;
@@ -3213,6 +3241,26 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
     int b = 1;                                     // the round before the first tile only builds tile 0 (into buffer 0)
     for (int64_t tbase = -TP; tbase < np; tbase += TP, b ^= 1) {
       if (tbase + TP < np) build(tbase + TP, b ^ 1);
+      if constexpr (FAST) {
+        if (tbase >= 0) {                          // the singlet column [j][0][0] of tile t: lanes = samples j (class 0 beyond V: unused sums)
+          const int tp = (int)min((int64_t)TP, np - tbase);
+          const uint8_t* s_ids = s_idb + (size_t)b * TP * VSC;
+          const double* s_T = s_Tb + (size_t)b * TP * NT;
+#pragma unroll 8
+          for (int ti = 0; ti < tp; ++ti) {
+            const int cj = (s_ids[ti * VSC + lane] >> 1) & 3, c0 = (s_ids[ti * VSC] >> 1) & 3;
+            acc0 += s_T[ti * NT + (cj * 4 + c0) * 2];
+          }
+        }
+      }
+      __syncthreads();
+      if constexpr (FAST) {
+        if (tbase + TP < np) phase1b_fast(tbase + TP, b ^ 1, ok);
+        __syncthreads();
+      }
+    }
+    if constexpr (FAST) {
+      s_pG[lane] = acc0;                           // (pG is the producer's own and idle now) -> the consumers' rows
       __syncthreads();
     }
     if (lane < 2) l00[(size_t)cell * A + lane] = acc00;
@@ -3220,6 +3268,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
   } else {
     // ================================================= consumers ================================================
     const bool owner = lane < V && j0 < V;
+    [[maybe_unused]] bool ok = true;               // (FAST: this wavefront's share of phase 1b)
     constexpr int NJM = kPcJ1;
     const int nj = wave == 1 ? kPcJ1 : kPcJ;
     double acc[NJM][A];
@@ -3235,7 +3284,23 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
         uint32_t tmp, m0_keep, colv, ti_c, wa0, wa1, wa2, wa3, wa4, wb0, wb1, wb2, wb3, wb4;
         if (wave == 1) {
           uint32_t wa5, wb5;
-          asm volatile(DMX_PJ_CONSUMER(DMX_PJ_WORDS6, DMX_PJ_RFL6, DMX_PJ_REST20)
+          if constexpr (FAST) {
+            asm volatile(DMX_PJ_CONSUMER(FA, DMX_PJ_WORDS6, DMX_PJ_RFL6, DMX_PJ_REST20)
+              :
+                [b0] "+v"(acc[0][1]),                [b1] "+v"(acc[1][1]),                [b2] "+v"(acc[2][1]),                [b3] "+v"(acc[3][1]),
+                [b4] "+v"(acc[4][1]),                [b5] "+v"(acc[5][1]),                [b6] "+v"(acc[6][1]),                [b7] "+v"(acc[7][1]),
+                [b8] "+v"(acc[8][1]),                [b9] "+v"(acc[9][1]),                [b10] "+v"(acc[10][1]),                [b11] "+v"(acc[11][1]),
+                [b12] "+v"(acc[12][1]),                [b13] "+v"(acc[13][1]),                [b14] "+v"(acc[14][1]),                [b15] "+v"(acc[15][1]),
+                [b16] "+v"(acc[16][1]),                [b17] "+v"(acc[17][1]),                [b18] "+v"(acc[18][1]),                [b19] "+v"(acc[19][1]),
+                [b20] "+v"(acc[20][1]),                [b21] "+v"(acc[21][1]),                [b22] "+v"(acc[22][1]),                [b23] "+v"(acc[23][1]),
+                [pj] "+v"(pj), [pi] "+v"(pi), [pt] "+v"(pt), [colv] "=&v"(colv),
+                [t] "=&s"(tmp), [m0k] "=&s"(m0_keep), [ti] "=&s"(ti_c),
+                [wa0] "=&s"(wa0), [wa1] "=&s"(wa1), [wa2] "=&s"(wa2), [wa3] "=&s"(wa3), [wa4] "=&s"(wa4), [wa5] "=&s"(wa5),
+                [wb0] "=&s"(wb0), [wb1] "=&s"(wb1), [wb2] "=&s"(wb2), [wb3] "=&s"(wb3), [wb4] "=&s"(wb4), [wb5] "=&s"(wb5)
+              : [tp] "s"(tp)
+              : DMX_PJ_CLOB);
+          } else {
+            asm volatile(DMX_PJ_CONSUMER(ST, DMX_PJ_WORDS6, DMX_PJ_RFL6, DMX_PJ_REST20)
               :
                 [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]),                [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
                 [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]),                [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
@@ -3255,8 +3320,24 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
                 [wb0] "=&s"(wb0), [wb1] "=&s"(wb1), [wb2] "=&s"(wb2), [wb3] "=&s"(wb3), [wb4] "=&s"(wb4), [wb5] "=&s"(wb5)
               : [tp] "s"(tp)
               : DMX_PJ_CLOB);
+          }
         } else {
-          asm volatile(DMX_PJ_CONSUMER(DMX_PJ_WORDS5, DMX_PJ_RFL5, DMX_PJ_REST16)
+          if constexpr (FAST) {
+            asm volatile(DMX_PJ_CONSUMER(FA, DMX_PJ_WORDS5, DMX_PJ_RFL5, DMX_PJ_REST16)
+              :
+                [b0] "+v"(acc[0][1]),                [b1] "+v"(acc[1][1]),                [b2] "+v"(acc[2][1]),                [b3] "+v"(acc[3][1]),
+                [b4] "+v"(acc[4][1]),                [b5] "+v"(acc[5][1]),                [b6] "+v"(acc[6][1]),                [b7] "+v"(acc[7][1]),
+                [b8] "+v"(acc[8][1]),                [b9] "+v"(acc[9][1]),                [b10] "+v"(acc[10][1]),                [b11] "+v"(acc[11][1]),
+                [b12] "+v"(acc[12][1]),                [b13] "+v"(acc[13][1]),                [b14] "+v"(acc[14][1]),                [b15] "+v"(acc[15][1]),
+                [b16] "+v"(acc[16][1]),                [b17] "+v"(acc[17][1]),                [b18] "+v"(acc[18][1]),                [b19] "+v"(acc[19][1]),
+                [pj] "+v"(pj), [pi] "+v"(pi), [pt] "+v"(pt), [colv] "=&v"(colv),
+                [t] "=&s"(tmp), [m0k] "=&s"(m0_keep), [ti] "=&s"(ti_c),
+                [wa0] "=&s"(wa0), [wa1] "=&s"(wa1), [wa2] "=&s"(wa2), [wa3] "=&s"(wa3), [wa4] "=&s"(wa4),
+                [wb0] "=&s"(wb0), [wb1] "=&s"(wb1), [wb2] "=&s"(wb2), [wb3] "=&s"(wb3), [wb4] "=&s"(wb4)
+              : [tp] "s"(tp)
+              : DMX_PJ_CLOB);
+          } else {
+            asm volatile(DMX_PJ_CONSUMER(ST, DMX_PJ_WORDS5, DMX_PJ_RFL5, DMX_PJ_REST16)
               :
                 [a0] "+v"(acc[0][0]), [b0] "+v"(acc[0][1]),                [a1] "+v"(acc[1][0]), [b1] "+v"(acc[1][1]),
                 [a2] "+v"(acc[2][0]), [b2] "+v"(acc[2][1]),                [a3] "+v"(acc[3][0]), [b3] "+v"(acc[3][1]),
@@ -3274,9 +3355,18 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
                 [wb0] "=&s"(wb0), [wb1] "=&s"(wb1), [wb2] "=&s"(wb2), [wb3] "=&s"(wb3), [wb4] "=&s"(wb4)
               : [tp] "s"(tp)
               : DMX_PJ_CLOB);
+          }
         }
       }
       __syncthreads();
+      if constexpr (FAST) {
+        if (tbase + TP < np) phase1b_fast(tbase + TP, b ^ 1, ok);
+        __syncthreads();
+      }
+    }
+    if constexpr (FAST) {
+      __syncthreads();                             // the producer's singlet column is in s_pG now
+      if (!ok) flag_cell(flagged, cell);
     }
     if (owner) {
 #pragma unroll
@@ -3284,24 +3374,27 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
         const int jx = j0 + jj;
         if (jj < nj && jx < V) {
           double* o = grid + (((size_t)cell * V + jx) * V + lane) * A;
-          o[0] = acc[jj][0]; o[1] = acc[jj][1];
+          o[0] = FAST ? s_pG[jx] : acc[jj][0]; o[1] = acc[jj][1];
         }
       }
     }
   }
-#undef DMX_PJ_STEP
-#undef DMX_PJ_ADD2
+#undef DMX_PJ_C0_SX
+#undef DMX_PJ_C1_SX
+#undef DMX_PJ_C0_SY
+#undef DMX_PJ_C1_SY
+#undef DMX_PJ_ADDS_ST
+#undef DMX_PJ_ADDS_FA
 #undef DMX_PJ_WORD4
-#undef DMX_PJ_COLADDR
-#undef DMX_PJ_XC0
-#undef DMX_PJ_XC1
-#undef DMX_PJ_YC0
-#undef DMX_PJ_YC1
+#undef DMX_PJ_COLADDR_ST
+#undef DMX_PJ_COLADDR_FA
+#undef DMX_PJ_READS_ST_SX
+#undef DMX_PJ_READS_ST_SY
+#undef DMX_PJ_READS_FA_SX
+#undef DMX_PJ_READS_FA_SY
 #undef DMX_PJ_FIRST4
 #undef DMX_PJ_REST16
 #undef DMX_PJ_MID
-#undef DMX_PJ_MIDX
-#undef DMX_PJ_MIDY
 #undef DMX_PJ_WORDS5
 #undef DMX_PJ_WORDS6
 #undef DMX_PJ_RFL6
@@ -5098,6 +5191,16 @@ int launch_doublet(dmx_engine* e) {
   }
   auto slabs_of = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
   if (use_cls && e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 64 && !getenv("DMX_NO_SYM")) {
+    if (V > 32 && !getenv("DMX_FAST_NO_PROD")) {
+      // 33..64 samples: the producer / consumer kernel over the printed entries (round 4; k_doublet_clsym<33,2> ran 2 wavefronts per SIMD)
+      HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
+      const size_t lds = (size_t)2 * 32 * 32 * 8 + (size_t)2 * 32 * 64 + (size_t)32 * 18 * 8 + 2 * 34 * 8 + 2 * 32 * (8 + 4 + 4) +
+                         (size_t)32 * 12 * 4;
+      hipLaunchKernelGGL((k_doublet_clsp<3, true>), dim3((unsigned)B), dim3(kThreads), lds, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids,
+                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, 0, e->d_grid, e->d_l00, e->d_flag);
+      HIP_TRY(hipGetLastError());
+      return launch_doublet_generic_w<true>(e);
+    }
     // GT inputs, default grid {0, 0.5}, FAST: class table + the printed entries only, one wavefront per barcode
     const int D = V / 2 + 1, Q = 64 / V;
     // offsets per lane NED and slabs NS with Q * NED * NS >= D: as few slabs as 17 accumulators per lane allow (more do not fit
@@ -5349,6 +5452,7 @@ namespace {
 bool k2_will_be_clsp(const dmx_engine* e) {
   const bool use_cls = e->n_classes > 0 && !getenv("DMX_NO_CLASSES");
   const bool fast_sym = e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && e->V <= 64 && !getenv("DMX_NO_SYM");
+  if (use_cls && fast_sym && e->A == 2 && e->V > 32 && !getenv("DMX_K2_GENERIC")) return !getenv("DMX_FAST_NO_PROD");
   return use_cls && e->A == 2 && !fast_sym && e->V > 32 && e->V <= 64 && !getenv("DMX_K2_GENERIC") && !getenv("DMX_CLS_NO_PROD") && !getenv("DMX_CLS_NO_UJ") &&
          !getenv("DMX_CLS_MINW3") && !getenv("DMX_CLS_NK8");
 }

@@ -220,7 +220,7 @@ def test_cfg3_full_size_fast_mode(mods):
 
 
 def test_cfg4_full_depth_fast_mode(mods):
-    """DMX_MODE_FAST on cfg4's depth and panel (100k SNPs x 64 samples, GT -> k_doublet_clsym): every printed entry of the two
+    """DMX_MODE_FAST on cfg4's depth and panel (100k SNPs x 64 samples, GT -> k_doublet_clsp<FAST>): every printed entry of the two
     sampled barcodes within 1e-9 of the oracle, the calls the oracle's, re-runs and other launch geometries bit-identical."""
     worst = run_full(mods, 4, 2, check_general=False, barcodes=1000, fast=True)
     assert worst < 1e-9

@@ -556,6 +556,42 @@ def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
             assert abs(summ[c][f] - want[fs if swap else f]) < TOL, (c, f)
 
 
+@pytest.mark.parametrize("V", [33, 48, 64])
+def test_fast_mode_class_kernels_of_33_to_64_samples_agree(eng, oracle, V, monkeypatch):
+    """GT panels of 33..64 samples in FAST mode run k_doublet_clsp<FAST> (round 4); DMX_FAST_NO_PROD=1 keeps k_doublet_clsym, the
+    round-3 kernel.  Both evaluate one orientation per unordered pair with the reference's operations, in different orientations:
+    printed entries within 1e-10 of each other and of STRICT, the singlet column and llks00 bit-equal, the same calls."""
+    from demuxlet_amd import synth, capi
+    from golden_util import printed_mask
+    rng = np.random.default_rng(777 + V)
+    S, B = 400, 9
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=0.05)
+    g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    sp = synth.make_pileup(rng, np.where(raw.alleles < 0, 0, raw.alleles), B, 0.4, 1.5, dense_layout=False, doublet_rate=0.3)
+    strict = run_engine(eng, host_pileup(eng, sp), g, (0.0, 0.5), 0.5)
+
+    def fast():
+        e = eng.Engine(V, (0.0, 0.5), 0.5, mode=capi.DMX_MODE_FAST)
+        e.set_genotypes(g); e.set_pileup(host_pileup(eng, sp))
+        e.run_singlet(); e.run_doublet()
+        out = e.get_doublet()
+        e.close()
+        return out
+    monkeypatch.delenv("DMX_FAST_NO_PROD", raising=False)
+    grid_a, l00_a, summ_a = fast()
+    monkeypatch.setenv("DMX_FAST_NO_PROD", "1")
+    grid_b, l00_b, summ_b = fast()
+    monkeypatch.delenv("DMX_FAST_NO_PROD")
+    m = np.broadcast_to(printed_mask(V, 2)[None], grid_a.shape)
+    assert np.abs(grid_a - grid_b)[m].max() < 1e-10 and np.abs(grid_a - strict["grid"])[m].max() < 1e-10
+    assert np.array_equal(l00_a, l00_b) and np.array_equal(l00_a, strict["l00"])
+    assert np.array_equal(grid_a[:, :, 0, 0], strict["grid"][:, :, 0, 0])            # the singlet column IS the reference's sequence
+    assert np.array_equal(grid_a[:, :, :, 1], grid_a[:, :, :, 1].transpose(0, 2, 1))  # mirrored
+    for f in ("i_sing1", "i_sing2", "n_best"):
+        assert np.array_equal(summ_a[f], summ_b[f]), f
+    assert all({int(x["j_best"]), int(x["k_best"])} == {int(y["j_best"]), int(y["k_best"])} for x, y in zip(summ_a, summ_b))
+
+
 @pytest.mark.parametrize("V,alphas,field,B,S", [
     (5, (0.0, 0.25, 0.5), "GP", 20, 400), (16, (0.0, 0.1, 0.3, 0.5), "GP", 12, 300), (12, (0.0, 0.1, 0.2, 0.3, 0.4, 0.5), "PL", 10, 300),
     (32, (0.0, 0.2, 0.5), "GP", 6, 300), (64, (0.0, 0.1, 0.2, 0.3, 0.5), "GP", 4, 200), (100, (0.0, 0.25, 0.5), "GP", 3, 150),
