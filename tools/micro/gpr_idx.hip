@@ -54,6 +54,31 @@ __global__ __launch_bounds__(256) void k_time(const double* in, double* out, int
                    "s_set_gpr_idx_off\n\t"
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [t] "=&s"(tmp) : [w] "s"(w), "v"(t0), "v"(t1)
                    : "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "m0", "scc");
+    else if (MODE == 4)   // round 4: the index image shifted into M0 (s_lshr_b32, a 32-bit encoding), ONE addition per change (FAST's phase 2)
+      asm volatile("s_set_gpr_idx_on %[w], 0x1\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %0, v[200:201], %0\n\ts_lshr_b32 m0, %[w], 0\n\tv_add_f64 %1, v[202:203], %1\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %2, v[200:201], %2\n\ts_lshr_b32 m0, %[w], 0\n\tv_add_f64 %3, v[202:203], %3\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %4, v[200:201], %4\n\ts_lshr_b32 m0, %[w], 0\n\tv_add_f64 %5, v[202:203], %5\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %6, v[200:201], %6\n\ts_lshr_b32 m0, %[w], 0\n\tv_add_f64 %7, v[202:203], %7\n\t"
+                   "s_set_gpr_idx_off\n\t"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [t] "=&s"(tmp) : [w] "s"(w | 0x1000u), "v"(t0), "v"(t1)
+                   : "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "m0", "scc");
+    else if (MODE == 5)   // ... TWO additions per change (STRICT's phase 2 as built)
+      asm volatile("s_set_gpr_idx_on %[w], 0x1\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %0, v[200:201], %0\n\tv_add_f64 %1, v[202:203], %1\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %2, v[200:201], %2\n\tv_add_f64 %3, v[202:203], %3\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %4, v[200:201], %4\n\tv_add_f64 %5, v[202:203], %5\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %6, v[200:201], %6\n\tv_add_f64 %7, v[202:203], %7\n\t"
+                   "s_set_gpr_idx_off\n\t"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [t] "=&s"(tmp) : [w] "s"(w | 0x1000u), "v"(t0), "v"(t1)
+                   : "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "m0", "scc");
+    else if (MODE == 6)   // ... FOUR additions per change
+      asm volatile("s_set_gpr_idx_on %[w], 0x1\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %0, v[200:201], %0\n\tv_add_f64 %1, v[202:203], %1\n\tv_add_f64 %2, v[200:201], %2\n\tv_add_f64 %3, v[202:203], %3\n\t"
+                   "s_lshr_b32 m0, %[w], 0\n\tv_add_f64 %4, v[200:201], %4\n\tv_add_f64 %5, v[202:203], %5\n\tv_add_f64 %6, v[200:201], %6\n\tv_add_f64 %7, v[202:203], %7\n\t"
+                   "s_set_gpr_idx_off\n\t"
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), [t] "=&s"(tmp) : [w] "s"(w | 0x1000u), "v"(t0), "v"(t1)
+                   : "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "m0", "scc");
     else
       asm volatile("s_set_gpr_idx_on %[w], 0x1\n\t"
                    "s_bfe_u32 %[t], %[w], 0x20000\n\ts_set_gpr_idx_idx %[t]\n\tv_add_f64 %0, v[200:201], %0\n\tv_add_f64 %1, v[202:203], %1\n\t"
@@ -97,6 +122,12 @@ int main() {
   }
   printf("index mode selects the right registers: %s\n", bad ? "NO" : "yes");
   const int n = 200000;
+  // round 4: cycles of SIMD time per EIGHT additions (one statement of the loop above) by the number of index changes in it
+  for (int w : {1, 2, 3, 4}) {
+    const double c0 = run<0>(w, din, dout, n) * 4, c4 = run<4>(w, din, dout, n) * 4, c5 = run<5>(w, din, dout, n) * 4, c6 = run<6>(w, din, dout, n) * 4;
+    printf("%d wave(s)/SIMD: SIMD cycles per 8 v_add_f64: no index change %.1f, 2 changes (4 adds each) %.1f, 4 changes (2 adds each, s_lshr_b32 m0) %.1f, 8 changes (1 add each) %.1f\n",
+           w, c0, c6, c5, c4);
+  }
   for (int w : {1, 2, 4}) {
     const double c0 = run<0>(w, din, dout, n), c1 = run<1>(w, din, dout, n), c2 = run<2>(w, din, dout, n), c3 = run<3>(w, din, dout, n);
     printf("%d wave(s)/SIMD: cycles per group {index change, two v_add_f64} — SIMD throughput / one wavefront's pace: adds alone %.1f / %.1f, with s_bfe + s_set_gpr_idx_on %.1f / %.1f, "
