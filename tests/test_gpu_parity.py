@@ -556,6 +556,43 @@ def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
             assert abs(summ[c][f] - want[fs if swap else f]) < TOL, (c, f)
 
 
+@pytest.mark.parametrize("S,delta", [(1, 1.0), (31, 1.0), (32, 1.0), (33, 1.0), (64, 1.0), (65, 1.0), (97, 1.0), (40, 0.03), (200, 0.16)])
+@pytest.mark.parametrize("V", [40, 64])
+def test_producer_consumer_class_kernel_at_tile_edges(eng, oracle, V, S, delta, monkeypatch):
+    """k_doublet_clsp works in tiles of 32 pairs, double-buffered, its phase 2 requesting up to two pairs ahead: barcodes of 0 (sparse case),
+    1, 31, 32, 33, 64, 65, 97 pairs — STRICT bit-identical to the uniform-j kernel of round 3 and to the general kernel, FAST within
+    1e-10 of STRICT on the printed entries, both against the oracle."""
+    from demuxlet_amd import synth, capi
+    from golden_util import printed_mask
+    rng = np.random.default_rng(9000 + 131 * V + S)
+    B = 13
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=0.1)
+    g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    sp = synth.make_pileup(rng, np.where(raw.alleles < 0, 0, raw.alleles), B, delta, 1.6, dense_layout=(delta >= 1.0), doublet_rate=0.3)
+    if delta < 0.1:
+        assert (np.diff(sp.cell_pair_off) == 0).any() and (np.diff(sp.cell_pair_off) > 0).any()
+    for k in ("DMX_CLS_NO_PROD", "DMX_NO_CLASSES", "DMX_FAST_NO_PROD"):
+        monkeypatch.delenv(k, raising=False)
+    base = run_engine(eng, host_pileup(eng, sp), g, (0.0, 0.5), 0.5)
+    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    proc = ref.processed.astype(bool)
+    assert np.abs(base["grid"][proc] - ref.llksAB[proc]).max() < TOL and np.abs(base["l00"][proc] - ref.llks00[proc]).max() < TOL
+    for env in ("DMX_CLS_NO_PROD", "DMX_NO_CLASSES"):
+        monkeypatch.setenv(env, "1")
+        out = run_engine(eng, host_pileup(eng, sp), g, (0.0, 0.5), 0.5)
+        monkeypatch.delenv(env)
+        for name in ("grid", "l00", "summ"):
+            assert np.array_equal(out[name], base[name]), (env, name)
+    e = eng.Engine(V, (0.0, 0.5), 0.5, mode=capi.DMX_MODE_FAST)
+    e.set_genotypes(g); e.set_pileup(host_pileup(eng, sp))
+    e.run_singlet(); e.run_doublet()
+    grid, l00, summ = e.get_doublet()
+    e.close()
+    m = np.broadcast_to(printed_mask(V, 2)[None], grid.shape)
+    assert np.abs(grid - base["grid"])[m].max() < 1e-10 and np.array_equal(l00, base["l00"])
+    assert np.array_equal(grid[:, :, 0, 0], base["grid"][:, :, 0, 0])
+
+
 @pytest.mark.parametrize("V", [33, 48, 64])
 def test_fast_mode_class_kernels_of_33_to_64_samples_agree(eng, oracle, V, monkeypatch):
     """GT panels of 33..64 samples in FAST mode run k_doublet_clsp<FAST> (round 4); DMX_FAST_NO_PROD=1 keeps k_doublet_clsym, the
