@@ -19,6 +19,8 @@ for case in range(n_cases):
     A = int(rng.choice([2, 2, 2, 3, 5]))
     alphas = tuple([0.0] + sorted(rng.choice(np.arange(1, 50), size=A - 2, replace=False) / 100.0) + [0.5]) if A > 2 else (0.0, 0.5)
     field = str(rng.choice(["GT", "GP", "PL"]))
+    if os.environ.get("DMX_FUZZ_CLSP"):          # the producer / consumer class kernel only: GT panels of 33..64 samples on the default grid
+        V, A, alphas, field = int(rng.integers(33, 65)), 2, (0.0, 0.5), "GT"
     S = int(rng.integers(20, 300)); B = int(rng.integers(2, 30 if V <= 32 else 8))
     raw = synth.make_raw_genotypes(rng, S, V, missing_rate=0.1 if (field == "GT" and rng.random() < 0.5) else 0.0)
     al = np.where(raw.alleles < 0, 0, raw.alleles)

@@ -12,6 +12,8 @@ def gen_case(rng, scale=1):
     if rng.random() < 0.15:
         alphas = tuple(sorted(rng.choice(np.arange(0, 51), size=A, replace=False) / 100.0))       # alpha[0] != 0, no 0.5
     field = str(rng.choice(["GT", "GT", "GP", "PL"]))
+    if os.environ.get("DMX_FUZZ_CLSP"):          # the producer / consumer class kernel only: GT panels of 33..64 samples on the default grid
+        V, A, alphas, field = int(rng.integers(33, 65)), 2, (0.0, 0.5), "GT"
     dense = bool(rng.random() < 0.3)
     S = int(rng.integers(5, 150 if V > 64 else 400 * (scale if V <= 32 else 1)))
     B = int(rng.integers(1, 6 if V > 64 else 40 * (scale if V <= 32 else 1)))

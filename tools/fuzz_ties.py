@@ -51,6 +51,8 @@ for case in range(n_cases):
     if rng.random() < 0.1:
         alphas = tuple(sorted(rng.choice(np.arange(1, 51), size=A, replace=False) / 100.0))       # alpha[0] != 0
     field = str(rng.choice(["GT", "GT", "GP", "PL"]))
+    if os.environ.get("DMX_FUZZ_CLSP"):          # the producer / consumer class kernel only: GT panels of 33..64 samples on the default grid
+        V, A, alphas, field = int(rng.integers(33, 65)), 2, (0.0, 0.5), "GT"
     S = int(rng.integers(4, 90)); B = int(rng.integers(3, 50 if V <= 33 else 12))
     raw = synth.make_raw_genotypes(rng, S, V)
     al = raw.alleles.copy()
