@@ -2967,10 +2967,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_clsp(PileupView pv, 
 
   // Phase 2 of one tile for a wavefront's samples j, one asm statement.  Per (pair, sample j): the class of j (wave-uniform) picks the row
   // of the lane's column by VGPR-relative addressing (see k_doublet_cls), then one addition per alpha.  Column sets X = v[152:167] and
-  // Y = v[136:151] (the top of the 168-register budget), class words of the pair being requested in v[130:134], its id byte in v135;
+  // Y = v[136:151] (the top of the 168-register budget), class words of the pair being requested in v[128:133], its id byte in v135;
   // two sets of class words in scalar registers (wa*, wb*).  Invariant at the top of a pair: its column requested, then the next pair's
   // words and id byte (NW LDS operations younger): s_waitcnt lgkmcnt(NW) is enough (LDS operations return in order).  The pairs beyond
-  // the tile that the last rounds request read LDS inside the workgroup's allocation (the id byte is masked to a class's 0x30, so the
+  // the tile that the last rounds request read LDS inside the workgroup's allocation (the id byte is masked to a class's two bits, so the
   // column reads stay 16-byte aligned) and are drained before the statement ends.  DS instructions of gfx9+ do not use M0, so the
   // indexing state left in it is harmless; M0 is restored at the end.
   // The id bytes are 0x10 | c << 2 (FAST: 0x10 | c << 1): a word of four, shifted right by whole bytes, IS the M0 of the indexing mode —
