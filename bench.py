@@ -694,7 +694,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(CONFIGS),
                     help="0 = the driver's default: cfg3 (+ nested cfg3-fast/cfg2/cfg5/cfg4-whole records) at N=1, cfg4 sharded at N>1")
     ap.add_argument("--cells", type=int, default=0, help="override the TOTAL barcode count (smaller = quicker run; not the headline)")
