@@ -351,8 +351,9 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
     counts = [shard_range(B_total, world, r)[1] - shard_range(B_total, world, r)[0] for r in range(world)]
     gathered = None
     beside = bool(cfg["doublet"]) and not os.environ.get("DMX_NO_OVERLAP")      # what dmx_demuxlet_run does too
-    # (dmx_engine_run itself runs K1 BEFORE K2 where K2 is k_doublet_clsp — GT classes, STRICT, 33..64 samples: that kernel leaves K1 no room)
-    k1_first = beside and cfg["field"] == "GT" and not fast and 32 < V <= 64 and A == 2 and not os.environ.get("DMX_FORCE_OVERLAP")
+    # (dmx_engine_run itself runs K1 beside K3 + K3b, AFTER K2, where K2 is k_doublet_clsp — GT classes, 33..64 samples, grid {0, 0.5}: that kernel leaves K1 no room)
+    k1_late = beside and cfg["field"] == "GT" and 32 < V <= 64 and A == 2 and tuple(cfg["alphas"]) == (0.0, 0.5) and not os.environ.get("DMX_FORCE_OVERLAP") \
+        and not os.environ.get("DMX_K1_FIRST")
 
     def step(ev=None):
         nonlocal gathered
@@ -484,7 +485,7 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                           "executed": executed,
                           "kernel_ms": {"k_singlet": k1_ms, "k_doublet": k2_only_ms, "k_reduce": k3_ms, "k_certify": k3b_ms,
                                         "torch_events_k_singlet": k1_span_ms, "torch_events_k_doublet+k_reduce+k_certify": k2_ms,
-                                        "k1_beside_k2": beside and not k1_first, "k1_before_k2_in_one_call": k1_first},
+                                        "k1_beside_k2": beside and not k1_late, "k1_beside_k3b_in_one_call": k1_late},
                           "kernel_ms_alone": alone,
                           "peak_tflops": FP64_VALU_PEAK_TFLOPS},
         }

@@ -689,7 +689,10 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
 // Same walk and ownership as k_singlet; per pair the lane evaluates log(GL . row_d) once per class d plus the llk0 term,
 // and stores those five terms and the SNP's packed class ids; chain lane (cell, k) then adds term[id[snp][k]] for the
 // tile's pairs in ascending order — the very doubles k_singlet would have formed for sample k, in the same order.
-template <int CW, int MINW = 4>
+// One barcode per wavefront (CW == 1).  L0M (panels of a multiple of 64 samples, cfg4's 64): the llk0 chain would be the ONLY chain of a second
+// pass over the tile — a whole pass of index arithmetic and look-ups for one active lane, a third of the kernel's instructions at V = 64 — so
+// it is merged into the first pass instead: every lane adds the tile's llk0 terms (uniform LDS reads) beside its own sample's, lane 0 stores.
+template <int CW, int MINW = 4, bool L0M = false>
 __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, int nrd_width, const float* __restrict__ rows,
                                                              const uint32_t* __restrict__ idw, const double* __restrict__ gp0,
                                                              const double* __restrict__ tabs,
@@ -725,26 +728,21 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
 #pragma unroll
   for (int d = T; d < 64; d <<= 1) max_np = max(max_np, __shfl_xor(max_np, d));
 
-  // chains: a = lane + 64*i over CW*(V+1) accumulators, a -> (cell a/(V+1), sample a%(V+1)); sample V is llk0.  A wavefront
+  // chains: a = lane + 64*i over the barcode's accumulators, sample a for a < V; a == V is llk0 unless it is merged (L0M).  A wavefront
   // carries 256 chains; wider panels are cut into chain slabs over blockIdx.y, each repeating the five logs per pair.
+  static_assert(CW == 1, "one barcode per wavefront");
   constexpr int MAXCH = 4;
-  const int nchain = CW * (V + 1);
+  const int nchain = L0M ? V : V + 1;
   double acc[MAXCH];
-  int32_t ch_pair0[MAXCH], ch_k[MAXCH];
-  int64_t ch_np[MAXCH];
-  int32_t ch_cell[MAXCH];
+  [[maybe_unused]] double acc0 = 0.0;            // L0M: the llk0 sum, on every lane of chain slab 0
+  int32_t ch_k[MAXCH];
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
     const int a = (int)blockIdx.y * 64 * MAXCH + lane + 64 * i;
-    const bool okc = a < nchain && slot0 + a / (V + 1) < pv.B;
-    const int ac = okc ? a / (V + 1) : 0;
     acc[i] = 0.0;
-    ch_pair0[i] = ac * T;
-    ch_k[i] = okc ? a % (V + 1) : -1;
-    ch_np[i] = okc ? __shfl(np, ac * T) : 0;
-    ch_cell[i] = __shfl(cell, ac * T);
-    if (!okc) { ch_np[i] = 0; }
+    ch_k[i] = (cell_ok && a < nchain) ? a : -1;
   }
+  const bool slab0 = blockIdx.y == 0;
 
   struct Raw { uint32_t n; int32_t snp; };
   struct Hdr { uint32_t n; int32_t snp; uint32_t rd4; int64_t off; };
@@ -834,43 +832,51 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
       }
     }
     DMX_WAVE_LDS_ORDER();
-    // ---- ordered sums: chain (cell, k) adds term[pair][class of sample k at the pair's SNP] for the tile's pairs
+    // ---- ordered sums: chain k adds term[pair][class of sample k at the pair's SNP] for the tile's pairs
+    const int64_t left = np - tile * T;            // (np is the wavefront's one barcode's: uniform)
+    const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
 #pragma unroll
     for (int i = 0; i < MAXCH; ++i) {
-      if (ch_k[i] < 0) continue;
-      const int64_t left = ch_np[i] - tile * T;
-      const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
-      const int k = ch_k[i];
+      const bool merged = L0M && i == 0 && slab0;  // this pass also carries the llk0 sum
+      if (ch_k[i] < 0 && !merged) continue;
+      const int k = ch_k[i] < 0 ? 0 : ch_k[i];     // (merged pass: lanes without a chain walk along with sample 0's look-ups, unused)
       const bool is0 = k == V;
       const int wq = is0 ? 0 : (k >> 4), sh = is0 ? 0 : 2 * (k & 15);
-      const double* tb = &term[ch_pair0[i] * TD];
-      const uint32_t* ib = &s_idw[ch_pair0[i] * nwd + wq];
+      const double* tb = &term[0];
+      const uint32_t* ib = &s_idw[wq];
       double s = acc[i];
       int p = 0;
-      for (; p + 16 <= cnt; p += 16) {            // ids first, then the 16 term reads, then the 16 ordered adds
-        uint32_t wv[16];
+      constexpr int NB = L0M ? 8 : 16;             // pairs per batch: ids first, then the term reads, then the ordered adds
+      for (; p + NB <= cnt; p += NB) {
+        uint32_t wv[NB];
         if (nwd == 1) {
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
+          for (int q4 = 0; q4 < NB / 4; ++q4) {
             const uint4 u = *reinterpret_cast<const uint4*>(&ib[p + 4 * q4]);
             wv[4 * q4] = u.x; wv[4 * q4 + 1] = u.y; wv[4 * q4 + 2] = u.z; wv[4 * q4 + 3] = u.w;
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < 16; ++q) wv[q] = ib[(p + q) * nwd];
+          for (int q = 0; q < NB; ++q) wv[q] = ib[(p + q) * nwd];
         }
-        double tv[16];
+        double tv[NB];
+        [[maybe_unused]] double t0v[NB];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < NB; ++q) {
           const uint32_t d = is0 ? 4u : ((wv[q] >> sh) & 3u);
           tv[q] = tb[(p + q) * TD + d];
+          if (merged) t0v[q] = tb[(p + q) * TD + 4];
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s += tv[q];   // ascending SNP order: the reference's order
+        for (int q = 0; q < NB; ++q) {               // ascending SNP order: the reference's order
+          s += tv[q];
+          if (merged) acc0 += t0v[q];
+        }
       }
       for (; p < cnt; ++p) {
         const uint32_t d = is0 ? 4u : ((ib[p * nwd] >> sh) & 3u);
         s += tb[p * TD + d];
+        if (merged) acc0 += tb[p * TD + 4];
       }
       acc[i] = s;
     }
@@ -879,9 +885,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
 #pragma unroll
   for (int i = 0; i < MAXCH; ++i) {
     if (ch_k[i] < 0) continue;
-    if (ch_k[i] < V) llks[(size_t)ch_cell[i] * V + ch_k[i]] = acc[i];
-    else llk0s[ch_cell[i]] = acc[i];
+    if (ch_k[i] < V) llks[(size_t)cell * V + ch_k[i]] = acc[i];
+    else llk0s[cell] = acc[i];
   }
+  if (L0M && slab0 && cell_ok && lane == 0) llk0s[cell] = acc0;
 }
 
 // Where every cell stands at the boundaries of the SNP blocks [b << shift, (b + 1) << shift): blk[cell][b] = {index of its first
@@ -4989,15 +4996,16 @@ int launch_singlet(dmx_engine* e) {
     const int wide_v = getenv("DMX_K1_WIDE_V") ? atoi(getenv("DMX_K1_WIDE_V")) : 20;      // kernel experiments only
     if (V >= wide_v && V <= 1024) {              // wide panels: chains look the class terms up themselves, one pass per tile
       const size_t dynw = (size_t)(kThreads / 64) * 64 * ((V + 15) / 16) * sizeof(uint32_t);
-      const dim3 blkw(kThreads), grdw((unsigned)((B + (kThreads / 64) - 1) / (kThreads / 64)), (unsigned)((V + 1 + 255) / 256));
-      if (dynw > 30 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_singlet_clsw<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynw));
-      if (getenv("DMX_K1W_MINW3")) {              // kernel experiments only
-        hipLaunchKernelGGL((k_singlet_clsw<1, 3>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,
-                           e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s);
-        return DMX_OK;
-      }
-      hipLaunchKernelGGL((k_singlet_clsw<1>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,
-                         e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s);
+      const bool l0m = V % 64 == 0 && !getenv("DMX_K1W_NO_L0M");     // llk0 merged into the first pass instead of a pass of its own (k_singlet_clsw)
+      const dim3 blkw(kThreads), grdw((unsigned)((B + (kThreads / 64) - 1) / (kThreads / 64)), (unsigned)((V + (l0m ? 0 : 1) + 255) / 256));
+#define DMX_K1W(...) do {                                                                                                          \
+      if (dynw > 30 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_singlet_clsw<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynw)); \
+      hipLaunchKernelGGL((k_singlet_clsw<__VA_ARGS__>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,    \
+                         e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s); } while (0)
+      if (getenv("DMX_K1W_MINW3")) { if (l0m) DMX_K1W(1, 3, true); else DMX_K1W(1, 3, false); }              // kernel experiments only
+      else if (l0m) DMX_K1W(1, 4, true);
+      else DMX_K1W(1, 4, false);
+#undef DMX_K1W
       return DMX_OK;
     }
     // measured on cfg2-shaped inputs (profiles/): CW 2 wins from 10 k barcodes (6.90 vs 7.14 ms; 5 k: 5.07 vs 3.94), CW 4 still
@@ -5460,9 +5468,10 @@ bool k2_will_be_clsp(const dmx_engine* e) {
 
 extern "C" int dmx_engine_run(dmx_engine* e) {
   if (!e) return set_error(DMX_ERR_ARG, "dmx_engine_run: null engine");
-  // K1 beside K2 pays where K2 leaves slots free.  k_doublet_clsp does not (three wavefronts per SIMD, all of them issuing): measured on
-  // the cfg4 shard 838.5 ms with K1 beside it against 828.5 ms one after the other, so there K1 simply goes first.  (DMX_FORCE_OVERLAP=1: beside anyway.)
-  const bool serial = getenv("DMX_NO_OVERLAP") || (e->have_pileup && k2_will_be_clsp(e) && !getenv("DMX_FORCE_OVERLAP"));
+  // K1 beside K2 pays where K2 leaves slots free.  k_doublet_clsp does not (three wavefronts per SIMD, all of them issuing: measured on the
+  // cfg4 shard, K1 beside it cost what it saved), so there K1 starts when K2 has finished and runs beside K3 + K3b (run_doublet_impl; cfg4 shard
+  // 573 -> 566 ms per step).  DMX_FORCE_OVERLAP=1: beside K2 anyway; DMX_K1_FIRST=1: K1, then K2, K3, K3b, one after the other.
+  const bool serial = getenv("DMX_NO_OVERLAP") || (e->have_pileup && k2_will_be_clsp(e) && getenv("DMX_K1_FIRST"));
   if (e->V < 2 || e->A < 2 || serial) {
     if (int rc = dmx_engine_run_singlet(e)) return rc;
     return (e->V < 2 || e->A < 2) ? DMX_OK : dmx_engine_run_doublet(e);
@@ -5501,7 +5510,10 @@ int run_doublet_impl(dmx_engine* e, bool with_singlet) {
   if (with_singlet) {                            // K1, enqueued after K2, on the low-priority stream
     hipStream_t main_stream = e->stream;
     hipEvent_t* rs = e->ring_s[e->n_ring_s % dmx_engine::kRing];
-    HIP_TRY(hipStreamWaitEvent(e->k1_stream, e->ev_fork, 0));
+    // K1 beside K2 — or, where K2 leaves it no room (k_doublet_clsp: three issuing wavefronts per SIMD), beside K3 + K3b, which like K1
+    // issue on about half of their cycles: K1 then starts when K2 has finished (DMX_FORCE_OVERLAP=1: beside K2 anyway)
+    const bool after_k2 = k2_will_be_clsp(e) && !getenv("DMX_FORCE_OVERLAP");
+    HIP_TRY(hipStreamWaitEvent(e->k1_stream, after_k2 ? e->ev[5] : e->ev_fork, 0));
     e->stream = e->k1_stream;
     int rc = DMX_OK;
     hipError_t he = hipEventRecord(e->ev[2], e->stream);
