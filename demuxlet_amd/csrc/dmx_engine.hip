@@ -124,6 +124,8 @@ __device__ __forceinline__ double div_by(double a, double b, double y) {
 __device__ __attribute__((noinline)) double div_slow(double a, double b) { return a / b; }
 
 constexpr int kPark = 12;              // doubles of parked k_certify state per barcode: 4 chains | 4 event words | clean[2] | ok | pad
+constexpr int kA2MaxV = 1024;            // widest soft-field panel of k_doublet_a2<256,16> (LDS: 32 / 16 / 8 genotype rows of V * 12 bytes + 12 KB)
+constexpr int kAnMaxV4 = 368, kAnMaxV8 = 344;   // k_doublet_an's widest panels (its pG block is 9 / 18 KB instead of 4.5): 160 KB of LDS in all
 constexpr uint32_t kSafeReads = 15;   // each read scales a likelihood by >= err(127)/3 > 2^-44: 15 reads stay above 2^-700
 
 // ---- genotype likelihoods of a (cell, SNP) pair (cmd_cram_demuxlet.cpp:427-452) -----------------------------------------
@@ -1149,14 +1151,16 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 // CHK = false drops the per-term argument-class test of phase 2 (a v_cmp_class_f64 per log): launched only when every genotype row was
 // found finite, non-negative and not vanishing (k_check_geno) — then every phase-2 sum is >= max_l g_j[l] * (1e-6 / (1 + 1e-6)) *
 // max_m g_k[m] > 2^-830, a normal positive number, and the test cannot fire.
-template <int TPC, int NK, int MINW = 1, bool GD = false, bool CHK = true>
+// TP: covered pairs per tile (32; 16 or 8 on panels of more than ~180 samples, whose 32 staged genotype rows would leave one workgroup per CU)
+template <int TPC, int NK, int MINW = 1, bool GD = false, bool CHK = true, int TP = 32>
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                          const double* __restrict__ alpha,
                                                          const int32_t* __restrict__ sched, int32_t V, int32_t GS,
                                                          double* __restrict__ grid, double* __restrict__ l00,
                                                          uint8_t* __restrict__ flagged) {
-  constexpr int A = 2, TP = 32;
+  constexpr int A = 2;
+  static_assert(TP == 32 || TP == 16 || TP == 8, "phase 1 runs on the first 2 * TP lanes of the cell's first wavefront");
   constexpr int CPW = kThreads / TPC;            // cells per workgroup
   constexpr int T00 = TP + 2;
 #define DMX_K2_SYNC() do { if (TPC == 64) { DMX_WAVE_LDS_ORDER(); } else { __syncthreads(); } } while (0)
@@ -1218,7 +1222,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
     if (tid < TP) {
       const bool v = tid < tp;
       const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
-      const uint32_t incl = seg_scan_incl<32>(n);
+      const uint32_t incl = seg_scan_incl<TP>(n);
       s_cnt[tid] = n;
       s_off[tid] = rd_base + (int64_t)(incl - n);
       s_snp[tid] = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
@@ -1236,7 +1240,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
       }
     }
     // ---- phase 1
-    if (tid < 64) {
+    if (tid < 2 * TP) {
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
@@ -5155,8 +5159,8 @@ int launch_doublet(dmx_engine* e) {
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
   }
-  if (A >= 3 && A <= 8 && V <= 128 && !force_generic) {
-    // longer alpha grids: the A = 2 kernel's structure with AP alphas per pair
+  if (A >= 3 && A <= 8 && V <= (A <= 4 ? kAnMaxV4 : kAnMaxV8) && !force_generic) {
+    // longer alpha grids: the A = 2 kernel's structure with AP alphas per pair (beyond ~130 samples with more than 64 KB of LDS, as k_doublet_a2)
     const int AP = A <= 4 ? 4 : 8;
     const int GS = (V * 3 + 3) & ~3;
     const size_t cell_bytes = (size_t)32 * AP * 9 * 8 + (size_t)32 * GS * 4 + (size_t)AP * 34 * 8 + 32 * (4 + 4 + 8);
@@ -5191,7 +5195,9 @@ int launch_doublet(dmx_engine* e) {
   // (FAST on the default grid reaches 256 soft-field samples: k_doublet_sym's slabs keep their LDS flat in V)
   const bool sym_wide = e->mode == DMX_MODE_FAST && !use_cls && A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V > 128 && V <= 256 &&
                         !getenv("DMX_NO_SYM") && !getenv("DMX_NO_SYM_WIDE");
-  if (A != 2 || force_generic || (V > (use_cls ? 1024 : 128) && !sym_wide)) {
+  // (round 4: the general A = 2 kernel itself runs up to kA2MaxV = 1024 samples — one workgroup may use all 160 KB of a gfx950 CU's LDS, and the
+  // tile shortens from 32 to 16 or 8 pairs as the rows grow; beyond, the generic kernel)
+  if (A != 2 || force_generic || (V > (use_cls ? 1024 : kA2MaxV) && !sym_wide)) {
     HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     if (int rc = launch_doublet_generic_w<false>(e)) return rc;
     HIP_TRY(hipGetLastError());
@@ -5355,7 +5361,7 @@ int launch_doublet(dmx_engine* e) {
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
   }
-  if (e->mode == DMX_MODE_FAST) {
+  if (e->mode == DMX_MODE_FAST && V <= 128) {     // (wider panels that are not k_doublet_sym's run the STRICT kernel below: bit-exact, inside FAST's contract)
     // one-cell-per-workgroup panels share u through LDS (cfg3 1.33x); one-wavefront cells (V <= 16) form it in registers
     const size_t fast_bytes = cell_bytes + (V > 16 ? (size_t)8 * 2 * V * 32 : 0);
 #define DMX_K2F(TPC, NK)                                                                                             \
@@ -5392,7 +5398,36 @@ int launch_doublet(dmx_engine* e) {
                          e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
     else DMX_K2A(256, 4);
   }
-  else DMX_K2A(256, 16);
+  else if (V <= 128) DMX_K2A(256, 16);            // <= 55 KB of LDS
+  else {
+    // 129..1024 samples (round 4; the generic kernel before): the same kernel with the tile as long as leaves TWO workgroups per CU
+    // (32 pairs up to 181 samples, 16 up to 377, 8 up to 770), else the longest that fits one workgroup's 160 KB; above 64 KB
+    // the limit is raised explicitly.  2.2-3.6x the generic kernel's rate, bit-identical to it (tools/probe_wide_strict.py).
+    auto bytes_of = [&](int tp) { return (size_t)tp * 18 * 8 + (size_t)tp * GS * 4 + 2 * (size_t)(tp + 2) * 8 + (size_t)tp * (4 + 4 + 8); };
+    constexpr size_t kStatic = sizeof(double) * kTab2 + 2 * 18 * sizeof(double), kTwo = 80 * 1024, kOne = 160 * 1024;   // (the kernel's static LDS: s_tab, s_w)
+    int tp = 0;
+    for (int c : {32, 16, 8}) if (!tp && bytes_of(c) + kStatic <= kTwo) tp = c;
+    for (int c : {32, 16, 8}) if (!tp && bytes_of(c) + kStatic <= kOne) tp = c;
+    if (const char* env = getenv("DMX_A2_TP")) { const int c = atoi(env); if ((c == 32 || c == 16 || c == 8) && bytes_of(c) + kStatic <= kOne) tp = c; }   // kernel experiments only
+    if (!tp) return set_error(DMX_ERR_ARG, "run_doublet: V = %d exceeds k_doublet_a2's LDS budget", (int)V);
+    const size_t lds = bytes_of(tp);
+#define DMX_K2AW(TPP)                                                                                                 \
+  do {                                                                                                                \
+    if (e->geno_safe) {                                                                                               \
+      if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2<256, 16, 1, false, false, TPP>),  \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+      hipLaunchKernelGGL((k_doublet_a2<256, 16, 1, false, false, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,  \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);  \
+    } else {                                                                                                          \
+      if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2<256, 16, 1, false, true, TPP>),   \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
+      hipLaunchKernelGGL((k_doublet_a2<256, 16, 1, false, true, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,   \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);  \
+    }                                                                                                                 \
+  } while (0)
+    if (tp == 32) DMX_K2AW(32); else if (tp == 16) DMX_K2AW(16); else DMX_K2AW(8);
+#undef DMX_K2AW
+  }
 #undef DMX_K2A
   HIP_TRY(hipGetLastError());
   return launch_doublet_generic_w<true>(e);

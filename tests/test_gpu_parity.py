@@ -429,10 +429,12 @@ def test_without_the_arbiter_only_the_order_inside_a_doublet_can_differ(eng, ora
         assert abs(float(a[14]) - float(b[14])) < 1.01e-4                            # LLK12
 
 
-@pytest.mark.parametrize("V,field", [(70, "GP"), (100, "GP"), (128, "PL"), (150, "GP"), (500, "GP")])
+@pytest.mark.parametrize("V,field", [(70, "GP"), (100, "GP"), (128, "PL"), (129, "GP"), (150, "GP"), (200, "PL"), (256, "GP"), (383, "PL"), (384, "GP"),
+                                     (385, "GP"), (500, "GP"), (721, "GP"), (1024, "PL"), (1025, "GP")])
 def test_wide_panels_against_oracle(eng, oracle, V, field):
     """Panels wider than one workgroup's 64 rows (pooled designs with 70-150 donors), soft genotype fields (no classes):
-    the A = 2 kernel in j-slabs up to V = 128, the generic kernel in accumulator slabs beyond."""
+    the A = 2 kernel in j-slabs up to V = 1024 (tiles of 32, 16 or 8 covered pairs as the staged genotype rows grow, up to 160 KB of a
+    CU's LDS), the generic kernel in accumulator slabs beyond."""
     from demuxlet_amd import synth
     rng = np.random.default_rng(900 + V)
     S, B = 150, 3
@@ -459,7 +461,11 @@ def test_wide_panels_against_oracle(eng, oracle, V, field):
     (32, (0.0, 0.2, 0.5), "GP", 6, 300),                        # 256 threads per cell
     (64, (0.0, 0.1, 0.2, 0.3, 0.5), "GP", 4, 200),              # AP = 8, j-slabs
     (100, (0.0, 0.25, 0.5), "GP", 3, 150),                      # AP = 4, NK = 8, j-slabs
-    (128, (0.0, 0.1, 0.2, 0.3, 0.4, 0.45, 0.48, 0.5), "GT", 2, 120),   # A = 8 exactly, the LDS maximum (72 KB per workgroup)
+    (128, (0.0, 0.1, 0.2, 0.3, 0.4, 0.45, 0.48, 0.5), "GT", 2, 120),   # A = 8 exactly, 72 KB of LDS per workgroup
+    (200, (0.0, 0.25, 0.5), "GP", 2, 100),                      # soft fields beyond 128 samples: the same kernel with up to 160 KB of LDS
+    (368, (0.0, 0.1, 0.3, 0.5), "PL", 2, 80),                   # AP = 4, the widest panel of k_doublet_an<256,8,4>
+    (344, (0.0, 0.1, 0.2, 0.3, 0.5), "GP", 2, 80),              # AP = 8, the widest panel of k_doublet_an<256,4,8>
+    (345, (0.0, 0.1, 0.2, 0.3, 0.5), "GP", 2, 60),              # one more sample: the generic kernel
 ])
 def test_longer_alpha_grids_against_oracle(eng, oracle, V, alphas, field, B, S):
     """Alpha grids of 3..8 entries run k_doublet_an (the A = 2 kernel's structure with the alphas padded to 4 or 8 per
