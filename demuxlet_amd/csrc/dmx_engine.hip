@@ -5192,8 +5192,8 @@ int launch_doublet(dmx_engine* e) {
     return launch_doublet_generic_w<true>(e);
   }
   // wide panels: the class kernel's LDS grows by 32 bytes per sample, the general A = 2 kernel's by 384 (64 KB at V = 128)
-  // (FAST on the default grid reaches 256 soft-field samples: k_doublet_sym's slabs keep their LDS flat in V)
-  const bool sym_wide = e->mode == DMX_MODE_FAST && !use_cls && A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V > 128 && V <= 256 &&
+  // (FAST on the default grid reaches 512 soft-field samples: k_doublet_sym's slabs keep their LDS flat in V)
+  const bool sym_wide = e->mode == DMX_MODE_FAST && !use_cls && A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V > 128 && V <= 512 &&
                         !getenv("DMX_NO_SYM") && !getenv("DMX_NO_SYM_WIDE");
   // (round 4: the general A = 2 kernel itself runs up to kA2MaxV = 1024 samples — one workgroup may use all 160 KB of a gfx950 CU's LDS, and the
   // tile shortens from 32 to 16 or 8 pairs as the rows grow; beyond, the generic kernel)
@@ -5335,7 +5335,7 @@ int launch_doublet(dmx_engine* e) {
     else if (V <= 48) DMX_K2S(256, 48, 8, false);
     else if (V <= 64) { if (V == 64) DMX_K2S(256, 64, 8, true); else DMX_K2S(256, 64, 8, false); }
     else {
-      // 64 < V <= 256: the entry list (V (V/2 + 1) + V, up to 33 280) in slabs of 9 entries per lane
+      // 64 < V <= 512: the entry list (V (V/2 + 1) + V, up to 132 096) in slabs of 9 entries per lane
       const unsigned ns = (unsigned)((V * (V / 2 + 1) + V + 256 * 9 - 1) / (256 * 9));
 #define DMX_K2SS(VMAX, SUB, FIX)                                                                                       \
   do {                                                                                                                \
@@ -5353,7 +5353,8 @@ int launch_doublet(dmx_engine* e) {
                        e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);        \
   } while (0)
       if (V <= 96) DMX_K2SS(96, 8, false); else if (V == 128) DMX_K2SS(128, 8, true); else if (V < 128) DMX_K2SS(128, 8, false);
-      else if (V <= 192) DMX_K2SS(192, 4, false); else DMX_K2SS(256, 4, false);        // (sub-tiles of 4 pairs: 40 / 53 KB of LDS per workgroup)
+      else if (V <= 192) DMX_K2SS(192, 4, false); else if (V <= 256) DMX_K2SS(256, 4, false);        // (sub-tiles of 4 pairs: 40 / 53 KB of LDS per workgroup)
+      else if (V <= 384) DMX_K2SS(384, 2, false); else DMX_K2SS(512, 2, false);        // (round 4: 257..512 samples, sub-tiles of 2 pairs: 40 / 53 KB)
 #undef DMX_K2SS
     }
 #undef DMX_K2SV
@@ -5891,7 +5892,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   else {
     // worth it when an engine has more than ~0.15 s of kernels ahead of it (at ~6e11 evaluations/s; FAST evaluates the printed
     // entries only): the host then writes range r and stages r + 2 while the GPU computes r + 1
-    const bool sym = job->mode == DMX_MODE_FAST && A == 2 && job->alpha[0] == 0.0 && job->alpha[1] == 0.5 && V <= 256;
+    const bool sym = job->mode == DMX_MODE_FAST && A == 2 && job->alpha[0] == 0.0 && job->alpha[1] == 0.5 && V <= 512;
     const double evals = (double)(V + 1) + (doublet_ok ? (sym ? (double)V + 0.5 * V * (V + 1) : (double)nAB) : 0.0);
     if (doublet_ok && (double)pl.n_pairs * evals / ngpu > 0.15 * 6e11 && B / ngpu >= 8 * 1024) by_overlap = 4;
   }

@@ -125,7 +125,7 @@ enum { DMX_MODE_STRICT = 0,
         * A printed log-likelihood moves by <= ~6e-11 (tests bound it by 1e-9 against the reference); .best stays identical.
         * Other alpha grids that start with 0 (`--alpha` is multi-valued, cmd_cram_demuxlet.cpp:57) evaluate the singlet column and every
         * (j, k) of the alphas n >= 1 in the same bilinear form (soft fields, up to 128 samples); GT inputs with such grids, grids with
-        * alpha[0] != 0 and wider panels (soft fields: 256 samples on the default grid, 128 on the others; GT inputs: 64) run the STRICT kernels,
+        * alpha[0] != 0 and wider panels (soft fields: 512 samples on the default grid, 128 on the others; GT inputs: 64) run the STRICT kernels,
         * whose results FAST's contract includes. */
        DMX_MODE_FAST = 1 };
 enum { DMX_ENGINE_NO_CERTIFY = 1   /* skip the device-side tie-order certificate (K3b): for callers that do not need the

@@ -502,10 +502,11 @@ def test_longer_alpha_grids_against_oracle(eng, oracle, V, alphas, field, B, S):
                                                (12, 20, 500, 0.4, "PL"), (16, 20, 600, 1.0, "PL"), (17, 12, 300, 0.4, "GP"), (21, 12, 300, 0.4, "GP"),
                                                (26, 12, 300, 0.4, "PL"), (29, 12, 300, 0.4, "GP"), (32, 10, 500, 0.3, "GP"), (33, 6, 300, 0.3, "GP"),
                                                (48, 6, 300, 0.3, "PL"), (57, 4, 300, 0.3, "GP"), (64, 4, 300, 0.3, "GP"), (100, 3, 200, 0.3, "GP"),
-                                               # 64 < V <= 256: the same entry set in slabs; beyond 256 soft fields take the generic kernel in both modes
+                                               # 64 < V <= 512: the same entry set in slabs; beyond 512 soft fields take the STRICT kernel in both modes
                                                (65, 3, 200, 0.3, "PL"), (96, 3, 200, 0.3, "GP"), (97, 2, 150, 0.4, "GP"), (128, 3, 200, 0.3, "GP"),
                                                (129, 2, 120, 0.3, "GP"), (160, 2, 120, 0.3, "PL"), (192, 2, 100, 0.4, "GP"), (193, 2, 100, 0.4, "GP"),
                                                (255, 2, 80, 0.4, "PL"), (256, 2, 100, 1.0, "GP"), (257, 2, 60, 0.4, "GP"),
+                                               (300, 2, 70, 0.4, "PL"), (384, 2, 64, 1.0, "GP"), (385, 2, 60, 0.4, "GP"), (512, 2, 60, 0.4, "GP"), (513, 2, 50, 0.4, "GP"),
                                                # GT inputs: the genotype-class form of the same entry set (k_doublet_clsym)
                                                (2, 30, 300, 0.5, "GT"), (4, 30, 300, 0.5, "GT"), (7, 30, 300, 0.5, "GT"), (8, 30, 800, 0.3, "GT"),
                                                (13, 20, 500, 0.4, "GT"), (16, 20, 600, 1.0, "GT"), (24, 12, 300, 0.4, "GT"), (31, 12, 300, 0.4, "GT"),
@@ -541,9 +542,9 @@ def test_fast_mode_stays_within_tolerance(eng, oracle, V, B, S, delta, field):
     d_ref, d_strict = np.abs(grid - ref.llksAB)[np.broadcast_to(m, grid.shape)].max(), np.abs(grid - strict["grid"])[np.broadcast_to(m, grid.shape)].max()
     print(f"V={V} {field}: FAST vs reference {d_ref:.2e}, FAST vs STRICT {d_strict:.2e} (printed entries)")
     assert d_ref < TOL and d_strict < 1e-10
-    if not (field == "GT" and V > 64) and V <= 256:        # wide GT panels keep the (bit-identical) STRICT class kernel, V > 256 the generic one
+    if not (field == "GT" and V > 64) and V <= 512:        # wide GT panels keep the (bit-identical) STRICT class kernel, V > 512 the STRICT soft-field one
         assert not np.array_equal(grid, strict["grid"])    # it IS a different operation sequence: keep the two modes honest
-    if V <= 64 or (V <= 256 and field != "GT"):
+    if V <= 64 or (V <= 512 and field != "GT"):
         # alpha grid {0, 0.5}: one evaluation per unordered pair, mirrored; the never-printed [j][k != 0][0] hold [j][0][0]
         assert np.array_equal(grid[:, :, :, 1], grid[:, :, :, 1].transpose(0, 2, 1))
         assert np.array_equal(grid[:, :, :, 0], np.broadcast_to(grid[:, :, 0:1, 0], grid[:, :, :, 0].shape))
