@@ -78,6 +78,8 @@ constexpr int kTabAll = kTabK1 + 2 * kPair + 2 * kTriple;
 constexpr int kTabLogLo = kTabAll;                      // then dmx_log_dd's second-order table (128 doubles)
 constexpr int kTabLog2 = kTabAll + 128;                 // then dmx_log2's 256-bin {invc, logc} table (the doublet kernels' log, round 4)
 constexpr int kTabTotal = kTabLog2 + DMX_LOG2_TABLE_DOUBLES;
+// canonical-class log table (k_build_canon_logs): entries in the order of the final GL tables — one read (257, the last = no read) | two | three
+constexpr int64_t kCanL2 = 257, kCanL3 = 257 + 128 * 128, kCanN = kCanL3 + (int64_t)dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes;
 constexpr int kLut2 = 2 * 128;                           // the doublet kernels read mat | err/3 only (the third LUT part is the singlet kernels')
 constexpr int kTab2 = kLut2 + DMX_LOG2_TABLE_DOUBLES;   // a doublet kernel's LDS table: read LUT (2 KB) | dmx_log2 table (4 KB) = 1 KB more than
                                                         // rounds 1-3's 3 + 2 KB: k_doublet_a2<64,4> keeps its three workgroups per CU (3 x 53.4 KB)
@@ -528,12 +530,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
 // the llk0 term), parks those doubles in a per-lane LDS scratch, and for every sample k of the chunk copies
 // scratch[class id of (snp, k)] into the chain buffer — the very double k_singlet would have computed for sample k
 // (same operands, same operations), so the sums that follow are bit-identical.  4+1 logs per pair instead of V+1.
-template <int CW, int KC>
+// CAN (round 4; canonical GT classes, see k_canon_apply; launched with chk == 0 only): classes 0..2 are the three SNP-independent rows of a called
+// genotype, so log(GL . row) of a pair with up to three tabulated reads is an entry of ltab (k_build_canon_logs: the same expression, the same
+// log, evaluated once per read combination instead of once per pair) — three of the five dot products and logs of a pair become one gather,
+// requested a tile ahead with the GL seed.  Class 3 (the SNP's own row, where oth[snp] says there is one) and the llk0 term are evaluated as before.
+template <int CW, int KC, bool CAN = false>
 __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int nrd_width, const float* __restrict__ rows, int chk,
                                                              const uint32_t* __restrict__ idw, const double* __restrict__ gp0,
                                                              const double* __restrict__ tabs,
                                                              const int32_t* __restrict__ sched, int32_t V,
-                                                             double* __restrict__ llks, double* __restrict__ llk0s) {
+                                                             double* __restrict__ llks, double* __restrict__ llk0s,
+                                                             const double* __restrict__ ltab, const uint8_t* __restrict__ oth, double chi, double clo) {
   static_assert(KC == 8 || KC == 4, "a chunk's 2-bit class ids must sit inside one 32-bit id word");
   constexpr int ablate = DMX_ABLATE;             // profiling builds only (tools/build_variant.sh); 0 in the product
   constexpr int T = 64 / CW;
@@ -605,15 +612,42 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
     return h;
   };
 
+  // CAN: the pair's three canonical-class terms from ltab (has: the reads are inside the final tables, i.e. gl_seed's r0 >= n)
+  struct CanSeed { double l0, l1, l2; bool has; };
+  auto can_seed = [&](uint32_t n, uint32_t rd4) {
+    CanSeed c; c.l0 = c.l1 = c.l2 = 0.0; c.has = false;
+    if constexpr (CAN) {
+      const uint32_t b0 = rd4 & 0xFFu, b1 = (rd4 >> 8) & 0xFFu, b2 = (rd4 >> 16) & 0xFFu;
+      const uint32_t q0 = b0 & 127u, q1 = b1 & 127u, q2 = b2 & 127u;
+      const bool two = n == 2 && ((b0 | b1) & 0x40u) == 0;
+      const bool three = n == 3 && max(max(q0, q1), q2) < (uint32_t)dmx::kTripleBq;
+      const uint32_t i2 = ((((b0 & 0x80u) >> 1) | (b0 & 0x3Fu)) << 7) | (((b1 & 0x80u) >> 1) | (b1 & 0x3Fu));
+      const uint32_t c0 = ((b0 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q0, c1 = ((b1 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q1,
+                     c2 = ((b2 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q2;
+      const uint32_t i3 = __umul24(__umul24(c0, (uint32_t)dmx::kTripleCodes) + c1, (uint32_t)dmx::kTripleCodes) + c2;
+      uint32_t i = n == 0 ? 256u : b0;
+      i = two ? (uint32_t)kCanL2 + i2 : i;
+      i = three ? (uint32_t)kCanL3 + i3 : i;
+      c.has = n < 2 || two || three;
+      if (c.has) {
+        const double2 v = *reinterpret_cast<const double2*>(ltab + 4 * (size_t)i);
+        c.l0 = v.x; c.l1 = v.y; c.l2 = ltab[4 * (size_t)i + 2];
+      }
+    }
+    return c;
+  };
   Hdr h1 = prepare(issue(0));
   Hdr h2 = prepare(issue(1));
   Raw pre = issue(2);
   GlSeed s1 = gl_seed(tabs, h1.n, h1.rd4);
+  CanSeed c1 = can_seed(h1.n, h1.rd4);
   for (int64_t tile = 0; tile * T < max_np; ++tile) {
     const Hdr cur = h1;
     const GlSeed cs = s1;
+    const CanSeed cc = c1;
     h1 = h2;
     s1 = gl_seed(tabs, h1.n, h1.rd4);              // tile+1: its read bytes were requested an iteration ago
+    c1 = can_seed(h1.n, h1.rd4);
     h2 = prepare(pre);                             // tile+2: scan, request its read bytes
     pre = issue(tile + 3);                         // tile+3: header loads in flight
     const bool valid = tile * T + ti < np;
@@ -621,7 +655,10 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
     // class rows, llk0 row and the first id word of this lane's SNP (SNP-major: contiguous across a dense tile)
     const int32_t snp_l = (ablate & 256) ? (cur.snp & 63) : cur.snp;     // ablation: every row load an L1 hit
     const float4* rp = reinterpret_cast<const float4*>(rows + (size_t)snp_l * 12);
-    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+    float4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0, r2 = r0;
+    bool has_o = false;
+    if constexpr (CAN) { has_o = valid && oth[snp_l] != 0; if (has_o) r2 = rp[2]; }   // (class 3's row: r2.y, r2.z, r2.w)
+    else { r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; }
     const double* g0 = gp0 + (size_t)snp_l * 3;
     const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
     const uint32_t* idrow = idw + (size_t)snp_l * nwd;
@@ -629,6 +666,19 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
 
     double G0, G1, G2;                                                       // :427-452
     gl_finish(cs, (ablate & 1) ? min(cur.n, cs.r0) : cur.n, cur.rd4, pv.reads, cur.off, s_tab, G0, G1, G2);
+    if constexpr (CAN) {
+      if (valid) {
+        double t0 = cc.l0, t1 = cc.l1, t2 = cc.l2;
+        if (!cc.has) {                               // deeper pairs / base qualities beyond the tables: the expressions of k_build_canon_logs
+          t0 = dmx_log_fast(G0 * chi + G1 * clo + G2 * clo, s_log);
+          t1 = dmx_log_fast(G0 * clo + G1 * chi + G2 * clo, s_log);
+          t2 = dmx_log_fast(G0 * clo + G1 * clo + G2 * chi, s_log);
+        }
+        scr[0] = t0; scr[64] = t1; scr[128] = t2;
+        if (has_o) scr[192] = dmx_log_fast(G0 * (double)r2.y + G1 * (double)r2.z + G2 * (double)r2.w, s_log);   // class 3
+        term[(c * NC + KC) * TS + ti] = dmx_log_fast(G0 * q0 + G1 * q1 + G2 * q2, s_log);                         // llk0 (:459)
+      }
+    } else
     if (valid) {
       const double x0 = G0 * (double)r0.x + G1 * (double)r0.y + G2 * (double)r0.z;     // class 0   (:456)
       const double x1 = G0 * (double)r0.w + G1 * (double)r1.x + G2 * (double)r1.y;     // class 1
@@ -2509,6 +2559,97 @@ __global__ void k_build_classes(const float* __restrict__ g, int32_t S, int32_t 
     ro[d * 3] = c[e][0]; ro[d * 3 + 1] = c[e][1]; ro[d * 3 + 2] = c[e][2];
   }
   atomicMax(max_cls, over ? kMaxCls + 1 : n);
+}
+
+// ---- canonical GT classes (round 4) ----------------------------------------------------------------------------------------------
+// --field GT gives every called genotype one of THREE rows that do not depend on the SNP: 1 - gt_error in the genotype's place, gt_error / 2
+// in the other two (bcf_filtered_reader.cpp:397-400); only a missing genotype's Hardy-Weinberg row (:381-388) is the SNP's own.  When a
+// matrix has that shape the classes are relabelled: id t < 3 = the row with hi in place t, id 3 = the SNP's other row (at most one; the
+// slot repeats canonical row 0 where there is none, like k_build_classes' unused slots).  log(GL . row_t) of a pair then depends on the
+// pair's reads only, and K1 reads it from a table (k_build_canon_logs) next to the GL tables.
+__device__ __forceinline__ bool canon_pattern(uint32_t a, uint32_t b, uint32_t c, uint32_t* hi, uint32_t* lo) {
+  const float fa = __uint_as_float(a), fb = __uint_as_float(b), fc = __uint_as_float(c);
+  if (!(fa >= 0.f && fb >= 0.f && fc >= 0.f) || !(fa < 3e38f && fb < 3e38f && fc < 3e38f)) return false;
+  if (b == c && fa > fb) { *hi = a; *lo = b; return true; }
+  if (a == c && fb > fa) { *hi = b; *lo = a; return true; }
+  if (a == b && fc > fa) { *hi = c; *lo = a; return true; }
+  return false;
+}
+__device__ __forceinline__ int canon_type(const uint32_t* r, uint32_t hi, uint32_t lo) {
+  if (r[0] == hi && r[1] == lo && r[2] == lo) return 0;
+  if (r[0] == lo && r[1] == hi && r[2] == lo) return 1;
+  if (r[0] == lo && r[1] == lo && r[2] == hi) return 2;
+  return -1;
+}
+// the lowest SNP that has a row of the pattern (its first such class names hi and lo: deterministic)
+__global__ void k_find_canon(const float* __restrict__ rows, int32_t S, int32_t* __restrict__ first) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const uint32_t* r = reinterpret_cast<const uint32_t*>(rows + (size_t)s * kMaxCls * 3);
+  uint32_t hi, lo;
+  for (int d = 0; d < kMaxCls; ++d)
+    if (canon_pattern(r[d * 3], r[d * 3 + 1], r[d * 3 + 2], &hi, &lo)) { atomicMin(first, (int32_t)s); return; }
+}
+// fail: an SNP with two different non-canonical rows among its classes
+__global__ void k_canon_check(const float* __restrict__ rows, int32_t S, uint32_t hi, uint32_t lo, int32_t* __restrict__ fail) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const uint32_t* r = reinterpret_cast<const uint32_t*>(rows + (size_t)s * kMaxCls * 3);
+  int others = 0; uint32_t o[3] = {0, 0, 0};
+  for (int d = 0; d < kMaxCls; ++d) {
+    const uint32_t* q = r + d * 3;
+    if (canon_type(q, hi, lo) >= 0) continue;
+    if (others && o[0] == q[0] && o[1] == q[1] && o[2] == q[2]) continue;       // (an unused slot repeating class 0)
+    if (others) { atomicOr(fail, 1); return; }
+    o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; others = 1;
+  }
+}
+__global__ void k_canon_apply(float* __restrict__ rows, uint8_t* __restrict__ ids, uint32_t* __restrict__ idw, uint32_t* __restrict__ idd,
+                              int32_t S, int32_t V, int32_t nwd2, uint32_t hi, uint32_t lo, uint8_t* __restrict__ oth) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  uint32_t* r = reinterpret_cast<uint32_t*>(rows + (size_t)s * kMaxCls * 3);
+  uint32_t map[kMaxCls], o[3] = {hi, lo, lo};
+  bool has_other = false;
+  for (int d = 0; d < kMaxCls; ++d) {
+    const int t = canon_type(r + d * 3, hi, lo);
+    if (t >= 0) map[d] = (uint32_t)t;
+    else { map[d] = 3u; o[0] = r[d * 3]; o[1] = r[d * 3 + 1]; o[2] = r[d * 3 + 2]; has_other = true; }
+  }
+  bool used3 = false;
+  for (int32_t k = 0; k < V; ++k) {
+    const uint32_t id = map[ids[(size_t)s * V + k] & 3u];
+    used3 |= id == 3u;
+    ids[(size_t)s * V + k] = (uint8_t)id;
+  }
+  const int nwd = (V + 15) / 16;
+  for (int wq = 0; wq < nwd; ++wq) {
+    uint32_t wv = 0;
+    for (int b = 0; b < 16 && wq * 16 + b < V; ++b) wv |= (uint32_t)ids[(size_t)s * V + wq * 16 + b] << (2 * b);
+    idw[(size_t)s * nwd + wq] = wv;
+  }
+  for (int wq = 0; wq < nwd2; ++wq) {
+    uint32_t wv = 0;
+    int k = (16 * wq) % V;
+    for (int b = 0; b < 16; ++b) { wv |= (uint32_t)ids[(size_t)s * V + k] << (2 * b); k = (k + 1 == V) ? 0 : k + 1; }
+    idd[(size_t)s * nwd2 + wq] = wv;
+  }
+  r[0] = hi; r[1] = lo; r[2] = lo;  r[3] = lo; r[4] = hi; r[5] = lo;  r[6] = lo; r[7] = lo; r[8] = hi;
+  r[9] = o[0]; r[10] = o[1]; r[11] = o[2];
+  oth[s] = (has_other && used3) ? 1 : 0;
+}
+// ltab[i][t] = log(GL_i . canonical row t), i over the final GL tables: 257 one-read entries (256 = no read), 16 384 two-read, 96^3 three-read
+__global__ void k_build_canon_logs(const double* __restrict__ tabs, double hi, double lo, double* __restrict__ ltab) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kCanN) return;
+  const double* G = i < kCanL2 ? tabs + kTab + kFirst + 3 * i
+                  : (i < kCanL3 ? tabs + kTabK1 + kPair + 4 * (i - kCanL2) : tabs + kTabK1 + 2 * kPair + kTriple + 4 * (i - kCanL3));
+  const double G0 = G[0], G1 = G[1], G2 = G[2];
+  const double x0 = G0 * hi + G1 * lo + G2 * lo;      // the very expressions of k_singlet_cls on the canonical rows (:456)
+  const double x1 = G0 * lo + G1 * hi + G2 * lo;
+  const double x2 = G0 * lo + G1 * lo + G2 * hi;
+  const double* T = tabs + kLut;
+  ltab[4 * i] = dmx_log_fast(x0, T); ltab[4 * i + 1] = dmx_log_fast(x1, T); ltab[4 * i + 2] = dmx_log_fast(x2, T); ltab[4 * i + 3] = 0.0;
 }
 
 // base + byte BYTE of w in ONE VALU instruction (SDWA operand select; the compiler emits v_bfe_u32 + v_add for the same expression)
@@ -4444,6 +4585,10 @@ struct dmx_engine {
   int32_t* d_sched = nullptr; size_t sched_cap = 0;
   int32_t* d_bad = nullptr;                                          // set by k_check_snp_ids
   bool have_gT = false;                                              // d_gT / d_g0T hold the current genotype matrix
+  // canonical GT classes (round 4): every called genotype of a --field GT matrix is one of three SNP-independent rows (hi, lo, lo) permuted
+  // (bcf_filtered_reader.cpp:397-400); class ids are then 0 / 1 / 2 = that row with hi in place 0 / 1 / 2 and 3 = the SNP's one other row (a missing
+  // genotype's HWE row, :381-388), and K1 takes log(GL . row) of the three canonical rows from a table indexed like the GL tables (d_ltab)
+  bool canon = false, ltab_valid = false; float can_hi = 0.f, can_lo = 0.f; double* d_ltab = nullptr; uint8_t* d_oth = nullptr;
   double* d_park = nullptr; size_t park_cap = 0;   // k_certify's per-barcode state between the launches of its SNP-blocked walk
   int64_t* d_blk = nullptr; size_t blk_cap = 0; int32_t blk_shift = 0, blk_n = 0;   // k_snp_blocks table of the staged (sparse) pileup; blk_n = 0: none
   bool geno_safe = false;                                            // every genotype row finite, non-negative, max >= 2^-400 (k_check_geno)
@@ -4588,6 +4733,8 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_bad) (void)hipFree(e->d_bad);
   if (e->d_blk) (void)hipFree(e->d_blk);
   if (e->d_park) (void)hipFree(e->d_park);
+  if (e->d_ltab) (void)hipFree(e->d_ltab);
+  if (e->d_oth) (void)hipFree(e->d_oth);
   for (int i = 0; i < 2; ++i) { if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]); if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]); }
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& r : e->ring_s) for (hipEvent_t& ev : r) if (ev) (void)hipEventDestroy(ev);
@@ -4623,6 +4770,7 @@ extern "C" int dmx_engine_set_phred_tables(dmx_engine* e, const double mat[256],
   const dmx::TripleTables& tt = dmx::build_triple_tables(lut, *pt);
   HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair, tt.third.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair + kTriple, tt.final3.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
+  e->ltab_valid = false;                         // (the canonical-class log table is a function of these tables)
   return DMX_OK;
 }
 
@@ -4683,6 +4831,47 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     e->geno_safe = h_unsafe == 0 && !getenv("DMX_FORCE_CHECK");
     e->n_classes = (h_max >= 1 && h_max <= kMaxCls) ? h_max : 0;
     if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); (void)hipFree(e->d_idw); (void)hipFree(e->d_idd); e->d_rows = nullptr; e->d_ids = nullptr; e->d_idw = nullptr; e->d_idd = nullptr; }
+    // canonical GT classes (see k_canon_apply): relabel when the matrix has that shape
+    e->canon = false; e->ltab_valid = false;
+    if (e->d_oth) { (void)hipFree(e->d_oth); e->d_oth = nullptr; }
+    if (e->n_classes && !getenv("DMX_NO_CANON")) {
+      int32_t* d_w = nullptr;
+      HIP_TRY(hipMalloc((void**)&d_w, 2 * sizeof(int32_t)));
+      int32_t h_w[2] = {0x7FFFFFFF, 0};
+      HIP_TRY(hipMemcpyAsync(d_w, h_w, sizeof h_w, hipMemcpyHostToDevice, e->stream));
+      hipLaunchKernelGGL(k_find_canon, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_rows, n_snps, d_w);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(h_w, d_w, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      if (h_w[0] < n_snps) {
+        float r[kMaxCls * 3];
+        HIP_TRY(hipMemcpy(r, e->d_rows + (size_t)h_w[0] * kMaxCls * 3, sizeof r, hipMemcpyDeviceToHost));
+        float hi = 0.f, lo = 0.f; bool found = false;
+        for (int d = 0; d < kMaxCls && !found; ++d) {
+          const float a = r[d * 3], b = r[d * 3 + 1], c = r[d * 3 + 2];
+          uint32_t ua, ub, uc; std::memcpy(&ua, &a, 4); std::memcpy(&ub, &b, 4); std::memcpy(&uc, &c, 4);
+          if (!(a >= 0.f && b >= 0.f && c >= 0.f) || !(a < 3e38f && b < 3e38f && c < 3e38f)) continue;
+          if (ub == uc && a > b) { hi = a; lo = b; found = true; }
+          else if (ua == uc && b > a) { hi = b; lo = a; found = true; }
+          else if (ua == ub && c > a) { hi = c; lo = a; found = true; }
+        }
+        if (found) {
+          uint32_t uh, ul; std::memcpy(&uh, &hi, 4); std::memcpy(&ul, &lo, 4);
+          hipLaunchKernelGGL(k_canon_check, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_rows, n_snps, uh, ul, d_w + 1);
+          HIP_TRY(hipGetLastError());
+          HIP_TRY(hipMemcpyAsync(h_w + 1, d_w + 1, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+          HIP_TRY(hipStreamSynchronize(e->stream));
+          if (h_w[1] == 0) {
+            HIP_TRY(hipMalloc((void**)&e->d_oth, (size_t)n_snps + 16));
+            hipLaunchKernelGGL(k_canon_apply, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_rows, e->d_ids, e->d_idw,
+                               e->d_idd, n_snps, e->V, e->nwd2, uh, ul, e->d_oth);
+            HIP_TRY(hipGetLastError());
+            e->canon = true; e->can_hi = hi; e->can_lo = lo;
+          }
+        }
+      }
+      (void)hipFree(d_w);
+    }
   }
   HIP_TRY(hipStreamSynchronize(e->stream));   // the host buffer may go away after return
   return DMX_OK;
@@ -5020,11 +5209,23 @@ int launch_singlet(dmx_engine* e) {
     if (dynb <= 16 * 1024) {
       const dim3 blk(kThreads), grd((unsigned)((B + (kThreads / 64) * CW - 1) / ((kThreads / 64) * CW)));
       const int chk = e->geno_safe ? 0 : 1;       // (DMX_FORCE_CHECK=1 keeps the test: bit-identical, tests/test_gpu_parity.py)
-#define DMX_K1C(CC, KK) hipLaunchKernelGGL((k_singlet_cls<CC, KK>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, chk, \
-                                           e->d_idw, e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s)
+      // canonical GT classes: three of a pair's five log terms from the table (k_singlet_cls<.., CAN>; DMX_NO_CANON_K1=1: the plain class form)
+      const bool can = e->canon && chk == 0 && !getenv("DMX_NO_CANON_K1");
+      if (can && !e->ltab_valid) {
+        if (!e->d_ltab) HIP_TRY(hipMalloc((void**)&e->d_ltab, sizeof(double) * 4 * (size_t)kCanN));
+        hipLaunchKernelGGL(k_build_canon_logs, dim3((unsigned)((kCanN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, (double)e->can_hi,
+                           (double)e->can_lo, e->d_ltab);
+        HIP_TRY(hipGetLastError());
+        e->ltab_valid = true;
+      }
+#define DMX_K1C_(CC, KK, CAN_) hipLaunchKernelGGL((k_singlet_cls<CC, KK, CAN_>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, chk, \
+                                           e->d_idw, e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s, e->d_ltab, e->d_oth,           \
+                                           (double)e->can_hi, (double)e->can_lo)
+#define DMX_K1C(CC, KK) do { if (can) DMX_K1C_(CC, KK, true); else DMX_K1C_(CC, KK, false); } while (0)
       if (KC == 4) { if (CW == 4) DMX_K1C(4, 4); else if (CW == 2) DMX_K1C(2, 4); else DMX_K1C(1, 4); }
       else         { if (CW == 4) DMX_K1C(4, 8); else if (CW == 2) DMX_K1C(2, 8); else DMX_K1C(1, 8); }
 #undef DMX_K1C
+#undef DMX_K1C_
       return DMX_OK;
     }
   }

@@ -177,6 +177,12 @@ class Engine:
     def set_stream(self, hip_stream: int) -> None:
         check(self._L.dmx_engine_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def set_phred_tables(self, mat: np.ndarray, err: np.ndarray) -> None:
+        """dmx_engine_set_phred_tables: the engine's own match / error tables (256 doubles each) instead of PhredHelper's."""
+        m = np.ascontiguousarray(mat, dtype=np.float64); e = np.ascontiguousarray(err, dtype=np.float64)
+        assert m.shape == (256,) and e.shape == (256,)
+        check(self._L.dmx_engine_set_phred_tables(self._h, m.ctypes.data, e.ctypes.data))
+
     def set_genotypes(self, g: np.ndarray) -> None:
         g = np.ascontiguousarray(g, dtype=np.float32)
         if g.ndim != 3 or g.shape[1] != self.V or g.shape[2] != 3:

@@ -377,6 +377,99 @@ def test_genotype_class_kernel_is_bit_identical_to_the_general_one(eng, oracle, 
     assert np.abs(a["grid"] - ref.llksAB).max() < TOL and np.abs(a["llks"] - ref.llks).max() < TOL
 
 
+@pytest.mark.parametrize("V,missing,dense,err", [(8, 0.0, True, 0.01), (8, 0.15, True, 0.01), (3, 0.5, False, 0.01), (16, 0.05, False, 0.1),
+                                                 (19, 0.3, True, 0.001), (5, 1.0, False, 0.01), (8, 0.1, True, 0.0)])
+def test_canonical_gt_classes_are_bit_identical_to_the_plain_class_form(eng, oracle, V, missing, dense, err):
+    """Round 4: called genotypes of a --field GT matrix share three SNP-independent rows; the classes are relabelled to them
+    (k_canon_apply) and K1 reads log(GL . row) of those three from a table (k_singlet_cls<.., CAN>).  Same expression, same log:
+    every output must equal the plain class form's (DMX_NO_CANON=1) bit for bit — on pairs of 0..6 reads with base qualities over
+    the whole 0..127 range (the tables cover up to three reads of quality < 48 / two < 64; the rest is evaluated in the kernel),
+    with and without missing genotypes (the SNP's own fourth row), through K1, K2 and K3."""
+    import os
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(7100 + V + int(100 * missing))
+    S, B = 400, 24
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=missing)
+    g = np.stack([eng.geno_from_gt(raw.alleles[s], err) for s in range(S)])
+    if dense:
+        npair = np.full(B, S); pair_snp = None
+    else:
+        cov = rng.random((B, S)) < 0.3
+        npair = cov.sum(axis=1)
+        pair_snp = np.concatenate([np.nonzero(cov[c])[0] for c in range(B)]).astype(np.int32)
+    P = int(npair.sum())
+    nrd = rng.choice(np.arange(7), size=P, p=[0.05, 0.45, 0.2, 0.15, 0.05, 0.05, 0.05]).astype(np.uint8)
+    nr = int(nrd.sum())
+    bq = np.where(rng.random(nr) < 0.8, rng.integers(2, 45, size=nr), rng.integers(0, 128, size=nr)).astype(np.uint8)
+    reads = bq | (rng.integers(0, 2, size=nr).astype(np.uint8) << 7)
+    cpo = np.concatenate([[0], np.cumsum(npair)]).astype(np.int64)
+    cro = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(B), npair), weights=nrd, minlength=B))]).astype(np.int64)
+    z = np.zeros(B, dtype=np.int32)
+    pl = eng.HostPileup(B, S, cpo, cro, pair_snp, nrd, reads, z, z, z)
+    os.environ.pop("DMX_NO_CANON", None)
+    a = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    os.environ["DMX_NO_CANON"] = "1"
+    try:
+        b = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    finally:
+        os.environ.pop("DMX_NO_CANON", None)
+    for f in ("llks", "llk0s", "grid", "l00", "summ"):
+        assert np.array_equal(a[f], b[f]), f
+
+    class SP: pass
+    sp = SP(); sp.reads = reads; sp.pair_snp = pair_snp; sp.n_snps = S; sp.n_cells = B; sp.pair_nrd = nrd
+    sp.cell_pair_off = cpo; sp.rd_totl = sp.rd_pass = sp.rd_uniq = z
+    ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
+    d = max(np.abs(a["llks"] - ref.llks).max(), np.abs(a["llk0s"] - ref.llk0s).max(), np.abs(a["grid"] - ref.llksAB).max())
+    assert d < TOL
+
+
+def test_canonical_gt_classes_fall_back_on_matrices_of_another_shape(eng, oracle):
+    """A matrix whose SNPs carry two different non-canonical rows (two genotype-error rates mixed) keeps k_build_classes' labels and the
+    plain class kernels; a phred table change rebuilds the canonical-class log table."""
+    import os
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(7177)
+    S, V, B = 300, 6, 20
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=0.1)
+    g1 = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    g2 = np.stack([eng.geno_from_gt(raw.alleles[s], 0.05) for s in range(S)])
+    g = g1.copy(); g[:, ::2] = g2[:, ::2]                      # every other sample with another error rate: up to 6 rows per SNP -> no classes at all or two "others"
+    g3 = g1.copy(); g3[:, 0] = g2[:, 0]                        # one odd sample: <= 4 rows on many SNPs, two non-canonical ones wherever it sits beside a missing genotype
+    sp = synth.make_pileup(rng, np.where(raw.alleles < 0, 0, raw.alleles), B, 0.4, 1.5)
+    pl = host_pileup(eng, sp)
+    for gm in (g, g3):
+        os.environ.pop("DMX_NO_CLASSES", None)
+        a = run_engine(eng, pl, gm, (0.0, 0.5), 0.5)
+        os.environ["DMX_NO_CLASSES"] = "1"
+        try:
+            b = run_engine(eng, pl, gm, (0.0, 0.5), 0.5)
+        finally:
+            os.environ.pop("DMX_NO_CLASSES", None)
+        for f in ("llks", "llk0s", "grid", "l00", "summ"):
+            assert np.array_equal(a[f], b[f]), f
+    # new phred tables: the canonical-class log table follows them
+    e = eng.Engine(V, (0.0, 0.5), 0.5)
+    e.set_genotypes(g1); e.set_pileup(pl)
+    e.run_singlet(); first = e.get_singlet()
+    mat, errt = eng.phred_tables()
+    errt2 = errt.copy(); errt2[20:] *= 0.5
+    e.set_phred_tables(1.0 - errt2, errt2)
+    e.run_singlet(); second = e.get_singlet()
+    e.close()
+    os.environ["DMX_NO_CANON"] = "1"
+    try:
+        e = eng.Engine(V, (0.0, 0.5), 0.5)
+        e.set_genotypes(g1); e.set_pileup(pl)
+        e.set_phred_tables(1.0 - errt2, errt2)
+        e.run_singlet(); want = e.get_singlet()
+        e.close()
+    finally:
+        os.environ.pop("DMX_NO_CANON", None)
+    assert not np.array_equal(first[0], second[0])
+    assert np.array_equal(second[0], want[0]) and np.array_equal(second[1], want[1])
+
+
 def test_all_base_qualities_and_depths(eng, oracle):
     """Base qualities over the whole ABI range 0..127 (the first-read tables cover < 64, the rest takes the generic loop,
     q <= 1 has the 0.75 error floor of PhredHelper.cpp:30) and pair depths 0..6, dense and sparse layouts."""
