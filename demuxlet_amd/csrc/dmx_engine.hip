@@ -4295,14 +4295,35 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
 // after every read, finished (:656-663) and handed from the alpha = 0.5 lane to its alpha = 0 neighbour.  NV = 9: the nine
 // values pG[l][m]; NV = 5 (alpha[0] == 0): the five distinct values of alpha 0.5 (weight p = (l + m) / 4, index l + m) beside the
 // three of alpha 0 (p = l / 2) — entries with equal weights go through identical operations, so the values are bit-identical.
+// seeds (NV = 5, the default grid; round 4): the lane's five values after the pair's first read — or first two, both of base quality < 64 — come from a
+// table built on the device with this very loop (k_build_certify_seeds: [256 + 16 384 read codes][alpha lane][6]), and the loop starts at read 1 or 2:
+// at 1.25 reads per pair it used to run max(cnt) ~ 2.6 times per tile of 32 pairs with most lanes idle, now 0.6 times.
+constexpr int kCSeedStride = 6;                  // doubles per (entry, alpha lane): five values + pad (16-byte aligned loads)
+constexpr int64_t kCSeedN = 256 + 128 * 128;
 template <int NV>
 __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32_t cnt, int64_t off, uint32_t rd4, const double* s_tab,
-                                                    const double (&wA)[NV], const double (&wR)[NV], int n1, double (&v)[NV]) {
+                                                    const double (&wA)[NV], const double (&wR)[NV], int n1, double (&v)[NV],
+                                                    const double* __restrict__ cseed = nullptr) {
   double pG[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) pG[i] = 1.0;                               // :597
-  for (uint32_t r = 0; __any(r < cnt); ++r) {
-    const bool live = r < cnt;
+  uint32_t r_start = 0;
+  if (NV == 5 && cseed) {
+    if (cnt >= 1 && cnt <= kSafeReads) {
+      const uint32_t b0 = rd4 & 0xFFu, b1 = (rd4 >> 8) & 0xFFu;
+      const bool two = cnt >= 2 && ((b0 | b1) & 0x40u) == 0;
+      const uint32_t i2 = ((((b0 & 0x80u) >> 1) | (b0 & 0x3Fu)) << 7) | (((b1 & 0x80u) >> 1) | (b1 & 0x3Fu));
+      const double* sp = cseed + ((size_t)(two ? 256u + i2 : b0) * 2 + (size_t)n1) * kCSeedStride;
+      const double2 a = *reinterpret_cast<const double2*>(sp), b = *reinterpret_cast<const double2*>(sp + 2);
+      pG[0] = a.x; pG[1] = a.y; pG[2] = b.x; pG[3] = b.y; pG[NV - 1] = sp[4];
+      r_start = two ? 2u : 1u;
+    }
+  }
+  // first read any lane still has to apply (wave-uniform)
+  uint32_t r = 0;
+  if (NV == 5 && cseed) r = __any(r_start == 0 && cnt > 0) ? 0u : (__any(r_start <= 1 && cnt > 1) ? 1u : 2u);
+  for (; __any(r < cnt); ++r) {
+    const bool live = r >= r_start && r < cnt;
     const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
     const uint32_t bq = byte & 127u;
     const bool alt = (byte >> 7) != 0;
@@ -4351,6 +4372,48 @@ __device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32
   (void)n1;
 }
 
+// The seeds of certify_pair_values<5>: one thread per read code (256 one-read codes, then 128 x 128 two-read codes of base quality < 64) runs the
+// loop of :597-639 for BOTH alpha lanes (0 and 0.5: the maximum of :626-627 runs across them) — the same operations on the same operands as the
+// two lanes of k_certify, hence the same bits.
+__global__ void k_build_certify_seeds(const double* __restrict__ tabs, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kCSeedN) return;
+  uint32_t bytes[2]; int nb;
+  if (e < 256) { bytes[0] = (uint32_t)e; bytes[1] = 0; nb = 1; }
+  else {
+    const uint32_t i2 = (uint32_t)(e - 256), c0 = i2 >> 7, c1 = i2 & 127u;
+    bytes[0] = ((c0 & 0x40u) << 1) | (c0 & 0x3Fu); bytes[1] = ((c1 & 0x40u) << 1) | (c1 & 0x3Fu); nb = 2;
+  }
+  double wA[2][5], wR[2][5], pG[2][5];
+  for (int n1 = 0; n1 < 2; ++n1)
+    for (int q = 0; q < 5; ++q) {                  // the weights of k_certify's FIVE form
+      const int l = n1 ? (q > 2 ? 2 : q) : min(q, 2), m = n1 ? q - l : 0;
+      const double p = 0.5 * l + (m - l) * 0.5 * (n1 ? 0.5 : 0.0);
+      wA[n1][q] = p; wR[n1][q] = 1.0 - p; pG[n1][q] = 1.0;
+    }
+  for (int r = 0; r < nb; ++r) {
+    const uint32_t byte = bytes[r], bq = byte & 127u;
+    const bool alt = (byte >> 7) != 0;
+    const double pR = alt ? tabs[128 + bq] : tabs[bq];
+    const double pA = alt ? tabs[bq] : tabs[128 + bq];
+    double mx[2] = {0.0, 0.0};
+    for (int n1 = 0; n1 < 2; ++n1)
+      for (int i = 0; i < 5; ++i) {
+        pG[n1][i] *= (pR * wR[n1][i] + pA * wA[n1][i]);
+        mx[n1] = fmax(mx[n1], pG[n1][i]);
+      }
+    const double m = fmax(mx[0], mx[1]);
+    const double y = rcp_refined(m);
+    for (int n1 = 0; n1 < 2; ++n1)
+      for (int i = 0; i < 5; ++i) pG[n1][i] = div_by(pG[n1][i], m, y);
+  }
+  for (int n1 = 0; n1 < 2; ++n1) {
+    double* o = out + ((size_t)e * 2 + n1) * kCSeedStride;
+    for (int i = 0; i < 5; ++i) o[i] = pG[n1][i];
+    o[5] = 0.0;
+  }
+}
+
 // K3b — the tie-order certificate (DESIGN.md "Ties").  At alpha = 0.5 the reference's llksAB[j][k] and llksAB[k][j] are one number
 // mathematically and differ by the rounding noise of its own evaluation order; its strict-< scan then names the doublet
 // "a-b" or "b-a" by that noise.  To print the same order one has to know BOTH accumulators as the reference computes them, bit for
@@ -4367,7 +4430,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
                                                       const float* __restrict__ gT,
                                                       const double* __restrict__ tabs, const double* __restrict__ alpha,
                                                       int32_t V, dmx_cell_summary* __restrict__ summ,
-                                                      const int64_t* __restrict__ blk, int32_t blk_i, int32_t nblk, double* __restrict__ park) {
+                                                      const int64_t* __restrict__ blk, int32_t blk_i, int32_t nblk, double* __restrict__ park,
+                                                      const double* __restrict__ cseed) {
   // blk != nullptr (round 4): this launch covers SNP block blk_i of nblk only — sparse pileups whose genotype matrix does not fit an XCD's L2
   // gather two pieces of a V*12-byte row per pair, and walking the SNP axis block by block (launch_certify; the table is k_snp_blocks',
   // shared with sparse K1) keeps the rows a launch touches L2-resident.  Between launches a barcode's state — the four chains, the open
@@ -4463,7 +4527,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
       double v[9];                                 // pG[1][l][m] of the pair (five: v[l + m])
       if constexpr (five) {
         double v5[5];
-        certify_pair_values<5>(pv, cnt, off, rd4, s_tab, wA5, wR5, n1, v5);
+        certify_pair_values<5>(pv, cnt, off, rd4, s_tab, wA5, wR5, n1, v5, cseed);
 #pragma unroll
         for (int l = 0; l < 3; ++l)
 #pragma unroll
@@ -4589,6 +4653,7 @@ struct dmx_engine {
   // (bcf_filtered_reader.cpp:397-400); class ids are then 0 / 1 / 2 = that row with hi in place 0 / 1 / 2 and 3 = the SNP's one other row (a missing
   // genotype's HWE row, :381-388), and K1 takes log(GL . row) of the three canonical rows from a table indexed like the GL tables (d_ltab)
   bool canon = false, ltab_valid = false; float can_hi = 0.f, can_lo = 0.f; double* d_ltab = nullptr; uint8_t* d_oth = nullptr;
+  double* d_cseed = nullptr; bool cseed_valid = false;   // certify_pair_values' seeds (k_build_certify_seeds; a function of the phred tables)
   double* d_park = nullptr; size_t park_cap = 0;   // k_certify's per-barcode state between the launches of its SNP-blocked walk
   int64_t* d_blk = nullptr; size_t blk_cap = 0; int32_t blk_shift = 0, blk_n = 0;   // k_snp_blocks table of the staged (sparse) pileup; blk_n = 0: none
   bool geno_safe = false;                                            // every genotype row finite, non-negative, max >= 2^-400 (k_check_geno)
@@ -4733,6 +4798,7 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_bad) (void)hipFree(e->d_bad);
   if (e->d_blk) (void)hipFree(e->d_blk);
   if (e->d_park) (void)hipFree(e->d_park);
+  if (e->d_cseed) (void)hipFree(e->d_cseed);
   if (e->d_ltab) (void)hipFree(e->d_ltab);
   if (e->d_oth) (void)hipFree(e->d_oth);
   for (int i = 0; i < 2; ++i) { if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]); if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]); }
@@ -4770,7 +4836,7 @@ extern "C" int dmx_engine_set_phred_tables(dmx_engine* e, const double mat[256],
   const dmx::TripleTables& tt = dmx::build_triple_tables(lut, *pt);
   HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair, tt.third.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair + kTriple, tt.final3.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
-  e->ltab_valid = false;                         // (the canonical-class log table is a function of these tables)
+  e->ltab_valid = false; e->cseed_valid = false;   // (the canonical-class log table and k_certify's seeds are functions of these tables)
   return DMX_OK;
 }
 
@@ -5656,8 +5722,18 @@ int launch_certify(dmx_engine* e) {
 #define DMX_K3B(MINW_, FIVE_, DENSE_)                                                                                  \
   for (int bi = 0; bi < n_launch; ++bi)                                                                                 \
     hipLaunchKernelGGL((k_certify<MINW_, FIVE_, DENSE_>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, \
-                       e->d_lut, e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park)
+                       e->d_lut, e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park, cseed)
   const bool five = e->alpha[0] == 0.0;
+  const double* cseed = nullptr;                  // the first one or two reads of a pair from a table (DMX_CERTIFY_NO_SEEDS=1: the whole loop)
+  if (five && !getenv("DMX_CERTIFY_NO_SEEDS")) {
+    if (!e->cseed_valid) {
+      if (!e->d_cseed) HIP_TRY(hipMalloc((void**)&e->d_cseed, sizeof(double) * 2 * kCSeedStride * (size_t)kCSeedN));
+      hipLaunchKernelGGL(k_build_certify_seeds, dim3((unsigned)((kCSeedN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, e->d_cseed);
+      HIP_TRY(hipGetLastError());
+      e->cseed_valid = true;
+    }
+    cseed = e->d_cseed;
+  }
   if (getenv("DMX_CERTIFY_MINW3")) { if (gT) DMX_K3B(3, false, true); else DMX_K3B(3, false, false); }      // kernel experiments only
   else if (gT) { if (five) DMX_K3B(4, true, true); else DMX_K3B(4, false, true); }
   else { if (five) DMX_K3B(4, true, false); else DMX_K3B(4, false, false); }

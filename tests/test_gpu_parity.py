@@ -470,6 +470,51 @@ def test_canonical_gt_classes_fall_back_on_matrices_of_another_shape(eng, oracle
     assert np.array_equal(second[0], want[0]) and np.array_equal(second[1], want[1])
 
 
+@pytest.mark.parametrize("V,field,dense", [(8, "GT", True), (32, "GP", True), (16, "PL", False), (40, "GT", False)])
+def test_certify_seed_tables_leave_every_record_unchanged(eng, V, field, dense):
+    """Round 4: k_certify takes the state after a pair's first one or two reads from a device-built table (k_build_certify_seeds) instead of
+    running the read loop from the start.  Same operations on the same operands: every per-barcode record (certificates, bracket values,
+    event words, flags) must equal the table-free walk's (DMX_CERTIFY_NO_SEEDS=1) bit for bit — pairs of 0..6 reads (deep ones: the slow
+    division), base qualities over the whole range (>= 64: outside the two-read table)."""
+    import os
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(8300 + V)
+    S, B = 500, 40
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=0.05 if field == "GT" else 0.0)
+    if field == "GT":
+        g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    elif field == "GP":
+        g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, np.where(raw.alleles < 0, 0, raw.alleles))])
+    else:
+        g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, np.where(raw.alleles < 0, 0, raw.alleles))])
+    if dense:
+        npair = np.full(B, S); pair_snp = None
+    else:
+        cov = rng.random((B, S)) < 0.3
+        npair = cov.sum(axis=1)
+        pair_snp = np.concatenate([np.nonzero(cov[c])[0] for c in range(B)]).astype(np.int32)
+    P = int(npair.sum())
+    nrd = rng.choice(np.arange(7), size=P, p=[0.05, 0.5, 0.25, 0.1, 0.04, 0.03, 0.03]).astype(np.uint8)
+    nrd[rng.random(P) < 0.002] = 20                                       # beyond kSafeReads: no seed, the plain division
+    nr = int(nrd.sum())
+    bq = np.where(rng.random(nr) < 0.85, rng.integers(2, 45, size=nr), rng.integers(0, 128, size=nr)).astype(np.uint8)
+    reads = bq | (rng.integers(0, 2, size=nr).astype(np.uint8) << 7)
+    cpo = np.concatenate([[0], np.cumsum(npair)]).astype(np.int64)
+    cro = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(B), npair), weights=nrd, minlength=B))]).astype(np.int64)
+    z = np.zeros(B, dtype=np.int32)
+    pl = eng.HostPileup(B, S, cpo, cro, pair_snp, nrd, reads, z, z, z)
+    os.environ.pop("DMX_CERTIFY_NO_SEEDS", None)
+    a = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    os.environ["DMX_CERTIFY_NO_SEEDS"] = "1"
+    try:
+        b = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    finally:
+        os.environ.pop("DMX_CERTIFY_NO_SEEDS", None)
+    from demuxlet_amd import capi
+    assert ((a["summ"]["flags"] & (capi.DMX_CELL_ORDER_CERTIFIED | capi.DMX_CELL_ORDER_RESOLVABLE)) != 0).sum() > B // 4
+    assert a["summ"].tobytes() == b["summ"].tobytes()
+
+
 def test_all_base_qualities_and_depths(eng, oracle):
     """Base qualities over the whole ABI range 0..127 (the first-read tables cover < 64, the rest takes the generic loop,
     q <= 1 has the 0.75 error floor of PhredHelper.cpp:30) and pair depths 0..6, dense and sparse layouts."""
