@@ -9,7 +9,7 @@ import sys
 
 rows = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
-    name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").split("(")[0]
+    name = r["Kernel_Name"].replace("void ", "", 1).replace("(anonymous namespace)::", "", 1).split("(")[0]     # (k_reduce is not a template: no leading "void")
     if not name.startswith("k_"):
         continue
     grid = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) * int(r.get("Grid_Size_Y", 1) or 1)
