@@ -19,7 +19,7 @@ DMX_ERR_ARG, DMX_ERR_HIP, DMX_ERR_STATE, DMX_ERR_IO, DMX_ERR_NOGPU, DMX_ERR_NOME
 DMX_MEM_HOST, DMX_MEM_DEVICE = 0, 1
 DMX_MODE_STRICT = 0
 DMX_MODE_FAST = 1
-DMX_CELL_NEAR_DOUBLET, DMX_CELL_NEAR_SINGLET, DMX_CELL_ORDER_CERTIFIED, DMX_CELL_ORDER_RESOLVABLE = 1, 2, 4, 8
+DMX_CELL_NEAR_DOUBLET, DMX_CELL_NEAR_SINGLET, DMX_CELL_ORDER_CERTIFIED, DMX_CELL_ORDER_RESOLVABLE, DMX_CELL_NEAR_RULE = 1, 2, 4, 8, 16
 DMX_ENGINE_NO_CERTIFY = 1
 
 # every symbol include/dmx.h declares (tests/test_abi.py checks the header against this list and the .so against both)
@@ -32,7 +32,7 @@ SYMBOLS = [
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
     "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_log2", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_engine_get_cell_grids", "dmx_write_doublet_summary", "dmx_debug_log_dd",
-    "dmx_resolve_tie_order", "dmx_engine_mean_kernel_times", "dmx_store_add_batch",
+    "dmx_resolve_tie_order", "dmx_engine_mean_kernel_times", "dmx_store_add_batch", "dmx_write_doublet_summary_grids", "dmx_engine_kernel_names",
 ]
 
 
@@ -86,6 +86,10 @@ class KernelTimeMeans(C.Structure):
                 ("n_singlet", C.c_int32), ("n_doublet", C.c_int32)]
 
 
+class KernelNames(C.Structure):
+    _fields_ = [("singlet", C.c_char * 96), ("doublet", C.c_char * 96), ("certify", C.c_char * 96), ("k1_placement", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
 class KernelBytes(C.Structure):
     _fields_ = [("singlet_bytes", C.c_double), ("doublet_bytes", C.c_double), ("reduce_bytes", C.c_double)]
 
@@ -96,7 +100,7 @@ class FinalInput(C.Structure):
                 ("write_pair", C.c_int32), ("barcodes", C.c_void_p), ("sample_ids", C.c_void_p),
                 ("rd_totl", C.c_void_p), ("rd_pass", C.c_void_p), ("rd_uniq", C.c_void_p), ("n_snp", C.c_void_p),
                 ("llks", C.c_void_p), ("llk0s", C.c_void_p), ("llksAB", C.c_void_p), ("llks00", C.c_void_p),
-                ("tie_pileup", C.c_void_p), ("tie_g", C.c_void_p), ("tie_tol", C.c_double), ("cell_grid", C.c_void_p)]
+                ("tie_pileup", C.c_void_p), ("tie_g", C.c_void_p), ("tie_tol", C.c_double)]
 
 
 class Job(C.Structure):
@@ -154,6 +158,8 @@ def load() -> C.CDLL:
         "dmx_resolve_tie_order": [vp, C.c_int64],
         "dmx_engine_mean_kernel_times": [vp, i32, vp],
         "dmx_store_add_batch": [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, i32],
+        "dmx_write_doublet_summary_grids": [vp, vp, vp, vp, C.c_char_p],
+        "dmx_engine_kernel_names": [vp, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)

@@ -27,11 +27,14 @@
 #include <functional>
 #include <thread>
 #include <type_traits>
+#include <unordered_map>
+#include <cxxabi.h>
 #include <string>
 #include <numeric>
 #include <vector>
 
 #include "dmx_internal.hpp"
+extern char** environ;
 #include "dmx_log.hpp"
 
 using dmx::set_error;
@@ -4285,6 +4288,13 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
     r.llk1 = hasb ? G[(size_t)jb * V * A] : kNaN; r.llk2 = hasb ? G[(size_t)kb * V * A] : kNaN;
     r.llk10 = hasb ? G[(size_t)jb * V * A + nb] : kNaN; r.llk20 = hasb ? G[(size_t)kb * V * A + nb] : kNaN;    // :824-825
     r.llk00_0 = l00[(size_t)cell * A]; r.llk00_best = l00[(size_t)cell * A + nb];
+    // (6) the BEST rule's own comparisons (:837,:844) with a margin below 1e-7: the writers re-evaluate the entries involved (dmx::near_rule)
+    if (hasb && has1 && i2 >= 0) {
+      const double tol = 1e-7, s1 = r.sing_llk1, s2 = r.sing_llk2;
+      if (fabs(r.llk12 - (s1 + 2)) < tol || fabs(s1 - (s2 + 2)) < tol ||
+          ((fabs(r.llk12 - r.llk1) < tol || fabs(r.llk12 - r.llk2) < tol) && r.llk12 > s1 + 2 - tol))
+        flags |= DMX_CELL_NEAR_RULE;
+    }
     r.n_pairs = npairs; r.flags = flags; r.reserved = 0; r.llk_ab = 0.0; r.llk_ba = 0.0;
     r.llk_ab_alt = 0.0; r.llk_ba_alt = 0.0; r.ev_x_ab = 0.0; r.ev_t_ab = 0.0; r.ev_x_ba = 0.0; r.ev_t_ba = 0.0;
     out[cell] = r;
@@ -4671,6 +4681,13 @@ struct dmx_engine {
   hipEvent_t ring_s[kRing][2] = {}, ring_d[kRing][4] = {};
   int64_t n_ring_s = 0, n_ring_d = 0; bool ring_certified[kRing] = {};
   bool timed[4] = {false, false, false, false};
+  // Experiment switches.  The DMX_* variables that steer kernel selection — kernel experiments, the tests' forced
+  // launch geometries — are copied ONCE, at dmx_engine_create, and only when DMX_EXPERIMENTS=1 is in the environment: a stray DMX_*
+  // variable in a user's shell never changes which kernel runs, and no launch reads the environment.
+  std::unordered_map<std::string, std::string> knobs;
+  const char* knob(const char* name) const { if (knobs.empty()) return nullptr; auto it = knobs.find(name); return it == knobs.end() ? nullptr : it->second.c_str(); }
+  // what the last run launched (dmx_engine_kernel_names): host function pointers of the K1 / K2 / K3b kernels, and where K1 ran
+  const void *k1_fn = nullptr, *k2_fn = nullptr, *k3b_fn = nullptr; int32_t k1_placement = 0;
 };
 
 namespace {
@@ -4755,6 +4772,9 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   if (!e) return set_error(DMX_ERR_NOMEM, "dmx_engine_create: out of memory");
   e->V = cfg->n_samples; e->A = cfg->n_alpha; e->device = cfg->device; e->mode = cfg->mode; e->prior = cfg->doublet_prior;
   e->alpha.assign(cfg->alpha, cfg->alpha + cfg->n_alpha);
+  if (const char* x = getenv("DMX_EXPERIMENTS")) if (x[0] == '1' && !x[1])
+    for (char** ev = environ; ev && *ev; ++ev)
+      if (!std::strncmp(*ev, "DMX_", 4)) if (const char* eq = std::strchr(*ev, '=')) e->knobs.emplace(std::string((const char*)*ev, (size_t)(eq - *ev)), std::string(eq + 1));
   HIP_TRY(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   e->stream = e->own_stream;
   {
@@ -4771,7 +4791,7 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabLogLo, dmx_log_table_lo_host, sizeof(double) * 128, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabLog2, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
-  e->certify = !(cfg->flags & DMX_ENGINE_NO_CERTIFY) && !getenv("DMX_NO_CERTIFY") && dmx::libm_log_within_brackets();
+  e->certify = !(cfg->flags & DMX_ENGINE_NO_CERTIFY) && !e->knob("DMX_NO_CERTIFY") && dmx::libm_log_within_brackets();
   HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
   HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
   double mat[256], err[256];
@@ -4894,13 +4914,13 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     HIP_TRY(hipMemcpyAsync(&h_unsafe, d_unsafe, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     (void)hipFree(d_max); (void)hipFree(d_unsafe);
-    e->geno_safe = h_unsafe == 0 && !getenv("DMX_FORCE_CHECK");
+    e->geno_safe = h_unsafe == 0 && !e->knob("DMX_FORCE_CHECK");
     e->n_classes = (h_max >= 1 && h_max <= kMaxCls) ? h_max : 0;
     if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); (void)hipFree(e->d_idw); (void)hipFree(e->d_idd); e->d_rows = nullptr; e->d_ids = nullptr; e->d_idw = nullptr; e->d_idd = nullptr; }
     // canonical GT classes (see k_canon_apply): relabel when the matrix has that shape
     e->canon = false; e->ltab_valid = false;
     if (e->d_oth) { (void)hipFree(e->d_oth); e->d_oth = nullptr; }
-    if (e->n_classes && !getenv("DMX_NO_CANON")) {
+    if (e->n_classes && !e->knob("DMX_NO_CANON")) {
       int32_t* d_w = nullptr;
       HIP_TRY(hipMalloc((void**)&d_w, 2 * sizeof(int32_t)));
       int32_t h_w[2] = {0x7FFFFFFF, 0};
@@ -5214,10 +5234,10 @@ int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int3
   }
   // sparse pileups over a genotype matrix that does not fit the L2: the SNP-block table of the blocked K1 walk (launch_singlet)
   e->blk_n = 0;
-  if (e->pv.pair_snp && e->P > 0 && e->S > 0 && !getenv("DMX_K1_NO_BLOCKS")) {
+  if (e->pv.pair_snp && e->P > 0 && e->S > 0 && !e->knob("DMX_K1_NO_BLOCKS")) {
     const double row_bytes = (double)e->V * 12.0 + 24.0;
     double target = 2.0 * 1024 * 1024;                                  // bytes of genotype rows per block
-    const char* env = getenv("DMX_K1_BLOCK_BYTES");                     // tests / kernel experiments: any block size, no size heuristics
+    const char* env = e->knob("DMX_K1_BLOCK_BYTES");                     // tests / kernel experiments: any block size, no size heuristics
     if (env) target = atof(env);
     int shift = 0;
     while (shift < 30 && (double)(2ll << shift) * row_bytes <= target) ++shift;
@@ -5244,24 +5264,29 @@ int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int3
 
 namespace {
 
+// Every K1 / K2 / K3b launch goes through these: the engine remembers WHICH kernel it launched (dmx_engine_kernel_names), so that nothing
+// outside launch_singlet / launch_doublet / launch_certify re-derives their selection (bench.py pairs its counter files with it).
+#define DMX_LAUNCH(SLOT, K, ...) do { e->SLOT = reinterpret_cast<const void*>(&K); hipLaunchKernelGGL(K, __VA_ARGS__); } while (0)
+#define DMX_LAUNCH_IF(COND, SLOT, K, ...) do { if (COND) e->SLOT = reinterpret_cast<const void*>(&K); hipLaunchKernelGGL(K, __VA_ARGS__); } while (0)
+
 int launch_singlet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V;
   // cells per wavefront: more cells amortise the ordered sums, fewer keep >= ~4 wavefronts per SIMD in flight (1024 SIMDs)
   int CW = (B >= 64 * 1024) ? 4 : (B >= 24 * 1024 ? 2 : 1);
   const int KC = (V <= 4) ? 4 : 8;
-  if (const char* cenv = getenv("DMX_K1_CW")) CW = atoi(cenv);     // kernel experiments only
-  if (e->n_classes > 0 && !getenv("DMX_NO_CLASSES") && !getenv("DMX_NO_K1_CLASSES")) {
+  if (const char* cenv = e->knob("DMX_K1_CW")) CW = atoi(cenv);     // kernel experiments only
+  if (e->n_classes > 0 && !e->knob("DMX_NO_CLASSES") && !e->knob("DMX_NO_K1_CLASSES")) {
     // --field GT inputs: log() once per genotype class instead of once per sample (bit-identical, see k_singlet_cls)
-    const int wide_v = getenv("DMX_K1_WIDE_V") ? atoi(getenv("DMX_K1_WIDE_V")) : 20;      // kernel experiments only
+    const int wide_v = e->knob("DMX_K1_WIDE_V") ? atoi(e->knob("DMX_K1_WIDE_V")) : 20;      // kernel experiments only
     if (V >= wide_v && V <= 1024) {              // wide panels: chains look the class terms up themselves, one pass per tile
       const size_t dynw = (size_t)(kThreads / 64) * 64 * ((V + 15) / 16) * sizeof(uint32_t);
-      const bool l0m = V % 64 == 0 && !getenv("DMX_K1W_NO_L0M");     // llk0 merged into the first pass instead of a pass of its own (k_singlet_clsw)
+      const bool l0m = V % 64 == 0 && !e->knob("DMX_K1W_NO_L0M");     // llk0 merged into the first pass instead of a pass of its own (k_singlet_clsw)
       const dim3 blkw(kThreads), grdw((unsigned)((B + (kThreads / 64) - 1) / (kThreads / 64)), (unsigned)((V + (l0m ? 0 : 1) + 255) / 256));
 #define DMX_K1W(...) do {                                                                                                          \
       if (dynw > 30 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_singlet_clsw<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynw)); \
-      hipLaunchKernelGGL((k_singlet_clsw<__VA_ARGS__>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,    \
+      DMX_LAUNCH(k1_fn, (k_singlet_clsw<__VA_ARGS__>), grdw, blkw, dynw, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_idw, e->d_gp0,    \
                          e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s); } while (0)
-      if (getenv("DMX_K1W_MINW3")) { if (l0m) DMX_K1W(1, 3, true); else DMX_K1W(1, 3, false); }              // kernel experiments only
+      if (e->knob("DMX_K1W_MINW3")) { if (l0m) DMX_K1W(1, 3, true); else DMX_K1W(1, 3, false); }              // kernel experiments only
       else if (l0m) DMX_K1W(1, 4, true);
       else DMX_K1W(1, 4, false);
 #undef DMX_K1W
@@ -5269,14 +5294,14 @@ int launch_singlet(dmx_engine* e) {
     }
     // measured on cfg2-shaped inputs (profiles/): CW 2 wins from 10 k barcodes (6.90 vs 7.14 ms; 5 k: 5.07 vs 3.94), CW 4 still
     // loses at 40 k (27.7 vs 24.6 ms)
-    if (!getenv("DMX_K1_CW")) CW = (B >= 128 * 1024) ? 4 : (B >= 10000 ? 2 : 1);
+    if (!e->knob("DMX_K1_CW")) CW = (B >= 128 * 1024) ? 4 : (B >= 10000 ? 2 : 1);
     const int nchc = (V + KC - 1) / KC;
     const size_t dynb = sizeof(double) * (size_t)(kThreads / 64) * nchc * CW * (KC + 1);
     if (dynb <= 16 * 1024) {
       const dim3 blk(kThreads), grd((unsigned)((B + (kThreads / 64) * CW - 1) / ((kThreads / 64) * CW)));
       const int chk = e->geno_safe ? 0 : 1;       // (DMX_FORCE_CHECK=1 keeps the test: bit-identical, tests/test_gpu_parity.py)
       // canonical GT classes: three of a pair's five log terms from the table (k_singlet_cls<.., CAN>; DMX_NO_CANON_K1=1: the plain class form)
-      const bool can = e->canon && chk == 0 && !getenv("DMX_NO_CANON_K1");
+      const bool can = e->canon && chk == 0 && !e->knob("DMX_NO_CANON_K1");
       if (can && !e->ltab_valid) {
         if (!e->d_ltab) HIP_TRY(hipMalloc((void**)&e->d_ltab, sizeof(double) * 4 * (size_t)kCanN));
         hipLaunchKernelGGL(k_build_canon_logs, dim3((unsigned)((kCanN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, (double)e->can_hi,
@@ -5284,7 +5309,7 @@ int launch_singlet(dmx_engine* e) {
         HIP_TRY(hipGetLastError());
         e->ltab_valid = true;
       }
-#define DMX_K1C_(CC, KK, CAN_) hipLaunchKernelGGL((k_singlet_cls<CC, KK, CAN_>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, chk, \
+#define DMX_K1C_(CC, KK, CAN_) DMX_LAUNCH(k1_fn, (k_singlet_cls<CC, KK, CAN_>), grd, blk, dynb, e->stream, e->pv, e->nrd_width, e->d_rows, chk, \
                                            e->d_idw, e->d_gp0, e->d_lut, e->d_sched, V, e->d_llks, e->d_llk0s, e->d_ltab, e->d_oth,           \
                                            (double)e->can_hi, (double)e->can_lo)
 #define DMX_K1C(CC, KK) do { if (can) DMX_K1C_(CC, KK, true); else DMX_K1C_(CC, KK, false); } while (0)
@@ -5313,7 +5338,7 @@ int launch_singlet(dmx_engine* e) {
   const int n_launch = blk ? e->blk_n : 1;
 #define DMX_K1(CC, KK, DD)                                                                                            \
   for (int bi_ = 0; bi_ < n_launch; ++bi_)                                                                             \
-    hipLaunchKernelGGL((k_singlet<CC, KK, DD>), grid, block, dyn, e->stream, e->pv, e->nrd_width, gq, g0q, e->d_lut,   \
+    DMX_LAUNCH(k1_fn, (k_singlet<CC, KK, DD>), grid, block, dyn, e->stream, e->pv, e->nrd_width, gq, g0q, e->d_lut,   \
                        e->d_sched, V, QS, e->d_llks, e->d_llk0s, blk, bi_, e->blk_n)
 #define DMX_K1_D(CC, KK) do { if (dense) DMX_K1(CC, KK, true); else DMX_K1(CC, KK, false); } while (0)
   if (KC == 4) { if (CW == 4) DMX_K1_D(4, 4); else if (CW == 2) DMX_K1_D(2, 4); else DMX_K1_D(1, 4); }
@@ -5338,7 +5363,7 @@ int launch_doublet_generic(dmx_engine* e) {
   // the fix-up pass strides a fixed grid over the cells (see the kernel); the first pass has one workgroup per cell
   const dim3 grid(FIXUP ? (unsigned)std::min(B, 256) : (unsigned)B, slabs), block(kThreads);
 #define DMX_K2(NN)                                                                                                   \
-  hipLaunchKernelGGL((k_doublet_generic<NRD, NN, FIXUP>), grid, block, 0, e->stream, e->pv, e->d_g, e->d_gp0, e->d_lut, \
+  DMX_LAUNCH_IF(!FIXUP, k2_fn, (k_doublet_generic<NRD, NN, FIXUP>), grid, block, 0, e->stream, e->pv, e->d_g, e->d_gp0, e->d_lut, \
                      e->d_alpha, e->d_sched, V, A, A_pad, TP, e->d_grid, e->d_l00, e->d_flag)
   if (per <= 1) DMX_K2(1);
   else if (per <= 2) DMX_K2(2);
@@ -5361,8 +5386,8 @@ int launch_doublet_generic_w(dmx_engine* e) {
 // The A = 2 kernel with its fix-up pass; other alpha grids (or V > 64) take the generic kernel.
 int launch_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
-  const bool force_generic = getenv("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
-  const bool use_cls = e->n_classes > 0 && !getenv("DMX_NO_CLASSES");
+  const bool force_generic = e->knob("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
+  const bool use_cls = e->n_classes > 0 && !e->knob("DMX_NO_CLASSES");
   if (A >= 3 && A <= 8 && use_cls && V <= 1024 && !force_generic) {
     // GT inputs, longer alpha grids: the class kernel with AP alphas per pair.  One cell per workgroup (the class table is
     // 4 x 4 x AP doubles per pair: 16-32 KB a tile); the k-block width follows the panel.
@@ -5376,7 +5401,7 @@ int launch_doublet(dmx_engine* e) {
   do {                                                                                                                 \
     if (cb > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_clsn<256, NK, APP>),       \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb));              \
-    hipLaunchKernelGGL((k_doublet_clsn<256, NK, APP>), dim3((unsigned)B, slabs(256, NK)), dim3(kThreads), cb, e->stream, \
+    DMX_LAUNCH(k2_fn, (k_doublet_clsn<256, NK, APP>), dim3((unsigned)B, slabs(256, NK)), dim3(kThreads), cb, e->stream, \
                        e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, A, VS,   \
                        e->d_grid, e->d_l00, e->d_flag);                                                                  \
   } while (0)
@@ -5387,7 +5412,7 @@ int launch_doublet(dmx_engine* e) {
     return launch_doublet_generic_w<true>(e);
   }
   if (e->mode == DMX_MODE_FAST && !use_cls && A >= 2 && A <= 8 && V <= 128 && e->alpha[0] == 0.0 && !(A == 2 && e->alpha[1] == 0.5) &&
-      !force_generic && !getenv("DMX_NO_ANF")) {
+      !force_generic && !e->knob("DMX_NO_ANF")) {
     // FAST, soft fields, any alpha grid that starts with 0 (the default grid {0, 0.5} has k_doublet_sym): the printed entries only,
     // bilinear form
     const int AP = A <= 2 ? 2 : (A <= 4 ? 4 : 8);
@@ -5403,7 +5428,7 @@ int launch_doublet(dmx_engine* e) {
     const size_t lds = cell_bytes * (kThreads / TPC);                                                                  \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_anf<TPC, NK, APP, VUS, SUBP, MINW, CHK>),  \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-    hipLaunchKernelGGL((k_doublet_anf<TPC, NK, APP, VUS, SUBP, MINW, CHK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs(TPC, NK)), \
+    DMX_LAUNCH(k2_fn, (k_doublet_anf<TPC, NK, APP, VUS, SUBP, MINW, CHK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs(TPC, NK)), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,                            \
                        e->d_alpha, e->d_sched, V, A, GS, e->d_grid, e->d_l00, e->d_flag);                                \
   } while (0)
@@ -5440,7 +5465,7 @@ int launch_doublet(dmx_engine* e) {
     const size_t lds = cell_bytes * (kThreads / TPC);                                                                  \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_an<TPC, NK, APP>),        \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-    hipLaunchKernelGGL((k_doublet_an<TPC, NK, APP>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs(TPC, NK)), \
+    DMX_LAUNCH(k2_fn, (k_doublet_an<TPC, NK, APP>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs(TPC, NK)), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,                            \
                        e->d_alpha, e->d_sched, V, A, GS, e->d_grid, e->d_l00, e->d_flag);                                \
   } while (0)
@@ -5461,7 +5486,7 @@ int launch_doublet(dmx_engine* e) {
   // wide panels: the class kernel's LDS grows by 32 bytes per sample, the general A = 2 kernel's by 384 (64 KB at V = 128)
   // (FAST on the default grid reaches 512 soft-field samples: k_doublet_sym's slabs keep their LDS flat in V)
   const bool sym_wide = e->mode == DMX_MODE_FAST && !use_cls && A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V > 128 && V <= 512 &&
-                        !getenv("DMX_NO_SYM") && !getenv("DMX_NO_SYM_WIDE");
+                        !e->knob("DMX_NO_SYM") && !e->knob("DMX_NO_SYM_WIDE");
   // (round 4: the general A = 2 kernel itself runs up to kA2MaxV = 1024 samples — one workgroup may use all 160 KB of a gfx950 CU's LDS, and the
   // tile shortens from 32 to 16 or 8 pairs as the rows grow; beyond, the generic kernel)
   if (A != 2 || force_generic || (V > (use_cls ? 1024 : kA2MaxV) && !sym_wide)) {
@@ -5471,13 +5496,13 @@ int launch_doublet(dmx_engine* e) {
     return launch_doublet_generic_w<true>(e);
   }
   auto slabs_of = [&](int tpc, int nk) { const int kb = (V + nk - 1) / nk, js = tpc / kb; return (unsigned)((V + js - 1) / js); };
-  if (use_cls && e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 64 && !getenv("DMX_NO_SYM")) {
-    if (V > 32 && !getenv("DMX_FAST_NO_PROD")) {
+  if (use_cls && e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V <= 64 && !e->knob("DMX_NO_SYM")) {
+    if (V > 32 && !e->knob("DMX_FAST_NO_PROD")) {
       // 33..64 samples: the producer / consumer kernel over the printed entries (round 4; k_doublet_clsym<33,2> ran 2 wavefronts per SIMD)
       HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
       const size_t lds = (size_t)2 * 32 * 32 * 8 + (size_t)2 * 32 * 64 + (size_t)32 * 18 * 8 + 2 * 34 * 8 + 2 * 32 * (8 + 4 + 4) +
                          (size_t)32 * 12 * 4;
-      hipLaunchKernelGGL((k_doublet_clsp<3, true>), dim3((unsigned)B), dim3(kThreads), lds, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids,
+      DMX_LAUNCH(k2_fn, (k_doublet_clsp<3, true>), dim3((unsigned)B), dim3(kThreads), lds, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids,
                          e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, 0, e->d_grid, e->d_l00, e->d_flag);
       HIP_TRY(hipGetLastError());
       return launch_doublet_generic_w<true>(e);
@@ -5491,13 +5516,13 @@ int launch_doublet(dmx_engine* e) {
     // registers, no spills): every slab repeats phase 1 and the class table, which is two thirds of a 17-offset slab's time
     // (cfg4, 6 144 barcodes: 267 ms against 302 ms)
     if (NS == 2 && (D + Q - 1) / Q <= 33) NS = 1;
-    if (const char* env = getenv("DMX_CLSYM_NED")) NS = (D + Q * atoi(env) - 1) / (Q * atoi(env));   // kernel experiments only
+    if (const char* env = e->knob("DMX_CLSYM_NED")) NS = (D + Q * atoi(env) - 1) / (Q * atoi(env));   // kernel experiments only
     const int need = (D + Q * NS - 1) / (Q * NS);
     HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     constexpr size_t cb = ((size_t)8 * 32 * 8 + 32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + 32 * 12 * 4 + 32 * 10 * 4 + 63) & ~(size_t)63;
     static_assert(cb % 64 == 0, "a barcode's LDS block keeps its class table 64-byte aligned (k_doublet_clsym ORs the class offset in)");
 #define DMX_K2CS(NED, MINW)                                                                                            \
-  hipLaunchKernelGGL((k_doublet_clsym<NED, MINW>), dim3((unsigned)((B + 3) / 4), (unsigned)NS), dim3(kThreads), cb * 4, e->stream, e->pv, \
+  DMX_LAUNCH(k2_fn, (k_doublet_clsym<NED, MINW>), dim3((unsigned)((B + 3) / 4), (unsigned)NS), dim3(kThreads), cb * 4, e->stream, e->pv, \
                      e->nrd_width, e->d_rows, e->d_idd, e->nwd2, e->d_gp0, e->d_lut, e->d_sched, V, e->d_grid, e->d_l00, e->d_flag)
     if (need <= 1) DMX_K2CS(1, 4); else if (need <= 2) DMX_K2CS(2, 4); else if (need <= 3) DMX_K2CS(3, 4); else if (need <= 5) DMX_K2CS(5, 4);
     else if (need <= 7) DMX_K2CS(7, 3); else if (need <= 9) DMX_K2CS(9, 3); else if (need <= 11) DMX_K2CS(11, 3);
@@ -5515,22 +5540,22 @@ int launch_doublet(dmx_engine* e) {
     HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
     const dim3 blk(kThreads);
 #define DMX_K2C(TPC, NK, ...)                                                                                        \
-  hipLaunchKernelGGL((k_doublet_cls<TPC, NK, ##__VA_ARGS__>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), blk,   \
+  DMX_LAUNCH(k2_fn, (k_doublet_cls<TPC, NK, ##__VA_ARGS__>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), blk,   \
                      cb * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0, e->d_lut,   \
                      e->d_alpha, e->d_sched, V, VS, e->d_grid, e->d_l00, e->d_flag)
     if (V <= 8) DMX_K2C(64, 1);
     else if (V <= 16) DMX_K2C(64, 4);
     else if (V <= 32) DMX_K2C(256, 4);
-    else if (getenv("DMX_CLS_MINW3")) DMX_K2C(256, 16, 3);    // kernel experiments only (36 spills: slower)
-    else if (getenv("DMX_CLS_NK8")) { if (atoi(getenv("DMX_CLS_NK8")) == 3) DMX_K2C(256, 8, 3); else DMX_K2C(256, 8); }
-    else if (V <= 64 && !getenv("DMX_CLS_NO_PROD") && !getenv("DMX_CLS_NO_UJ")) {
+    else if (e->knob("DMX_CLS_MINW3")) DMX_K2C(256, 16, 3);    // kernel experiments only (36 spills: slower)
+    else if (e->knob("DMX_CLS_NK8")) { if (atoi(e->knob("DMX_CLS_NK8")) == 3) DMX_K2C(256, 8, 3); else DMX_K2C(256, 8); }
+    else if (V <= 64 && !e->knob("DMX_CLS_NO_PROD") && !e->knob("DMX_CLS_NO_UJ")) {
       // producer / consumer form (round 4): one barrier per tile, wavefront 0 builds the next tile's class table, 3 wavefronts per SIMD
       const size_t lds = (size_t)2 * 32 * 32 * 8 + (size_t)2 * 32 * 64 + (size_t)32 * 18 * 8 + 2 * 34 * 8 + 2 * 32 * (8 + 4 + 4) +
                          (size_t)32 * 12 * 4;
-      hipLaunchKernelGGL((k_doublet_clsp<3>), dim3((unsigned)B), dim3(kThreads), lds, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0,
+      DMX_LAUNCH(k2_fn, (k_doublet_clsp<3>), dim3((unsigned)B), dim3(kThreads), lds, e->stream, e->pv, e->nrd_width, e->d_rows, e->d_ids, e->d_gp0,
                          e->d_lut, e->d_alpha, e->d_sched, V, VS, e->d_grid, e->d_l00, e->d_flag);
     }
-    else if (V <= 64 && !getenv("DMX_CLS_NO_UJ")) DMX_K2C(256, 16, 2, true);   // uniform-j form (a wavefront's 16 samples j share their class per pair)
+    else if (V <= 64 && !e->knob("DMX_CLS_NO_UJ")) DMX_K2C(256, 16, 2, true);   // uniform-j form (a wavefront's 16 samples j share their class per pair)
     else DMX_K2C(256, 16);
 #undef DMX_K2C
     HIP_TRY(hipGetLastError());
@@ -5543,15 +5568,15 @@ int launch_doublet(dmx_engine* e) {
 #define DMX_K2A(TPC, NK)                                                                                             \
   do {                                                                                                                \
     if (e->geno_safe)                                                                                                 \
-      hipLaunchKernelGGL((k_doublet_a2<TPC, NK, 1, false, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
+      DMX_LAUNCH(k2_fn, (k_doublet_a2<TPC, NK, 1, false, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                          cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,    \
                          e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);                               \
     else                                                                                                              \
-  hipLaunchKernelGGL((k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
+  DMX_LAUNCH(k2_fn, (k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
                      e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);                                   \
   } while (0)
-  if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && (V <= 128 || sym_wide) && !getenv("DMX_NO_SYM")) {
+  if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && (V <= 128 || sym_wide) && !e->knob("DMX_NO_SYM")) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do {                                                                                                                \
@@ -5565,11 +5590,11 @@ int launch_doublet(dmx_engine* e) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
     }                                                                                                                  \
     if (e->geno_safe)                                                                                                  \
-      hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX, 3, 0, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
+      DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX, 3, 0, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                          block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,         \
                          e->d_grid, e->d_l00, e->d_flag);                                                              \
     else                                                                                                               \
-    hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
+    DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
@@ -5580,12 +5605,12 @@ int launch_doublet(dmx_engine* e) {
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-    hipLaunchKernelGGL((k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
+    DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
-    const int32_t sym_flags = getenv("DMX_SYM_NO_DMA") ? (1 << 16) : 0;       // kernel experiments only
-    const bool wide_cells = getenv("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
+    const int32_t sym_flags = e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0;       // kernel experiments only
+    const bool wide_cells = e->knob("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
     if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
     else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
     else if (V <= 8) { if (64 % V == 0) DMX_K2S(64, 8, 4, true); else DMX_K2S(64, 8, 4, false); }
@@ -5594,7 +5619,7 @@ int launch_doublet(dmx_engine* e) {
     else if (V <= 27) DMX_K2S(64, 27, 4, false);
     else if (V <= 32) {
       if (V == 32) {
-        const int var = getenv("DMX_SYM_VARIANT") ? atoi(getenv("DMX_SYM_VARIANT")) : 0;      // kernel experiments only
+        const int var = e->knob("DMX_SYM_VARIANT") ? atoi(e->knob("DMX_SYM_VARIANT")) : 0;      // kernel experiments only
         if (var == 1) DMX_K2SV(64, 32, 2, true, 4); else if (var == 2) DMX_K2SV(64, 32, 4, true, 4); else if (var == 3) DMX_K2SV(64, 32, 8, true, 3);
         else if (var == 4) DMX_K2SV(64, 32, 2, true, 3); else if (var == 5) DMX_K2SV(64, 32, 8, true, 2); else DMX_K2S(64, 32, 4, true);
       } else DMX_K2S(64, 32, 4, false);
@@ -5613,10 +5638,10 @@ int launch_doublet(dmx_engine* e) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, SUB, FIX, 3, 9, false>),       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
     if (e->geno_safe)                                                                                                  \
-      hipLaunchKernelGGL((k_doublet_sym<256, VMAX, SUB, FIX, 3, 9, false>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
+      DMX_LAUNCH(k2_fn, (k_doublet_sym<256, VMAX, SUB, FIX, 3, 9, false>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
                          e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);      \
     else                                                                                                               \
-    hipLaunchKernelGGL((k_doublet_sym<256, VMAX, SUB, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
+    DMX_LAUNCH(k2_fn, (k_doublet_sym<256, VMAX, SUB, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
                        e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);        \
   } while (0)
       if (V <= 96) DMX_K2SS(96, 8, false); else if (V == 128) DMX_K2SS(128, 8, true); else if (V < 128) DMX_K2SS(128, 8, false);
@@ -5637,7 +5662,7 @@ int launch_doublet(dmx_engine* e) {
     const size_t lds = fast_bytes * (kThreads / TPC);                                                                \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2f<TPC, NK>),          \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
-    hipLaunchKernelGGL((k_doublet_a2f<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), \
+    DMX_LAUNCH(k2_fn, (k_doublet_a2f<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                              \
   } while (0)
@@ -5653,16 +5678,16 @@ int launch_doublet(dmx_engine* e) {
   else if (V <= 16) DMX_K2A(64, 4);
   else if (V <= 32) {
     // 4 wavefronts per SIMD (128 VGPRs, a few spills outside the hot loop) measured 2.8 % faster than 3 (158 VGPRs) on cfg3
-    if (!getenv("DMX_A2_NO_GD") && !getenv("DMX_A2_MINW1")) {   // rows widened to binary64 at staging: 1-2.5 % (cfg3, 5 000 barcodes: 741-753 vs 760 ms)
+    if (!e->knob("DMX_A2_NO_GD") && !e->knob("DMX_A2_MINW1")) {   // rows widened to binary64 at staging: 1-2.5 % (cfg3, 5 000 barcodes: 741-753 vs 760 ms)
       const size_t cbd = (size_t)32 * 18 * 8 + (size_t)32 * GS * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
       if (e->geno_safe)
-        hipLaunchKernelGGL((k_doublet_a2<256, 4, 4, true, false>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
+        DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4, true, false>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
                            e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
       else
-      hipLaunchKernelGGL((k_doublet_a2<256, 4, 4, true>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
+      DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4, true>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
                          e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
-    } else if (!getenv("DMX_A2_MINW1"))
-      hipLaunchKernelGGL((k_doublet_a2<256, 4, 4>), dim3((unsigned)B, slabs_of(256, 4)), block, cell_bytes, e->stream, e->pv, e->nrd_width, e->d_g,
+    } else if (!e->knob("DMX_A2_MINW1"))
+      DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4>), dim3((unsigned)B, slabs_of(256, 4)), block, cell_bytes, e->stream, e->pv, e->nrd_width, e->d_g,
                          e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
     else DMX_K2A(256, 4);
   }
@@ -5676,7 +5701,7 @@ int launch_doublet(dmx_engine* e) {
     int tp = 0;
     for (int c : {32, 16, 8}) if (!tp && bytes_of(c) + kStatic <= kTwo) tp = c;
     for (int c : {32, 16, 8}) if (!tp && bytes_of(c) + kStatic <= kOne) tp = c;
-    if (const char* env = getenv("DMX_A2_TP")) { const int c = atoi(env); if ((c == 32 || c == 16 || c == 8) && bytes_of(c) + kStatic <= kOne) tp = c; }   // kernel experiments only
+    if (const char* env = e->knob("DMX_A2_TP")) { const int c = atoi(env); if ((c == 32 || c == 16 || c == 8) && bytes_of(c) + kStatic <= kOne) tp = c; }   // kernel experiments only
     if (!tp) return set_error(DMX_ERR_ARG, "run_doublet: V = %d exceeds k_doublet_a2's LDS budget", (int)V);
     const size_t lds = bytes_of(tp);
 #define DMX_K2AW(TPP)                                                                                                 \
@@ -5684,12 +5709,12 @@ int launch_doublet(dmx_engine* e) {
     if (e->geno_safe) {                                                                                               \
       if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2<256, 16, 1, false, false, TPP>),  \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-      hipLaunchKernelGGL((k_doublet_a2<256, 16, 1, false, false, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,  \
+      DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 16, 1, false, false, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,  \
                          e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);  \
     } else {                                                                                                          \
       if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2<256, 16, 1, false, true, TPP>),   \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
-      hipLaunchKernelGGL((k_doublet_a2<256, 16, 1, false, true, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,   \
+      DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 16, 1, false, true, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,   \
                          e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);  \
     }                                                                                                                 \
   } while (0)
@@ -5710,22 +5735,22 @@ int launch_certify(dmx_engine* e) {
   // — OFF by default: measured at cfg5 it cuts K3b's L2-side traffic (profiles/r04_certify_blocks.txt) but costs time (10.15 against 9.28 ms: the kernel is
   // bound by its own instruction stream, and 25 launches with their partial tiles cost more than the L2 hits save); DMX_CERTIFY_BLOCKS=1 turns it on,
   // and forced small blocks (DMX_K1_BLOCK_BYTES) always use it so that the tests cover the parked-state path
-  const int64_t* blk = (e->pv.pair_snp && e->blk_n > 1 && (getenv("DMX_CERTIFY_BLOCKS") || getenv("DMX_K1_BLOCK_BYTES"))) ? e->d_blk : nullptr;
-  const int bstride = (blk && getenv("DMX_CERTIFY_BLOCK_STRIDE")) ? std::max(1, atoi(getenv("DMX_CERTIFY_BLOCK_STRIDE"))) : 1;   // table blocks per launch
+  const int64_t* blk = (e->pv.pair_snp && e->blk_n > 1 && (e->knob("DMX_CERTIFY_BLOCKS") || e->knob("DMX_K1_BLOCK_BYTES"))) ? e->d_blk : nullptr;
+  const int bstride = (blk && e->knob("DMX_CERTIFY_BLOCK_STRIDE")) ? std::max(1, atoi(e->knob("DMX_CERTIFY_BLOCK_STRIDE"))) : 1;   // table blocks per launch
   const int n_launch = blk ? (e->blk_n + bstride - 1) / bstride : 1;
   double* park = nullptr;
   if (blk) {
     if (int rc = ensure_dev((void**)&e->d_park, &e->park_cap, sizeof(double) * kPark * (size_t)std::max(B, 1))) return rc;
     park = e->d_park;
   }
-  const float* gT = (!e->pv.pair_snp && e->have_gT && !getenv("DMX_CERTIFY_NO_GT")) ? e->d_gT : nullptr;   // dense pileups: SNP-minor columns
+  const float* gT = (!e->pv.pair_snp && e->have_gT && !e->knob("DMX_CERTIFY_NO_GT")) ? e->d_gT : nullptr;   // dense pileups: SNP-minor columns
 #define DMX_K3B(MINW_, FIVE_, DENSE_)                                                                                  \
   for (int bi = 0; bi < n_launch; ++bi)                                                                                 \
-    hipLaunchKernelGGL((k_certify<MINW_, FIVE_, DENSE_>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, \
+    DMX_LAUNCH(k3b_fn, (k_certify<MINW_, FIVE_, DENSE_>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, \
                        e->d_lut, e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park, cseed)
   const bool five = e->alpha[0] == 0.0;
   const double* cseed = nullptr;                  // the first one or two reads of a pair from a table (DMX_CERTIFY_NO_SEEDS=1: the whole loop)
-  if (five && !getenv("DMX_CERTIFY_NO_SEEDS")) {
+  if (five && !e->knob("DMX_CERTIFY_NO_SEEDS")) {
     if (!e->cseed_valid) {
       if (!e->d_cseed) HIP_TRY(hipMalloc((void**)&e->d_cseed, sizeof(double) * 2 * kCSeedStride * (size_t)kCSeedN));
       hipLaunchKernelGGL(k_build_certify_seeds, dim3((unsigned)((kCSeedN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, e->d_cseed);
@@ -5734,7 +5759,7 @@ int launch_certify(dmx_engine* e) {
     }
     cseed = e->d_cseed;
   }
-  if (getenv("DMX_CERTIFY_MINW3")) { if (gT) DMX_K3B(3, false, true); else DMX_K3B(3, false, false); }      // kernel experiments only
+  if (e->knob("DMX_CERTIFY_MINW3")) { if (gT) DMX_K3B(3, false, true); else DMX_K3B(3, false, false); }      // kernel experiments only
   else if (gT) { if (five) DMX_K3B(4, true, true); else DMX_K3B(4, false, true); }
   else { if (five) DMX_K3B(4, true, false); else DMX_K3B(4, false, false); }
 #undef DMX_K3B
@@ -5756,7 +5781,7 @@ extern "C" int dmx_engine_run_singlet(dmx_engine* e) {
   HIP_TRY(hipEventRecord(e->ev[3], e->stream));
   HIP_TRY(hipEventRecord(rs[1], e->stream));
   ++e->n_ring_s;
-  e->timed[1] = true; e->have_sing = true;
+  e->timed[1] = true; e->have_sing = true; e->k1_placement = 0;
   return DMX_OK;
 }
 
@@ -5769,13 +5794,9 @@ extern "C" int dmx_engine_run_doublet(dmx_engine* e) { return run_doublet_impl(e
 // round (cfg3 FAST: 10 000 one-barcode wavefronts on 3 072 slots).  Fork and join are events on the engine's stream, so that for the
 // caller everything is ordered on that stream exactly as after run_singlet + run_doublet; the results are the same bits.
 namespace {
-// the doublet kernel launch_doublet will pick is k_doublet_clsp (GT classes, STRICT grid of two alphas, 33..64 samples)
-bool k2_will_be_clsp(const dmx_engine* e) {
-  const bool use_cls = e->n_classes > 0 && !getenv("DMX_NO_CLASSES");
-  const bool fast_sym = e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && e->V <= 64 && !getenv("DMX_NO_SYM");
-  if (use_cls && fast_sym && e->A == 2 && e->V > 32 && !getenv("DMX_K2_GENERIC")) return !getenv("DMX_FAST_NO_PROD");
-  return use_cls && e->A == 2 && !fast_sym && e->V > 32 && e->V <= 64 && !getenv("DMX_K2_GENERIC") && !getenv("DMX_CLS_NO_PROD") && !getenv("DMX_CLS_NO_UJ") &&
-         !getenv("DMX_CLS_MINW3") && !getenv("DMX_CLS_NK8");
+// the doublet kernel launch_doublet picked is k_doublet_clsp (GT classes, grid {0, 0.5}, 33..64 samples): what launch_doublet itself recorded
+bool k2_is_clsp(const dmx_engine* e) {
+  return e->k2_fn == reinterpret_cast<const void*>(&k_doublet_clsp<3, false>) || e->k2_fn == reinterpret_cast<const void*>(&k_doublet_clsp<3, true>);
 }
 }  // namespace
 
@@ -5784,10 +5805,12 @@ extern "C" int dmx_engine_run(dmx_engine* e) {
   // K1 beside K2 pays where K2 leaves slots free.  k_doublet_clsp does not (three wavefronts per SIMD, all of them issuing: measured on the
   // cfg4 shard, K1 beside it cost what it saved), so there K1 starts when K2 has finished and runs beside K3 + K3b (run_doublet_impl; cfg4 shard
   // 573 -> 566 ms per step).  DMX_FORCE_OVERLAP=1: beside K2 anyway; DMX_K1_FIRST=1: K1, then K2, K3, K3b, one after the other.
-  const bool serial = getenv("DMX_NO_OVERLAP") || (e->have_pileup && k2_will_be_clsp(e) && getenv("DMX_K1_FIRST"));
+  const bool serial = e->knob("DMX_NO_OVERLAP") || e->knob("DMX_K1_FIRST");
   if (e->V < 2 || e->A < 2 || serial) {
     if (int rc = dmx_engine_run_singlet(e)) return rc;
-    return (e->V < 2 || e->A < 2) ? DMX_OK : dmx_engine_run_doublet(e);
+    const int rc = (e->V < 2 || e->A < 2) ? DMX_OK : dmx_engine_run_doublet(e);
+    e->k1_placement = 0;
+    return rc;
   }
   return run_doublet_impl(e, true);
 }
@@ -5825,7 +5848,8 @@ int run_doublet_impl(dmx_engine* e, bool with_singlet) {
     hipEvent_t* rs = e->ring_s[e->n_ring_s % dmx_engine::kRing];
     // K1 beside K2 — or, where K2 leaves it no room (k_doublet_clsp: three issuing wavefronts per SIMD), beside K3 + K3b, which like K1
     // issue on about half of their cycles: K1 then starts when K2 has finished (DMX_FORCE_OVERLAP=1: beside K2 anyway)
-    const bool after_k2 = k2_will_be_clsp(e) && !getenv("DMX_FORCE_OVERLAP");
+    const bool after_k2 = k2_is_clsp(e) && !e->knob("DMX_FORCE_OVERLAP");
+    e->k1_placement = after_k2 ? 2 : 1;
     HIP_TRY(hipStreamWaitEvent(e->k1_stream, after_k2 ? e->ev[5] : e->ev_fork, 0));
     e->stream = e->k1_stream;
     int rc = DMX_OK;
@@ -5903,11 +5927,14 @@ extern "C" int dmx_engine_get_cell_grids(dmx_engine* e, const int32_t* cells, in
   if (!e->have_grid) return set_error(DMX_ERR_STATE, "dmx_engine_get_cell_grids: run_doublet has not been called");
   HIP_TRY(hipSetDevice(e->device));
   const size_t nAB = (size_t)e->V * e->V * e->A;
-  for (int32_t i = 0; i < n; ++i) {
+  for (int32_t i = 0; i < n; ++i)                  // every id before the first copy: an error must not leave copies into the caller's buffer in flight
     if (cells[i] < 0 || cells[i] >= e->pv.B) return set_error(DMX_ERR_ARG, "dmx_engine_get_cell_grids: cell %d out of range (0..%d)", cells[i], e->pv.B - 1);
-    HIP_TRY(hipMemcpyAsync(out + (size_t)i * nAB, e->d_grid + (size_t)cells[i] * nAB, sizeof(double) * nAB, hipMemcpyDeviceToHost, e->stream));
-  }
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  hipError_t he = hipSuccess;
+  for (int32_t i = 0; i < n && he == hipSuccess; ++i)
+    he = hipMemcpyAsync(out + (size_t)i * nAB, e->d_grid + (size_t)cells[i] * nAB, sizeof(double) * nAB, hipMemcpyDeviceToHost, e->stream);
+  const hipError_t hs = hipStreamSynchronize(e->stream);                  // also after a failed copy: nothing stays in flight into `out`
+  HIP_TRY(he);
+  HIP_TRY(hs);
   return DMX_OK;
 }
 
@@ -5967,6 +5994,37 @@ extern "C" int dmx_engine_algorithmic_bytes(dmx_engine* e, dmx_kernel_bytes* out
   out->singlet_bytes = in + B * (V + 1) * 8;
   out->doublet_bytes = in + B * (V * V * A + A) * 8;
   out->reduce_bytes = B * (V * V * A + A) * 8 + B * (double)sizeof(dmx_cell_summary);
+  return DMX_OK;
+}
+
+namespace {
+// "k_doublet_a2<256, 4, 4, true, false, 32>" — the demangled name rocprofv3 prints, without return type, namespace and parameter list
+void kernel_name(const void* fn, char out[96]) {
+  out[0] = 0;
+  if (!fn) return;
+  const char* mangled = hipKernelNameRefByPtr(fn, nullptr);
+  if (!mangled) return;
+  int st = 0;
+  char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+  std::string n = (st == 0 && dem) ? dem : mangled;
+  if (dem) std::free(dem);
+  if (n.rfind("void ", 0) == 0) n.erase(0, 5);
+  int depth = 0; size_t cut = n.size();                                  // the parameter list: the first '(' outside template brackets that is not "(anonymous namespace)"
+  for (size_t i = 0; i < n.size(); ++i) {
+    if (n[i] == '<') ++depth; else if (n[i] == '>') --depth;
+    else if (n[i] == '(' && depth == 0 && n.compare(i, 21, "(anonymous namespace)") != 0) { cut = i; break; }
+  }
+  n.erase(cut);
+  for (const char* pre : {"(anonymous namespace)::", "dmx::"}) for (size_t q; (q = n.find(pre)) != std::string::npos;) n.erase(q, std::strlen(pre));
+  std::snprintf(out, 96, "%s", n.c_str());
+}
+}  // namespace
+
+extern "C" int dmx_engine_kernel_names(dmx_engine* e, dmx_kernel_names* out) {
+  if (!e || !out) return set_error(DMX_ERR_ARG, "dmx_engine_kernel_names: null argument");
+  std::memset(out, 0, sizeof *out);
+  kernel_name(e->k1_fn, out->singlet); kernel_name(e->k2_fn, out->doublet); kernel_name(e->k3b_fn, out->certify);
+  out->k1_placement = e->k1_placement;
   return DMX_OK;
 }
 
@@ -6288,9 +6346,8 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
         if (int rc = dmx_engine_get_doublet(e, nullptr, x.l00.data(), x.summ.data())) return rc;
         if (int rc = dmx_engine_get_sing(e, x.sing.data())) return rc;
         x.cell_grid.assign(nb1, nullptr);
-        if (job->arbiter) {
-          constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
-          for (size_t c = 0; c < nb; ++c) if ((x.summ[c].flags & kNear) && x.summ[c].n_pairs > 0) {
+        if (job->arbiter) {                       // (dmx::cell_needs: the one predicate the writers use too)
+          for (size_t c = 0; c < nb; ++c) if (dmx::cell_needs(x.summ[c], job->alpha, A, true) & dmx::kNeedGrid) {
             x.flagged_grid.emplace_back(nAB);
             HIP_TRY(hipSetDevice(e->device));
             HIP_TRY(hipMemcpyAsync(x.flagged_grid.back().data(), e->d_grid + c * nAB, sizeof(double) * nAB, hipMemcpyDeviceToHost, e->stream));
@@ -6298,14 +6355,14 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
           }
           HIP_TRY(hipStreamSynchronize(e->stream));
           size_t f = 0;
-          for (size_t c = 0; c < nb; ++c) if ((x.summ[c].flags & kNear) && x.summ[c].n_pairs > 0) x.cell_grid[c] = x.flagged_grid[f++].data();
+          for (size_t c = 0; c < nb; ++c) if (dmx::cell_needs(x.summ[c], job->alpha, A, true) & dmx::kNeedGrid) x.cell_grid[c] = x.flagged_grid[f++].data();
         }
       }
     }
     if (dev_pl && doublet_ok && job->arbiter) {
-      // which barcodes can the writers' arbiter touch?  Those with a near-tie flag, and those whose best doublet sits at alpha = 0.5
-      // without a (resolved) tie-order certificate (dmx::write_doublet_core).  Their pairs and read bytes come to the host now.
-      constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
+      // which barcodes can the writers' arbiter touch?  dmx::cell_needs says (a near-tie flag, a best doublet at alpha = 0.5 without a
+      // (resolved) tie-order certificate, a BEST-rule comparison within 1e-7) — the predicate write_doublet_core itself checks before it
+      // writes.  Their pairs and read bytes come to the host now.
       const size_t w = (size_t)pl.nrd_width;
       x.tie_cell.assign(nb1, -1);
       x.t_po.assign(1, 0); x.t_ro.assign(1, 0);
@@ -6314,8 +6371,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
         dmx_cell_summary sm = x.summ[k];
         if (sm.n_pairs <= 0) continue;
         if (sm.flags & DMX_CELL_ORDER_RESOLVABLE) (void)dmx::resolve_tie_order(&sm);
-        const bool open_order = sm.n_best >= 0 && sm.n_best < A && job->alpha[sm.n_best] == 0.5 && !(sm.flags & DMX_CELL_ORDER_CERTIFIED);
-        if (!(sm.flags & kNear) && !open_order) continue;
+        if (!(dmx::cell_needs(sm, job->alpha, A, true) & dmx::kNeedPileup)) continue;
         const int32_t c = sliced ? order[(size_t)x.lo + k] : (int32_t)k;
         x.tie_cell[k] = (int32_t)need.size();
         need.push_back(c);

@@ -1005,14 +1005,25 @@ int dmx::write_doublet_impl(const dmx_final_input* in, const char* out_prefix, b
 }
 
 // .sing2 and .best from the per-cell records of the device reduction (K3) — the multi-GPU path gathers exactly these.
-extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double* sing, const dmx_cell_summary* summary,
-                                         const char* out_prefix) {
-  if (int rc = check_common(in, "dmx_write_doublet_summary")) return rc;
-  if (!out_prefix || !sing || !summary || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: null sing/summary/llks00/alpha/prefix");
-  if (in->write_pair) return set_error(DMX_ERR_ARG, "dmx_write_doublet_summary: .pair rows need the full grid (use dmx_write_doublet)");
+namespace {
+int write_summary_impl(const dmx_final_input* in, const double* sing, const dmx_cell_summary* summary, const double* const* cell_grid,
+                       const char* out_prefix, const char* who) {
+  if (int rc = check_common(in, who)) return rc;
+  if (!out_prefix || !sing || !summary || !in->llks00 || !in->alpha) return set_error(DMX_ERR_ARG, "%s: null sing/summary/llks00/alpha/prefix", who);
+  if (in->write_pair) return set_error(DMX_ERR_ARG, "%s: .pair rows need the full grid (use dmx_write_doublet)", who);
   dmx::DoubletSource src{};
-  src.sing = sing; src.summary = summary; src.cell_grid = in->cell_grid;
-  return dmx::write_doublet_core(in, src, out_prefix, false, "dmx_write_doublet_summary");
+  src.sing = sing; src.summary = summary; src.cell_grid = cell_grid;
+  return dmx::write_doublet_core(in, src, out_prefix, false, who);
+}
+}  // namespace
+
+extern "C" int dmx_write_doublet_summary(const dmx_final_input* in, const double* sing, const dmx_cell_summary* summary, const char* out_prefix) {
+  return write_summary_impl(in, sing, summary, nullptr, out_prefix, "dmx_write_doublet_summary");
+}
+// (ABI 7) the grids of the near-tie-flagged barcodes as an argument: dmx_final_input is passed by pointer without a size member and does not grow
+extern "C" int dmx_write_doublet_summary_grids(const dmx_final_input* in, const double* sing, const dmx_cell_summary* summary,
+                                               const double* const* cell_grid, const char* out_prefix) {
+  return write_summary_impl(in, sing, summary, cell_grid, out_prefix, "dmx_write_doublet_summary_grids");
 }
 
 // The doublet-stage writers (.sing2, .best, optionally .pair).  A cell's rows come either from its grid — the whole
@@ -1022,6 +1033,30 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
   const int32_t V = in->n_samples, A = in->n_alpha;
   if (V < 2 || A < 2) return set_error(DMX_ERR_ARG, "%s: needs >= 2 samples and >= 2 alphas (got %d, %d)", who, V, A);
   if (in->write_pair && !src.grid_all) return set_error(DMX_ERR_ARG, "%s: .pair rows need the full grid", who);
+  const double tol = in->tie_tol > 0 ? in->tie_tol : 1e-7;
+  const bool arbiter = in->tie_pileup && in->tie_g;
+  if (arbiter && in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "%s: the tie arbiter needs a HOST pileup", who);
+  const std::vector<int32_t> cells = output_cells(in, true);
+  // ---- before a byte is written: every barcode the arbiter will walk has its pileup staged, and the records-only fall-back — a
+  // near-tie-flagged barcode without a grid has its WHOLE grid re-evaluated on the host — stays a fall-back (pairs x V x V x A host logs)
+  if (arbiter && src.summary) {
+    double fallback_logs = 0;
+    int64_t n_fallback = 0;
+    for (int32_t c : cells) {
+      dmx_cell_summary sm = src.summary[c];
+      if (sm.flags & DMX_CELL_ORDER_RESOLVABLE) (void)dmx::resolve_tie_order(&sm);
+      const int need = dmx::cell_needs(sm, in->alpha, A, true);
+      if ((need & dmx::kNeedPileup) && src.tie_cell && src.tie_cell[c] < 0)
+        return set_error(DMX_ERR_STATE, "%s: the tie arbiter needs barcode %s, whose pileup was not staged (nothing was written)", who, in->barcodes[c]);
+      if ((need & dmx::kNeedGrid) && !src.grid_all && !(src.cell_grid && src.cell_grid[c])) {
+        fallback_logs += (double)sm.n_pairs * (double)V * V * A;
+        ++n_fallback;
+      }
+    }
+    if (fallback_logs > 2e9)
+      return set_error(DMX_ERR_ARG, "%s: %lld near-tie-flagged barcodes came without their grids; re-evaluating them on the host would take %.3g log() calls "
+                       "— pass the grids (dmx_engine_get_cell_grids, dmx_write_doublet_summary_grids)", who, (long long)n_fallback, fallback_logs);
+  }
   const std::string pre(out_prefix);
   File sing2, pairf, best;
   if (!sing2.open(pre + ".sing2", append) || !best.open(pre + ".best", append) || (in->write_pair && !pairf.open(pre + ".pair", append)))
@@ -1032,12 +1067,9 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
 
   const size_t ng = (size_t)V * V * A;
   const double prior = in->doublet_prior;
-  const double tol = in->tie_tol > 0 ? in->tie_tol : 1e-7;
-  const bool arbiter = in->tie_pileup && in->tie_g;
   dmx::ReadLut lut;
   std::shared_ptr<const dmx::MixTables> mix;
   if (arbiter) {
-    if (in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "%s: the tie arbiter needs a HOST pileup", who);
     double mat[256], err[256];
     dmx_phred_tables(mat, err);
     dmx::build_read_lut(mat, err, &lut);
@@ -1055,7 +1087,6 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
     }
     mix = mix_cached;
   }
-  const std::vector<int32_t> cells = output_cells(in, true);
   FILE* const files[kOutFiles] = {sing2.f, pairf.f, best.f};
   std::vector<std::string> alpha_txt((size_t)A);                           // "\t%.3lf\t" of every alpha
   for (int32_t a = 0; a < A; ++a) { alpha_txt[(size_t)a].push_back('\t'); put_fixed(alpha_txt[(size_t)a], in->alpha[a], 3); alpha_txt[(size_t)a].push_back('\t'); }
@@ -1065,7 +1096,7 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
                                    : std::max<size_t>(1, 16384 / rows_per_cell);
   std::atomic<int32_t> tie_missing{-1};           // a barcode the arbiter needed although src.tie_cell says its pileup is not staged
   const int frc = format_in_order(cells.size(), per_chunk, files, [&](size_t first, size_t last, Chunk& ck) {
-  std::vector<double> scratch;
+  std::vector<double> scratch, sg_fix;
   std::vector<dmx::GridReq> reqs;
   for (size_t q = first; q < last; ++q) {
     const int32_t c = cells[q];
@@ -1179,6 +1210,30 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
         if (nj != jb) { std::swap(l1, l2); std::swap(l10, l20); }
         jb = nj; kb = nk;
         l12 = swap_to_ba ? reqs[1].value : reqs[0].value;
+      }
+    }
+
+    // ---- the BEST rule's own comparisons (:837,:844).  They are made on accumulators whose device values differ from the reference's by the
+    // last bit of a log here and there (<= 7e-12 STRICT on soft fields, <= 6e-11 FAST): a barcode whose margin to one of the four thresholds is
+    // smaller than that would print SNG where the reference prints AMB or DBL.  K3 flags margins below 1e-7 (DMX_CELL_NEAR_RULE; the host repeats
+    // the test on the values it is about to compare), and the (at most five) entries involved are then the reference's own: re-evaluated in its
+    // operation order with the host libm.
+    const bool rule_flag = smp && (smp->flags & DMX_CELL_NEAR_RULE) && smp->n_pairs > 0;
+    if (arbiter && !host_grid && (rule_flag || dmx::near_rule(l12, l1, l2, sing1, sing2v, tol))) {
+      if (tc < 0) { if (rule_flag) tie_missing = c; }                      // (unflagged: the margin is 1e-7 give or take the device's 1e-11 — nothing to decide)
+      else {
+        reqs.assign({{jb, kb, nb, 0.0}, {jb, 0, 0, 0.0}, {kb, 0, 0, 0.0}, {i_sing1, 0, 0, 0.0}, {i_sing2, 0, 0, 0.0}});
+        dmx::exact_grid_entries(*in->tie_pileup, in->tie_g, V, A, in->alpha, lut, mix.get(), tc, reqs);
+        l12 = reqs[0].value; l1 = reqs[1].value; l2 = reqs[2].value; sing1 = reqs[3].value; sing2v = reqs[4].value;
+        // the rows below print these entries too: one value per entry in all files
+        if (grid) {
+          if (grid != scratch.data()) { scratch.assign(grid, grid + ng); grid = scratch.data(); }
+          for (const dmx::GridReq& r : reqs) scratch[((size_t)r.j * V + r.k) * A + r.n] = r.value;
+        } else {
+          sg_fix.assign(sg, sg + V);
+          for (size_t i = 1; i < reqs.size(); ++i) sg_fix[(size_t)reqs[i].j] = reqs[i].value;
+          sg = sg_fix.data();
+        }
       }
     }
 

@@ -65,6 +65,30 @@ struct DoubletSource {
   const dmx_cell_summary* summary = nullptr;     // [n_cells]
   const int32_t* tie_cell = nullptr;             // [n_cells] -> the cell's index in in->tie_pileup (NULL: the same index; -1: not staged there)
 };
+// What the doublet-stage writers need of a barcode BEYOND its K3 record — ONE predicate for the code that stages (dmx_demuxlet_run's fetch, a
+// multi-GPU rank choosing what rides along in the gather) and the code that writes (write_doublet_core); ADVICE r4: the two used to be maintained
+// apart.  `sm` = the record after resolve_tie_order (a DMX_CELL_ORDER_RESOLVABLE record that this host's libm settles counts as certified).
+//   kNeedGrid    a near-tie flag: which candidates sit within 1e-7 of a decision is not in the record
+//   kNeedPileup  the arbiter re-evaluates entries of this barcode in the reference's operation order: the near-tie flags, an alpha = 0.5 best doublet
+//                without a tie-order certificate, or a comparison of the BEST rule (cmd_cram_demuxlet.cpp:837,:844) with a margin below 1e-7
+enum { kNeedGrid = 1, kNeedPileup = 2 };
+inline int cell_needs(const dmx_cell_summary& sm, const double* alpha, int32_t A, bool arbiter) {
+  if (!arbiter || sm.n_pairs <= 0) return 0;
+  int need = 0;
+  if (sm.flags & (DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET)) need |= kNeedGrid | kNeedPileup;
+  if (sm.n_best >= 0 && sm.n_best < A && alpha[sm.n_best] == 0.5 && !(sm.flags & DMX_CELL_ORDER_CERTIFIED)) need |= kNeedPileup;
+  if (sm.flags & DMX_CELL_NEAR_RULE) need |= kNeedPileup;
+  return need;
+}
+// a comparison of the BEST rule within tol of flipping: LLK12 > LLK1, LLK12 > LLK2, LLK12 > SNG.LLK1 + 2 (:837), SNG.LLK1 > SNG.LLK2 + 2 (:844).
+// The same expression on the device (k_reduce) and on the host (the writers, on the values they are about to compare).
+// LLK1 and LLK2 are singlet entries, so they are <= SNG.LLK1 and the first two comparisons follow from the third wherever the values are
+// consistent: they are tested only where the third does not already rule the doublet out (a panel with duplicated samples has LLK12 == LLK1
+// to the last bit in most barcodes; flagging those would stage their pileups for a comparison that decides nothing).
+inline bool near_rule(double l12, double l1, double l2, double s1, double s2, double tol) {
+  auto close = [tol](double a, double b) { const double d = a - b; return d < tol && d > -tol; };
+  return close(l12, s1 + 2) || close(s1, s2 + 2) || ((close(l12, l1) || close(l12, l2)) && l12 > s1 + 2 - tol);
+}
 // dmx_engine_set_pileup for cells cells[0..nb) of a HOST pileup (NULL: all, in order), re-based while it streams to the device
 // (a DEVICE pileup: host_po / host_ro = host copies of its offset arrays when the caller has them, else they are fetched)
 int engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, int32_t nb, const int64_t* host_po = nullptr, const int64_t* host_ro = nullptr);

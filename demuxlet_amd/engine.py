@@ -254,6 +254,12 @@ class Engine:
     def reset_kernel_times(self) -> None:
         check(self._L.dmx_engine_mean_kernel_times(self._h, 1, None))
 
+    def kernel_names(self) -> dict:
+        """Which kernels the last run launched (dmx_engine_kernel_names): {'singlet', 'doublet', 'certify': rocprofv3-style names, 'k1_placement'}."""
+        n = capi.KernelNames()
+        check(self._L.dmx_engine_kernel_names(self._h, C.byref(n)))
+        return {"singlet": n.singlet.decode(), "doublet": n.doublet.decode(), "certify": n.certify.decode(), "k1_placement": int(n.k1_placement)}
+
     def algorithmic_bytes(self) -> capi.KernelBytes:
         b = capi.KernelBytes()
         check(self._L.dmx_engine_algorithmic_bytes(self._h, C.byref(b)))
@@ -309,16 +315,17 @@ def _final_struct(fa: FinalArgs, llks=None, llk0s=None, grid=None, l00=None, tie
                           fa.min_total, fa.min_uniq, fa.min_snp, int(fa.write_pair), C.cast(bc, C.c_void_p),
                           C.cast(sm, C.c_void_p), arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data,
                           arrs[3].ctypes.data, p(llks), p(llk0s), p(grid), p(l00), tp,
-                          tie_g.ctypes.data if tie_pileup is not None else None, 0.0, None)
+                          tie_g.ctypes.data if tie_pileup is not None else None, 0.0)
+    fin._cell_grid = None
     if cell_grids:                                   # {cell id: llksAB[V][V][A]} of the near-tie-flagged barcodes
-        ptrs = (C.c_void_p * len(fa.barcodes))()
+        ptrs = (C.c_void_p * len(fa.barcodes))()     # (an argument of dmx_write_doublet_summary_grids since ABI 7, not a member of the struct)
         for c, gr in cell_grids.items():
             gr = np.ascontiguousarray(gr, dtype=np.float64)
             assert gr.size == len(fa.sample_ids) ** 2 * len(alphas)
             keep.append(gr)
             ptrs[int(c)] = gr.ctypes.data
         keep.append(ptrs)
-        fin.cell_grid = C.cast(ptrs, C.c_void_p)
+        fin._cell_grid = C.cast(ptrs, C.c_void_p)
     return fin, keep
 
 
@@ -347,7 +354,10 @@ def write_doublet_summary(fa: FinalArgs, sing, l00, summary, out_prefix: str, ti
     fin, keep = _final_struct(fa, l00=l00, tie_pileup=tie_pileup, tie_g=tie_g, cell_grids=cell_grids)
     sing = np.ascontiguousarray(sing, dtype=np.float64)
     summary = np.ascontiguousarray(summary, dtype=capi.SUMMARY_DTYPE)
-    check(capi.load().dmx_write_doublet_summary(C.byref(fin), sing.ctypes.data, summary.ctypes.data, out_prefix.encode()))
+    if fin._cell_grid is not None:
+        check(capi.load().dmx_write_doublet_summary_grids(C.byref(fin), sing.ctypes.data, summary.ctypes.data, fin._cell_grid, out_prefix.encode()))
+    else:
+        check(capi.load().dmx_write_doublet_summary(C.byref(fin), sing.ctypes.data, summary.ctypes.data, out_prefix.encode()))
 
 
 def resolve_tie_order(summary: np.ndarray) -> int:

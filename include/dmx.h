@@ -22,7 +22,11 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 6   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up, dmx_engine_run; 6: dmx_engine_get_cell_grids, dmx_final_input.cell_grid (a trailing field: zero-initialised structs of ABI 5 callers mean "none") */
+#define DMX_ABI_VERSION 7   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up, dmx_engine_run; 6: dmx_engine_get_cell_grids;
+                               7: DMX_CELL_NEAR_RULE, dmx_write_doublet_summary_grids, dmx_engine_kernel_names.  ABI 6 had grown dmx_final_input in place by a
+                               trailing `cell_grid` member; a by-pointer input struct without a size member cannot grow (a caller compiled against ABI 5
+                               passes a shorter object), so ABI 7 WITHDRAWS that member — the struct has its ABI 5 layout again and the grids travel as an
+                               argument of the new entry point.  Additions only otherwise: callers of ABI <= 5 run unchanged. */
 
 typedef enum {
   DMX_OK = 0,
@@ -156,8 +160,12 @@ enum { DMX_CELL_NEAR_DOUBLET = 1,   /* another doublet entry (not the alpha = 0.
        DMX_CELL_NEAR_SINGLET = 2,   /* the best two singlets within 1e-7 of each other, or a third within 1e-7 of the second */
        DMX_CELL_ORDER_CERTIFIED = 4, /* the order (j_best, k_best) of an alpha = 0.5 best doublet and llk12 are the reference's, bit for
                                        bit (device certificate, DESIGN.md "Ties"): the host tie arbiter has nothing left to decide */
-       DMX_CELL_ORDER_RESOLVABLE = 8 /* the certificate stayed open over a single log() per accumulator: one host log() call each
-                                       (dmx_write_doublet* do it) yields the reference's order and llk12 without the pileup */ };
+       DMX_CELL_ORDER_RESOLVABLE = 8,/* the certificate stayed open over a single log() per accumulator: one host log() call each
+                                       (dmx_write_doublet* do it) yields the reference's order and llk12 without the pileup */
+       DMX_CELL_NEAR_RULE = 16      /* (ABI 7) one of the four comparisons of the BEST rule (cmd_cram_demuxlet.cpp:837,:844) — LLK12 > LLK1, LLK12 > LLK2,
+                                       LLK12 > SNG.LLK1 + 2, SNG.LLK1 > SNG.LLK2 + 2 — has a margin below 1e-7: the device's log differs from libm's
+                                       in the last bit of ~1.5 % of its evaluations, so SNG / DBL / AMB of such a barcode is decided by the writers from
+                                       the (at most six) entries involved re-evaluated in the reference's operation order with the host libm */ };
 
 int dmx_engine_create(const dmx_engine_config*, dmx_engine** out);
 int dmx_engine_destroy(dmx_engine*);
@@ -202,6 +210,11 @@ int dmx_engine_last_kernel_times(dmx_engine*, dmx_kernel_times* out);
  * Synchronises the engine's stream.  reset != 0 forgets the launches seen so far; out may be NULL (reset only). */
 typedef struct { double singlet_ms, doublet_ms, reduce_ms, certify_ms; int32_t n_singlet, n_doublet; } dmx_kernel_time_means;
 int dmx_engine_mean_kernel_times(dmx_engine*, int32_t reset, dmx_kernel_time_means* out);
+/* (ABI 7) Which kernels the engine's last run launched, by the demangled names rocprofv3 prints ("k_doublet_a2<256, 4, 4, true, false, 32>";
+ * empty = not run), and where K1 ran: 0 = a launch of its own (run_singlet), 1 = beside K2 on the low-priority stream (dmx_engine_run), 2 = beside
+ * K3 + K3b (dmx_engine_run when K2 leaves K1 no room).  A benchmark pairs its committed counter files with these names instead of guessing. */
+typedef struct { char singlet[96], doublet[96], certify[96]; int32_t k1_placement; int32_t reserved[3]; } dmx_kernel_names;
+int dmx_engine_kernel_names(dmx_engine*, dmx_kernel_names* out);
 /* Algorithmic HBM bytes one launch of each kernel must move for the staged problem. */
 typedef struct { double singlet_bytes, doublet_bytes, reduce_bytes; } dmx_kernel_bytes;
 int dmx_engine_algorithmic_bytes(dmx_engine*, dmx_kernel_bytes* out);
@@ -230,11 +243,7 @@ typedef struct {
   const dmx_pileup* tie_pileup;    /* NULL = no arbiter */
   const float*  tie_g;             /* [n_snps][V][3] */
   double  tie_tol;                 /* 0 = default 1e-7 */
-  /* dmx_write_doublet_summary only: [n_cells] pointers to single cells' llksAB[V][V][A] (NULL entries = none, NULL array = none).
-   * A barcode whose K3 record carries DMX_CELL_NEAR_DOUBLET / _NEAR_SINGLET is decided from its grid (dmx_engine_get_cell_grids
-   * fetches exactly those), with the tie arbiter re-evaluating the contenders as dmx_write_doublet does. */
-  const double* const* cell_grid;
-} dmx_final_input;
+} dmx_final_input;                 /* fixed layout since ABI 5: passed by pointer without a size member, it never grows */
 
 int dmx_write_single(const dmx_final_input*, const char* path);                    /* <out>.single */
 int dmx_write_doublet(const dmx_final_input*, const char* out_prefix);            /* <out>.sing2, <out>.best, [<out>.pair] */
@@ -243,10 +252,17 @@ int dmx_write_doublet(const dmx_final_input*, const char* out_prefix);          
  * in->llksAB is ignored; in->write_pair must be 0 (the .pair rows need the grid).  With in->tie_pileup the order of
  * the two samples of an alpha = 0.5 best doublet is arbitrated exactly.  Barcodes K3 flagged as near-ties
  * (another sample pair, another alpha or another singlet within 1e-7 of a decision: duplicate samples, a handful of covered SNPs)
- * need more than their record: pass their grids in in->cell_grid; without a grid but with in->tie_pileup the barcode's WHOLE grid is
- * re-evaluated on the host in the reference's operation order (exact, pairs x V x V x A host log() calls for that barcode); with
- * neither, the device's own choice among the near-tied candidates is printed (each within 1e-7 of the reference's best). */
+ * need more than their record: pass their grids to dmx_write_doublet_summary_grids; without a grid but with in->tie_pileup the barcode's
+ * WHOLE grid is re-evaluated on the host in the reference's operation order (exact, pairs x V x V x A host log() calls for that barcode;
+ * refused with DMX_ERR_ARG beyond 2e9 such calls in one job — pass the grids); with neither, the device's own choice among the near-tied
+ * candidates is printed (each within 1e-7 of the reference's best).  A barcode with DMX_CELL_NEAR_RULE has the entries of the BEST rule
+ * re-evaluated when in->tie_pileup is there (no grid needed). */
 int dmx_write_doublet_summary(const dmx_final_input*, const double* sing, const dmx_cell_summary* summary, const char* out_prefix);
+/* (ABI 7) The same with cell_grid[n_cells]: pointers to single cells' llksAB[V][V][A] (NULL entries = none; a NULL array = none =
+ * dmx_write_doublet_summary).  A barcode whose K3 record carries DMX_CELL_NEAR_DOUBLET / _NEAR_SINGLET is decided from its grid
+ * (dmx_engine_get_cell_grids fetches exactly those), with the tie arbiter re-evaluating the contenders as dmx_write_doublet does. */
+int dmx_write_doublet_summary_grids(const dmx_final_input*, const double* sing, const dmx_cell_summary* summary,
+                                    const double* const* cell_grid, const char* out_prefix);
 /* For consumers of the K3 records themselves: turn every DMX_CELL_ORDER_RESOLVABLE record among summary[0..n) into a certified one
  * by asking this host's libm for the one or two log() values the device left open (the writers above do the same internally).
  * Returns the number of records that stay unresolved (>= 0), or a negative dmx_status. */

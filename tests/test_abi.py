@@ -36,7 +36,26 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.dmx_abi_version() == 6
+    assert lib.dmx_abi_version() == 7
+
+
+def test_by_pointer_input_structs_do_not_grow():
+    """dmx_final_input is passed by pointer and has no size member, so a member added at its end is read past the end of
+    an older caller's object.  ABI 6's trailing `cell_grid` was withdrawn in ABI 7 (the grids are an argument of
+    dmx_write_doublet_summary_grids): the struct has its ABI 5 layout — it ends with tie_tol — in the header, the C compiler and the binding."""
+    from demuxlet_amd import capi
+    text = (ROOT / "include" / "dmx.h").read_text()
+    body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} dmx_final_input;", text, flags=re.S).group(1)
+    members = re.findall(r"(\w+)\s*;", re.sub(r"/\*.*?\*/", "", body, flags=re.S))
+    assert members[-1] == "tie_tol" and "cell_grid" not in members
+    assert capi.FinalInput._fields_[-1][0] == "tie_tol"
+    src = '#include "dmx.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%zu %zu\\n", sizeof(dmx_final_input), offsetof(dmx_final_input, tie_tol));return 0;}\n'
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "s.c").write_text(src)
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(Path(d) / "s.c"), "-o", str(Path(d) / "s")])
+        size, off = map(int, subprocess.check_output([str(Path(d) / "s")], text=True).split())
+    assert size == C.sizeof(capi.FinalInput) == off + 8 and off == capi.FinalInput.tie_tol.offset
 
 
 def test_code_object_is_gfx950_only():

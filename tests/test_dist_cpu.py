@@ -168,3 +168,108 @@ def test_sharded_run_world2_gloo(name, tmp_path):
     gd = Golden(name)
     for suf in ("single", "sing2", "best"):
         assert (tmp_path / f"o.{suf}").read_bytes() == gd.files[suf], suf
+
+
+def _near_rule(l12, l1, l2, s1, s2, tol=1e-7):
+    """k_reduce's DMX_CELL_NEAR_RULE predicate (dmx::near_rule): a comparison of cmd_cram_demuxlet.cpp:837,:844 within tol of flipping."""
+    return abs(l12 - (s1 + 2)) < tol or abs(s1 - (s2 + 2)) < tol or ((abs(l12 - l1) < tol or abs(l12 - l2) < tol) and l12 > s1 + 2 - tol)
+
+
+@pytest.mark.parametrize("certified", [False, True])
+def test_best_rule_thresholds_follow_the_exact_values(oracle, certified, tmp_path):
+    """the BEST rule (cmd_cram_demuxlet.cpp:837 `LLK12 > LLK1 && LLK12 > LLK2 && LLK12 > SNG.LLK1 + 2`, :844 `SNG.LLK1 >
+    SNG.LLK2 + 2`) is evaluated on device-derived accumulators.  Records whose values sit 1e-12 on the WRONG side of a threshold — what a
+    device that lost the last bit of a log to libm produces when the exact margin is that small — must still print the reference's
+    SNG- / DBL- / AMB-: the record carries DMX_CELL_NEAR_RULE (margin < 1e-7) and the writers re-evaluate the entries involved in the
+    reference's operation order.  Six kinds of sabotage over the golden jobs; every file byte-identical to the reference's; and without
+    the pileup (no arbiter) the sabotaged record is what gets printed, so the test has teeth."""
+    from demuxlet_amd import build, capi, engine
+    build.build()
+    kinds_seen = set()
+    for name in ("gt_v4_a2_pair", "gp_v8_a2_minsnp", "pl_v12_a6_pair", "gt_v5_dense", "gt_v24_a2_deep", "gp_v32_a2_dense"):
+        gd = Golden(name)
+        st = build_store(engine, gd.problem(oracle))
+        pl = st.freeze()
+        assert st.barcodes() == gd.ref_barcodes
+        cnt = gd.z["ref_counters"]
+        B, V, A = len(gd.ref_barcodes), len(gd.sample_ids), len(gd.alphas)
+        grid, l00 = gd.z["ref_llksAB"], gd.z["ref_llks00"]
+        summ = np.zeros(B, dtype=capi.SUMMARY_DTYPE)
+        for c in range(B):
+            if gd.z["ref_processed"][c]:
+                summ[c] = summary_from_grid(grid[c], l00[c], gd.alphas, gd.doublet_prior, cnt[c, 3], capi.SUMMARY_DTYPE)
+        sing = np.ascontiguousarray(grid[:, :, 0, 0]).copy()
+        bad = summ.copy()
+        eps = 1e-12
+        n_sab = 0
+        for q, c in enumerate(np.flatnonzero(summ["n_pairs"] > 0)):
+            r = summ[c]
+            i1, i2, jb, kb, nb = (int(r[k]) for k in ("i_sing1", "i_sing2", "j_best", "k_best", "n_best"))
+            s1, s2, l12, l1, l2 = float(r["sing_llk1"]), float(r["sing_llk2"]), float(r["llk12"]), float(r["llk1"]), float(r["llk2"])
+            dbl = l12 > l1 and l12 > l2 and l12 > s1 + 2
+            sng = (not dbl) and s1 > s2 + 2
+            if certified:                               # as after K3b: both accumulators of the alpha = 0.5 best pair known
+                if gd.alphas[nb] != 0.5:
+                    continue
+                a, b = min(jb, kb), max(jb, kb)
+                bad[c]["flags"] |= capi.DMX_CELL_ORDER_CERTIFIED
+                bad[c]["llk_ab"], bad[c]["llk_ba"] = grid[c, a, b, nb], grid[c, b, a, nb]
+            kind = None
+            if dbl:                                     # the record loses the doublet by 1e-12 on one of the three comparisons
+                kind = ("dbl_vs_l1", "dbl_vs_l2", "dbl_vs_sng")[q % 3]
+                if kind == "dbl_vs_l1": bad[c]["llk1"] = l12 + eps          # LLK1 itself is [jb][0][0]: the writer re-evaluates it
+                elif kind == "dbl_vs_l2": bad[c]["llk2"] = l12 + eps
+                else: bad[c]["llk12"] = s1 + 2 - eps
+            elif sng and q % 2 == 0:                     # SNG in the reference, AMB in the record
+                kind = "sng_to_amb"
+                sing[c, i2] = s1 - 2 + eps; bad[c]["sing_llk2"] = sing[c, i2]
+            elif sng and l1 <= s1 and l2 <= s1:          # SNG in the reference, DBL in the record
+                kind = "sng_to_dbl"
+                bad[c]["llk12"] = s1 + 2 + eps
+            elif (not dbl) and (not sng) and s1 - 2 - eps > np.partition(sing[c], -3)[-3] if V >= 3 else False:   # AMB in the reference, SNG in the record
+                kind = "amb_to_sng"
+                sing[c, i2] = s1 - 2 - eps; bad[c]["sing_llk2"] = sing[c, i2]
+            if kind is None:
+                continue
+            assert _near_rule(float(bad[c]["llk12"]), float(bad[c]["llk1"]), float(bad[c]["llk2"]), float(sing[c, i1]), float(sing[c, i2]))
+            bad[c]["flags"] |= capi.DMX_CELL_NEAR_RULE   # what k_reduce sets on such a record
+            kinds_seen.add(kind); n_sab += 1
+        if not n_sab:
+            continue
+        fa = engine.FinalArgs(gd.ref_barcodes, gd.sample_ids, gd.alphas, gd.doublet_prior, cnt[:, 0], cnt[:, 1], cnt[:, 2], cnt[:, 3],
+                              gd.min_total, gd.min_uniq, gd.min_snp, False)
+        pre = str(tmp_path / f"{name}_arb")
+        engine.write_doublet_summary(fa, sing, l00, bad, pre, tie_pileup=pl, tie_g=gd.g)
+        assert Path(pre + ".best").read_bytes() == gd.files["best"], name
+        assert Path(pre + ".sing2").read_bytes() == gd.files["sing2"], name
+        pre = str(tmp_path / f"{name}_raw")              # no arbiter: the record's own (wrong) comparisons are printed
+        engine.write_doublet_summary(fa, sing, l00, bad, pre)
+        got, ref = Path(pre + ".best").read_bytes().split(b"\n"), gd.files["best"].split(b"\n")
+        assert len(got) == len(ref) and sum(x.split(b"\t")[5][:3] != y.split(b"\t")[5][:3] for x, y in zip(got[1:-1], ref[1:-1])) == n_sab, name
+    assert {"dbl_vs_l1", "dbl_vs_l2", "dbl_vs_sng", "sng_to_amb"} <= kinds_seen, kinds_seen
+
+
+def test_records_only_fallback_is_bounded(oracle, tmp_path):
+    """a near-tie-flagged barcode without its grid has its whole grid re-evaluated on the host — a fall-back, not a way of
+    life: beyond 2e9 host log() calls the writer refuses before it writes anything and names the entry point that takes the grids."""
+    from demuxlet_amd import build, capi, engine
+    build.build()
+    gd = Golden("gt_v4_a2_pair")
+    st = build_store(engine, gd.problem(oracle))
+    pl = st.freeze()
+    cnt = gd.z["ref_counters"]
+    B = len(gd.ref_barcodes)
+    grid, l00 = gd.z["ref_llksAB"], gd.z["ref_llks00"]
+    summ = np.zeros(B, dtype=capi.SUMMARY_DTYPE)
+    for c in range(B):
+        if gd.z["ref_processed"][c]:
+            summ[c] = summary_from_grid(grid[c], l00[c], gd.alphas, gd.doublet_prior, cnt[c, 3], capi.SUMMARY_DTYPE)
+    c0 = int(np.flatnonzero(summ["n_pairs"] > 0)[0])
+    summ[c0]["flags"] |= capi.DMX_CELL_NEAR_DOUBLET
+    summ[c0]["n_pairs"] = 2_000_000_000              # (a record claiming 2e9 covered SNPs: 2e9 x 4 x 4 x 2 logs)
+    fa = engine.FinalArgs(gd.ref_barcodes, gd.sample_ids, gd.alphas, gd.doublet_prior, cnt[:, 0], cnt[:, 1], cnt[:, 2], cnt[:, 3],
+                          gd.min_total, gd.min_uniq, gd.min_snp, False)
+    with pytest.raises(capi.DmxError) as ei:
+        engine.write_doublet_summary(fa, grid[:, :, 0, 0], l00, summ, str(tmp_path / "o"), tie_pileup=pl, tie_g=gd.g)
+    assert ei.value.code == capi.DMX_ERR_ARG and "dmx_write_doublet_summary_grids" in str(ei.value)
+    assert not (tmp_path / "o.best").exists() and not (tmp_path / "o.sing2").exists()

@@ -1156,3 +1156,39 @@ def oracle_from_pileup_files(oracle, sp, g, alphas, barcodes, sample_ids, prefix
     csr = oracle.Csr(list(barcodes), sp.cell_pair_off, pair_snp, np.concatenate([[0], np.cumsum(sp.pair_nrd.astype(np.int64))]), words.astype(np.uint32),
                      sp.rd_totl, sp.rd_pass, sp.rd_uniq)
     return oracle.run_csr(csr, list(sample_ids), g, oracle.Params(tuple(alphas), 0.5, 0, 0, 0, True), str(prefix))
+
+
+def test_experiment_switches_are_fenced(eng, monkeypatch):
+    """the DMX_* variables that pick kernel variants are experiment switches, not API.  An engine copies them once, at
+    dmx_engine_create, and only when DMX_EXPERIMENTS=1; a stray variable in a user's environment changes nothing, and neither does one set
+    after the engine exists.  dmx_engine_kernel_names says which kernels ran (rocprofv3's names)."""
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(5)
+    S, V, B = 300, 8, 16
+    raw = synth.make_raw_genotypes(rng, S, V)
+    g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    pl = host_pileup(eng, synth.make_pileup(rng, raw.alleles, B, 0.4, 1.5))
+
+    def names(after_create=None):
+        e = eng.Engine(V, (0.0, 0.5), 0.5)
+        if after_create:
+            after_create()
+        e.set_genotypes(g); e.set_pileup(pl); e.run(); e.sync()
+        n = e.kernel_names(); e.close()
+        return n
+
+    monkeypatch.setenv("DMX_EXPERIMENTS", "1")
+    monkeypatch.delenv("DMX_NO_CLASSES", raising=False)
+    base = names()
+    assert base["singlet"].startswith("k_singlet_cls<") and base["doublet"].startswith("k_doublet_cls<") and base["certify"].startswith("k_certify<"), base
+    assert base["k1_placement"] == 1
+    monkeypatch.setenv("DMX_NO_CLASSES", "1")
+    forced = names()
+    assert forced["singlet"].startswith("k_singlet<") and forced["doublet"].startswith("k_doublet_a2<"), forced       # honoured with the fence open
+    monkeypatch.setenv("DMX_EXPERIMENTS", "0")
+    assert names() == base                                                                                            # ignored with the fence shut
+    monkeypatch.delenv("DMX_EXPERIMENTS")
+    assert names() == base
+    monkeypatch.setenv("DMX_EXPERIMENTS", "1")
+    monkeypatch.delenv("DMX_NO_CLASSES")
+    assert names(after_create=lambda: monkeypatch.setenv("DMX_NO_CLASSES", "1")) == base                              # read at create, not per launch

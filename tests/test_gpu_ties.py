@@ -111,7 +111,16 @@ def run_both_paths(eng, oracle, tmp_path, g, pl, alphas, mode, what, min_fetched
         for suf in ("sing2", "best"):
             assert_same_file(tmp_path / f"{pre}.{suf}", tmp_path / f"ref.{suf}", f"{what}, records path ({'device grids' if pre == 'rec' else 'host grids'})")
     covered = int((summ["n_pairs"] > 0).sum())
+    # DMX_CELL_NEAR_RULE (round 5): K3 flags exactly the barcodes with a comparison of the BEST rule (:837,:844) within 1e-7 of flipping
+    cov = summ["n_pairs"] > 0
+    s1, s2, l12, l1, l2 = (summ[k].astype(np.float64) for k in ("sing_llk1", "sing_llk2", "llk12", "llk1", "llk2"))
+    with np.errstate(invalid="ignore"):
+        want_rule = (np.abs(l12 - (s1 + 2)) < 1e-7) | (np.abs(s1 - (s2 + 2)) < 1e-7) | (((np.abs(l12 - l1) < 1e-7) | (np.abs(l12 - l2) < 1e-7)) & (l12 > s1 + 2 - 1e-7))
+    has_rule = (summ["flags"] & capi.DMX_CELL_NEAR_RULE) != 0
+    certified = (summ["flags"] & capi.DMX_CELL_ORDER_CERTIFIED) != 0   # (K3b rewrites llk12 with the reference's bits: 1e-11 beside a 1e-7 window)
+    assert np.array_equal(has_rule[cov & ~certified], want_rule[cov & ~certified]), (int(has_rule.sum()), int(want_rule.sum()))
     near = int(((summ["flags"] & (capi.DMX_CELL_NEAR_DOUBLET | capi.DMX_CELL_NEAR_SINGLET)) != 0).sum())
+    print(f"{what}: {int(has_rule[cov].sum())} of {covered} barcodes flagged DMX_CELL_NEAR_RULE")
     print(f"{what}: {covered} covered barcodes, {near} flagged near-tie by K3, grid fetched for {fetched} "
           f"({100.0 * fetched / max(covered, 1):.1f} %)")
     # the flags are what routes a barcode to the arbiter: every K3-flagged barcode had its grid fetched, and nothing but flagged

@@ -1,3 +1,4 @@
+export DMX_EXPERIMENTS=1   # the kernel-variant switches are honoured only with this (dmx_engine_create)
 #!/bin/bash
 # GPU box: K3b (k_certify) time at cfg3 / cfg5 / cfg4-shard sizes, FAST, for the variants selected by environment switches.
 for cfg in 3 5 4; do

@@ -1,3 +1,4 @@
+export DMX_EXPERIMENTS=1   # the kernel-variant switches are honoured only with this (dmx_engine_create)
 #!/bin/bash
 # GPU box: per-kernel times of bench configurations for several library variants / environment switches.
 #   tools/probe_variants.sh "<cfg> [bench flags]" "<VAR=val ...>" ...      ("-" = no switch)

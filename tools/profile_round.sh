@@ -8,7 +8,7 @@
 set -u
 TAG=${1:-r02}; CFG=${2:-3}; EXTRA=${3:-}
 export TMPDIR=/tmp
-export DMX_NO_OVERLAP=1      # kernel-level profiles: K1 and K2 one after the other (bench.py otherwise runs K1 beside K2, dmx_engine_run)
+export DMX_EXPERIMENTS=1 DMX_NO_OVERLAP=1      # kernel-level profiles: K1 and K2 one after the other (bench.py otherwise runs K1 beside K2, dmx_engine_run)
 SFX=""; case "$EXTRA" in *--fast*) SFX="_fast";; esac
 OUT=$PWD/gpurun_out/prof_${TAG}_cfg${CFG}${SFX}; mkdir -p $OUT
 KRE="k_singlet|k_doublet_|k_reduce|k_certify"

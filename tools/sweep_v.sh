@@ -1,3 +1,4 @@
+export DMX_EXPERIMENTS=1   # the kernel-variant switches are honoured only with this (dmx_engine_create)
 #!/bin/bash
 # K2 throughput against panel width (run on the GPU box): tools/sweep_v.sh "64 96 128" "GP GT" 400
 for v in $1; do for fld in $2; do
