@@ -740,6 +740,224 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
   }
 }
 
+// K1 over CANONICAL genotype classes, lean form (round 5; V <= 16, one-byte read counts, arrays below 4 GiB — cfg2 — else k_singlet_cls<.., CAN>).
+// Same ownership, same expressions, same order of additions as k_singlet_cls<CW, KC, true>: every output is bit-identical.  What changed is
+// everything AROUND the arithmetic, which was three quarters of that kernel's instruction stream (profiles/pmc_cfg2_strict.json: 76 % of its
+// VALU instructions were not FP64) and all of its exposed latency:
+//   * ONE table gather per pair instead of two: ctab[i] = {GL0, GL1, GL2, log(GL . row_0), log(GL . row_1), log(GL . row_2)} (64-byte entries,
+//     k_build_ctab: the GL of gl_seed + gl_finish and the logs of k_build_canon_logs, evaluated once per read combination), indexed by the
+//     read count and the RAW leading read bytes — one read: the byte; two reads: the 16-bit word (all 65 536 combinations, no quality test);
+//     three reads of quality < 48: the 96^3 code.  Anything else (0.25 % of the pairs at 1.25 reads per pair) walks the read loop as before.
+//   * ONE record per SNP instead of four arrays: SnpRec = {gp0[3], the id word, the "has a fourth row" flag} (32 bytes, k_build_snprec).
+//   * 32-bit element offsets from wave-uniform array bases (SGPR base + VGPR offset loads) instead of 64-bit pointer arithmetic per load.
+//   * A three-deep software pipeline in which NOTHING a tile consumes was requested in the same iteration: tile t + 3's read counts, tile
+//     t + 2's scan and leading read bytes, tile t + 1's table entry and SNP record are in flight while tile t computes (the memory system
+//     returns a wavefront's loads in order, so the old kernel's wait for the current tile's rows also waited for the prefetches behind them).
+struct SnpRec { double q0, q1, q2; uint32_t idw; uint32_t oth; };
+static_assert(sizeof(SnpRec) == 32, "SnpRec");
+constexpr uint32_t kCt2 = 257, kCt3 = 257 + 65536;                              // ctab regions: one read (256 = none) | two reads (raw bytes) | three reads
+constexpr int64_t kCtN = (int64_t)kCt3 + (int64_t)dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes;
+
+__global__ void k_build_snprec(const double* __restrict__ gp0, const uint32_t* __restrict__ idw, const uint8_t* __restrict__ oth, int32_t S, int32_t nwd,
+                               SnpRec* __restrict__ out) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  SnpRec r;
+  r.q0 = gp0[3 * s]; r.q1 = gp0[3 * s + 1]; r.q2 = gp0[3 * s + 2]; r.idw = idw[s * nwd]; r.oth = oth[s];
+  out[s] = r;
+}
+
+// ctab entry i: the pair's genotype likelihoods exactly as gl_seed + gl_finish produce them (the host tables where they reach, the kernel's own
+// read loop beyond), and the three canonical-class terms with k_build_canon_logs' expressions and log.
+__global__ void k_build_ctab(const double* __restrict__ tabs, double hi, double lo, double* __restrict__ ctab) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= kCtN) return;
+  uint32_t n, rd4;
+  if (i < kCt2) { n = i == 256 ? 0u : 1u; rd4 = (uint32_t)i & 0xFFu; }
+  else if (i < kCt3) { n = 2u; rd4 = (uint32_t)(i - kCt2); }
+  else {
+    uint32_t c = (uint32_t)(i - kCt3);
+    const uint32_t c2 = c % (uint32_t)dmx::kTripleCodes; c /= (uint32_t)dmx::kTripleCodes;
+    const uint32_t c1 = c % (uint32_t)dmx::kTripleCodes, c0 = c / (uint32_t)dmx::kTripleCodes;
+    auto byte_of = [](uint32_t code) { return code >= (uint32_t)dmx::kTripleBq ? (0x80u | (code - (uint32_t)dmx::kTripleBq)) : code; };
+    n = 3u; rd4 = byte_of(c0) | (byte_of(c1) << 8) | (byte_of(c2) << 16);
+  }
+  const GlSeed sd = gl_seed(tabs, n, rd4);
+  double G0, G1, G2;
+  gl_finish(sd, n, rd4, nullptr, 0, tabs, G0, G1, G2);
+  const double* T = tabs + kLut;
+  double* o = ctab + 8 * i;
+  o[0] = G0; o[1] = G1; o[2] = G2;
+  o[3] = dmx_log_fast(G0 * hi + G1 * lo + G2 * lo, T);
+  o[4] = dmx_log_fast(G0 * lo + G1 * hi + G2 * lo, T);
+  o[5] = dmx_log_fast(G0 * lo + G1 * lo + G2 * hi, T);
+  o[6] = 0.0; o[7] = 0.0;
+}
+
+template <int CW, int KC>
+__global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, const SnpRec* __restrict__ snprec, const float* __restrict__ rows,
+                                                             const double* __restrict__ ctab, const double* __restrict__ tabs,
+                                                             const int32_t* __restrict__ sched, int32_t V,
+                                                             double* __restrict__ llks, double* __restrict__ llk0s, double chi, double clo) {
+  static_assert(KC == 8 || KC == 4, "a chunk's 2-bit class ids must sit inside one 32-bit id word");
+  constexpr int T = 64 / CW;
+  constexpr int TS = T + 2;
+  constexpr int NC = KC + 1;
+  constexpr int NW = kThreads / 64;
+  static_assert(CW * NC <= 64, "one lane per chain");
+  extern __shared__ double s_dyn[];              // [NW][nch][CW*NC] running accumulators
+  __shared__ double s_log_tab[DMX_LOG_TABLE_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double s_term[NW][CW * NC * TS];
+  __shared__ double s_scr[NW][64 * 4];
+  const double* s_log = s_log_tab;
+
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const int nch = (V + KC - 1) / KC;
+  for (int i = t; i < DMX_LOG_TABLE_DOUBLES; i += kThreads) s_log_tab[i] = tabs[kLut + i];
+  for (int i = t; i < NW * nch * CW * NC; i += kThreads) s_dyn[i] = 0.0;
+  __syncthreads();                               // the only workgroup barrier
+
+  double* term = s_term[w];
+  double* scr = &s_scr[w][lane];                 // class-major [d][lane] (see k_singlet_cls)
+  double* accs = s_dyn + (size_t)w * nch * CW * NC;
+  const int slot0 = (blockIdx.x * NW + w) * CW;
+  if (slot0 >= pv.B) return;
+
+  const int c = lane / T, ti = lane % T;
+  const bool cell_ok = slot0 + c < pv.B;
+  const int32_t cell = cell_ok ? sched[slot0 + c] : 0;
+  const uint32_t p_beg = cell_ok ? (uint32_t)pv.cell_pair_off[cell] : 0u;               // (the launcher checked: every offset fits 32 bits)
+  const uint32_t np = cell_ok ? (uint32_t)(pv.cell_pair_off[cell + 1] - pv.cell_pair_off[cell]) : 0u;
+  uint32_t rd_base = cell_ok ? (uint32_t)pv.cell_read_off[cell] : 0u;
+  uint32_t max_np = np;
+#pragma unroll
+  for (int d = T; d < 64; d <<= 1) max_np = max(max_np, (uint32_t)__shfl_xor((int)max_np, d));
+  const int a_c = lane / NC, a_kk = lane % NC;
+  const bool a_ok = lane < CW * NC && slot0 + a_c < pv.B;
+  const uint32_t a_np = (uint32_t)__shfl((int)np, (a_ok ? a_c : 0) * T);
+  const int32_t a_cell = __shfl(cell, (a_ok ? a_c : 0) * T);
+  const uint8_t* __restrict__ nrd8 = (const uint8_t*)pv.pair_nrd;
+  const uint8_t* __restrict__ reads = pv.reads;
+  const int32_t* __restrict__ psnp = pv.pair_snp;
+
+  // stage A: read count (and SNP id) of the lane's pair of a tile
+  struct Raw { uint32_t n; uint32_t snp; };
+  auto stage_a = [&](uint32_t tile) {
+    Raw r;
+    const uint32_t pi = tile * T + ti;
+    const bool v = pi < np;
+    const uint32_t pa = v ? p_beg + pi : 0u;
+    r.n = v ? (uint32_t)nrd8[pa] : 0u;
+    r.snp = v ? (psnp ? (uint32_t)psnp[pa] : pi) : 0u;
+    return r;
+  };
+  // stage B: the pair's read offset (scan over the cell's lanes) and its leading read bytes
+  struct Hdr { uint32_t n, snp, rd4, off; };
+  auto stage_b = [&](const Raw& r) {
+    Hdr h;
+    h.n = r.n; h.snp = r.snp;
+    const uint32_t incl = seg_scan_incl<T>(r.n);
+    h.off = rd_base + (incl - r.n);
+    rd_base += seg_last<T>(incl, lane);
+    uint32_t v;
+    __builtin_memcpy(&v, reads + (r.n ? h.off : 0u), 4);        // (the launcher checked: four bytes past the last read are readable)
+    h.rd4 = v;
+    return h;
+  };
+  // stage C: the pair's table entry and its SNP's record
+  struct Seed { double g0, g1, g2, l0, l1, l2; SnpRec rec; bool fast; };
+  auto stage_c = [&](const Hdr& h) {
+    Seed sd;
+    const uint32_t n = h.n, rd4 = h.rd4;
+    uint32_t idx = n == 0 ? 256u : (rd4 & 0xFFu);
+    idx = n == 2 ? kCt2 + (rd4 & 0xFFFFu) : idx;
+    bool fast = n <= 2;
+    if (n == 3) {
+      const uint32_t q0 = rd4 & 127u, q1 = (rd4 >> 8) & 127u, q2 = (rd4 >> 16) & 127u;
+      if (max(max(q0, q1), q2) < (uint32_t)dmx::kTripleBq) {
+        const uint32_t c0 = ((rd4 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q0, c1 = ((rd4 & 0x8000u) ? (uint32_t)dmx::kTripleBq : 0u) + q1,
+                       c2 = ((rd4 & 0x800000u) ? (uint32_t)dmx::kTripleBq : 0u) + q2;
+        idx = kCt3 + __umul24(__umul24(c0, (uint32_t)dmx::kTripleCodes) + c1, (uint32_t)dmx::kTripleCodes) + c2;
+        fast = true;
+      }
+    }
+    sd.fast = fast;
+    const double2* e = reinterpret_cast<const double2*>(ctab + 8u * idx);
+    const double2 a = e[0], b = e[1], cc = e[2];
+    sd.g0 = a.x; sd.g1 = a.y; sd.g2 = b.x; sd.l0 = b.y; sd.l1 = cc.x; sd.l2 = cc.y;
+    const uint4* rp = reinterpret_cast<const uint4*>(snprec + h.snp);
+    const uint4 r0 = rp[0], r1 = rp[1];
+    sd.rec.q0 = __hiloint2double((int)r0.y, (int)r0.x); sd.rec.q1 = __hiloint2double((int)r0.w, (int)r0.z);
+    sd.rec.q2 = __hiloint2double((int)r1.y, (int)r1.x); sd.rec.idw = r1.z; sd.rec.oth = r1.w;
+    return sd;
+  };
+
+  Hdr h1 = stage_b(stage_a(0));
+  Hdr h2 = stage_b(stage_a(1));
+  Raw pre = stage_a(2);
+  Seed s1 = stage_c(h1);
+  for (uint32_t tile = 0; tile * T < max_np; ++tile) {
+    const Hdr cur = h1;
+    const Seed cs = s1;
+    h1 = h2;
+    s1 = stage_c(h1);                              // tile + 1
+    h2 = stage_b(pre);                             // tile + 2
+    pre = stage_a(tile + 3);                       // tile + 3
+    const bool valid = tile * T + ti < np;
+
+    double G0 = cs.g0, G1 = cs.g1, G2 = cs.g2, t0 = cs.l0, t1 = cs.l1, t2 = cs.l2;
+    if (valid && !cs.fast) {                       // deeper pairs, qualities beyond the tables: the read loop and the three logs, as k_singlet_cls<.., CAN>
+      const GlSeed sd = gl_seed(tabs, cur.n, cur.rd4);
+      gl_finish(sd, cur.n, cur.rd4, reads, (int64_t)cur.off, tabs, G0, G1, G2);
+      t0 = dmx_log_fast(G0 * chi + G1 * clo + G2 * clo, s_log);
+      t1 = dmx_log_fast(G0 * clo + G1 * chi + G2 * clo, s_log);
+      t2 = dmx_log_fast(G0 * clo + G1 * clo + G2 * chi, s_log);
+    }
+    if (valid) {
+      scr[0] = t0; scr[64] = t1; scr[128] = t2;
+      if (cs.rec.oth) {                            // class 3: the SNP's own fourth row (a missing genotype's Hardy-Weinberg row)
+        const float* r3 = rows + (size_t)cur.snp * 12 + 9;
+        scr[192] = dmx_log_fast(G0 * (double)r3[0] + G1 * (double)r3[1] + G2 * (double)r3[2], s_log);
+      }
+      term[(c * NC + KC) * TS + ti] = dmx_log_fast(G0 * cs.rec.q0 + G1 * cs.rec.q1 + G2 * cs.rec.q2, s_log);          // llk0 (:459)
+    }
+    for (int q = 0; q < nch; ++q) {
+      const int k0 = q * KC;
+      if (valid) {
+        const uint32_t bits = cs.rec.idw >> (2 * k0);         // the chunk's KC class ids, 2 bits each (V <= 16: one id word)
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk)
+          term[(c * NC + kk) * TS + ti] = scr[((bits >> (2 * kk)) & 3u) << 6];     // sample k0+kk's term (slots past V-1 are never summed)
+      }
+      DMX_WAVE_LDS_ORDER();
+      if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
+        const uint32_t done = tile * T;
+        const int cnt = a_np >= done + T ? T : (a_np > done ? (int)(a_np - done) : 0);
+        const double* row = &term[lane * TS];
+        double s = accs[q * (CW * NC) + lane];
+        int i = 0;
+        for (; i + 16 <= cnt; i += 16) {
+          double2 v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const double2*>(&row[i + 2 * j]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s += v[j].x; s += v[j].y; }
+        }
+        for (; i < cnt; ++i) s += row[i];           // ascending SNP order: the reference's order
+        accs[q * (CW * NC) + lane] = s;
+      }
+      DMX_WAVE_LDS_ORDER();
+    }
+  }
+  if (a_ok) {
+    for (int q = 0; q < nch; ++q) {
+      const double s = accs[q * (CW * NC) + lane];
+      if (a_kk < KC) { const int k = q * KC + a_kk; if (k < V) llks[(size_t)a_cell * V + k] = s; }
+      else if (q == 0) llk0s[a_cell] = s;
+    }
+  }
+}
+
 // K1 over genotype classes, wide-panel form (V >= 20, measured crossover): all V+1 accumulators of a cell are summed in one pass per tile.
 // Same walk and ownership as k_singlet; per pair the lane evaluates log(GL . row_d) once per class d plus the llk0 term,
 // and stores those five terms and the SNP's packed class ids; chain lane (cell, k) then adds term[id[snp][k]] for the
@@ -4663,6 +4881,9 @@ struct dmx_engine {
   // (bcf_filtered_reader.cpp:397-400); class ids are then 0 / 1 / 2 = that row with hi in place 0 / 1 / 2 and 3 = the SNP's one other row (a missing
   // genotype's HWE row, :381-388), and K1 takes log(GL . row) of the three canonical rows from a table indexed like the GL tables (d_ltab)
   bool canon = false, ltab_valid = false; float can_hi = 0.f, can_lo = 0.f; double* d_ltab = nullptr; uint8_t* d_oth = nullptr;
+  SnpRec* d_snprec = nullptr; bool snprec_valid = false; double* d_ctab = nullptr; bool ctab_valid = false;   // k_singlet_can's per-SNP records and merged GL / class-log table
+  bool off32 = false;                                     // every absolute pair index and read offset of the staged pileup fits 32 bits
+  bool reads_padded = false;                              // four bytes past the staged pileup's last read byte are readable (k_singlet_can's unconditional 4-byte loads)
   double* d_cseed = nullptr; bool cseed_valid = false;   // certify_pair_values' seeds (k_build_certify_seeds; a function of the phred tables)
   double* d_park = nullptr; size_t park_cap = 0;   // k_certify's per-barcode state between the launches of its SNP-blocked walk
   int64_t* d_blk = nullptr; size_t blk_cap = 0; int32_t blk_shift = 0, blk_n = 0;   // k_snp_blocks table of the staged (sparse) pileup; blk_n = 0: none
@@ -4821,6 +5042,8 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_cseed) (void)hipFree(e->d_cseed);
   if (e->d_ltab) (void)hipFree(e->d_ltab);
   if (e->d_oth) (void)hipFree(e->d_oth);
+  if (e->d_snprec) (void)hipFree(e->d_snprec);
+  if (e->d_ctab) (void)hipFree(e->d_ctab);
   for (int i = 0; i < 2; ++i) { if (e->h_stage[i]) (void)hipHostFree(e->h_stage[i]); if (e->ev_stage[i]) (void)hipEventDestroy(e->ev_stage[i]); }
   for (hipEvent_t& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& r : e->ring_s) for (hipEvent_t& ev : r) if (ev) (void)hipEventDestroy(ev);
@@ -4856,7 +5079,7 @@ extern "C" int dmx_engine_set_phred_tables(dmx_engine* e, const double mat[256],
   const dmx::TripleTables& tt = dmx::build_triple_tables(lut, *pt);
   HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair, tt.third.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair + kTriple, tt.final3.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
-  e->ltab_valid = false; e->cseed_valid = false;   // (the canonical-class log table and k_certify's seeds are functions of these tables)
+  e->ltab_valid = false; e->cseed_valid = false; e->ctab_valid = false;   // (the canonical-class log tables and k_certify's seeds are functions of these tables)
   return DMX_OK;
 }
 
@@ -4918,7 +5141,7 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     e->n_classes = (h_max >= 1 && h_max <= kMaxCls) ? h_max : 0;
     if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); (void)hipFree(e->d_idw); (void)hipFree(e->d_idd); e->d_rows = nullptr; e->d_ids = nullptr; e->d_idw = nullptr; e->d_idd = nullptr; }
     // canonical GT classes (see k_canon_apply): relabel when the matrix has that shape
-    e->canon = false; e->ltab_valid = false;
+    e->canon = false; e->ltab_valid = false; e->ctab_valid = false; e->snprec_valid = false;
     if (e->d_oth) { (void)hipFree(e->d_oth); e->d_oth = nullptr; }
     if (e->n_classes && !e->knob("DMX_NO_CANON")) {
       int32_t* d_w = nullptr;
@@ -5257,6 +5480,22 @@ int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int3
     HIP_TRY(hipMalloc((void**)&e->d_llk0s, sizeof(double) * (size_t)cap));
     e->out_cap = cap;
   }
+  // k_singlet_can's preconditions: every ABSOLUTE pair index / read offset the kernels form fits 32 bits (a view of a caller's device arrays
+  // indexes the caller's whole arrays), and the four bytes behind the last read byte are readable (the engine's own copies are allocated
+  // with slack; a caller's device array is, when its allocation extends that far)
+  {
+    const bool own_reads = e->pv.reads == (const uint8_t*)e->own[4];
+    const uint64_t maxP = own_reads ? (uint64_t)e->P : (uint64_t)std::max<int64_t>(pl->n_pairs, e->P);
+    const uint64_t maxR = (uint64_t)std::max<int64_t>(e->pv.R, e->R);
+    e->off32 = maxP + 4 * 64 < (1ull << 32) && maxR + 64 < (1ull << 32);
+    e->reads_padded = own_reads;
+    if (!own_reads && e->pv.reads) {
+      hipDeviceptr_t base = nullptr; size_t size = 0;
+      if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)e->pv.reads) == hipSuccess)
+        e->reads_padded = (const uint8_t*)base + size >= e->pv.reads + maxR + 4;
+      (void)hipGetLastError();
+    }
+  }
   e->have_sing = e->have_grid = false;
   e->have_pileup = true;
   return DMX_OK;
@@ -5302,6 +5541,29 @@ int launch_singlet(dmx_engine* e) {
       const int chk = e->geno_safe ? 0 : 1;       // (DMX_FORCE_CHECK=1 keeps the test: bit-identical, tests/test_gpu_parity.py)
       // canonical GT classes: three of a pair's five log terms from the table (k_singlet_cls<.., CAN>; DMX_NO_CANON_K1=1: the plain class form)
       const bool can = e->canon && chk == 0 && !e->knob("DMX_NO_CANON_K1");
+      // the lean canonical-class kernel (round 5): one id word per SNP, one-byte read counts, every offset in 32 bits, padded read bytes
+      const bool lean = can && V <= 16 && e->nrd_width == 1 && e->reads_padded && e->off32 && (uint64_t)e->S * 48 < (1ull << 32) && !e->knob("DMX_K1_NO_LEAN");
+      if (lean) {
+        if (!e->snprec_valid) {
+          if (e->d_snprec) { (void)hipFree(e->d_snprec); e->d_snprec = nullptr; }
+          HIP_TRY(hipMalloc((void**)&e->d_snprec, sizeof(SnpRec) * (size_t)std::max(e->S, 1)));
+          hipLaunchKernelGGL(k_build_snprec, dim3((unsigned)((e->S + 255) / 256)), dim3(256), 0, e->stream, e->d_gp0, e->d_idw, e->d_oth, e->S, (V + 15) / 16, e->d_snprec);
+          HIP_TRY(hipGetLastError());
+          e->snprec_valid = true;
+        }
+        if (!e->ctab_valid) {
+          if (!e->d_ctab) HIP_TRY(hipMalloc((void**)&e->d_ctab, sizeof(double) * 8 * (size_t)kCtN));
+          hipLaunchKernelGGL(k_build_ctab, dim3((unsigned)((kCtN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, (double)e->can_hi, (double)e->can_lo, e->d_ctab);
+          HIP_TRY(hipGetLastError());
+          e->ctab_valid = true;
+        }
+#define DMX_K1L(CC, KK) DMX_LAUNCH(k1_fn, (k_singlet_can<CC, KK>), grd, blk, dynb, e->stream, e->pv, e->d_snprec, e->d_rows, e->d_ctab, e->d_lut, e->d_sched, V, \
+                                   e->d_llks, e->d_llk0s, (double)e->can_hi, (double)e->can_lo)
+        if (KC == 4) { if (CW == 4) DMX_K1L(4, 4); else if (CW == 2) DMX_K1L(2, 4); else DMX_K1L(1, 4); }
+        else         { if (CW == 4) DMX_K1L(4, 8); else if (CW == 2) DMX_K1L(2, 8); else DMX_K1L(1, 8); }
+#undef DMX_K1L
+        return DMX_OK;
+      }
       if (can && !e->ltab_valid) {
         if (!e->d_ltab) HIP_TRY(hipMalloc((void**)&e->d_ltab, sizeof(double) * 4 * (size_t)kCanN));
         hipLaunchKernelGGL(k_build_canon_logs, dim3((unsigned)((kCanN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, (double)e->can_hi,

@@ -1,5 +1,5 @@
-export DMX_EXPERIMENTS=1   # the kernel-variant switches are honoured only with this (dmx_engine_create)
 #!/bin/bash
+export DMX_EXPERIMENTS=1   # the kernel-variant switches are honoured only with this (dmx_engine_create)
 # GPU box: K3b (k_certify) time at cfg3 / cfg5 / cfg4-shard sizes, FAST, for the variants selected by environment switches.
 for cfg in 3 5 4; do
   cells=""; [ $cfg = 4 ] && cells="--cells 12500"

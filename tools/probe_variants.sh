@@ -1,5 +1,5 @@
-export DMX_EXPERIMENTS=1   # the kernel-variant switches are honoured only with this (dmx_engine_create)
 #!/bin/bash
+export DMX_EXPERIMENTS=1   # the kernel-variant switches are honoured only with this (dmx_engine_create)
 # GPU box: per-kernel times of bench configurations for several library variants / environment switches.
 #   tools/probe_variants.sh "<cfg> [bench flags]" "<VAR=val ...>" ...      ("-" = no switch)
 spec=$1; shift
