@@ -753,18 +753,19 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
 //   * A three-deep software pipeline in which NOTHING a tile consumes was requested in the same iteration: tile t + 3's read counts, tile
 //     t + 2's scan and leading read bytes, tile t + 1's table entry and SNP record are in flight while tile t computes (the memory system
 //     returns a wavefront's loads in order, so the old kernel's wait for the current tile's rows also waited for the prefetches behind them).
-struct SnpRec { double q0, q1, q2; uint32_t idw; uint32_t oth; };
+struct SnpRec { double q0, q1, q2; uint32_t idw; uint32_t oth; };          // stored as two 16-byte halves in two arrays (SoA): [S] {q0, q1} | [S] {q2, idw, oth}
 static_assert(sizeof(SnpRec) == 32, "SnpRec");
 constexpr uint32_t kCt2 = 257, kCt3 = 257 + 65536;                              // ctab regions: one read (256 = none) | two reads (raw bytes) | three reads
 constexpr int64_t kCtN = (int64_t)kCt3 + (int64_t)dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes;
+constexpr int kCtBq = 42, kCtLds = 2 * kCtBq + 1;                                // LDS copy of region 1: one read of quality < 42 (code allele * 42 + bq; the CLI caps at 40), 84 = no read
 
 __global__ void k_build_snprec(const double* __restrict__ gp0, const uint32_t* __restrict__ idw, const uint8_t* __restrict__ oth, int32_t S, int32_t nwd,
-                               SnpRec* __restrict__ out) {
+                               uint4* __restrict__ out) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
-  SnpRec r;
-  r.q0 = gp0[3 * s]; r.q1 = gp0[3 * s + 1]; r.q2 = gp0[3 * s + 2]; r.idw = idw[s * nwd]; r.oth = oth[s];
-  out[s] = r;
+  const double q0 = gp0[3 * s], q1 = gp0[3 * s + 1], q2 = gp0[3 * s + 2];
+  out[s] = make_uint4((uint32_t)__double2loint(q0), (uint32_t)__double2hiint(q0), (uint32_t)__double2loint(q1), (uint32_t)__double2hiint(q1));
+  out[(size_t)S + s] = make_uint4((uint32_t)__double2loint(q2), (uint32_t)__double2hiint(q2), idw[s * nwd], (uint32_t)oth[s]);
 }
 
 // ctab entry i: the pair's genotype likelihoods exactly as gl_seed + gl_finish produce them (the host tables where they reach, the kernel's own
@@ -794,8 +795,17 @@ __global__ void k_build_ctab(const double* __restrict__ tabs, double hi, double 
   o[6] = 0.0; o[7] = 0.0;
 }
 
-template <int CW, int KC>
-__global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, const SnpRec* __restrict__ snprec, const float* __restrict__ rows,
+// The first version of this kernel (everything gathered from the global table) was bound by the CU's vector L1: one tag look-up per lane and
+// gather instruction, 273 per 64-pair tile = 0.94 look-ups per cycle and CU (profiles/r05_k1_probe.txt) — not by issue, not by bandwidth.  The LDS
+// serves 16 lanes per cycle, so the table entries of the commonest pairs — no read, or ONE read of quality < 42 (the CLI caps at 40): 78 % of the
+// pairs at 1.25 reads per pair — come from a 4 KB LDS copy and only the other lanes gather from the global table, a tile ahead.  The copy has to fit
+// beside 5 workgroups per CU (10 000 barcodes at two per wavefront are ONE round of 5 wavefronts per SIMD; a workgroup of ten wavefronts sharing a
+// bigger copy is admitted once per CU only — measured): 32 000 bytes per workgroup (the LDS is handed out in 1 280-byte pieces: 32 432 bytes were
+// admitted four times per CU), found by keeping the running sums in registers and, for matrices without a fourth genotype row (OTH = false: no
+// missing genotypes), three class planes of scratch instead of four.  OTH = true keeps the
+// global gathers for every lane.
+template <int CW, int KC, bool OTH>
+__global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, const uint4* __restrict__ snprec, const float* __restrict__ rows,
                                                              const double* __restrict__ ctab, const double* __restrict__ tabs,
                                                              const int32_t* __restrict__ sched, int32_t V,
                                                              double* __restrict__ llks, double* __restrict__ llk0s, double chi, double clo) {
@@ -804,22 +814,27 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   constexpr int TS = T + 2;
   constexpr int NC = KC + 1;
   constexpr int NW = kThreads / 64;
+  constexpr int NPL = OTH ? 4 : 3;               // class planes of scratch
   static_assert(CW * NC <= 64, "one lane per chain");
-  extern __shared__ double s_dyn[];              // [NW][nch][CW*NC] running accumulators
   __shared__ double s_log_tab[DMX_LOG_TABLE_DOUBLES];
   __shared__ __attribute__((aligned(16))) double s_term[NW][CW * NC * TS];
-  __shared__ double s_scr[NW][64 * 4];
+  __shared__ double s_scr[NW][64 * NPL];
+  __shared__ __attribute__((aligned(16))) double s_ct[OTH ? 2 : kCtLds * 6];
   const double* s_log = s_log_tab;
 
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int nch = (V + KC - 1) / KC;
+  const int nch = (V + KC - 1) / KC;             // 1 or 2 (V <= 16)
   for (int i = t; i < DMX_LOG_TABLE_DOUBLES; i += kThreads) s_log_tab[i] = tabs[kLut + i];
-  for (int i = t; i < NW * nch * CW * NC; i += kThreads) s_dyn[i] = 0.0;
+  if constexpr (!OTH)
+    for (int i = t; i < kCtLds * 6; i += kThreads) {
+      const int e = i / 6, f = i % 6;
+      const int b = e == 2 * kCtBq ? 256 : (e >= kCtBq ? (0x80 | (e - kCtBq)) : e);   // the read byte (allele << 7) | bq of code e
+      s_ct[i] = ctab[8 * b + f];
+    }
   __syncthreads();                               // the only workgroup barrier
 
   double* term = s_term[w];
   double* scr = &s_scr[w][lane];                 // class-major [d][lane] (see k_singlet_cls)
-  double* accs = s_dyn + (size_t)w * nch * CW * NC;
   const int slot0 = (blockIdx.x * NW + w) * CW;
   if (slot0 >= pv.B) return;
 
@@ -836,9 +851,12 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   const bool a_ok = lane < CW * NC && slot0 + a_c < pv.B;
   const uint32_t a_np = (uint32_t)__shfl((int)np, (a_ok ? a_c : 0) * T);
   const int32_t a_cell = __shfl(cell, (a_ok ? a_c : 0) * T);
+  double acc[2] = {0.0, 0.0};                    // the chain's running sums (chunk 0, chunk 1), in registers
   const uint8_t* __restrict__ nrd8 = (const uint8_t*)pv.pair_nrd;
   const uint8_t* __restrict__ reads = pv.reads;
   const int32_t* __restrict__ psnp = pv.pair_snp;
+  const uint4* __restrict__ recA = snprec;
+  const uint4* __restrict__ recB = snprec + pv.S;
 
   // stage A: read count (and SNP id) of the lane's pair of a tile
   struct Raw { uint32_t n; uint32_t snp; };
@@ -864,31 +882,39 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
     h.rd4 = v;
     return h;
   };
-  // stage C: the pair's table entry and its SNP's record
-  struct Seed { double g0, g1, g2, l0, l1, l2; SnpRec rec; bool fast; };
+  // stage C: the pair's table entry (LDS copy: no read, or one read of quality < 48; else the global table) and its SNP's record
+  struct Seed { double g0, g1, g2, l0, l1, l2; double q0, q1, q2; uint32_t idw, oth; bool fast; };
   auto stage_c = [&](const Hdr& h) {
     Seed sd;
     const uint32_t n = h.n, rd4 = h.rd4;
-    uint32_t idx = n == 0 ? 256u : (rd4 & 0xFFu);
-    idx = n == 2 ? kCt2 + (rd4 & 0xFFFFu) : idx;
-    bool fast = n <= 2;
-    if (n == 3) {
-      const uint32_t q0 = rd4 & 127u, q1 = (rd4 >> 8) & 127u, q2 = (rd4 >> 16) & 127u;
-      if (max(max(q0, q1), q2) < (uint32_t)dmx::kTripleBq) {
-        const uint32_t c0 = ((rd4 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q0, c1 = ((rd4 & 0x8000u) ? (uint32_t)dmx::kTripleBq : 0u) + q1,
-                       c2 = ((rd4 & 0x800000u) ? (uint32_t)dmx::kTripleBq : 0u) + q2;
-        idx = kCt3 + __umul24(__umul24(c0, (uint32_t)dmx::kTripleCodes) + c1, (uint32_t)dmx::kTripleCodes) + c2;
-        fast = true;
+    const bool in_lds = !OTH && (n == 0 || (n == 1 && (rd4 & 0x7Fu) < (uint32_t)kCtBq));
+    double2 a, b, cc;
+    if (in_lds) {
+      const uint32_t e = n == 0 ? (uint32_t)(2 * kCtBq) : (((rd4 & 0x80u) ? (uint32_t)kCtBq : 0u) + (rd4 & 0x7Fu));
+      const double2* p = reinterpret_cast<const double2*>(s_ct + 6u * e);
+      a = p[0]; b = p[1]; cc = p[2];
+      sd.fast = true;
+    } else {
+      uint32_t idx = n == 0 ? 256u : (rd4 & 0xFFu);
+      idx = n == 2 ? kCt2 + (rd4 & 0xFFFFu) : idx;
+      bool fast = n <= 2;
+      if (n == 3) {
+        const uint32_t q0 = rd4 & 127u, q1 = (rd4 >> 8) & 127u, q2 = (rd4 >> 16) & 127u;
+        if (max(max(q0, q1), q2) < (uint32_t)dmx::kTripleBq) {
+          const uint32_t c0 = ((rd4 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q0, c1 = ((rd4 & 0x8000u) ? (uint32_t)dmx::kTripleBq : 0u) + q1,
+                         c2 = ((rd4 & 0x800000u) ? (uint32_t)dmx::kTripleBq : 0u) + q2;
+          idx = kCt3 + __umul24(__umul24(c0, (uint32_t)dmx::kTripleCodes) + c1, (uint32_t)dmx::kTripleCodes) + c2;
+          fast = true;
+        }
       }
+      sd.fast = fast;
+      const double2* e = reinterpret_cast<const double2*>(ctab + 8u * idx);
+      a = e[0]; b = e[1]; cc = e[2];
     }
-    sd.fast = fast;
-    const double2* e = reinterpret_cast<const double2*>(ctab + 8u * idx);
-    const double2 a = e[0], b = e[1], cc = e[2];
     sd.g0 = a.x; sd.g1 = a.y; sd.g2 = b.x; sd.l0 = b.y; sd.l1 = cc.x; sd.l2 = cc.y;
-    const uint4* rp = reinterpret_cast<const uint4*>(snprec + h.snp);
-    const uint4 r0 = rp[0], r1 = rp[1];
-    sd.rec.q0 = __hiloint2double((int)r0.y, (int)r0.x); sd.rec.q1 = __hiloint2double((int)r0.w, (int)r0.z);
-    sd.rec.q2 = __hiloint2double((int)r1.y, (int)r1.x); sd.rec.idw = r1.z; sd.rec.oth = r1.w;
+    const uint4 r0 = recA[h.snp], r1 = recB[h.snp];
+    sd.q0 = __hiloint2double((int)r0.y, (int)r0.x); sd.q1 = __hiloint2double((int)r0.w, (int)r0.z);
+    sd.q2 = __hiloint2double((int)r1.y, (int)r1.x); sd.idw = r1.z; sd.oth = r1.w;
     return sd;
   };
 
@@ -915,46 +941,51 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
     }
     if (valid) {
       scr[0] = t0; scr[64] = t1; scr[128] = t2;
-      if (cs.rec.oth) {                            // class 3: the SNP's own fourth row (a missing genotype's Hardy-Weinberg row)
-        const float* r3 = rows + (size_t)cur.snp * 12 + 9;
-        scr[192] = dmx_log_fast(G0 * (double)r3[0] + G1 * (double)r3[1] + G2 * (double)r3[2], s_log);
-      }
-      term[(c * NC + KC) * TS + ti] = dmx_log_fast(G0 * cs.rec.q0 + G1 * cs.rec.q1 + G2 * cs.rec.q2, s_log);          // llk0 (:459)
-    }
-    for (int q = 0; q < nch; ++q) {
-      const int k0 = q * KC;
-      if (valid) {
-        const uint32_t bits = cs.rec.idw >> (2 * k0);         // the chunk's KC class ids, 2 bits each (V <= 16: one id word)
-#pragma unroll
-        for (int kk = 0; kk < KC; ++kk)
-          term[(c * NC + kk) * TS + ti] = scr[((bits >> (2 * kk)) & 3u) << 6];     // sample k0+kk's term (slots past V-1 are never summed)
-      }
-      DMX_WAVE_LDS_ORDER();
-      if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
-        const uint32_t done = tile * T;
-        const int cnt = a_np >= done + T ? T : (a_np > done ? (int)(a_np - done) : 0);
-        const double* row = &term[lane * TS];
-        double s = accs[q * (CW * NC) + lane];
-        int i = 0;
-        for (; i + 16 <= cnt; i += 16) {
-          double2 v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const double2*>(&row[i + 2 * j]);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { s += v[j].x; s += v[j].y; }
+      if constexpr (OTH)
+        if (cs.oth) {                              // class 3: the SNP's own fourth row (a missing genotype's Hardy-Weinberg row)
+          const float* r3 = rows + (size_t)cur.snp * 12 + 9;
+          scr[192] = dmx_log_fast(G0 * (double)r3[0] + G1 * (double)r3[1] + G2 * (double)r3[2], s_log);
         }
-        for (; i < cnt; ++i) s += row[i];           // ascending SNP order: the reference's order
-        accs[q * (CW * NC) + lane] = s;
+      term[(c * NC + KC) * TS + ti] = dmx_log_fast(G0 * cs.q0 + G1 * cs.q1 + G2 * cs.q2, s_log);          // llk0 (:459)
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (q < nch) {
+        const int k0 = q * KC;
+        if (valid) {
+          const uint32_t bits = cs.idw >> (2 * k0);           // the chunk's KC class ids, 2 bits each (V <= 16: one id word)
+#pragma unroll
+          for (int kk = 0; kk < KC; ++kk)
+            term[(c * NC + kk) * TS + ti] = scr[((bits >> (2 * kk)) & 3u) << 6];   // sample k0+kk's term (slots past V-1 are never summed; class 3 only with OTH)
+        }
+        DMX_WAVE_LDS_ORDER();
+        if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
+          const uint32_t done = tile * T;
+          const int cnt = a_np >= done + T ? T : (a_np > done ? (int)(a_np - done) : 0);
+          const double* row = &term[lane * TS];
+          double s = acc[q];
+          int i = 0;
+          for (; i + 16 <= cnt; i += 16) {
+            double2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const double2*>(&row[i + 2 * j]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s += v[j].x; s += v[j].y; }
+          }
+          for (; i < cnt; ++i) s += row[i];         // ascending SNP order: the reference's order
+          acc[q] = s;
+        }
+        DMX_WAVE_LDS_ORDER();
       }
-      DMX_WAVE_LDS_ORDER();
     }
   }
   if (a_ok) {
-    for (int q = 0; q < nch; ++q) {
-      const double s = accs[q * (CW * NC) + lane];
-      if (a_kk < KC) { const int k = q * KC + a_kk; if (k < V) llks[(size_t)a_cell * V + k] = s; }
-      else if (q == 0) llk0s[a_cell] = s;
-    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      if (q < nch) {
+        if (a_kk < KC) { const int k = q * KC + a_kk; if (k < V) llks[(size_t)a_cell * V + k] = acc[q]; }
+        else if (q == 0) llk0s[a_cell] = acc[q];
+      }
   }
 }
 
@@ -2826,7 +2857,7 @@ __global__ void k_canon_check(const float* __restrict__ rows, int32_t S, uint32_
   }
 }
 __global__ void k_canon_apply(float* __restrict__ rows, uint8_t* __restrict__ ids, uint32_t* __restrict__ idw, uint32_t* __restrict__ idd,
-                              int32_t S, int32_t V, int32_t nwd2, uint32_t hi, uint32_t lo, uint8_t* __restrict__ oth) {
+                              int32_t S, int32_t V, int32_t nwd2, uint32_t hi, uint32_t lo, uint8_t* __restrict__ oth, int32_t* __restrict__ any_oth) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   uint32_t* r = reinterpret_cast<uint32_t*>(rows + (size_t)s * kMaxCls * 3);
@@ -2858,6 +2889,7 @@ __global__ void k_canon_apply(float* __restrict__ rows, uint8_t* __restrict__ id
   r[0] = hi; r[1] = lo; r[2] = lo;  r[3] = lo; r[4] = hi; r[5] = lo;  r[6] = lo; r[7] = lo; r[8] = hi;
   r[9] = o[0]; r[10] = o[1]; r[11] = o[2];
   oth[s] = (has_other && used3) ? 1 : 0;
+  if (has_other && used3) atomicOr(any_oth, 1);
 }
 // ltab[i][t] = log(GL_i . canonical row t), i over the final GL tables: 257 one-read entries (256 = no read), 16 384 two-read, 96^3 three-read
 __global__ void k_build_canon_logs(const double* __restrict__ tabs, double hi, double lo, double* __restrict__ ltab) {
@@ -4881,7 +4913,8 @@ struct dmx_engine {
   // (bcf_filtered_reader.cpp:397-400); class ids are then 0 / 1 / 2 = that row with hi in place 0 / 1 / 2 and 3 = the SNP's one other row (a missing
   // genotype's HWE row, :381-388), and K1 takes log(GL . row) of the three canonical rows from a table indexed like the GL tables (d_ltab)
   bool canon = false, ltab_valid = false; float can_hi = 0.f, can_lo = 0.f; double* d_ltab = nullptr; uint8_t* d_oth = nullptr;
-  SnpRec* d_snprec = nullptr; bool snprec_valid = false; double* d_ctab = nullptr; bool ctab_valid = false;   // k_singlet_can's per-SNP records and merged GL / class-log table
+  uint4* d_snprec = nullptr; bool snprec_valid = false; double* d_ctab = nullptr; bool ctab_valid = false;   // k_singlet_can's per-SNP records and merged GL / class-log table
+  bool any_oth = false;                                   // some SNP of the canonical-class matrix has a fourth row (k_canon_apply's oth)
   bool off32 = false;                                     // every absolute pair index and read offset of the staged pileup fits 32 bits
   bool reads_padded = false;                              // four bytes past the staged pileup's last read byte are readable (k_singlet_can's unconditional 4-byte loads)
   double* d_cseed = nullptr; bool cseed_valid = false;   // certify_pair_values' seeds (k_build_certify_seeds; a function of the phred tables)
@@ -5145,8 +5178,8 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     if (e->d_oth) { (void)hipFree(e->d_oth); e->d_oth = nullptr; }
     if (e->n_classes && !e->knob("DMX_NO_CANON")) {
       int32_t* d_w = nullptr;
-      HIP_TRY(hipMalloc((void**)&d_w, 2 * sizeof(int32_t)));
-      int32_t h_w[2] = {0x7FFFFFFF, 0};
+      HIP_TRY(hipMalloc((void**)&d_w, 3 * sizeof(int32_t)));
+      int32_t h_w[3] = {0x7FFFFFFF, 0, 0};
       HIP_TRY(hipMemcpyAsync(d_w, h_w, sizeof h_w, hipMemcpyHostToDevice, e->stream));
       hipLaunchKernelGGL(k_find_canon, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_rows, n_snps, d_w);
       HIP_TRY(hipGetLastError());
@@ -5173,9 +5206,11 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
           if (h_w[1] == 0) {
             HIP_TRY(hipMalloc((void**)&e->d_oth, (size_t)n_snps + 16));
             hipLaunchKernelGGL(k_canon_apply, dim3((unsigned)((n_snps + 255) / 256)), dim3(256), 0, e->stream, e->d_rows, e->d_ids, e->d_idw,
-                               e->d_idd, n_snps, e->V, e->nwd2, uh, ul, e->d_oth);
+                               e->d_idd, n_snps, e->V, e->nwd2, uh, ul, e->d_oth, d_w + 2);
             HIP_TRY(hipGetLastError());
-            e->canon = true; e->can_hi = hi; e->can_lo = lo;
+            HIP_TRY(hipMemcpyAsync(h_w + 2, d_w + 2, sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            e->canon = true; e->can_hi = hi; e->can_lo = lo; e->any_oth = h_w[2] != 0;
           }
         }
       }
@@ -5557,11 +5592,16 @@ int launch_singlet(dmx_engine* e) {
           HIP_TRY(hipGetLastError());
           e->ctab_valid = true;
         }
-#define DMX_K1L(CC, KK) DMX_LAUNCH(k1_fn, (k_singlet_can<CC, KK>), grd, blk, dynb, e->stream, e->pv, e->d_snprec, e->d_rows, e->d_ctab, e->d_lut, e->d_sched, V, \
-                                   e->d_llks, e->d_llk0s, (double)e->can_hi, (double)e->can_lo)
+        // (a matrix with a fourth genotype row somewhere — missing genotypes — keeps four class planes of scratch and gathers every entry from the
+        //  global table; without one the commonest entries come from an LDS copy: see the kernel)
+        const bool oth = e->any_oth;
+#define DMX_K1L_(CC, KK, OO) DMX_LAUNCH(k1_fn, (k_singlet_can<CC, KK, OO>), grd, blk, 0, e->stream, e->pv, e->d_snprec, e->d_rows, e->d_ctab, e->d_lut, e->d_sched, V, \
+                                        e->d_llks, e->d_llk0s, (double)e->can_hi, (double)e->can_lo)
+#define DMX_K1L(CC, KK) do { if (oth) DMX_K1L_(CC, KK, true); else DMX_K1L_(CC, KK, false); } while (0)
         if (KC == 4) { if (CW == 4) DMX_K1L(4, 4); else if (CW == 2) DMX_K1L(2, 4); else DMX_K1L(1, 4); }
         else         { if (CW == 4) DMX_K1L(4, 8); else if (CW == 2) DMX_K1L(2, 8); else DMX_K1L(1, 8); }
 #undef DMX_K1L
+#undef DMX_K1L_
         return DMX_OK;
       }
       if (can && !e->ltab_valid) {
