@@ -882,19 +882,15 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
     h.rd4 = v;
     return h;
   };
-  // stage C: the pair's table entry (LDS copy: no read, or one read of quality < 48; else the global table) and its SNP's record
-  struct Seed { double g0, g1, g2, l0, l1, l2; double q0, q1, q2; uint32_t idw, oth; bool fast; };
+  // stage C: the pair's table entry — requested from the global table a tile ahead unless the LDS copy has it (no read, or one read of quality
+  // < kCtBq), in which case stage D reads it when the tile computes — and its SNP's record
+  struct Seed { double2 a, b, cc; double q0, q1, q2; uint32_t idw, oth; bool fast; };
+  auto in_lds_copy = [](uint32_t n, uint32_t rd4) { return !OTH && (n == 0 || (n == 1 && (rd4 & 0x7Fu) < (uint32_t)kCtBq)); };
   auto stage_c = [&](const Hdr& h) {
     Seed sd;
     const uint32_t n = h.n, rd4 = h.rd4;
-    const bool in_lds = !OTH && (n == 0 || (n == 1 && (rd4 & 0x7Fu) < (uint32_t)kCtBq));
-    double2 a, b, cc;
-    if (in_lds) {
-      const uint32_t e = n == 0 ? (uint32_t)(2 * kCtBq) : (((rd4 & 0x80u) ? (uint32_t)kCtBq : 0u) + (rd4 & 0x7Fu));
-      const double2* p = reinterpret_cast<const double2*>(s_ct + 6u * e);
-      a = p[0]; b = p[1]; cc = p[2];
-      sd.fast = true;
-    } else {
+    sd.fast = true;
+    if (!in_lds_copy(n, rd4)) {
       uint32_t idx = n == 0 ? 256u : (rd4 & 0xFFu);
       idx = n == 2 ? kCt2 + (rd4 & 0xFFFFu) : idx;
       bool fast = n <= 2;
@@ -909,74 +905,101 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
       }
       sd.fast = fast;
       const double2* e = reinterpret_cast<const double2*>(ctab + 8u * idx);
-      a = e[0]; b = e[1]; cc = e[2];
+      sd.a = e[0]; sd.b = e[1]; sd.cc = e[2];
     }
-    sd.g0 = a.x; sd.g1 = a.y; sd.g2 = b.x; sd.l0 = b.y; sd.l1 = cc.x; sd.l2 = cc.y;
     const uint4 r0 = recA[h.snp], r1 = recB[h.snp];
     sd.q0 = __hiloint2double((int)r0.y, (int)r0.x); sd.q1 = __hiloint2double((int)r0.w, (int)r0.z);
     sd.q2 = __hiloint2double((int)r1.y, (int)r1.x); sd.idw = r1.z; sd.oth = r1.w;
     return sd;
   };
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) v2d_t* LdsD2;        // (an LDS-address-space pointer: the two sources must not be merged into flat loads)
 
-  Hdr h1 = stage_b(stage_a(0));
-  Hdr h2 = stage_b(stage_a(1));
-  Raw pre = stage_a(2);
-  Seed s1 = stage_c(h1);
-  for (uint32_t tile = 0; tile * T < max_np; ++tile) {
-    const Hdr cur = h1;
-    const Seed cs = s1;
-    h1 = h2;
-    s1 = stage_c(h1);                              // tile + 1
-    h2 = stage_b(pre);                             // tile + 2
-    pre = stage_a(tile + 3);                       // tile + 3
-    const bool valid = tile * T + ti < np;
+  // the sums of chunk q belong to lane (cell a_c, slot a_kk): sample q * KC + a_kk, or (slot KC, chunk 0) the llk0 chain
+  const bool sum_lane[2] = {a_ok && (a_kk < KC ? a_kk < V : true), a_ok && a_kk < KC && KC + a_kk < V};
+  uint32_t min_np = cell_ok ? np : 0xFFFFFFFFu;  // tiles below it are whole for every barcode of the wavefront: their sums need no counting
+#pragma unroll
+  for (int d = T; d < 64; d <<= 1) min_np = min(min_np, (uint32_t)__shfl_xor((int)min_np, d));
 
-    double G0 = cs.g0, G1 = cs.g1, G2 = cs.g2, t0 = cs.l0, t1 = cs.l1, t2 = cs.l2;
-    if (valid && !cs.fast) {                       // deeper pairs, qualities beyond the tables: the read loop and the three logs, as k_singlet_cls<.., CAN>
+  // stage D: one tile.  Lanes beyond their barcode's last pair carry n = 0, SNP 0 (stage A): they compute like any other lane, into slots the
+  // sums never reach — no per-lane validity test anywhere below.
+  auto compute = [&](const Hdr& cur, Seed& cs, uint32_t tile) {
+    if (in_lds_copy(cur.n, cur.rd4)) {             // the LDS copy's entry
+      const uint32_t e = cur.n == 0 ? (uint32_t)(2 * kCtBq) : (((cur.rd4 & 0x80u) ? (uint32_t)kCtBq : 0u) + (cur.rd4 & 0x7Fu));
+      LdsD2 p = (LdsD2)(const __attribute__((address_space(3))) double*)(s_ct + 6u * e);
+      const v2d_t va = p[0], vb = p[1], vc = p[2];
+      cs.a.x = va.x; cs.a.y = va.y; cs.b.x = vb.x; cs.b.y = vb.y; cs.cc.x = vc.x; cs.cc.y = vc.y;
+    }
+    double G0 = cs.a.x, G1 = cs.a.y, G2 = cs.b.x, t0 = cs.b.y, t1 = cs.cc.x, t2 = cs.cc.y;
+    if (!cs.fast) {                                // deeper pairs, qualities beyond the tables: the read loop and the three logs, as k_singlet_cls<.., CAN>
       const GlSeed sd = gl_seed(tabs, cur.n, cur.rd4);
       gl_finish(sd, cur.n, cur.rd4, reads, (int64_t)cur.off, tabs, G0, G1, G2);
       t0 = dmx_log_fast(G0 * chi + G1 * clo + G2 * clo, s_log);
       t1 = dmx_log_fast(G0 * clo + G1 * chi + G2 * clo, s_log);
       t2 = dmx_log_fast(G0 * clo + G1 * clo + G2 * chi, s_log);
     }
-    if (valid) {
-      scr[0] = t0; scr[64] = t1; scr[128] = t2;
-      if constexpr (OTH)
-        if (cs.oth) {                              // class 3: the SNP's own fourth row (a missing genotype's Hardy-Weinberg row)
-          const float* r3 = rows + (size_t)cur.snp * 12 + 9;
-          scr[192] = dmx_log_fast(G0 * (double)r3[0] + G1 * (double)r3[1] + G2 * (double)r3[2], s_log);
-        }
-      term[(c * NC + KC) * TS + ti] = dmx_log_fast(G0 * cs.q0 + G1 * cs.q1 + G2 * cs.q2, s_log);          // llk0 (:459)
-    }
+    scr[0] = t0; scr[64] = t1; scr[128] = t2;
+    if constexpr (OTH)
+      if (cs.oth) {                                // class 3: the SNP's own fourth row (a missing genotype's Hardy-Weinberg row)
+        const float* r3 = rows + (size_t)cur.snp * 12 + 9;
+        scr[192] = dmx_log_fast(G0 * (double)r3[0] + G1 * (double)r3[1] + G2 * (double)r3[2], s_log);
+      }
+    term[(c * NC + KC) * TS + ti] = dmx_log_fast(G0 * cs.q0 + G1 * cs.q1 + G2 * cs.q2, s_log);            // llk0 (:459)
+    const uint32_t done = tile * T;
+    const bool whole = done + T <= min_np;         // (wave-uniform)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q < nch) {
-        const int k0 = q * KC;
-        if (valid) {
-          const uint32_t bits = cs.idw >> (2 * k0);           // the chunk's KC class ids, 2 bits each (V <= 16: one id word)
+        const uint32_t bits = cs.idw >> (2 * q * KC);         // the chunk's KC class ids, 2 bits each (V <= 16: one id word)
 #pragma unroll
-          for (int kk = 0; kk < KC; ++kk)
-            term[(c * NC + kk) * TS + ti] = scr[((bits >> (2 * kk)) & 3u) << 6];   // sample k0+kk's term (slots past V-1 are never summed; class 3 only with OTH)
-        }
+        for (int kk = 0; kk < KC; ++kk)
+          term[(c * NC + kk) * TS + ti] = scr[((bits >> (2 * kk)) & 3u) << 6];     // sample q*KC+kk's term (slots past V-1 are never summed; class 3 only with OTH)
         DMX_WAVE_LDS_ORDER();
-        if (a_ok && (a_kk < KC ? k0 + a_kk < V : q == 0)) {
-          const uint32_t done = tile * T;
-          const int cnt = a_np >= done + T ? T : (a_np > done ? (int)(a_np - done) : 0);
+        if (sum_lane[q]) {
           const double* row = &term[lane * TS];
-          double s = acc[q];
-          int i = 0;
-          for (; i + 16 <= cnt; i += 16) {
-            double2 v[8];
+          double sacc = acc[q];
+          if (whole) {                             // ascending SNP order: the reference's order
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const double2*>(&row[i + 2 * j]);
+            for (int i = 0; i < T; i += 16) {
+              double2 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s += v[j].x; s += v[j].y; }
+              for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const double2*>(&row[i + 2 * j]);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) { sacc += v[j].x; sacc += v[j].y; }
+            }
+          } else {
+            const int cnt = a_np >= done + T ? T : (a_np > done ? (int)(a_np - done) : 0);
+            for (int i = 0; i < cnt; ++i) sacc += row[i];
           }
-          for (; i < cnt; ++i) s += row[i];         // ascending SNP order: the reference's order
-          acc[q] = s;
+          acc[q] = sacc;
         }
         DMX_WAVE_LDS_ORDER();
       }
+    }
+  };
+
+  // two tiles per trip so that the two Seed sets alternate instead of being copied (the compiler's loop-carried copies were a tenth of the stream)
+  Hdr h1 = stage_b(stage_a(0));
+  Hdr h2 = stage_b(stage_a(1));
+  Raw pre = stage_a(2);
+  Seed sA = stage_c(h1), sB = sA;
+  for (uint32_t tile = 0; tile * T < max_np; tile += 2) {
+    {
+      const Hdr cur = h1;
+      h1 = h2;
+      sB = stage_c(h1);                            // tile + 1
+      h2 = stage_b(pre);                           // tile + 2
+      pre = stage_a(tile + 3);                     // tile + 3
+      compute(cur, sA, tile);
+    }
+    if ((tile + 1) * T >= max_np) break;
+    {
+      const Hdr cur = h1;
+      h1 = h2;
+      sA = stage_c(h1);
+      h2 = stage_b(pre);
+      pre = stage_a(tile + 4);
+      compute(cur, sB, tile + 1);
     }
   }
   if (a_ok) {
