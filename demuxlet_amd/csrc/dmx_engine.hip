@@ -274,6 +274,23 @@ __device__ __forceinline__ double shfl_xor1(double x) {
 __device__ __forceinline__ double lds_read_f64(const double* p) {
   return *(const volatile __attribute__((address_space(3))) double*)(const __attribute__((address_space(3))) double*)p;
 }
+// base + byte BYTE of w in ONE VALU instruction (SDWA operand select; the compiler emits v_bfe_u32 + v_add for the same expression)
+template <int BYTE> __device__ __forceinline__ uint32_t add_byte_of(uint32_t base, uint32_t w) {
+  uint32_t r;
+  if constexpr (BYTE == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(base), "v"(w));
+  else if constexpr (BYTE == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(base), "v"(w));
+  else if constexpr (BYTE == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(base), "v"(w));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(w));
+  return r;
+}
+
+// base + 16-bit half HALF of w, likewise (SDWA word select)
+template <int HALF> __device__ __forceinline__ uint32_t add_word_of(uint32_t base, uint32_t w) {
+  uint32_t r;
+  if constexpr (HALF == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(base), "v"(w));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(base), "v"(w));
+  return r;
+}
 #ifndef DMX_LDS_NOMERGE
 #define DMX_LDS_NOMERGE 1                         // cfg3 FAST K2 309 -> 291 ms (0 restores the merged reads: kernel experiments only)
 #endif
@@ -753,19 +770,24 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_cls(PileupView pv, int 
 //   * A three-deep software pipeline in which NOTHING a tile consumes was requested in the same iteration: tile t + 3's read counts, tile
 //     t + 2's scan and leading read bytes, tile t + 1's table entry and SNP record are in flight while tile t computes (the memory system
 //     returns a wavefront's loads in order, so the old kernel's wait for the current tile's rows also waited for the prefetches behind them).
-struct SnpRec { double q0, q1, q2; uint32_t idw; uint32_t oth; };          // stored as two 16-byte halves in two arrays (SoA): [S] {q0, q1} | [S] {q2, idw, oth}
-static_assert(sizeof(SnpRec) == 32, "SnpRec");
+// per-SNP record, four 16-byte parts in four arrays (SoA; a dense tile reads each contiguously): [S] {q0, q1} | [S] {q2, ids 0..3} | [S] {ids 4..11} | [S] {ids 12..15, oth, 0}
+// (gp0 = q; id k = a 16-bit 512 * class of sample k: the byte offset of the class's plane in the scratch)
+constexpr size_t kSnpRecBytes = 64;
 constexpr uint32_t kCt2 = 257, kCt3 = 257 + 65536;                              // ctab regions: one read (256 = none) | two reads (raw bytes) | three reads
 constexpr int64_t kCtN = (int64_t)kCt3 + (int64_t)dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes;
 constexpr int kCtBq = 42, kCtLds = 2 * kCtBq + 1;                                // LDS copy of region 1: one read of quality < 42 (code allele * 42 + bq; the CLI caps at 40), 84 = no read
 
-__global__ void k_build_snprec(const double* __restrict__ gp0, const uint32_t* __restrict__ idw, const uint8_t* __restrict__ oth, int32_t S, int32_t nwd,
+__global__ void k_build_snprec(const double* __restrict__ gp0, const uint8_t* __restrict__ ids, const uint8_t* __restrict__ oth, int32_t S, int32_t V,
                                uint4* __restrict__ out) {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   const double q0 = gp0[3 * s], q1 = gp0[3 * s + 1], q2 = gp0[3 * s + 2];
+  uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // sample k's class id as the BYTE OFFSET of its class plane in the scratch: half-word k = id * 512
+  for (int k = 0; k < V && k < 16; ++k) w[k >> 1] |= ((uint32_t)(ids[s * V + k] & 3u) * 512u) << (16 * (k & 1));
   out[s] = make_uint4((uint32_t)__double2loint(q0), (uint32_t)__double2hiint(q0), (uint32_t)__double2loint(q1), (uint32_t)__double2hiint(q1));
-  out[(size_t)S + s] = make_uint4((uint32_t)__double2loint(q2), (uint32_t)__double2hiint(q2), idw[s * nwd], (uint32_t)oth[s]);
+  out[(size_t)S + s] = make_uint4((uint32_t)__double2loint(q2), (uint32_t)__double2hiint(q2), w[0], w[1]);
+  out[2 * (size_t)S + s] = make_uint4(w[2], w[3], w[4], w[5]);
+  out[3 * (size_t)S + s] = make_uint4(w[6], w[7], (uint32_t)oth[s], 0u);
 }
 
 // ctab entry i: the pair's genotype likelihoods exactly as gl_seed + gl_finish produce them (the host tables where they reach, the kernel's own
@@ -804,7 +826,7 @@ __global__ void k_build_ctab(const double* __restrict__ tabs, double hi, double 
 // admitted four times per CU), found by keeping the running sums in registers and, for matrices without a fourth genotype row (OTH = false: no
 // missing genotypes), three class planes of scratch instead of four.  OTH = true keeps the
 // global gathers for every lane.
-template <int CW, int KC, bool OTH>
+template <int CW, int KC, bool OTH, int NCH>     // NCH: chunks of KC samples (1 or 2; V <= NCH * KC)
 __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, const uint4* __restrict__ snprec, const float* __restrict__ rows,
                                                              const double* __restrict__ ctab, const double* __restrict__ tabs,
                                                              const int32_t* __restrict__ sched, int32_t V,
@@ -823,7 +845,8 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   const double* s_log = s_log_tab;
 
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const int nch = (V + KC - 1) / KC;             // 1 or 2 (V <= 16)
+  constexpr int nch = NCH;
+  constexpr int NIDW = NCH * KC / 2;             // id words per SNP (two samples each)
   for (int i = t; i < DMX_LOG_TABLE_DOUBLES; i += kThreads) s_log_tab[i] = tabs[kLut + i];
   if constexpr (!OTH)
     for (int i = t; i < kCtLds * 6; i += kThreads) {
@@ -834,7 +857,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   __syncthreads();                               // the only workgroup barrier
 
   double* term = s_term[w];
-  double* scr = &s_scr[w][lane];                 // class-major [d][lane] (see k_singlet_cls)
+  double* scr = &s_scr[w][lane];                 // class-major [d][lane] (conflict-free whatever class each lane looks up, see k_singlet_cls): a sample's
+                                                 // term is at (lane address + 512 * class) — ONE v_add_u32_sdwa per look-up with the ids stored as that offset
+  const uint32_t scr_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)scr;   // (its LDS byte address)
   const int slot0 = (blockIdx.x * NW + w) * CW;
   if (slot0 >= pv.B) return;
 
@@ -857,6 +882,9 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   const int32_t* __restrict__ psnp = pv.pair_snp;
   const uint4* __restrict__ recA = snprec;
   const uint4* __restrict__ recB = snprec + pv.S;
+  const uint4* __restrict__ recC = snprec + 2 * (size_t)pv.S;
+  const uint4* __restrict__ recD = snprec + 3 * (size_t)pv.S;
+  constexpr bool need_c = NIDW > 2, need_d = OTH || NIDW > 6;
 
   // stage A: read count (and SNP id) of the lane's pair of a tile
   struct Raw { uint32_t n; uint32_t snp; };
@@ -884,7 +912,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   };
   // stage C: the pair's table entry — requested from the global table a tile ahead unless the LDS copy has it (no read, or one read of quality
   // < kCtBq), in which case stage D reads it when the tile computes — and its SNP's record
-  struct Seed { double2 a, b, cc; double q0, q1, q2; uint32_t idw, oth; bool fast; };
+  struct Seed { double2 a, b, cc; double q0, q1, q2; uint32_t idb[NIDW], oth; bool fast; };
   auto in_lds_copy = [](uint32_t n, uint32_t rd4) { return !OTH && (n == 0 || (n == 1 && (rd4 & 0x7Fu) < (uint32_t)kCtBq)); };
   auto stage_c = [&](const Hdr& h) {
     Seed sd;
@@ -909,7 +937,10 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
     }
     const uint4 r0 = recA[h.snp], r1 = recB[h.snp];
     sd.q0 = __hiloint2double((int)r0.y, (int)r0.x); sd.q1 = __hiloint2double((int)r0.w, (int)r0.z);
-    sd.q2 = __hiloint2double((int)r1.y, (int)r1.x); sd.idw = r1.z; sd.oth = r1.w;
+    sd.q2 = __hiloint2double((int)r1.y, (int)r1.x); sd.idb[0] = r1.z; sd.idb[1] = r1.w;
+    sd.oth = 0u;
+    if constexpr (need_c) { const uint4 r2 = recC[h.snp]; sd.idb[2] = r2.x; sd.idb[3] = r2.y; if constexpr (NIDW > 4) { sd.idb[4] = r2.z; sd.idb[5] = r2.w; } }
+    if constexpr (need_d) { const uint4 r3 = recD[h.snp]; if constexpr (NIDW > 6) { sd.idb[6] = r3.x; sd.idb[7] = r3.y; } sd.oth = r3.z; }
     return sd;
   };
   typedef double v2d_t __attribute__((ext_vector_type(2)));
@@ -950,10 +981,19 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q < nch) {
-        const uint32_t bits = cs.idw >> (2 * q * KC);         // the chunk's KC class ids, 2 bits each (V <= 16: one id word)
-#pragma unroll
-        for (int kk = 0; kk < KC; ++kk)
-          term[(c * NC + kk) * TS + ti] = scr[((bits >> (2 * kk)) & 3u) << 6];     // sample q*KC+kk's term (slots past V-1 are never summed; class 3 only with OTH)
+        // sample q*KC+kk's term = scratch[its class][lane]: address = lane address + the sample's id (slots past V-1 are never summed; class 3 only with OTH)
+        typedef const __attribute__((address_space(3))) double* LdsD;
+        const int h0 = q * (KC / 2);               // the chunk's first id word (two samples per word)
+        term[(c * NC + 0) * TS + ti] = *(LdsD)(uintptr_t)add_word_of<0>(scr_a, cs.idb[h0]);
+        term[(c * NC + 1) * TS + ti] = *(LdsD)(uintptr_t)add_word_of<1>(scr_a, cs.idb[h0]);
+        term[(c * NC + 2) * TS + ti] = *(LdsD)(uintptr_t)add_word_of<0>(scr_a, cs.idb[h0 + 1]);
+        term[(c * NC + 3) * TS + ti] = *(LdsD)(uintptr_t)add_word_of<1>(scr_a, cs.idb[h0 + 1]);
+        if constexpr (KC == 8) {
+          term[(c * NC + 4) * TS + ti] = *(LdsD)(uintptr_t)add_word_of<0>(scr_a, cs.idb[h0 + 2]);
+          term[(c * NC + 5) * TS + ti] = *(LdsD)(uintptr_t)add_word_of<1>(scr_a, cs.idb[h0 + 2]);
+          term[(c * NC + 6) * TS + ti] = *(LdsD)(uintptr_t)add_word_of<0>(scr_a, cs.idb[h0 + 3]);
+          term[(c * NC + 7) * TS + ti] = *(LdsD)(uintptr_t)add_word_of<1>(scr_a, cs.idb[h0 + 3]);
+        }
         DMX_WAVE_LDS_ORDER();
         if (sum_lane[q]) {
           const double* row = &term[lane * TS];
@@ -2926,16 +2966,6 @@ __global__ void k_build_canon_logs(const double* __restrict__ tabs, double hi, d
   const double x2 = G0 * lo + G1 * lo + G2 * hi;
   const double* T = tabs + kLut;
   ltab[4 * i] = dmx_log_fast(x0, T); ltab[4 * i + 1] = dmx_log_fast(x1, T); ltab[4 * i + 2] = dmx_log_fast(x2, T); ltab[4 * i + 3] = 0.0;
-}
-
-// base + byte BYTE of w in ONE VALU instruction (SDWA operand select; the compiler emits v_bfe_u32 + v_add for the same expression)
-template <int BYTE> __device__ __forceinline__ uint32_t add_byte_of(uint32_t base, uint32_t w) {
-  uint32_t r;
-  if constexpr (BYTE == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(base), "v"(w));
-  else if constexpr (BYTE == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(base), "v"(w));
-  else if constexpr (BYTE == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(base), "v"(w));
-  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(base), "v"(w));
-  return r;
 }
 
 // K2 over genotype classes (A = 2).  Same ownership and order as k_doublet_a2; per tile of 32 pairs:
@@ -5600,12 +5630,12 @@ int launch_singlet(dmx_engine* e) {
       // canonical GT classes: three of a pair's five log terms from the table (k_singlet_cls<.., CAN>; DMX_NO_CANON_K1=1: the plain class form)
       const bool can = e->canon && chk == 0 && !e->knob("DMX_NO_CANON_K1");
       // the lean canonical-class kernel (round 5): one id word per SNP, one-byte read counts, every offset in 32 bits, padded read bytes
-      const bool lean = can && V <= 16 && e->nrd_width == 1 && e->reads_padded && e->off32 && (uint64_t)e->S * 48 < (1ull << 32) && !e->knob("DMX_K1_NO_LEAN");
+      const bool lean = can && V <= 16 && e->nrd_width == 1 && e->reads_padded && e->off32 && (uint64_t)e->S * 64 < (1ull << 32) && !e->knob("DMX_K1_NO_LEAN");
       if (lean) {
         if (!e->snprec_valid) {
           if (e->d_snprec) { (void)hipFree(e->d_snprec); e->d_snprec = nullptr; }
-          HIP_TRY(hipMalloc((void**)&e->d_snprec, sizeof(SnpRec) * (size_t)std::max(e->S, 1)));
-          hipLaunchKernelGGL(k_build_snprec, dim3((unsigned)((e->S + 255) / 256)), dim3(256), 0, e->stream, e->d_gp0, e->d_idw, e->d_oth, e->S, (V + 15) / 16, e->d_snprec);
+          HIP_TRY(hipMalloc((void**)&e->d_snprec, kSnpRecBytes * (size_t)std::max(e->S, 1)));
+          hipLaunchKernelGGL(k_build_snprec, dim3((unsigned)((e->S + 255) / 256)), dim3(256), 0, e->stream, e->d_gp0, e->d_ids, e->d_oth, e->S, V, e->d_snprec);
           HIP_TRY(hipGetLastError());
           e->snprec_valid = true;
         }
@@ -5618,11 +5648,12 @@ int launch_singlet(dmx_engine* e) {
         // (a matrix with a fourth genotype row somewhere — missing genotypes — keeps four class planes of scratch and gathers every entry from the
         //  global table; without one the commonest entries come from an LDS copy: see the kernel)
         const bool oth = e->any_oth;
-#define DMX_K1L_(CC, KK, OO) DMX_LAUNCH(k1_fn, (k_singlet_can<CC, KK, OO>), grd, blk, 0, e->stream, e->pv, e->d_snprec, e->d_rows, e->d_ctab, e->d_lut, e->d_sched, V, \
-                                        e->d_llks, e->d_llk0s, (double)e->can_hi, (double)e->can_lo)
-#define DMX_K1L(CC, KK) do { if (oth) DMX_K1L_(CC, KK, true); else DMX_K1L_(CC, KK, false); } while (0)
-        if (KC == 4) { if (CW == 4) DMX_K1L(4, 4); else if (CW == 2) DMX_K1L(2, 4); else DMX_K1L(1, 4); }
-        else         { if (CW == 4) DMX_K1L(4, 8); else if (CW == 2) DMX_K1L(2, 8); else DMX_K1L(1, 8); }
+#define DMX_K1L_(CC, KK, OO, NN) DMX_LAUNCH(k1_fn, (k_singlet_can<CC, KK, OO, NN>), grd, blk, 0, e->stream, e->pv, e->d_snprec, e->d_rows, e->d_ctab, e->d_lut, e->d_sched, V, \
+                                            e->d_llks, e->d_llk0s, (double)e->can_hi, (double)e->can_lo)
+#define DMX_K1L(CC, KK, NN) do { if (oth) DMX_K1L_(CC, KK, true, NN); else DMX_K1L_(CC, KK, false, NN); } while (0)
+        if (KC == 4) { if (CW == 4) DMX_K1L(4, 4, 1); else if (CW == 2) DMX_K1L(2, 4, 1); else DMX_K1L(1, 4, 1); }
+        else if (nchc == 1) { if (CW == 4) DMX_K1L(4, 8, 1); else if (CW == 2) DMX_K1L(2, 8, 1); else DMX_K1L(1, 8, 1); }
+        else                { if (CW == 4) DMX_K1L(4, 8, 2); else if (CW == 2) DMX_K1L(2, 8, 2); else DMX_K1L(1, 8, 2); }
 #undef DMX_K1L
 #undef DMX_K1L_
         return DMX_OK;
