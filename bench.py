@@ -350,10 +350,9 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
 
     counts = [shard_range(B_total, world, r)[1] - shard_range(B_total, world, r)[0] for r in range(world)]
     gathered = None
-    beside = bool(cfg["doublet"]) and not os.environ.get("DMX_NO_OVERLAP")      # what dmx_demuxlet_run does too
-    # (dmx_engine_run itself runs K1 beside K3 + K3b, AFTER K2, where K2 is k_doublet_clsp — GT classes, 33..64 samples, grid {0, 0.5}: that kernel leaves K1 no room)
-    k1_late = beside and cfg["field"] == "GT" and 32 < V <= 64 and A == 2 and tuple(cfg["alphas"]) == (0.0, 0.5) and not os.environ.get("DMX_FORCE_OVERLAP") \
-        and not os.environ.get("DMX_K1_FIRST")
+    # dmx_engine_run (what dmx_demuxlet_run does too): K1 beside K2 -> K3 -> K3b in one call.  tools/profile_round.sh wants the kernels one after
+    # the other (DMX_EXPERIMENTS=1 DMX_NO_OVERLAP=1: the engine honours experiment switches only behind that fence, and so does this script)
+    beside = bool(cfg["doublet"]) and not (os.environ.get("DMX_EXPERIMENTS") == "1" and os.environ.get("DMX_NO_OVERLAP"))
 
     def step(ev=None):
         nonlocal gathered
@@ -398,6 +397,8 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
     # (dmx_engine_mean_kernel_times: mean over the TIMED launches, at most the last 16); torch's events on the same stream give
     # the K1 and K2 + K3 + K3b spans as a cross-check.  The roofline of the dominant kernel uses these timed-launch means.
     km = eng.mean_kernel_times()
+    launched = eng.kernel_names()                   # which kernels the timed steps launched, and where K1 ran (dmx_engine_kernel_names)
+    k1_late = launched["k1_placement"] == 2         # K1 beside K3 + K3b, after K2 (where K2 leaves K1 no room: k_doublet_clsp)
     k1_ms = float(km.singlet_ms)
     k2_only_ms = float(km.doublet_ms) if cfg["doublet"] else 0.0
     k3_ms, k3b_ms = (float(km.reduce_ms), float(km.certify_ms)) if cfg["doublet"] else (0.0, 0.0)
@@ -428,6 +429,13 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         traffic, valu, counts_file = None, None, None
         pj = pmc_profile(cfgno, B, mode, cfg["delta"] >= 1.0)
+        dom_launched = launched["doublet" if cfg["doublet"] else "singlet"]
+        counts_stale = None
+        if pj and dom_launched and pj.get("kernel") and pj["kernel"] != dom_launched:
+            # the committed counters belong to another kernel than the one this run launched (a kernel change without a refreshed
+            # profiles/pmc_*.json): quote no counter-derived fraction rather than a stale one
+            counts_stale = {"counts": pj.get("counts_file"), "counted_kernel": pj["kernel"], "launched_kernel": dom_launched}
+            pj = None
         if pj:
             traffic, counts_file = pj.get("hbm_bytes_per_launch"), pj.get("counts_file")
             if pj.get("issue_cycles_per_launch"):
@@ -476,8 +484,9 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
             # FETCH_SIZE x2 + WRITE_SIZE of one launch of this workload, from the committed pass named in `counts`
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": dom_bytes,
-                         "kernel_ms": dom_ms, "counts": counts_file},
+                         "kernel_ms": dom_ms, "counts": counts_file, "kernel_launched": dom_launched, "counts_stale": counts_stale},
             "roofline_valu": valu,
+            "kernels_launched": launched,
             # logical = the REFERENCE's count of log() evaluations for this workload (P*(V+1) + P*(V*V*A+A)) over K1 + K2 + K3 + K3b time;
             # GT inputs and FAST execute fewer (genotype classes / printed-entry set)
             "fp64_valu": {"logical_log_terms_per_s": logs / world / kernels_s,
@@ -493,6 +502,7 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
             out["ranks_seen"] = dist.get_world_size()
             out["per_rank_ms_per_step"] = per_rank_ms
             out["gather_ms"] = gather_ms
+            out["rank_devices"] = getattr(cx, "devices_txt", None)
         if cfg["doublet"]:
             out["pair_evals_per_s"] = total_pairs * V * V * A * steps / elapsed
         if with_log:
@@ -533,12 +543,16 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
             bcs = [f"BC{i:07d}-1" for i in range(B)]
             sms = [f"SM{j:02d}" for j in range(V)]
             e2e = {"what": "dmx_demuxlet_run on this workload from a frozen HOST pileup (no --write-pair, tie arbiter on, 1 GPU): wall seconds per stage"}
+            light = with_e2e == "e2e6"               # the realistic-coverage record: both modes, host and device pileup, no BAM/VCF leg
+            covered = int((np.diff(h["cell_pair_off"]) > 0).sum())
             with tempfile.TemporaryDirectory() as td_dir:
                 for name, md in (("strict", engine.capi.DMX_MODE_STRICT), ("fast", engine.capi.DMX_MODE_FAST)):
                     tm = engine.demuxlet_run(hp, g, sms, cfg["alphas"], os.path.join(td_dir, name), barcodes=bcs, timing=True, mode=md)
                     tm.pop("reserved", None)
                     tm["arbiter_format_write_frac"] = tm["write_s"] / tm["total_s"]
                     tm["triples_per_s"] = dp.n_pairs * V / tm["total_s"]
+                    # barcodes whose grid the arbiter fetched (K3's near-tie flags): at ~2 000 covered SNPs per droplet no longer a corner case
+                    tm["grid_fetched_frac"] = tm["n_cells_grid_fetched"] / max(covered, 1)
                     e2e[name] = tm
                     # the same job from the DEVICE-resident pileup (dmx_pileup.memory = DMX_MEM_DEVICE: no host slicing, no H2D of the CSR;
                     # only the per-cell counters and the barcodes are host memory); same files, byte for byte
@@ -551,13 +565,14 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                         open(os.path.join(td_dir, f"{name}.{suf}"), "rb").read() == open(os.path.join(td_dir, f"{name}_dev.{suf}"), "rb").read()
                         for suf in ("single", "sing2", "best"))
                     e2e[name + "_device_pileup"] = td
-            try:
-                e2e["from_bam_and_vcf"] = cli_leg()
-            except Exception as ex:                      # the leg is a side record: never let it take the bench line down
-                e2e["from_bam_and_vcf"] = {"error": repr(ex)}
+            if not light:
+                try:
+                    e2e["from_bam_and_vcf"] = cli_leg()
+                except Exception as ex:                  # the leg is a side record: never let it take the bench line down
+                    e2e["from_bam_and_vcf"] = {"error": repr(ex)}
             out["end_to_end"] = e2e
             del hp, h
-        if with_cpu:                                     # the CPU baseline is a rank-0, N=1 leg only
+        if with_cpu:                                     # the CPU baseline: rank 0, after the timed region, on the first barcodes of ITS range
             out["cpu_baseline"] = cpu_baseline(dp, g, cfg)
             out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     eng.close()
@@ -586,13 +601,13 @@ def compact_line(full):
     """The ONE stdout line: the driver's keys + config + roofline + roofline_valu + cpu_baseline + a ~200-byte object per nested
     configuration.  No prose.  Everything else is in the full record (bench_full.json, stderr)."""
     line = pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                       "dtype", "data", "pair_evals_per_s", "ranks_seen", "per_rank_ms_per_step", "gather_ms"))
+                       "dtype", "data", "pair_evals_per_s", "ranks_seen", "per_rank_ms_per_step", "gather_ms", "rank_devices"))
     line["vs_baseline"] = None
     line["config"] = pick(full["config"], ("workload", "tag", "barcodes_total", "barcodes_per_gpu", "snps", "samples", "alphas",
                                             "covered_pairs_per_gpu", "reads_per_gpu", "mode"))
     line["config"]["sharding"] = f"{full['n_gpus']} contiguous barcode ranges + one RCCL gather per step" if full["n_gpus"] > 1 else "single GPU"
     line["roofline"] = pick(full["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
-                                                "kernel_ms", "counts"))
+                                                "kernel_ms", "counts", "kernel_launched", "counts_stale"))
     line["roofline"].setdefault("traffic", None)
     alone = (full.get("fp64_valu") or {}).get("kernel_ms_alone")
     if alone:                                   # the dominant kernel with nothing beside it (two extra untimed steps)
@@ -618,6 +633,9 @@ def compact_line(full):
     if e2e:
         line["end_to_end"] = {m: pick(e2e[m], ("total_s", "stage_s", "wait_s", "write_s", "files_identical_to_the_host_run"))
                               for m in ("strict", "fast", "strict_device_pileup", "fast_device_pileup") if m in e2e}
+        if e2e.get("cfg6"):                         # the realistic-coverage job: seconds, writer-thread seconds, share of barcodes whose grid K3's flags fetched
+            line["end_to_end"]["cfg6"] = {m: pick(e2e["cfg6"][m], ("total_s", "write_s", "grid_fetched_frac"))
+                                          for m in ("strict", "fast", "strict_device_pileup", "fast_device_pileup") if m in e2e["cfg6"]}
         cli = e2e.get("from_bam_and_vcf") or {}
         if "all_cores" in cli:
             line["end_to_end"]["bam_vcf_scan_reads_per_s"] = cli["all_cores"].get("scan_reads_per_s")
@@ -760,6 +778,7 @@ def main():
             ids = [None] * cx.world
             dist.all_gather_object(ids, (cx.local, getattr(pr, "pci_domain_id", None), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", None)))
             cx.devices = ids
+            cx.devices_txt = [f"{i[0]}" + (f"@{i[1]:04x}:{i[2]:02x}:{i[3]:02x}" if None not in i[1:] else "") for i in ids]   # local ordinal @ PCI domain:bus:device
             if len({i[0] for i in ids}) != cx.world:
                 sys.exit(f"bench.py: {cx.world} ranks on {len({i[0] for i in ids})} distinct local devices")
             if all(i[2] is not None for i in ids) and len({i[1:] for i in ids}) != cx.world and cx.rank == 0:
@@ -791,8 +810,10 @@ def main():
         if cx.use_dist:
             dist.barrier()
         single = cx.world == 1 and not cx.use_dist
+        # (the CPU baseline runs on rank 0 after the timed region, at every N: a SCALE line is judged by the same rule as the N = 1 line;
+        #  the other ranks wait for it at the next barrier)
         out = run_config(cx, cfgno, cfg, "fast" if args.fast else "strict", args.steps, args.warmup,
-                         with_cpu=single and not args.no_cpu_baseline, with_log=single, with_e2e=single and default_run and not args.only)
+                         with_cpu=not args.no_cpu_baseline, with_log=single, with_e2e=single and default_run and not args.only)
         keys = ("value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu", "fp64_valu", "pair_evals_per_s",
                 "ranks_seen", "per_rank_ms_per_step", "gather_ms")
         if single and default_run and not args.only:
@@ -802,8 +823,9 @@ def main():
             # cfg4 WHOLE on this one GPU (2 steps each: a STRICT pass is ~7 s) is the N = 1 point of the strong-scaling curve whose
             # N > 1 points the driver measures with `--gpus N` (same workload, same code path minus the gather)
             # ... and its 12 500-barcode shard, one GPU's share of the 8-GPU run: what a perfectly scaling N = 8 step costs (plus the gather)
-            for no, mode, kk, shard in ((3, "fast", k, 0), (2, "strict", k, 0), (5, "strict", k, 0), (5, "fast", k, 0), (4, "strict", 2, 0), (4, "fast", 2, 0),
-                                        (4, "strict", 3, 12_500)):
+            # cfg6 = SURVEY 8d's "realistic run reported alongside": 2 000 covered SNPs per barcode of 100 k (what a 10x droplet looks like), GT
+            for no, mode, kk, shard in ((3, "fast", k, 0), (2, "strict", k, 0), (5, "strict", k, 0), (5, "fast", k, 0), (6, "strict", k, 0), (6, "fast", k, 0),
+                                        (4, "strict", 2, 0), (4, "fast", 2, 0), (4, "strict", 3, 12_500)):
                 c = dict(CONFIGS[no])
                 if shard:
                     c["B"] = shard
@@ -811,7 +833,9 @@ def main():
                 if args.cells:
                     c["B"] = min(c["B"], args.cells)
                     c["name"] += f" [override: {c['B']} barcodes]"
-                r = run_config(cx, no, c, mode, kk, w, with_cpu=False, with_log=False)
+                r = run_config(cx, no, c, mode, kk, w, with_cpu=False, with_log=False, with_e2e=(no == 6 and mode == "fast") and "e2e6")
+                if r.get("end_to_end"):
+                    out["end_to_end"]["cfg6"] = r.pop("end_to_end")
                 if shard:
                     r["config"]["tag"] = f"cfg{no}-shard/{mode}"
                 also.append({key: r[key] for key in keys if key in r})

@@ -71,7 +71,7 @@ def _run_bench(*argv, env_extra=None, timeout=300):
     return subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
 
 
-@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("n", [2, 3, 8])
 def test_bench_gpus_n_launches_n_ranks_itself(n, tmp_path):
     """`python bench.py --gpus N` with no launcher in the environment (how the driver runs N = 1) starts N ranks itself and the line says
     n_gpus = ranks_seen = N.  Injected compute over gloo: the launch, the checks, the ranges, the gather, the timing

@@ -54,7 +54,10 @@ def test_bench_default_line_is_cfg3_with_nested_records():
     assert d["config"]["workload"].startswith("cfg3") and d["config"]["mode"] == "strict" and d["pair_evals_per_s"] > 0
     assert d["roofline"]["kernel"] == "k_doublet" and d["scaling"] == "weak"
     names = [a["workload"] for a in d["also"]]
-    assert names == ["cfg3/fast", "cfg2/strict", "cfg5/strict", "cfg5/fast", "cfg4/strict", "cfg4/fast", "cfg4-shard/strict"]
+    assert names == ["cfg3/fast", "cfg2/strict", "cfg5/strict", "cfg5/fast", "cfg6/strict", "cfg6/fast", "cfg4/strict", "cfg4/fast", "cfg4-shard/strict"]
+    assert set(d["end_to_end"]["cfg6"]) >= {"strict", "fast"} and 0 <= d["end_to_end"]["cfg6"]["fast"]["grid_fetched_frac"] <= 1
+    # the counter-derived fractions are quoted only for the kernel the committed counters were collected on (dmx_engine_kernel_names)
+    assert d["roofline"]["kernel_launched"].startswith("k_doublet_a2<")
     for a in d["also"]:
         assert a["value"] > 0 and a["roofline_frac"] > 0 and a["kernel_ms"] > 0 and a["ms_per_step"] >= a["kernel_ms"] * 0.999
     assert d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.001 and d["roofline"]["counts"].startswith("profiles/pmc_cfg3_strict")
@@ -71,6 +74,8 @@ def test_bench_sharded_path_with_a_one_rank_group():
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     assert d["ranks_seen"] == 1 and len(d["per_rank_ms_per_step"]) == 1 and d["gather_ms"] >= 0
     assert d["config"]["workload"].startswith("cfg4") and d["config"]["barcodes_total"] == 96
+    # an N > 1 line is judged like the N = 1 line: it carries its own CPU baseline (rank 0, after the timed region) and the ranks' devices
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and len(d["rank_devices"]) == 1
 
 
 def test_bench_gpus_n_without_a_launcher():

@@ -232,6 +232,19 @@ def test_cfg5_full_size_fast_mode(mods):
     assert worst < 1e-9
 
 
+def test_cfg6_full_size(mods):
+    """SURVEY 8(d)'s realistic-coverage shape (bench.py's cfg6: 20k barcodes x 100k SNPs x 16 samples, GT, delta = 0.02 -> ~2 000 covered SNPs
+    per barcode, what a 10x droplet looks like; cmd_cram_demuxlet.cpp:592): 12 barcodes through the oracle + the size-independent properties
+    on all 20k, genotype-class kernels == general kernels bit for bit."""
+    run_full(mods, 6, 12, check_general=True)
+
+
+def test_cfg6_full_size_fast_mode(mods):
+    """DMX_MODE_FAST on cfg6 (GT, 16 samples, sparse -> k_doublet_clsym)."""
+    worst = run_full(mods, 6, 12, check_general=False, fast=True)
+    assert worst < 1e-9
+
+
 def test_cfg4_slice_on_distinct_devices_with_write_pair(mods, tmp_path, monkeypatch):
     """The same slice with dmx_job.n_gpus = min(8, visible devices) (what `demuxlet --gpus N --write-pair` runs): two engines per
     DEVICE, ranges of the sorted barcodes alternating between them, the `.pair` rows appended in barcode order.  Skipped on a 1-GPU box
