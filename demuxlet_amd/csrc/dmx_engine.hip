@@ -6585,7 +6585,13 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     // entries only): the host then writes range r and stages r + 2 while the GPU computes r + 1
     const bool sym = job->mode == DMX_MODE_FAST && A == 2 && job->alpha[0] == 0.0 && job->alpha[1] == 0.5 && V <= 512;
     const double evals = (double)(V + 1) + (doublet_ok ? (sym ? (double)V + 0.5 * V * (V + 1) : (double)nAB) : 0.0);
-    if (doublet_ok && (double)pl.n_pairs * evals / ngpu > 0.15 * 6e11 && B / ngpu >= 8 * 1024) by_overlap = 4;
+    // A device-resident pileup has nothing to stage: what ranges buy there is only the writer thread's overlap (0.06-0.08 s at cfg3 size), and
+    // they cost GPU time — a range of 2 500 one-barcode wavefronts fills 3 072 slots less well than one launch of 10 000, and two engines'
+    // workgroups interleave so that both ranges finish together.  Measured at cfg3 size, FAST / STRICT: one range 0.383 / 1.29 s, two 0.407 /
+    // 1.31, four 0.55 / 1.39 (profiles/r05_e2e_ranges.txt; chaining the ranges by events was worse still).  So such a job is cut only when
+    // every range still makes several full rounds of wavefronts.
+    const int min_cells = dev_pl ? 40 * 1024 : 8 * 1024;
+    if (doublet_ok && (double)pl.n_pairs * evals / ngpu > 0.15 * 6e11 && B / ngpu >= min_cells) by_overlap = 4;
   }
   int R = std::max(ngpu * by_overlap, by_mem);
   R = ((R + ngpu - 1) / ngpu) * ngpu;                                 // whole waves
