@@ -1180,7 +1180,7 @@ def test_experiment_switches_are_fenced(eng, monkeypatch):
     monkeypatch.setenv("DMX_EXPERIMENTS", "1")
     monkeypatch.delenv("DMX_NO_CLASSES", raising=False)
     base = names()
-    assert base["singlet"].startswith("k_singlet_cls<") and base["doublet"].startswith("k_doublet_cls<") and base["certify"].startswith("k_certify<"), base
+    assert base["singlet"].startswith("k_singlet_can<") and base["doublet"].startswith("k_doublet_cls<") and base["certify"].startswith("k_certify<"), base
     assert base["k1_placement"] == 1
     monkeypatch.setenv("DMX_NO_CLASSES", "1")
     forced = names()
