@@ -860,6 +860,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   double* scr = &s_scr[w][lane];                 // class-major [d][lane] (conflict-free whatever class each lane looks up, see k_singlet_cls): a sample's
                                                  // term is at (lane address + 512 * class) — ONE v_add_u32_sdwa per look-up with the ids stored as that offset
   const uint32_t scr_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)scr;   // (its LDS byte address)
+  const uint32_t ct_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)s_ct;
   const int slot0 = (blockIdx.x * NW + w) * CW;
   if (slot0 >= pv.B) return;
 
@@ -912,13 +913,15 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   };
   // stage C: the pair's table entry — requested from the global table a tile ahead unless the LDS copy has it (no read, or one read of quality
   // < kCtBq), in which case stage D reads it when the tile computes — and its SNP's record
-  struct Seed { double2 a, b, cc; double q0, q1, q2; uint32_t idb[NIDW], oth; bool fast; };
+  struct Seed { double2 a, b, cc; double q0, q1, q2; uint32_t idb[NIDW], oth, lds; bool fast; };   // lds: byte offset of the entry in the LDS copy, or ~0u
   auto in_lds_copy = [](uint32_t n, uint32_t rd4) { return !OTH && (n == 0 || (n == 1 && (rd4 & 0x7Fu) < (uint32_t)kCtBq)); };
   auto stage_c = [&](const Hdr& h) {
     Seed sd;
     const uint32_t n = h.n, rd4 = h.rd4;
     sd.fast = true;
+    sd.lds = (n == 0 ? (uint32_t)(2 * kCtBq) : (((rd4 & 0x80u) ? (uint32_t)kCtBq : 0u) + (rd4 & 0x7Fu))) * 48u;
     if (!in_lds_copy(n, rd4)) {
+      sd.lds = ~0u;
       uint32_t idx = n == 0 ? 256u : (rd4 & 0xFFu);
       idx = n == 2 ? kCt2 + (rd4 & 0xFFFFu) : idx;
       bool fast = n <= 2;
@@ -955,9 +958,8 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, cons
   // stage D: one tile.  Lanes beyond their barcode's last pair carry n = 0, SNP 0 (stage A): they compute like any other lane, into slots the
   // sums never reach — no per-lane validity test anywhere below.
   auto compute = [&](const Hdr& cur, Seed& cs, uint32_t tile) {
-    if (in_lds_copy(cur.n, cur.rd4)) {             // the LDS copy's entry
-      const uint32_t e = cur.n == 0 ? (uint32_t)(2 * kCtBq) : (((cur.rd4 & 0x80u) ? (uint32_t)kCtBq : 0u) + (cur.rd4 & 0x7Fu));
-      LdsD2 p = (LdsD2)(const __attribute__((address_space(3))) double*)(s_ct + 6u * e);
+    if (cs.lds != ~0u) {                           // the LDS copy's entry
+      LdsD2 p = (LdsD2)(uintptr_t)(ct_a + cs.lds);
       const v2d_t va = p[0], vb = p[1], vc = p[2];
       cs.a.x = va.x; cs.a.y = va.y; cs.b.x = vb.x; cs.b.y = vb.y; cs.cc.x = vc.x; cs.cc.y = vc.y;
     }
