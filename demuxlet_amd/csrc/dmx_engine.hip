@@ -291,6 +291,13 @@ template <int HALF> __device__ __forceinline__ uint32_t add_word_of(uint32_t bas
   else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(base), "v"(w));
   return r;
 }
+#ifndef DMX_FAST_LITE_LOG
+#define DMX_FAST_LITE_LOG 1                       // FAST phase-2 terms through dmx_log2_lite (6 FP64 instructions; csrc/dmx_log.hpp) — 0: dmx_log2 (10), as rounds 2-4
+#endif
+// the log of FAST mode's phase-2 terms (k_doublet_sym / _a2f / _anf)
+__device__ __forceinline__ double dmx_log2_fastmode(double x, const double* __restrict__ T, const DmxLogPins& K) {
+  return DMX_FAST_LITE_LOG ? dmx_log2_lite(x, T, K) : dmx_log2_fast_pinned(x, T, K);
+}
 #ifndef DMX_LDS_NOMERGE
 #define DMX_LDS_NOMERGE 1                         // cfg3 FAST K2 309 -> 291 ms (0 restores the merged reads: kernel experiments only)
 #endif
@@ -1941,8 +1948,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             const double s0 = __builtin_fma(a2, x[2], __builtin_fma(a1, x[1], a0 * x[0]));
             const double s1 = __builtin_fma(a2, y[2], __builtin_fma(a1, y[1], a0 * y[0]));
             ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-            acc[kk][0] += dmx_log2_fast_pinned(s0, s_log, lk);
-            acc[kk][1] += dmx_log2_fast_pinned(s1, s_log, lk);
+            acc[kk][0] += dmx_log2_fastmode(s0, s_log, lk);
+            acc[kk][1] += dmx_log2_fastmode(s1, s_log, lk);
           }
         }
       }
@@ -1979,8 +1986,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_doublet_a2f(PileupView pv, int 
             const double s0 = __builtin_fma(a2, x2, __builtin_fma(a1, x01.y, a0 * x01.x));
             const double s1 = __builtin_fma(a2, y2, __builtin_fma(a1, y01.y, a0 * y01.x));
             ok &= __builtin_amdgcn_class(s0, 0x100) && __builtin_amdgcn_class(s1, 0x100);
-            acc[kk][0] += dmx_log2_fast_pinned(s0, s_log, lk);
-            acc[kk][1] += dmx_log2_fast_pinned(s1, s_log, lk);
+            acc[kk][0] += dmx_log2_fastmode(s0, s_log, lk);
+            acc[kk][1] += dmx_log2_fastmode(s1, s_log, lk);
           }
         }
       }
@@ -2305,7 +2312,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
                          x2 = DMX_LDS_NOMERGE ? lds_read_f64(&up[2 * VUS + ek[i]]) : up[2 * VUS + ek[i]];
             const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
             if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100);
-            acc[i] += dmx_log2_fast_pinned(sj, s_log, lk);
+            acc[i] += dmx_log2_fastmode(sj, s_log, lk);
           }
         }
       }
@@ -2791,7 +2798,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_anf(PileupView pv, i
               const double x0 = lds_read_f64(&up[o]), x1 = lds_read_f64(&up[o + VU]), x2 = lds_read_f64(&up[o + 2 * VU]);
               const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
               if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100) || kb * NK + kk >= V;
-              acc[kk][n - 1] += dmx_log2_fast_pinned(sj, s_log, lk);
+              acc[kk][n - 1] += dmx_log2_fastmode(sj, s_log, lk);
             }
             __builtin_amdgcn_sched_barrier(0);     // one alpha's NK evaluations in flight at a time (register budget)
           }
@@ -2799,7 +2806,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_anf(PileupView pv, i
             const double* u0 = s_u + (size_t)pi * NU + (A - 1) * 3 * VU;
             const double sj = __builtin_fma(a2, u0[2], __builtin_fma(a1, u0[1], a0 * u0[0]));
             ok &= __builtin_amdgcn_class(sj, 0x100);
-            accS += dmx_log2_fast_pinned(sj, s_log, lk);
+            accS += dmx_log2_fastmode(sj, s_log, lk);
           }
         }
       }
@@ -6391,10 +6398,10 @@ namespace {
 template <int WHICH>   // 0: dmx_log (128 bins; the singlet kernels), 2: dmx_log2 (256 bins; the doublet kernels)
 __global__ void k_debug_log(const double* __restrict__ x, double* __restrict__ y, int64_t n, const double* __restrict__ tab) {
   __shared__ double s_log[DMX_LOG2_TABLE_DOUBLES];
-  for (int i = threadIdx.x; i < (WHICH == 2 ? DMX_LOG2_TABLE_DOUBLES : DMX_LOG_TABLE_DOUBLES); i += blockDim.x) s_log[i] = tab[i];
+  for (int i = threadIdx.x; i < (WHICH >= 2 ? DMX_LOG2_TABLE_DOUBLES : DMX_LOG_TABLE_DOUBLES); i += blockDim.x) s_log[i] = tab[i];
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double v = WHICH == 2 ? dmx_log2_fast(x[i], s_log) : dmx_log_fast(x[i], s_log);
+    const double v = WHICH == 3 ? dmx_log2_lite(x[i], s_log, dmx_log_pins()) : (WHICH == 2 ? dmx_log2_fast(x[i], s_log) : dmx_log_fast(x[i], s_log));
     y[i] = dmx_log_is_special(x[i]) ? log(x[i]) : v;
   }
 }
@@ -6491,9 +6498,10 @@ int debug_device_log(int which, const double* x, double* y, int64_t n, int32_t d
   HIP_TRY(hipMalloc((void**)&dy, std::max<size_t>(sizeof(double) * (size_t)n, 16)));
   HIP_TRY(hipMalloc((void**)&dt, sizeof(double) * DMX_LOG2_TABLE_DOUBLES));
   HIP_TRY(hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-  if (which == 2) HIP_TRY(hipMemcpy(dt, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  if (which >= 2) HIP_TRY(hipMemcpy(dt, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
   else HIP_TRY(hipMemcpy(dt, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
-  if (which == 2) hipLaunchKernelGGL((k_debug_log<2>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
+  if (which == 3) hipLaunchKernelGGL((k_debug_log<3>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
+  else if (which == 2) hipLaunchKernelGGL((k_debug_log<2>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
   else hipLaunchKernelGGL((k_debug_log<0>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(y, dy, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
@@ -6503,6 +6511,7 @@ int debug_device_log(int which, const double* x, double* y, int64_t n, int32_t d
 }  // namespace
 extern "C" int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(0, x, y, n, device); }
 extern "C" int dmx_debug_device_log2(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(2, x, y, n, device); }
+extern "C" int dmx_debug_device_log2_lite(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(3, x, y, n, device); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // cmd_cram_demuxlet.cpp:390-881 in one call: store (or a frozen pileup) + genotype matrix in, four text files out.

@@ -23,7 +23,7 @@ extern "C" {
 #endif
 
 #define DMX_ABI_VERSION 7   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up, dmx_engine_run; 6: dmx_engine_get_cell_grids;
-                               7: DMX_CELL_NEAR_RULE, dmx_write_doublet_summary_grids, dmx_engine_kernel_names.  ABI 6 had grown dmx_final_input in place by a
+                               7: DMX_CELL_NEAR_RULE, dmx_write_doublet_summary_grids, dmx_engine_kernel_names, dmx_debug_device_log2_lite.  ABI 6 had grown dmx_final_input in place by a
                                trailing `cell_grid` member; a by-pointer input struct without a size member cannot grow (a caller compiled against ABI 5
                                passes a shorter object), so ABI 7 WITHDRAWS that member — the struct has its ABI 5 layout again and the grids travel as an
                                argument of the new entry point.  Additions only otherwise: callers of ABI <= 5 run unchanged. */
@@ -272,6 +272,7 @@ int dmx_resolve_tie_order(dmx_cell_summary* summary, int64_t n);
  * to show the device function performs exactly the IEEE operation sequence whose accuracy is measured on the host. */
 int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device);
 int dmx_debug_device_log2(const double* x, double* y, int64_t n, int32_t device);   /* dmx_log2: the doublet kernels' log (256 bins, ABI 6) */
+int dmx_debug_device_log2_lite(const double* x, double* y, int64_t n, int32_t device);   /* (ABI 7) DMX_MODE_FAST's phase-2 log: dmx_log2's table, series cut after r^4/4 — 6 FP64 instructions, |error| <= 6e-15 absolute, unbiased (csrc/dmx_log.hpp) */
 /* Diagnostics: the device's log() ceiling, measured by a register-resident microkernel (no memory traffic): which = 0 the
  * kernels' dmx_log, which = 1 ocml's log().  bench.py reports both next to the kernels' achieved log rate. */
 int dmx_debug_log_rate(int32_t which, int32_t iters, int32_t device, double* logs_per_second);   /* which: 0 dmx_log, 1 ocml log(), 2 dmx_log2 */

@@ -192,6 +192,32 @@ def test_device_k2_log_is_the_emulated_arithmetic(emul):
 
 
 @pytest.mark.gpu
+def test_fast_mode_log_error_is_small_and_unbiased():
+    """DMX_MODE_FAST's phase-2 log (dmx_log2_lite: 6 FP64 instructions, the series cut after r^4/4) — the budget csrc/dmx_log.hpp states: every value
+    within 6.5e-15 ABSOLUTE of log(x), and next to no bias over the range likelihood terms live in (the first dropped term r^5/5 has the sign of r,
+    which is symmetric inside a table bin; folding ln 2 into one constant leaves k x 2.3e-17 for a binary exponent k): the mean error over
+    [1e-7, 1] stays below 2e-16, so the 1e5 terms of the deepest accumulator drift by < 2e-11 where FAST's contract is 1e-9."""
+    import mpmath
+    from demuxlet_amd import build, capi
+    build.build()
+    L = capi.load()
+    rng = np.random.default_rng(77)
+    x = np.concatenate([rng.uniform(1e-6, 1.0, 600000), np.exp(rng.uniform(np.log(1e-30), 0.0, 300000)), rng.uniform(0.9, 1.1, 100000)])
+    y = np.empty_like(x)
+    capi.check(L.dmx_debug_device_log2_lite(x.ctypes.data, y.ctypes.data, len(x), 0))
+    ref = np.log(x)                                    # glibc: < 1 ulp, i.e. < 1.2e-16 relative — far below the budget
+    err = y - ref
+    assert np.abs(err).max() < 6.5e-15 + 4 * np.finfo(float).eps * np.abs(ref).max(), np.abs(err).max()
+    lik = x >= 1e-7                                    # what a likelihood term can be: GL >= 1e-6 / (1 + 3e-6), genotype rows of a few 1e-1
+    assert abs(err[lik].mean()) < 2e-16, err[lik].mean()
+    mpmath.mp.prec = 100                               # and a few points against real arithmetic
+    for v in (0.999, 0.5, 0.3333, 1e-3, 1e-6, 0.7071):
+        got = np.empty(1); arg = np.array([v])
+        capi.check(L.dmx_debug_device_log2_lite(arg.ctypes.data, got.ctypes.data, 1, 0))
+        assert abs(float(mpmath.mpf(got[0]) - mpmath.log(mpmath.mpf(v)))) < 6.5e-15
+
+
+@pytest.mark.gpu
 def test_device_shared_reciprocal_division_is_ieee():
     """The kernels divide three (nine) numerators by one denominator with a shared Newton-refined reciprocal; the result
     must be the correctly rounded quotient, i.e. numpy's / bit for bit, over the operand ranges the kernels see."""
