@@ -2072,7 +2072,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   // straight into the LDS (global_load_lds: no registers, uniform source base per row), one sub-tile ahead of their use, into the
   // other half of a double buffer — the first sub-tile's while phase 1 runs.  cfg3 FAST: 394 -> 349 ms on one box.
   constexpr bool DMA_T = TPC >= 32;              // (four barcodes per wavefront, TPC = 16: too many small masked loads, measured +17 %)
-  constexpr size_t cell_bytes = (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)(DMA_T ? 2 : 1) * SUB * GSS * 4 + (size_t)SUB * 3 * VUS * 8;
+  // row buffers: two (the next sub-tile's rows travel while this one computes) — THREE for the two-barcodes-per-wavefront form (V <= 16, small rows:
+  // round 5), whose sparse workloads gather rows from a matrix beyond the L2 (cfg5: 38 MB) and waited for them half of their time with one sub-tile of lead
+  constexpr int NBUF = DMA_T ? (TPC == 32 ? 3 : 2) : 1;
+  constexpr size_t cell_bytes = (size_t)TP * 6 * 8 + (size_t)TP * 4 * 8 + 2 * T00 * 8 + TP * (4 + 4 + 8) + (size_t)NBUF * SUB * GSS * 4 + (size_t)SUB * 3 * VUS * 8;
   unsigned char* base = s_raw + (size_t)cw * cell_bytes;
   double* s_q1 = (double*)base;                                  // [TP][6]    pG of alpha 0.5: q[l+m], five distinct values
   double* s_u0 = s_q1 + TP * 6;                                  // [TP][4]    u of (alpha 0, sample 0)
@@ -2081,7 +2084,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   int32_t* s_snp = (int32_t*)(s_off + TP);                       // [TP]
   uint32_t* s_cnt = (uint32_t*)(s_snp + TP);                     // [TP]
   float* s_g0 = (float*)(s_cnt + TP);                            // [SUB][GSS] genotype rows of the sub-tile's SNPs (DMA: x 2)
-  double* s_u = (double*)(s_g0 + (DMA_T ? 2 : 1) * SUB * GSS);   // [SUB][3][VUS]
+  double* s_u = (double*)(s_g0 + NBUF * SUB * GSS);              // [SUB][3][VUS]
 
   const int slot = blockIdx.x * CPW + cw;
   if (TPC == 64 && slot >= pv.B) return;         // whole wavefront idle (no workgroup barriers below in this mode)
@@ -2134,7 +2137,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #pragma unroll
       for (int h = 0; h < (GSS + TPC - 1) / TPC; ++h) {
         const int r = tid + TPC * h;
-        if (r < row_len) __builtin_amdgcn_global_load_lds((gptr)(src + r), (lptr)(s_g0 + (buf * SUB + pi) * GSS + wv + TPC * h - c * TPC), 4, 0, 0);
+        // (a piece with no element of the row is skipped by the whole barcode: TPC * h < row_len is uniform, so the number of loads a request
+        //  puts in flight is SUB * ceil(row_len / TPC) exactly — what the counted wait of the three-buffer form relies on)
+        if (TPC * h < row_len && r < row_len) __builtin_amdgcn_global_load_lds((gptr)(src + r), (lptr)(s_g0 + (buf * SUB + pi) * GSS + wv + TPC * h - c * TPC), 4, 0, 0);
       }
     }
       }
@@ -2162,7 +2167,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
     }
     DMX_K2_SYNC();
     rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
-    if (dma) request_rows(0, 0);                   // sub-tile 0's rows travel while phase 1 runs
+    if (dma) {
+      request_rows(0, 0);                          // sub-tile 0's rows travel while phase 1 runs
+      if (NBUF == 3 && SUB < tp) request_rows(SUB, 1);
+    }
     // ---- phase 1: pG[n][3][3] of the pair (:600-663), exactly as k_doublet_a2; kept: alpha 0.5's nine values, and for
     //      alpha 0 the three u values of sample 0 (the only k the singlet column [j][0][0] needs)
     if (tid < 2 * TP) {
@@ -2264,11 +2272,22 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #pragma unroll 1
     for (int sub = 0; sub < tp; sub += SUB) {
       const int ns = min(SUB, tp - sub);
-      const int buf = dma ? (sub / SUB) & 1 : 0;
+      const int buf = dma ? (NBUF == 3 ? (sub / SUB) % 3 : (sub / SUB) & 1) : 0;
       float* s_g = s_g0 + buf * SUB * GSS;
       if (dma) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this sub-tile's rows have landed ...
-        if (sub + SUB < tp) request_rows(sub + SUB, buf ^ 1);   // ... the next one's take off (its buffer was last read two syncs ago)
+        if constexpr (NBUF == 3) {
+          // this sub-tile's rows have landed when at most the loads THIS BARCODE requested after them are in flight (loads return in order): kReq = SUB
+          // rows x pieces per row, per request and barcode (request_rows).  The wavefront's other barcode issues its own requests in between (or
+          // none: its tile may be shorter), which can only make this wait longer, never too short.
+          static_assert((GSS + TPC - 1) / TPC <= 2 && 2 * SUB <= 15, "vmcnt field / pieces per row");
+          if (sub + SUB >= tp) __builtin_amdgcn_s_waitcnt(0x0F70);                            // nothing requested after them: vmcnt(0)
+          else if (row_len > TPC) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * SUB));             // vmcnt(kReq), two pieces per row
+          else __builtin_amdgcn_s_waitcnt(0x0F70 | SUB);                                      // one piece per row
+          if (sub + 2 * SUB < tp) request_rows(sub + 2 * SUB, (buf + 2) % 3);   // two sub-tiles ahead (that buffer was last read a sub-tile ago, two syncs back)
+        } else {
+          __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this sub-tile's rows have landed ...
+          if (sub + SUB < tp) request_rows(sub + SUB, buf ^ 1);   // ... the next one's take off (its buffer was last read two syncs ago)
+        }
       } else {
       // genotype rows of the sub-tile -> LDS (coalesced along the row)
         int r = tid % row_len, pi = tid / row_len;
@@ -5946,7 +5965,7 @@ int launch_doublet(dmx_engine* e) {
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do {                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
-    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 32 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC == 32 ? 3 : (TPC >= 32 ? 2 : 1)) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) {                                                                                             \
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX>),                  \
@@ -5966,7 +5985,7 @@ int launch_doublet(dmx_engine* e) {
 #define DMX_K2SV(TPC, VMAX, SUB, FIX, MINW)                                                                            \
   do {                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
-    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC >= 32 ? 2 : 1) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
+    constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC == 32 ? 3 : (TPC >= 32 ? 2 : 1)) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
     if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
