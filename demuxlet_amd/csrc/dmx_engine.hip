@@ -2037,6 +2037,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
                                                           uint8_t* __restrict__ flagged) {
   const int32_t V = V_and_flags & 0xFFFF;
   const bool no_dma = (V_and_flags >> 16) & 1;   // kernel experiments (DMX_SYM_NO_DMA)
+  const bool abl_p1 = (V_and_flags >> 17) & 1;   // timing experiment (DMX_SYM_ABLATE_P1; results WRONG): phase 1's global loads all hit the same lines
   // Narrow panels put SEVERAL barcodes in one wavefront (TPC = 32: two, TPC = 16: four): their entries fill the lanes (V = 16: 160
   // entries = 5 per lane of 32; V = 8: 48 = 3 per lane of 16) and the per-tile phases 0-1 are shared instruction-wise.  The tile is
   // what one pass of phase 1 covers: two lanes per pair.
@@ -2177,8 +2178,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
       const bool on = ti1 < tp;
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
-      const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
-      const int32_t snp1 = on ? s_snp[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, abl_p1 ? (off & 63) : off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
+      const int32_t snp1 = on ? (abl_p1 ? (s_snp[ti1] & 15) : s_snp[ti1]) : 0;
       const float* g0r = g + (size_t)snp1 * row_len;             // sample 0's row (alpha-0 lanes use it)
       const float gf0 = g0r[0], gf1 = g0r[1], gf2 = g0r[2];
       double q[5], wA[5], wR[5];                                           // the weights live in registers during phase 1 only
@@ -5993,7 +5994,7 @@ int launch_doublet(dmx_engine* e) {
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
-    const int32_t sym_flags = e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0;       // kernel experiments only
+    const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0);       // kernel experiments only
     const bool wide_cells = e->knob("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
     if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
     else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
