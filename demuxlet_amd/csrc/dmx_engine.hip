@@ -2038,6 +2038,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   const int32_t V = V_and_flags & 0xFFFF;
   const bool no_dma = (V_and_flags >> 16) & 1;   // kernel experiments (DMX_SYM_NO_DMA)
   const bool abl_p1 = (V_and_flags >> 17) & 1;   // timing experiment (DMX_SYM_ABLATE_P1; results WRONG): phase 1's global loads all hit the same lines
+  const bool abl_p2 = (V_and_flags >> 18) & 1;   // timing experiment (DMX_SYM_ABLATE_P2; results WRONG): no phase-2 evaluations
+  const bool abl_u = (V_and_flags >> 19) & 1;    // timing experiment (DMX_SYM_ABLATE_U; results WRONG): u is not formed
   // Narrow panels put SEVERAL barcodes in one wavefront (TPC = 32: two, TPC = 16: four): their entries fill the lanes (V = 16: 160
   // entries = 5 per lane of 32; V = 8: 48 = 3 per lane of 16) and the per-tile phases 0-1 are shared instruction-wise.  The tile is
   // what one pass of phase 1 covers: two lanes per pair.
@@ -2108,6 +2110,14 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   double acc[NE];
 #pragma unroll
   for (int i = 0; i < NE; ++i) acc[i] = 0.0;
+  // u-formation identity: entry tid + TPC * i of a sub-tile's SUB * V (pair, sample) values
+  constexpr int NU = (SUB * VMAX + TPC - 1) / TPC;
+  int uq[NU];                                    // (pair << 16) | sample; negative: no such entry
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const int e = tid + TPC * i;
+    uq[i] = e < SUB * V ? ((e / V) << 16) | (e % V) : (int)0x80000000;
+  }
   bool ok = true;
   const DmxLogPins lk = dmx_log_pins();
   // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1
@@ -2300,27 +2310,36 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
         }
       }
       DMX_K2_SYNC();
-      // u[pi][l][k] = sum_m pG[1][l][m] g_k[m]  (k < V), and row V = the alpha-0 u of sample 0
-#pragma unroll 1
-      for (int e = tid; e < ns * (V + 1); e += TPC) {
-        const int k = e % (V + 1), pi = e / (V + 1);
-        double* u = &s_u[(size_t)pi * 3 * VUS + k];
-        if (k == V) {
+      // u[pi][l][k] = sum_m pG[1][l][m] g_k[m]  (k < V), and row V = the alpha-0 u of sample 0.  Round 5: the lane's NU entries are formed TOGETHER,
+      // branch-free, with the (pair, k) of each entry computed once per kernel — as a rolled loop with a division and a branch per entry this step
+      // was a fifth of the kernel (timing builds without it: cfg3 FAST 95 -> 49 ms of 247, cfg5 FAST 29.9 -> 20.4 of 45.8), three exposed LDS round
+      // trips per entry for 9 multiply-adds.
+      if (!abl_u) {
+        if (tid < ns * 3) { const int pi = tid / 3, l = tid - 3 * pi; s_u[(size_t)pi * 3 * VUS + l * VUS + V] = s_u0[(sub + pi) * 4 + l]; }
+        double un[NU][3];
 #pragma unroll
-          for (int l = 0; l < 3; ++l) u[l * VUS] = s_u0[(sub + pi) * 4 + l];
-        } else {
+        for (int i = 0; i < NU; ++i) {
+          const int pi = (uq[i] >> 16) & 0x7FFF, k = uq[i] & 0xFFFF;        // (an entry past the sub-tile's SUB * V: pair 0, sample 0, not stored)
           const double* P = &s_q1[(sub + pi) * 6];                 // pG[1][l][m] = P[l + m]
           const float* gr = &s_g[pi * GSS + k * 3];
           const double b0 = (double)gr[0], b1 = (double)gr[1], b2 = (double)gr[2];
 #pragma unroll
-          for (int l = 0; l < 3; ++l) u[l * VUS] = __builtin_fma(P[l + 2], b2, __builtin_fma(P[l + 1], b1, P[l] * b0));
+          for (int l = 0; l < 3; ++l) un[i][l] = __builtin_fma(P[l + 2], b2, __builtin_fma(P[l + 1], b1, P[l] * b0));
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          const int pi = (uq[i] >> 16) & 0x7FFF, k = uq[i] & 0xFFFF;
+          if (uq[i] >= 0 && pi < ns) {
+            double* u = &s_u[(size_t)pi * 3 * VUS + k];
+            u[0] = un[i][0]; u[VUS] = un[i][1]; u[2 * VUS] = un[i][2];
+          }
         }
       }
       DMX_K2_SYNC();
       constexpr int UPI = MINW >= 4 ? 1 : SUB;       // pairs unrolled together (register budget)
 #pragma unroll UPI
       for (int pi = 0; pi < SUB; ++pi) {
-        if (pi < ns) {
+        if (pi < ns && !abl_p2) {
           const float* gr = &s_g[pi * GSS];
           const double* up = &s_u[pi * 3 * VUS];
           double a0 = 0.0, a1 = 0.0, a2 = 0.0;
@@ -5994,7 +6013,8 @@ int launch_doublet(dmx_engine* e) {
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
-    const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0);       // kernel experiments only
+    const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0) |
+                              (e->knob("DMX_SYM_ABLATE_P2") ? (1 << 18) : 0) | (e->knob("DMX_SYM_ABLATE_U") ? (1 << 19) : 0);       // kernel experiments only
     const bool wide_cells = e->knob("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
     if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
     else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
