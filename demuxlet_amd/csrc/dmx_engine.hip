@@ -2040,6 +2040,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   const bool abl_p1 = (V_and_flags >> 17) & 1;   // timing experiment (DMX_SYM_ABLATE_P1; results WRONG): phase 1's global loads all hit the same lines
   const bool abl_p2 = (V_and_flags >> 18) & 1;   // timing experiment (DMX_SYM_ABLATE_P2; results WRONG): no phase-2 evaluations
   const bool abl_u = (V_and_flags >> 19) & 1;    // timing experiment (DMX_SYM_ABLATE_U; results WRONG): u is not formed
+  const bool abl_rd = (V_and_flags >> 20) & 1;   // timing experiment (DMX_SYM_ABLATE_RD; results WRONG): phase 1 without its read loop
+  const bool abl_00 = (V_and_flags >> 21) & 1;   // timing experiment (DMX_SYM_ABLATE_00; results WRONG): no llks00 sums
   // Narrow panels put SEVERAL barcodes in one wavefront (TPC = 32: two, TPC = 16: four): their entries fill the lanes (V = 16: 160
   // entries = 5 per lane of 32; V = 8: 48 = 3 per lane of 16) and the per-tile phases 0-1 are shared instruction-wise.  The tile is
   // what one pass of phase 1 covers: two lanes per pair.
@@ -2195,7 +2197,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
       double q[5], wA[5], wR[5];                                           // the weights live in registers during phase 1 only
 #pragma unroll
       for (int i = 0; i < 5; ++i) { q[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }   // :597
-      for (uint32_t r = 0; __any(r < cnt); ++r) {
+      for (uint32_t r = 0; __any(r < (abl_rd ? 0u : cnt)); ++r) {
         const bool live = r < cnt;
         const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
         const uint32_t bq = byte & 127u;
@@ -2264,7 +2266,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
     }
     DMX_K2_SYNC();
     // ---- llks00: lane n < 2 of the cell adds its alpha's terms in pair order
-    if (tid < 2) {
+    if (tid < 2 && !abl_00) {
       const double* row = &s_t00[tid * T00];
       if (tp == TP) {                              // eight terms at a time: loads first, then the ordered adds
 #pragma unroll 1
@@ -6014,7 +6016,8 @@ int launch_doublet(dmx_engine* e) {
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
     const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0) |
-                              (e->knob("DMX_SYM_ABLATE_P2") ? (1 << 18) : 0) | (e->knob("DMX_SYM_ABLATE_U") ? (1 << 19) : 0);       // kernel experiments only
+                              (e->knob("DMX_SYM_ABLATE_P2") ? (1 << 18) : 0) | (e->knob("DMX_SYM_ABLATE_U") ? (1 << 19) : 0) |
+                              (e->knob("DMX_SYM_ABLATE_RD") ? (1 << 20) : 0) | (e->knob("DMX_SYM_ABLATE_00") ? (1 << 21) : 0);       // kernel experiments only
     const bool wide_cells = e->knob("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
     if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
     else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
