@@ -291,6 +291,11 @@ template <int HALF> __device__ __forceinline__ uint32_t add_word_of(uint32_t bas
   else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(base), "v"(w));
   return r;
 }
+#ifndef DMX_FAST_PRODUCT
+#define DMX_FAST_PRODUCT 0                        // 1: FAST k_doublet_sym takes ONE log per entry and full sub-tile, of the product of its terms — an experiment
+                                                  // build only: cfg3 FAST K2 217 -> 159 ms, but the sums then round differently from the
+                                                  // reference's own sequence of adds and sit up to 1.3e-9 from it at cfg3's depth (rms 2.6e-10; a log per term: 4e-11)
+#endif
 #ifndef DMX_FAST_LITE_LOG
 #define DMX_FAST_LITE_LOG 1                       // FAST phase-2 terms through dmx_log2_lite (6 FP64 instructions; csrc/dmx_log.hpp) — 0: dmx_log2 (10), as rounds 2-4
 #endif
@@ -550,6 +555,199 @@ __global__ __launch_bounds__(kThreads, 4) void k_singlet(PileupView pv, int nrd_
       else if (q == 0) llk0s[a_cell] = s;
     }
   }
+}
+
+#ifndef DMX_K1O_U
+#define DMX_K1O_U 4
+#endif
+// the C library's log() for an argument outside dmx_log's domain (never for real likelihoods), out of line: one copy per kernel, not per term
+__device__ __attribute__((noinline)) double log_slow(double x) { return log(x); }
+
+// K1 with OWNED accumulators (round 5; soft fields, up to 64 samples).  k_singlet's lanes are pairs: they park V + 1 log terms per pair in the
+// LDS, and nine lanes of the wavefront then add them up chunk by chunk — a serial 64-add chain per chunk of eight samples with 9 of 64 lanes
+// active, a third of that kernel's issue cycles, on top of an LDS store and load per term.  Here a sample's running sum lives in a register of
+// ONE lane for the whole walk (k_doublet_*'s ownership):
+//   phase 1  lane (cell c = lane / TPC, pair ti = lane % TPC): GL of its pair (:427-452) and the llk0 term (:459) -> LDS;
+//   phase 2  lane (cell c, sample j = lane % TPC): for the tile's pairs in ascending order: the pair's GL (a broadcast LDS read), its own three
+//            genotype probabilities at that SNP (SNP-major rows g[snp][k][l]: the cell's lanes read one contiguous row), the dot product, the log, the add.
+// Same operands, same operations, same order of additions as k_singlet: the same bits (tests/test_gpu_parity.py::test_k1_owned_sums_are_k_singlets_bits).
+// CHK = false (k_check_geno passed the matrix): GL >= 1e-6 / (1 + 3e-6) and a row's maximum >= 1e-30 make every log argument a normal positive
+// number, and the per-term class test is dropped (k_doublet_a2's CHK).
+template <int TPC, bool DENSE, bool CHK>
+__global__ __launch_bounds__(kThreads, 5) void k_singlet_own(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                             const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                             const int32_t* __restrict__ sched, int32_t V,
+                                                             double* __restrict__ llks, double* __restrict__ llk0s,
+                                                             const int64_t* __restrict__ blk, int32_t blk_i, int32_t nblk) {
+  static_assert(TPC == 16 || TPC == 32 || TPC == 64, "lanes per cell");
+  constexpr int CW = 64 / TPC, T = TPC;          // cells per wavefront; pairs per cell and tile
+  constexpr int TS = T + 2;                      // stride of a cell's llk0 terms (doubles): 16-byte aligned rows
+  constexpr int NW = kThreads / 64;
+  constexpr int U = DMX_K1O_U;                   // pairs per batch of phase 2: their rows are requested together, a batch ahead of their use
+  static_assert(T % U == 0, "batches");
+  __shared__ double s_tab[kTabK1];
+  __shared__ __attribute__((aligned(16))) double s_gl[NW][64 * 4];     // [pair lane][G0 G1 G2 -]
+  __shared__ __attribute__((aligned(16))) double s_t0[NW][CW * TS];    // [cell][pair] llk0 terms
+  __shared__ uint32_t s_row[NW][64];                                   // byte offset of the pair's genotype row
+  const double* s_first = s_tab + kTab;
+  const double* s_log = s_tab + kLut;
+  const double* s_final = s_first + kFirst;
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  for (int i = t; i < kTabK1; i += kThreads) s_tab[i] = tabs[i];
+  __syncthreads();                               // the only workgroup barrier
+  const int slot0 = (blockIdx.x * NW + w) * CW;
+  if (slot0 >= pv.B) return;
+  double* gl = s_gl[w];
+  double* t0s = s_t0[w];
+  uint32_t* rowo = s_row[w];
+
+  const int c = lane / T, ti = lane % T;         // phase 1: pair ti of cell c; phase 2: sample ti of cell c
+  const bool cell_ok = slot0 + c < pv.B;
+  const int32_t cell = cell_ok ? sched[slot0 + c] : 0;
+  const int64_t* bt = blk ? blk + ((size_t)cell * (nblk + 1) + blk_i) * 2 : nullptr;     // (k_singlet's SNP-blocked walk)
+  const int64_t p_beg = cell_ok ? (blk ? bt[0] : pv.cell_pair_off[cell]) : 0;
+  const int64_t np = cell_ok ? (blk ? bt[2] : pv.cell_pair_off[cell + 1]) - p_beg : 0;
+  int64_t rd_base = cell_ok ? (blk ? bt[1] : pv.cell_read_off[cell]) : 0;
+  int64_t max_np = np;
+#pragma unroll
+  for (int d = T; d < 64; d <<= 1) max_np = max(max_np, __shfl_xor(max_np, d));
+  const bool own = cell_ok && ti < V;
+  const bool own0 = cell_ok && ti == 0;          // the cell's first lane also owns llk0
+  double acc = 0.0, acc0 = 0.0;
+  if (blk && blk_i > 0) {                        // resume: the sums of the blocks before this one
+    if (own) acc = llks[(size_t)cell * V + ti];
+    if (own0) acc0 = llk0s[cell];
+  }
+  const uint32_t row_bytes = (uint32_t)V * 12u;
+  const uint32_t my_off = (uint32_t)min(ti, V - 1) * 12u;          // lanes past the panel re-read its last sample (ignored)
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, (int)min((size_t)0x7FFFFFFF, (size_t)pv.S * V * 12), 0x00020000);
+
+  struct Raw { uint32_t n; int32_t snp; };
+  struct Hdr { uint32_t n; int32_t snp; uint32_t rd4; int64_t off; };
+  auto issue = [&](int64_t tile) {               // loads only
+    Raw r;
+    const int64_t pi = tile * T + ti;
+    const bool v = pi < np;
+    r.n = v ? load_nrd(pv.pair_nrd, p_beg + pi, nrd_width) : 0u;
+    r.snp = v ? (DENSE ? (int32_t)pi : pv.pair_snp[p_beg + pi]) : 0;
+    return r;
+  };
+  auto prepare = [&](const Raw& r) {             // prefix-scan the read counts of the cell's T pairs, request the bytes
+    Hdr h;
+    h.n = r.n; h.snp = r.snp;
+    const uint32_t incl = seg_scan_incl<T>(r.n);
+    h.off = rd_base + (int64_t)(incl - r.n);
+    rd_base += seg_last<T>(incl, lane);
+    h.rd4 = load_rd4(pv, h.off, r.n);
+    return h;
+  };
+  Hdr nxt = prepare(issue(0));
+  Raw pre = issue(1);
+  for (int64_t tile = 0; tile * T < max_np; ++tile) {
+    const Hdr cur = nxt;
+    nxt = prepare(pre);                          // tile+1: its counts arrived a tile ago
+    pre = issue(tile + 2);                       // tile+2: loads in flight
+    // ---- phase 1: genotype likelihoods of this lane's pair (:427-452), exactly k_singlet's
+    double G0, G1, G2;
+    {
+      const uint32_t n = cur.n;
+      const uint32_t b0 = cur.rd4 & 0xFFu;
+      const double* f = s_final + 3 * (n ? b0 : 256u);
+      G0 = f[0]; G1 = f[1]; G2 = f[2];
+      if (n >= 2) {
+        const double* f1 = s_first + 3 * b0;
+        double g0 = f1[0], g1 = f1[1], g2 = f1[2];
+        const bool safe = n <= kSafeReads;
+        for (uint32_t r = 1; r < n; ++r) {
+          const uint32_t byte = (r < 4) ? ((cur.rd4 >> (8 * r)) & 0xFFu) : (uint32_t)pv.reads[cur.off + r];
+          const uint32_t bq = byte & 127u;
+          const bool alt = (byte >> 7) != 0;
+          const double m = s_tab[bq], e3 = s_tab[128 + bq], h = s_tab[256 + bq];
+          g0 *= alt ? e3 : m;                                                // :437
+          g1 *= h;                                                           // :438
+          g2 *= alt ? m : e3;                                                // :439
+          const double tmp = g0 + g1 + g2;                                   // :440
+          if (safe) {
+            const double y = rcp_refined(tmp);
+            g0 = div_by(g0, tmp, y); g1 = div_by(g1, tmp, y); g2 = div_by(g2, tmp, y);   // :441-443
+          } else {
+            g0 /= tmp; g1 /= tmp; g2 /= tmp;
+          }
+        }
+        g0 += 1e-6; g1 += 1e-6; g2 += 1e-6;                                  // :446-448
+        const double tmp = g0 + g1 + g2;
+        const double y = rcp_refined(tmp);
+        G0 = div_by(g0, tmp, y); G1 = div_by(g1, tmp, y); G2 = div_by(g2, tmp, y);       // :449-452
+      }
+    }
+    {
+      const double* __restrict__ g0row = gp0 + (size_t)cur.snp * 3;
+      const double x = G0 * g0row[0] + G1 * g0row[1] + G2 * g0row[2];        // :459
+      double tm = dmx_log_fast(x, s_log);
+      if (CHK) { if (__builtin_expect(!__builtin_amdgcn_class(x, 0x100), 0)) tm = log_slow(x); }
+      t0s[c * TS + ti] = tm;
+      *reinterpret_cast<double2*>(&gl[lane * 4]) = make_double2(G0, G1);
+      gl[lane * 4 + 2] = G2;
+      rowo[lane] = (uint32_t)cur.snp * row_bytes;
+    }
+    DMX_WAVE_LDS_ORDER();
+    const int64_t left = np - tile * T;
+    const int cnt = left >= T ? T : (left > 0 ? (int)left : 0);
+    // ---- llk0: the cell's first lane adds the tile's terms in pair order
+    if (own0) {
+      const double* row = &t0s[c * TS];
+      int i = 0;
+      for (; i + 8 <= cnt; i += 8) {               // loads first, then the ordered adds
+        double2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const double2*>(&row[i + 2 * j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc0 += v[j].x; acc0 += v[j].y; }
+      }
+      for (; i < cnt; ++i) acc0 += row[i];
+    }
+    // ---- phase 2: lane (c, sample ti) adds its term of every pair of the tile, ascending
+    const bool whole = __all(cnt == T);
+    int cmax = cnt;
+#pragma unroll
+    for (int d = T; d < 64; d <<= 1) cmax = max(cmax, __shfl_xor(cmax, d));
+    auto request = [&](int p0, float (&a)[U][3]) {          // the rows of pairs p0 .. p0+U-1: this lane's three probabilities of each
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t vo = rowo[c * T + p0 + u] + my_off;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) a[u][l] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_g, vo + 4u * l, 0, 0));
+      }
+    };
+    auto batch = [&](int p0, const float (&a)[U][3], auto whole_c) {
+      constexpr bool WHOLE = decltype(whole_c)::value;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double2 g01 = *reinterpret_cast<const double2*>(&gl[(c * T + p0 + u) * 4]);
+        const double g2 = gl[(c * T + p0 + u) * 4 + 2];
+        const double x = g01.x * (double)a[u][0] + g01.y * (double)a[u][1] + g2 * (double)a[u][2];      // :456
+        double tm = dmx_log_fast(x, s_log);
+        if (CHK) { if (__builtin_expect(!__builtin_amdgcn_class(x, 0x100), 0)) tm = log_slow(x); }
+        if (WHOLE) acc += tm;
+        else if (p0 + u < cnt) acc += tm;
+      }
+    };
+    if (whole) {                                   // two row buffers: batch b+1's rows travel while batch b computes
+      float ra[2][U][3];
+      request(0, ra[0]);
+#pragma unroll
+      for (int b = 0; b < T / U; ++b) {
+        if (b + 1 < T / U) request((b + 1) * U, ra[(b + 1) & 1]);
+        batch(b * U, ra[b & 1], std::true_type{});
+      }
+    } else {
+#pragma unroll 1
+      for (int p0 = 0; p0 < cmax; p0 += U) { float ra[U][3]; request(p0, ra); batch(p0, ra, std::false_type{}); }
+    }
+    DMX_WAVE_LDS_ORDER();
+  }
+  if (own) llks[(size_t)cell * V + ti] = acc;
+  if (own0) llk0s[cell] = acc0;
 }
 
 // K1 over genotype classes (see "Genotype classes" below: <= 4 distinct probability rows per SNP, --field GT).
@@ -2042,6 +2240,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   const bool abl_u = (V_and_flags >> 19) & 1;    // timing experiment (DMX_SYM_ABLATE_U; results WRONG): u is not formed
   const bool abl_rd = (V_and_flags >> 20) & 1;   // timing experiment (DMX_SYM_ABLATE_RD; results WRONG): phase 1 without its read loop
   const bool abl_00 = (V_and_flags >> 21) & 1;   // timing experiment (DMX_SYM_ABLATE_00; results WRONG): no llks00 sums
+  const bool no_prod = (V_and_flags >> 22) & 1;  // kernel experiment (DMX_SYM_NO_PRODUCT): a log per term also in full sub-tiles
   // Narrow panels put SEVERAL barcodes in one wavefront (TPC = 32: two, TPC = 16: four): their entries fill the lanes (V = 16: 160
   // entries = 5 per lane of 32; V = 8: 48 = 3 per lane of 16) and the per-tile phases 0-1 are shared instruction-wise.  The tile is
   // what one pass of phase 1 covers: two lanes per pair.
@@ -2339,6 +2538,39 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
       }
       DMX_K2_SYNC();
       constexpr int UPI = MINW >= 4 ? 1 : SUB;       // pairs unrolled together (register budget)
+      // Round-5 experiment (DMX_FAST_PRODUCT builds only; not shipped): a full sub-tile takes ONE log per entry — of the product of its SUB terms
+      // (a multiply per term; the log's ~13 instructions and its table read once per SUB terms).  Every term is in [1e-66, 1e78] when k_check_geno
+      // has passed the rows, and realistic ones in [1e-6, 1]: a product of four is a normal number, and the result is CLOSER to the exact sum than
+      // the reference's.  That is the problem: the reference's llk carries the rounding of its own 50 000 adds (half an ulp of the running sum each,
+      // rms 2e-12 at cfg3's depth), which only the same adds of the same terms reproduce — the per-term form agrees with it to 4e-11, this one to 1.3e-9.
+      constexpr bool PROD = !CHK && SUB <= 4 && DMX_FAST_PRODUCT;
+      if (PROD && ns == SUB && !abl_p2 && !no_prod) {
+        double a[SUB][3];
+        if (FIXJ) {
+#pragma unroll
+          for (int pi = 0; pi < SUB; ++pi) {
+            const float* gr = &s_g[pi * GSS + ej[0] * 3];
+            a[pi][0] = (double)gr[0]; a[pi][1] = (double)gr[1]; a[pi][2] = (double)gr[2];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+          double pr = 1.0;
+#pragma unroll
+          for (int pi = 0; pi < SUB; ++pi) {
+            if (!FIXJ) {
+              const float* gr = &s_g[pi * GSS + ej[i] * 3];
+              a[pi][0] = (double)gr[0]; a[pi][1] = (double)gr[1]; a[pi][2] = (double)gr[2];
+            }
+            const double* up = &s_u[pi * 3 * VUS];
+            const double x0 = DMX_LDS_NOMERGE ? lds_read_f64(&up[ek[i]]) : up[ek[i]], x1 = DMX_LDS_NOMERGE ? lds_read_f64(&up[VUS + ek[i]]) : up[VUS + ek[i]],
+                         x2 = DMX_LDS_NOMERGE ? lds_read_f64(&up[2 * VUS + ek[i]]) : up[2 * VUS + ek[i]];
+            const double sj = __builtin_fma(a[pi][2], x2, __builtin_fma(a[pi][1], x1, a[pi][0] * x0));
+            pr = pi ? pr * sj : sj;
+          }
+          acc[i] += dmx_log2_fastmode(pr, s_log, lk);
+        }
+      } else
 #pragma unroll UPI
       for (int pi = 0; pi < SUB; ++pi) {
         if (pi < ns && !abl_p2) {
@@ -5045,6 +5277,7 @@ struct dmx_engine {
   const char* knob(const char* name) const { if (knobs.empty()) return nullptr; auto it = knobs.find(name); return it == knobs.end() ? nullptr : it->second.c_str(); }
   // what the last run launched (dmx_engine_kernel_names): host function pointers of the K1 / K2 / K3b kernels, and where K1 ran
   const void *k1_fn = nullptr, *k2_fn = nullptr, *k3b_fn = nullptr; int32_t k1_placement = 0;
+  bool k2_sym = false;                                               // launch_doublet picked a k_doublet_sym form (FAST, soft fields, grid {0, 0.5})
 };
 
 namespace {
@@ -5742,6 +5975,23 @@ int launch_singlet(dmx_engine* e) {
   // rows of a launch stay L2-resident; the sums are parked in llks / llk0s between launches (see the kernel).
   const int64_t* blk = (!dense && e->blk_n > 1) ? e->d_blk : nullptr;
   const int n_launch = blk ? e->blk_n : 1;
+  // soft fields, 9..64 samples: the kernel whose lanes own their samples' sums (k_singlet_own; DMX_K1_NO_OWN=1: k_singlet, bit-identical)
+  if (V >= 9 && V <= 64 && (size_t)e->S * V * 12 <= 0x7FFFFFFFull && !e->knob("DMX_K1_NO_OWN")) {
+    const int tpc = V <= 16 ? 16 : (V <= 32 ? 32 : 64);
+    const int cwo = 64 / tpc;
+    const dim3 grd((unsigned)((B + NW * cwo - 1) / (NW * cwo)));
+    const bool chk = !e->geno_safe || e->knob("DMX_FORCE_CHECK");
+#define DMX_K1O_(TT, DD, CC)                                                                                           \
+    for (int bi_ = 0; bi_ < n_launch; ++bi_)                                                                           \
+      DMX_LAUNCH(k1_fn, (k_singlet_own<TT, DD, CC>), grd, block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, \
+                         e->d_sched, V, e->d_llks, e->d_llk0s, blk, bi_, e->blk_n)
+#define DMX_K1O(TT) do { if (dense) { if (chk) DMX_K1O_(TT, true, true); else DMX_K1O_(TT, true, false); }            \
+                         else { if (chk) DMX_K1O_(TT, false, true); else DMX_K1O_(TT, false, false); } } while (0)
+    if (tpc == 16) DMX_K1O(16); else if (tpc == 32) DMX_K1O(32); else DMX_K1O(64);
+#undef DMX_K1O
+#undef DMX_K1O_
+    return DMX_OK;
+  }
 #define DMX_K1(CC, KK, DD)                                                                                            \
   for (int bi_ = 0; bi_ < n_launch; ++bi_)                                                                             \
     DMX_LAUNCH(k1_fn, (k_singlet<CC, KK, DD>), grid, block, dyn, e->stream, e->pv, e->nrd_width, gq, g0q, e->d_lut,   \
@@ -5792,6 +6042,7 @@ int launch_doublet_generic_w(dmx_engine* e) {
 // The A = 2 kernel with its fix-up pass; other alpha grids (or V > 64) take the generic kernel.
 int launch_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
+  e->k2_sym = false;
   const bool force_generic = e->knob("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
   const bool use_cls = e->n_classes > 0 && !e->knob("DMX_NO_CLASSES");
   if (A >= 3 && A <= 8 && use_cls && V <= 1024 && !force_generic) {
@@ -5985,7 +6236,7 @@ int launch_doublet(dmx_engine* e) {
   if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && (V <= 128 || sym_wide) && !e->knob("DMX_NO_SYM")) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
-  do {                                                                                                                \
+  do { e->k2_sym = true;                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
     constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC == 32 ? 3 : (TPC >= 32 ? 2 : 1)) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
@@ -6005,7 +6256,7 @@ int launch_doublet(dmx_engine* e) {
                        e->d_grid, e->d_l00, e->d_flag);                                                                \
   } while (0)
 #define DMX_K2SV(TPC, VMAX, SUB, FIX, MINW)                                                                            \
-  do {                                                                                                                \
+  do { e->k2_sym = true;                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
     constexpr size_t cb_ = (size_t)TP_ * 6 * 8 + TP_ * 4 * 8 + 2 * (TP_ + 2) * 8 + TP_ * 16 + (size_t)(TPC == 32 ? 3 : (TPC >= 32 ? 2 : 1)) * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     const size_t lds = cb_ * (kThreads / TPC);                                                                         \
@@ -6017,7 +6268,7 @@ int launch_doublet(dmx_engine* e) {
   } while (0)
     const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0) |
                               (e->knob("DMX_SYM_ABLATE_P2") ? (1 << 18) : 0) | (e->knob("DMX_SYM_ABLATE_U") ? (1 << 19) : 0) |
-                              (e->knob("DMX_SYM_ABLATE_RD") ? (1 << 20) : 0) | (e->knob("DMX_SYM_ABLATE_00") ? (1 << 21) : 0);       // kernel experiments only
+                              (e->knob("DMX_SYM_ABLATE_RD") ? (1 << 20) : 0) | (e->knob("DMX_SYM_ABLATE_00") ? (1 << 21) : 0) | (e->knob("DMX_SYM_NO_PRODUCT") ? (1 << 22) : 0);       // kernel experiments only
     const bool wide_cells = e->knob("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
     if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
     else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
@@ -6038,7 +6289,7 @@ int launch_doublet(dmx_engine* e) {
       // 64 < V <= 512: the entry list (V (V/2 + 1) + V, up to 132 096) in slabs of 9 entries per lane
       const unsigned ns = (unsigned)((V * (V / 2 + 1) + V + 256 * 9 - 1) / (256 * 9));
 #define DMX_K2SS(VMAX, SUB, FIX)                                                                                       \
-  do {                                                                                                                \
+  do { e->k2_sym = true;                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1;                                                  \
     constexpr size_t cb_ = (size_t)32 * 6 * 8 + 32 * 4 * 8 + 2 * 34 * 8 + 32 * 16 + (size_t)2 * SUB * GSS_ * 4 + (size_t)SUB * 3 * VUS_ * 8; \
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_sym<256, VMAX, SUB, FIX, 3, 9>),              \
@@ -6256,7 +6507,13 @@ int run_doublet_impl(dmx_engine* e, bool with_singlet) {
     hipEvent_t* rs = e->ring_s[e->n_ring_s % dmx_engine::kRing];
     // K1 beside K2 — or, where K2 leaves it no room (k_doublet_clsp: three issuing wavefronts per SIMD), beside K3 + K3b, which like K1
     // issue on about half of their cycles: K1 then starts when K2 has finished (DMX_FORCE_OVERLAP=1: beside K2 anyway)
-    const bool after_k2 = k2_is_clsp(e) && !e->knob("DMX_FORCE_OVERLAP");
+    // The same holds for k_doublet_sym under ONE long K1 launch (round 5): its workgroups fill the CU's LDS three deep (46-53 KB each); a K1
+    // workgroup (29 KB, alive for the whole launch) that takes the place of a retired one leaves no room for the next K2 workgroup, and the CU runs
+    // two of K2's three until K1 ends — cfg3 FAST: K2 218 ms alone, 244 with a K1 beside it that takes 20 ms alone; step 260.5 -> 251.1 ms with K1
+    // after K2.  A K1 walked in SNP blocks (sparse pileups over a matrix beyond the L2: a launch of short workgroups per block) does fit in
+    // between: cfg5 FAST 49.0 ms beside K2, 53.2 after it.  STRICT's k_doublet_a2 keeps K1 beside it (cfg3 1 221.5 against 1 227.8, cfg5 144.2 / 150.2).
+    const bool k1_blocked = e->pv.pair_snp != nullptr && e->blk_n > 1;
+    const bool after_k2 = (k2_is_clsp(e) || (e->k2_sym && !k1_blocked) || e->knob("DMX_K1_AFTER_K2")) && !e->knob("DMX_FORCE_OVERLAP");
     e->k1_placement = after_k2 ? 2 : 1;
     HIP_TRY(hipStreamWaitEvent(e->k1_stream, after_k2 ? e->ev[5] : e->ev_fork, 0));
     e->stream = e->k1_stream;

@@ -873,7 +873,8 @@ def test_fast_mode_end_to_end_files(eng, oracle, tmp_path):
 
 
 @pytest.mark.parametrize("V,field,dense", [(8, "GT", True), (8, "GP", True), (5, "GT", False), (16, "PL", False), (24, "GT", False), (40, "GP", True),
-                                           (48, "GT", True), (64, "GT", False), (37, "GT", False)])      # 33..64 GT: the uniform-j class kernel
+                                           (48, "GT", True), (64, "GT", False), (37, "GT", False),       # 33..64 GT: the uniform-j class kernel
+                                           (32, "GP", True), (21, "PL", False), (9, "GP", False), (64, "PL", True)])   # soft fields, 9..64: k_singlet_own
 def test_every_launch_geometry_gives_the_same_bits(eng, oracle, V, field, dense, monkeypatch):
     """The launchers pick cells-per-wavefront (1, 2, 4) by barcode count, the narrow or the wide class K1 by panel width, and the
     specialised or the generic K2; the big-count choices are never reached by small tests.  Forcing each of them must not
@@ -892,7 +893,7 @@ def test_every_launch_geometry_gives_the_same_bits(eng, oracle, V, field, dense,
     sp = synth.make_pileup(rng, al, B, 1.0 if dense else 0.3, 2.0, dense_layout=dense, doublet_rate=0.3)
     pl = host_pileup(eng, sp)
     for k in ("DMX_K1_CW", "DMX_K1_WIDE_V", "DMX_K2_GENERIC", "DMX_NO_CLASSES", "DMX_NO_K1_CLASSES", "DMX_K1_BLOCK_BYTES", "DMX_K1_NO_BLOCKS",
-              "DMX_FORCE_CHECK", "DMX_CLS_NO_UJ", "DMX_CLS_NO_PROD"):
+              "DMX_FORCE_CHECK", "DMX_CLS_NO_UJ", "DMX_CLS_NO_PROD", "DMX_K1_NO_OWN"):
         monkeypatch.delenv(k, raising=False)
     base = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
     ref = oracle_from_pileup(oracle, sp, g, (0.0, 0.5), 0.5)
@@ -904,6 +905,10 @@ def test_every_launch_geometry_gives_the_same_bits(eng, oracle, V, field, dense,
                 {"DMX_NO_K1_CLASSES": "1", "DMX_K1_BLOCK_BYTES": str(256 * (12 * V + 24))},
                 {"DMX_NO_K1_CLASSES": "1", "DMX_K1_BLOCK_BYTES": str(64 * (12 * V + 24)), "DMX_K1_CW": "2"},
                 {"DMX_NO_K1_CLASSES": "1", "DMX_K1_BLOCK_BYTES": str(16 * (12 * V + 24)), "DMX_K1_CW": "4"},
+                # the general K1 of 9..64 samples is k_singlet_own (lanes own their samples' sums; round 5): against k_singlet (pair lanes, chunked
+                # ordered sums), plain, in SNP blocks, and with the argument-class test kept
+                {"DMX_NO_K1_CLASSES": "1"}, {"DMX_NO_K1_CLASSES": "1", "DMX_K1_NO_OWN": "1"}, {"DMX_NO_K1_CLASSES": "1", "DMX_FORCE_CHECK": "1"},
+                {"DMX_NO_K1_CLASSES": "1", "DMX_K1_NO_OWN": "1", "DMX_K1_BLOCK_BYTES": str(64 * (12 * V + 24))},
                 # the per-term argument-class test kept although this panel is provably safe (k_check_geno)
                 {"DMX_FORCE_CHECK": "1"}, {"DMX_FORCE_CHECK": "1", "DMX_NO_CLASSES": "1"},
                 # the class K2 of 33..64-sample GT panels in its look-up form instead of the uniform-j form (VGPR-relative row selection)
