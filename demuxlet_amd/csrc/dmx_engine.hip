@@ -611,6 +611,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_own(PileupView pv, int 
   int64_t max_np = np;
 #pragma unroll
   for (int d = T; d < 64; d <<= 1) max_np = max(max_np, __shfl_xor(max_np, d));
+  const DmxLogPins lk = dmx_log_pins();          // the log's addend constants in registers (same operations, same bits: csrc/dmx_log.hpp)
   const bool own = cell_ok && ti < V;
   const bool own0 = cell_ok && ti == 0;          // the cell's first lane also owns llk0
   double acc = 0.0, acc0 = 0.0;
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_own(PileupView pv, int 
     {
       const double* __restrict__ g0row = gp0 + (size_t)cur.snp * 3;
       const double x = G0 * g0row[0] + G1 * g0row[1] + G2 * g0row[2];        // :459
-      double tm = dmx_log_fast(x, s_log);
+      double tm = dmx_log_fast_pinned(x, s_log, lk);
       if (CHK) { if (__builtin_expect(!__builtin_amdgcn_class(x, 0x100), 0)) tm = log_slow(x); }
       t0s[c * TS + ti] = tm;
       *reinterpret_cast<double2*>(&gl[lane * 4]) = make_double2(G0, G1);
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(kThreads, 5) void k_singlet_own(PileupView pv, int 
         const double2 g01 = *reinterpret_cast<const double2*>(&gl[(c * T + p0 + u) * 4]);
         const double g2 = gl[(c * T + p0 + u) * 4 + 2];
         const double x = g01.x * (double)a[u][0] + g01.y * (double)a[u][1] + g2 * (double)a[u][2];      // :456
-        double tm = dmx_log_fast(x, s_log);
+        double tm = dmx_log_fast_pinned(x, s_log, lk);
         if (CHK) { if (__builtin_expect(!__builtin_amdgcn_class(x, 0x100), 0)) tm = log_slow(x); }
         if (WHOLE) acc += tm;
         else if (p0 + u < cnt) acc += tm;
