@@ -1276,9 +1276,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
   constexpr int T = 64 / CW;
   constexpr int NW = kThreads / 64;
   constexpr int TD = 6;                          // doubles per pair in LDS: 4 class terms, llk0 term, 1 pad
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_dynraw[];   // per wavefront: id words [64][nwd]
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dynraw[];   // per wavefront: id words [nwd][64]
   __shared__ double s_tab[kTabK1];
   __shared__ __attribute__((aligned(16))) double s_term[NW][64 * TD];
+  __shared__ __attribute__((aligned(16))) double s_t0[NW][64];      // L0M: the tile's llk0 terms, contiguous (the merged sum reads them two at a time)
   const double* s_log = s_tab + kLut;
   const double* s_first = s_tab + kTab;
   const double* s_final = s_first + kFirst;
@@ -1289,6 +1290,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
   __syncthreads();                               // the only workgroup barrier
 
   double* term = s_term[w];
+  double* t0s = s_t0[w];
   uint32_t* s_idw = reinterpret_cast<uint32_t*>(s_dynraw) + (size_t)w * 64 * nwd;
   const int slot0 = (blockIdx.x * NW + w) * CW;
   if (slot0 >= pv.B) return;
@@ -1356,7 +1358,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
     const double* g0 = gp0 + (size_t)cur.snp * 3;
     const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
-    for (int wq = 0; wq < nwd; ++wq) s_idw[lane * nwd + wq] = idw[(size_t)cur.snp * nwd + wq];
+    for (int wq = 0; wq < nwd; ++wq) s_idw[wq * 64 + lane] = idw[(size_t)cur.snp * nwd + wq];   // [word][pair]: a chain reads four pairs' words at once
 
     double G0, G1, G2;                                                       // :427-452, as in k_singlet
     {
@@ -1405,6 +1407,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
         const double xs[5] = {x0, x1, x2, x3, x4};
         for (int d = 0; d < 5; ++d) if (!__builtin_amdgcn_class(xs[d], 0x100)) tr[d] = log(xs[d]);
       }
+      if (L0M) t0s[lane] = tr[4];
     }
     DMX_WAVE_LDS_ORDER();
     // ---- ordered sums: chain k adds term[pair][class of sample k at the pair's SNP] for the tile's pairs
@@ -1415,45 +1418,53 @@ __global__ __launch_bounds__(kThreads, MINW) void k_singlet_clsw(PileupView pv, 
       const bool merged = L0M && i == 0 && slab0;  // this pass also carries the llk0 sum
       if (ch_k[i] < 0 && !merged) continue;
       const int k = ch_k[i] < 0 ? 0 : ch_k[i];     // (merged pass: lanes without a chain walk along with sample 0's look-ups, unused)
-      const bool is0 = k == V;
+      const bool is0 = !L0M && k == V;             // (with L0M no chain is the llk0 chain: the test and its select compile away)
       const int wq = is0 ? 0 : (k >> 4), sh = is0 ? 0 : 2 * (k & 15);
       const double* tb = &term[0];
-      const uint32_t* ib = &s_idw[wq];
-      double s = acc[i];
-      int p = 0;
-      constexpr int NB = L0M ? 8 : 16;             // pairs per batch: ids first, then the term reads, then the ordered adds
-      for (; p + NB <= cnt; p += NB) {
-        uint32_t wv[NB];
-        if (nwd == 1) {
+      const uint32_t* ib = &s_idw[wq * 64];
+      // Round 5: the walk is instantiated with and without the merged llk0 sum (it used to test `merged` — a scalar branch — at every pair), the id
+      // words of eight pairs come as two 16-byte reads from the transposed [word][pair] layout (they were eight reads through eight separately
+      // advanced addresses): 10 -> 4 VALU instructions per (pair, chain) — extract, scale-and-add, the two adds.
+      auto walk = [&](auto merged_c) {
+        constexpr bool MG = decltype(merged_c)::value;
+        double s = acc[i];
+        int p = 0;
+        constexpr int NB = L0M ? 8 : 16;           // pairs per batch: ids first, then the term reads, then the ordered adds
+        for (; p + NB <= cnt; p += NB) {
+          uint32_t wv[NB];
 #pragma unroll
           for (int q4 = 0; q4 < NB / 4; ++q4) {
             const uint4 u = *reinterpret_cast<const uint4*>(&ib[p + 4 * q4]);
             wv[4 * q4] = u.x; wv[4 * q4 + 1] = u.y; wv[4 * q4 + 2] = u.z; wv[4 * q4 + 3] = u.w;
           }
-        } else {
+          double tv[NB];
+          [[maybe_unused]] double t0v[NB];
 #pragma unroll
-          for (int q = 0; q < NB; ++q) wv[q] = ib[(p + q) * nwd];
-        }
-        double tv[NB];
-        [[maybe_unused]] double t0v[NB];
+          for (int q = 0; q < NB; ++q) {
+            const uint32_t d = is0 ? 4u : ((wv[q] >> sh) & 3u);
+            tv[q] = tb[(p + q) * TD + d];
+          }
+          if (MG) {                                  // (uniform addresses; taking the terms from their pairs' lanes with v_readlane instead: 28.6 -> 34.1 ms)
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {
-          const uint32_t d = is0 ? 4u : ((wv[q] >> sh) & 3u);
-          tv[q] = tb[(p + q) * TD + d];
-          if (merged) t0v[q] = tb[(p + q) * TD + 4];
-        }
+            for (int q = 0; q < NB; q += 2) {
+              const double2 u = *reinterpret_cast<const double2*>(&t0s[p + q]);
+              t0v[q] = u.x; t0v[q + 1] = u.y;
+            }
+          }
 #pragma unroll
-        for (int q = 0; q < NB; ++q) {               // ascending SNP order: the reference's order
-          s += tv[q];
-          if (merged) acc0 += t0v[q];
+          for (int q = 0; q < NB; ++q) {             // ascending SNP order: the reference's order
+            s += tv[q];
+            if (MG) acc0 += t0v[q];
+          }
         }
-      }
-      for (; p < cnt; ++p) {
-        const uint32_t d = is0 ? 4u : ((ib[p * nwd] >> sh) & 3u);
-        s += tb[p * TD + d];
-        if (merged) acc0 += tb[p * TD + 4];
-      }
-      acc[i] = s;
+        for (; p < cnt; ++p) {
+          const uint32_t d = is0 ? 4u : ((ib[p] >> sh) & 3u);
+          s += tb[p * TD + d];
+          if (MG) acc0 += tb[p * TD + 4];
+        }
+        acc[i] = s;
+      };
+      if (merged) walk(std::true_type{}); else walk(std::false_type{});
     }
     DMX_WAVE_LDS_ORDER();
   }
