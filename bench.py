@@ -95,12 +95,89 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(dp, g, cfg, target_s=12.0):
-    """The oracle (CPU restatement of the reference, 1 thread) on the first cells of the SAME workload."""
+def cpu_sample_cells(dp, cfg, target_s):
+    """How many of the workload's first barcodes the oracle gets: sized from its measured cost on this class of host (~6 ns per
+    singlet term, ~19 ns per doublet pair-evaluation) so that ONE run lands near target_s."""
+    V, A = cfg["V"], len(cfg["alphas"])
+    ns_per_pair = 6.0 * (V + 1) + (19.0 * (V * V * A + A) if cfg["doublet"] else 0.0)
+    pairs_per_cell = max(1.0, dp.n_pairs / max(dp.n_cells, 1))
+    return int(max(1, min(dp.n_cells, round(target_s / (1e-9 * ns_per_pair * pairs_per_cell)))))
+
+
+def engine_rows(cx, eng, cfg, n):
+    """What the engine holds for its first n barcodes — called right after the LAST TIMED step, before anything else runs on the engine,
+    so these ARE the timed path's results (dmx_engine_run: K1 beside / after K2, K3, K3b) at the timed size."""
+    torch, st = cx.torch, cx.synth_torch
+    B, V, A = eng.B, cfg["V"], len(cfg["alphas"])
+    v = eng.device_view()
+    rows = dict(llks=st.tensor_from_ptr(v.llks, (B, V), torch.float64, cx.dev)[:n].cpu().numpy(),
+                llk0s=st.tensor_from_ptr(v.llk0s, (B,), torch.float64, cx.dev)[:n].cpu().numpy())
+    if cfg["doublet"]:
+        words = cx.engine.capi.SUMMARY_DTYPE.itemsize // 8
+        rows["l00"] = st.tensor_from_ptr(v.llks00, (B, A), torch.float64, cx.dev)[:n].cpu().numpy()
+        sm = st.tensor_from_ptr(v.summary, (B, words), torch.float64, cx.dev)[:n].cpu().numpy()
+        rows["summ"] = np.ascontiguousarray(sm).view(cx.engine.capi.SUMMARY_DTYPE).reshape(-1)
+        rows["grid"] = eng.get_cell_grids(np.arange(n, dtype=np.int32))
+    return rows
+
+
+def calls_of_grid(grid):
+    """The calls cmd_cram_demuxlet.cpp:746-758 (best / next singlet: strict <, first maximum) and :799-814 (best doublet over j != k, alpha
+    index >= 1) make from one barcode's llksAB[V][V][A]: (best singlet, next singlet, {j, k} of the best doublet, its alpha index)."""
+    V, _, A = grid.shape
+    i1 = i2 = -1; m1 = m2 = -1e300
+    for j in range(V):
+        x = grid[j, 0, 0]
+        if m1 < x: m2, i2, i1, m1 = m1, i1, j, x
+        elif m2 < x: i2, m2 = j, x
+    jb = kb = nb = -1; mab = -1e300
+    for j in range(V):
+        for k in range(V):
+            if j == k: continue
+            for a in range(1, A):
+                if mab < grid[j, k, a]: jb, kb, nb, mab = j, k, a, grid[j, k, a]
+    return i1, i2, frozenset((jb, kb)), nb
+
+
+def parity_check(rows, want, cfg, fast):
+    """The engine's rows of the timed steps against the oracle's values for the same barcodes (the CPU leg evaluates them anyway): the
+    largest absolute difference over llks, llk0s, llksAB (FAST: the entries demuxlet prints or decides on — the singlet column and every
+    alpha >= 1 entry; the rest FAST does not compute) and llks00, and whether K3's records make the oracle's calls."""
+    n = len(want.llk0s)
+    d = max(float(np.abs(rows["llks"][:n] - want.llks).max()), float(np.abs(rows["llk0s"][:n] - want.llk0s).max()))
+    if cfg["doublet"]:
+        V, A = cfg["V"], len(cfg["alphas"])
+        dg = np.abs(rows["grid"][:n] - want.llksAB)
+        if fast:
+            mask = np.zeros((V, V, A), dtype=bool); mask[:, 0, 0] = True; mask[:, :, 1:] = True
+            dg = dg[:, mask]
+        d = max(d, float(dg.max()), float(np.abs(rows["l00"][:n] - want.llks00).max()))
+        from demuxlet_amd import capi
+        near = capi.DMX_CELL_NEAR_DOUBLET | capi.DMX_CELL_NEAR_SINGLET
+        same, flagged = True, 0
+        for c in range(n):
+            sm = rows["summ"][c]
+            if int(sm["n_pairs"]) == 0:
+                continue
+            i1, i2, jk, nb = calls_of_grid(want.llksAB[c])
+            same = same and (int(sm["i_sing1"]), int(sm["i_sing2"]), frozenset((int(sm["j_best"]), int(sm["k_best"]))), int(sm["n_best"])) == (i1, i2, jk, nb)
+            flagged += int((int(sm["flags"]) & near) != 0)                # near-tie barcodes: the writers decide those from the grid (host arbiter)
+        out = {"barcodes": n, "max_abs_delta": d, "calls_identical": bool(same), "near_tie_flagged": flagged}
+    else:
+        out = {"barcodes": n, "max_abs_delta": d, "calls_identical": bool(np.array_equal(np.argmax(rows["llks"][:n], axis=1), np.argmax(want.llks, axis=1)))}
+    out.update(tolerance=1e-9, ok=bool(d <= 1e-9 and out["calls_identical"]),
+               what="engine rows after the last timed step vs oracle/dmx_oracle.c on the same barcodes at the timed size"
+                    + (" (FAST: printed entries)" if fast and cfg["doublet"] else ""))
+    return out
+
+
+def cpu_baseline(dp, g, cfg, target_s=12.0, rows=None, fast=False, legs=True):
+    """The oracle (CPU restatement of the reference, 1 thread) on the first cells of the SAME workload.  With `rows` (engine_rows of
+    the same barcodes) the oracle's values are compared with the engine's: `parity_check`.  legs=False: that comparison only."""
     from oracle import oracle_py as O
     V = cfg["V"]
 
-    def prepare(c0, ncells):
+    def prepare(c0, ncells, want_grid=False):
         h = dp.host_slice(c0, ncells)
         words = ((h["reads"] >> 7).astype(np.uint32) << 24) | ((h["reads"] & 0x7F).astype(np.uint32) << 16) | 1
         pair_snp = h["pair_snp"] if h["pair_snp"] is not None else np.tile(np.arange(dp.n_snps, dtype=np.int32), ncells)
@@ -108,7 +185,7 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
                     np.concatenate([[0], np.cumsum(h["pair_nrd"].astype(np.int64))]), words,
                     np.zeros(ncells, np.int32), np.zeros(ncells, np.int32), np.zeros(ncells, np.int32))
         return O.CsrPlan(csr, [f"s{j}" for j in range(V)], g, O.Params(tuple(cfg["alphas"]), 0.5), None,
-                         singlet_only=not cfg["doublet"], want_grid=False)
+                         singlet_only=not cfg["doublet"], want_grid=want_grid)
 
     def execute(plan, repeats=1):
         t0 = time.perf_counter()
@@ -116,17 +193,20 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
             plan.execute()
         return time.perf_counter() - t0, plan.n_pairs * repeats
 
-    # size the sample from the oracle's measured cost on this class of host (~6 ns per singlet term, ~19 ns per doublet
-    # pair-evaluation) so that ONE run lands near target_s
     A = len(cfg["alphas"])
-    ns_per_pair = 6.0 * (V + 1) + (19.0 * (V * V * A + A) if cfg["doublet"] else 0.0)
     pairs_per_cell = max(1.0, dp.n_pairs / max(dp.n_cells, 1))
-    n = int(max(1, min(dp.n_cells, round(target_s / (1e-9 * ns_per_pair * pairs_per_cell)))))
-    t, pairs = execute(prepare(0, n))
+    n = len(rows["llk0s"]) if rows is not None else cpu_sample_cells(dp, cfg, target_s)
+    plan = prepare(0, n, want_grid=rows is not None and cfg["doublet"])
+    t, pairs = execute(plan)
     # oracle/dmx_oracle.c, gcc -O2 -ffp-contract=off: a CSR walk of the reference's arithmetic — the reference's own std::map walk is
     # slower (see reference_slice below), so this baseline is conservative
     out = dict(value=pairs * V / t, unit="cell-SNP-sample triples/s", cores=1, kind="port",
                sample=f"first {n} barcodes of the same workload ({pairs} covered pairs), oracle/dmx_oracle.c on 1 thread, {t:.1f} s", seconds=t)
+    if rows is not None:
+        out["parity_check"] = parity_check(rows, plan.out, cfg, fast)
+    del plan
+    if not legs:
+        return out
     if cfg["doublet"]:
         out["pair_evals_per_s"] = pairs * V * V * A / t
     ref = reference_slice_leg(dp, g, cfg)
@@ -140,6 +220,7 @@ def cpu_baseline(dp, g, cfg, target_s=12.0):
         import threading
         bytes_per_cell = pairs_per_cell * 24.0
         n_mt = int(max(1, min(n, dp.n_cells // cores, 32e9 / (cores * bytes_per_cell))))
+        cores = max(1, min(cores, dp.n_cells // n_mt))           # (a workload of fewer barcodes than cores: one barcode per thread, fewer threads)
         reps = int(max(1, round(0.5 * n / n_mt)))                # each thread: about half the serial leg's work
         prep = [prepare(i * n_mt, n_mt) for i in range(cores)]
         res = [None] * cores
@@ -202,6 +283,40 @@ def reference_slice_leg(dp, g, cfg, n_cells=24, n_snps=2000):
                 kind="reference lines 390-881, verbatim, behind I/O stand-ins (oracle/_ref/ref_slice_harness; see DESIGN.md §3)",
                 sample=f"first {n_cells} barcodes x first {n_snps} SNPs of the same workload ({pairs} covered pairs), incl. the reference's "
                        f"S*V^2*9 pair-table precompute and its four text files")
+
+
+def write_pair_leg(cx, cfg, dp, g, B, S, V):
+    """BASELINE config 4's defining option (`--write-pair`, cmd_cram_demuxlet.cpp:55 "(HUGE)", rows :772-797) on this workload through
+    dmx_demuxlet_run from the device-resident pileup, STRICT and FAST: stage seconds, the `.pair` file's rows and bytes, rows per second of the
+    writer stage.  Outside the timed region."""
+    import tempfile
+    engine = cx.engine
+    nreads = np.diff(dp.cell_read_off.cpu().numpy()).astype(np.int32)
+    bcs = [f"BC{i:07d}-1" for i in range(B)]
+    sms = [f"SM{j:02d}" for j in range(V)]
+    A = len(cfg["alphas"])
+    n_half = sum(1 for a in cfg["alphas"][1:] if a == 0.5)
+    rows = B * (V + V * (V - 1) * (A - 1 - n_half) + V * (V - 1) // 2 * n_half)
+    out = {"what": f"dmx_demuxlet_run with write_pair on {B} barcodes x {S} SNPs x {V} samples from a device-resident pileup (1 GPU, tie arbiter on): "
+                   "wall seconds per stage; write_s = the writer thread (arbiter + .single/.sing2/.best/.pair text + fwrite), beside the GPU",
+           "pair_rows": rows, "host_cores": host_cores()}
+    with tempfile.TemporaryDirectory() as td:
+        out["tmp_fs"] = os.popen(f"stat -f -c %T {td}").read().strip()
+        for name, md in (("strict", engine.capi.DMX_MODE_STRICT), ("fast", engine.capi.DMX_MODE_FAST)):
+            ds = dp.as_struct()
+            ds.rd_totl = ds.rd_pass = ds.rd_uniq = nreads.ctypes.data
+            tm = engine.demuxlet_run(ds, g, sms, cfg["alphas"], os.path.join(td, name), barcodes=bcs, timing=True, mode=md, write_pair=True)
+            tm.pop("reserved", None)
+            nbytes = os.path.getsize(os.path.join(td, name + ".pair"))
+            tm.update(pair_bytes=nbytes, pair_rows_per_s_of_write_s=rows / max(tm["write_s"], 1e-9), pair_GB_per_s_of_write_s=nbytes / max(tm["write_s"], 1e-9) / 1e9,
+                      triples_per_s=dp.n_pairs * V / tm["total_s"])
+            if name == "strict":                      # the file holds what :772-797 prints: one header + `rows` lines
+                with open(os.path.join(td, name + ".pair"), "rb") as f:
+                    head = f.readline()
+                    tm["header_ok"] = head == b"BARCODE\tSM1.ID\tSM2.ID\tLLK12\tPOSTPRB\n"
+            out[name] = tm
+            os.remove(os.path.join(td, name + ".pair"))
+    return out
 
 
 def cli_leg(n_reads=2_000_000, n_snps=60_000, n_samples=16, n_barcodes=3_000):
@@ -300,7 +415,7 @@ class Ctx:
     pass
 
 
-def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e=False):
+def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e=False, parity_s=0.0, defer_cpu=False):
     """Generate the workload of one configuration on this rank's GPU, time `steps` passes, return the record (rank 0)."""
     torch, dist, engine, synth, synth_torch = cx.torch, cx.dist, cx.engine, cx.synth, cx.synth_torch
     dev, world, rank, local = cx.dev, cx.world, cx.rank, cx.local
@@ -393,6 +508,12 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
     else:
         total_pairs = float(dp.n_pairs)
 
+    # the timed path's own results for the barcodes the CPU leg evaluates: taken NOW, after the last timed step and
+    # before the untimed one-after-the-other steps below overwrite them
+    rows = None
+    if rank == 0 and (with_cpu or parity_s > 0):
+        rows = engine_rows(cx, eng, cfg, cpu_sample_cells(dp, cfg, 12.0 if with_cpu else parity_s))
+
     # per-kernel times: the engine brackets every launch of K1, K2, K3 and K3b with HIP events on the stream it launches on
     # (dmx_engine_mean_kernel_times: mean over the TIMED launches, at most the last 16); torch's events on the same stream give
     # the K1 and K2 + K3 + K3b spans as a cross-check.  The roofline of the dominant kernel uses these timed-launch means.
@@ -471,7 +592,9 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
             "metric": METRIC,
             "value": triples * steps / elapsed, "unit": "triples/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            # N > 1 = cfg4's fixed 100k barcodes cut N ways (strong).  The N = 1 line is cfg3, another workload: it is no point of that curve and
+            # claims neither (the curve's N = 1 point is this line's also[cfg4/strict])
+            "scaling": "strong" if world > 1 else "none",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": cfg["name"] + (" [DMX_MODE_FAST]" if fast else ""), "tag": f"cfg{cfgno}/{mode}", "barcodes_total": B_total,
                        "barcodes_per_gpu": B, "snps": S, "samples": V, "alphas": list(cfg["alphas"]),
@@ -532,7 +655,9 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                                          "frac_of_peak_log_as_c_log": (ops1 + logs / world * (c_log - 1)) / kernels_s / 1e12 / FP64_VALU_PEAK_TFLOPS})
             else:
                 out["fp64_valu"]["logical_tflops_log_as_1_op"] = ops1 / kernels_s / 1e12
-        if with_e2e and cfg["doublet"]:
+        if with_e2e == "e2e4wp" and cfg["doublet"]:
+            out["end_to_end_write_pair"] = write_pair_leg(cx, cfg, dp, g, B, S, V)
+        elif with_e2e and cfg["doublet"]:
             # The same workload through the one-call C-ABI entry (dmx_demuxlet_run: frozen host pileup -> H2D -> K1/K2/K3(+K3b) ->
             # tie arbiter -> .single/.sing2/.best), stage seconds from dmx_job_timing.  Outside the timed region; host -> device
             # copies included (this is the PCIe-inclusive picture DESIGN.md asks for).
@@ -572,14 +697,25 @@ def run_config(cx, cfgno, cfg, mode, steps, warmup, with_cpu, with_log, with_e2e
                     e2e["from_bam_and_vcf"] = {"error": repr(ex)}
             out["end_to_end"] = e2e
             del hp, h
-        if with_cpu:                                     # the CPU baseline: rank 0, after the timed region, on the first barcodes of ITS range
-            out["cpu_baseline"] = cpu_baseline(dp, g, cfg)
-            out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if with_cpu and defer_cpu:
+            # N > 1: the CPU leg runs on rank 0 after the LAST barrier and the group's shutdown (main), so that no rank waits in a collective
+            # while one host thread works for half a minute
+            cx.deferred_cpu = (dp, g, cfg, rows, fast)
+        elif with_cpu:                                   # the CPU baseline: rank 0, after the timed region, on the first barcodes of ITS range
+            attach_cpu_baseline(out, cpu_baseline(dp, g, cfg, rows=rows, fast=fast))
+        elif rows is not None:                           # nested records: the comparison only, on a few barcodes
+            out["parity_check"] = cpu_baseline(dp, g, cfg, rows=rows, fast=fast, legs=False)["parity_check"]
     eng.close()
     del eng, dp, gathered, raw, g
     gc.collect()
     torch.cuda.empty_cache()
     return out
+
+
+def attach_cpu_baseline(out, cb):
+    out["parity_check"] = cb.pop("parity_check", None)
+    out["cpu_baseline"] = cb
+    cb["gpu_over_cpu"] = out["value"] / cb["value"]
 
 
 def sig(x, n=6):
@@ -614,6 +750,8 @@ def compact_line(full):
         line["roofline"]["kernel_ms_alone"] = alone.get(full["roofline"]["kernel"])
     if full.get("roofline_valu"):
         line["roofline_valu"] = pick(full["roofline_valu"], ("bound", "frac", "frac_measured_costs", "kernel"))
+    if full.get("parity_check"):                # the timed path's rows against the oracle, same barcodes, timed size
+        line["parity_check"] = pick(full["parity_check"], ("barcodes", "max_abs_delta", "calls_identical", "near_tie_flagged", "tolerance", "ok"))
     cb = full.get("cpu_baseline")
     if cb:
         c = pick(cb, ("value", "unit", "cores", "kind", "sample", "seconds", "gpu_over_cpu"))
@@ -627,7 +765,9 @@ def compact_line(full):
                              steps=a["steps"], kernel_ms=a["roofline"]["kernel_ms"], roofline_frac=a["roofline"]["frac"],
                              roofline_valu_frac=(a.get("roofline_valu") or {}).get("frac"),
                              roofline_valu_frac_measured=(a.get("roofline_valu") or {}).get("frac_measured_costs"),
-                             **pick(a, ("ranks_seen", "gather_ms")))
+                             **pick(a, ("ranks_seen", "gather_ms")),
+                             **({"parity": [a["parity_check"]["barcodes"], a["parity_check"]["max_abs_delta"], a["parity_check"]["calls_identical"]]}
+                                if a.get("parity_check") else {}))
                         for a in full["also"]]
     e2e = full.get("end_to_end")
     if e2e:
@@ -636,6 +776,10 @@ def compact_line(full):
         if e2e.get("cfg6"):                         # the realistic-coverage job: seconds, writer-thread seconds, share of barcodes whose grid K3's flags fetched
             line["end_to_end"]["cfg6"] = {m: pick(e2e["cfg6"][m], ("total_s", "write_s", "grid_fetched_frac"))
                                           for m in ("strict", "fast", "strict_device_pileup", "fast_device_pileup") if m in e2e["cfg6"]}
+        if e2e.get("cfg4_shard_write_pair"):        # cfg4's 12 500-barcode shard with --write-pair: seconds, and the writer's .pair rate
+            wp = e2e["cfg4_shard_write_pair"]
+            line["end_to_end"]["cfg4_shard_write_pair"] = dict(pair_rows=wp["pair_rows"], **{m: pick(wp[m], ("total_s", "wait_s", "write_s", "pair_bytes", "pair_rows_per_s_of_write_s"))
+                                                                                             for m in ("strict", "fast") if m in wp})
         cli = e2e.get("from_bam_and_vcf") or {}
         if "all_cores" in cli:
             line["end_to_end"]["bam_vcf_scan_reads_per_s"] = cli["all_cores"].get("scan_reads_per_s")
@@ -810,12 +954,14 @@ def main():
         if cx.use_dist:
             dist.barrier()
         single = cx.world == 1 and not cx.use_dist
-        # (the CPU baseline runs on rank 0 after the timed region, at every N: a SCALE line is judged by the same rule as the N = 1 line;
-        #  the other ranks wait for it at the next barrier)
+        # (the CPU baseline runs on rank 0 at every N: a SCALE line is judged by the same rule as the N = 1 line.  Its engine rows are taken
+        #  right after the timed steps; with a process group the oracle itself runs after the group's last barrier — see the end of main)
+        cx.deferred_cpu = None
         out = run_config(cx, cfgno, cfg, "fast" if args.fast else "strict", args.steps, args.warmup,
-                         with_cpu=not args.no_cpu_baseline, with_log=single, with_e2e=single and default_run and not args.only)
+                         with_cpu=not args.no_cpu_baseline, with_log=single, with_e2e=single and default_run and not args.only,
+                         defer_cpu=cx.use_dist)
         keys = ("value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu", "fp64_valu", "pair_evals_per_s",
-                "ranks_seen", "per_rank_ms_per_step", "gather_ms")
+                "ranks_seen", "per_rank_ms_per_step", "gather_ms", "parity_check")
         if single and default_run and not args.only:
             # nested records of the same run: the other single-GPU BASELINE configurations and the opt-in mode, fewer steps each
             also = []
@@ -833,9 +979,15 @@ def main():
                 if args.cells:
                     c["B"] = min(c["B"], args.cells)
                     c["name"] += f" [override: {c['B']} barcodes]"
-                r = run_config(cx, no, c, mode, kk, w, with_cpu=False, with_log=False, with_e2e=(no == 6 and mode == "fast") and "e2e6")
+                # every nested record is oracle-checked on its first barcode(s) too (~2 s of one host thread each; one cfg4 barcode is ~15 s, so
+                # cfg4 gets one per kernel: the shard's STRICT k_doublet_clsp and the whole job's FAST one)
+                par = 0.0 if args.no_cpu_baseline or (no == 4 and mode == "strict" and not shard) else 2.0
+                r = run_config(cx, no, c, mode, kk, w, with_cpu=False, with_log=False,
+                               with_e2e=((no == 6 and mode == "fast") and "e2e6") or (bool(shard) and "e2e4wp"), parity_s=par)
                 if r.get("end_to_end"):
                     out["end_to_end"]["cfg6"] = r.pop("end_to_end")
+                if r.get("end_to_end_write_pair"):            # cfg4's shard with --write-pair: the job, not only the kernels
+                    out["end_to_end"]["cfg4_shard_write_pair"] = r.pop("end_to_end_write_pair")
                 if shard:
                     r["config"]["tag"] = f"cfg{no}-shard/{mode}"
                 also.append({key: r[key] for key in keys if key in r})
@@ -846,6 +998,13 @@ def main():
             if cx.rank == 0:
                 out["also"] = [{key: r[key] for key in keys if key in r}]
         cx.inputs = None
+    if cx.use_dist or inject:
+        dist.barrier()
+        dist.destroy_process_group()
+    if cx.rank == 0 and getattr(cx, "deferred_cpu", None):
+        dp, g, c, rows, fast = cx.deferred_cpu
+        attach_cpu_baseline(out, cpu_baseline(dp, g, c, rows=rows, fast=fast))
+        cx.deferred_cpu = None
     if cx.rank == 0:
         full_path = Path(os.environ.get("DMX_BENCH_FULL", str(ROOT / "bench_full.json")))
         out["full_record"] = full_path.name
@@ -858,9 +1017,6 @@ def main():
         line = json.dumps(compact_line(out), separators=(",", ":"))
         assert len(line) < 6144, len(line)
         os.write(json_fd, (line + "\n").encode())
-    if cx.use_dist or inject:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -296,6 +296,12 @@ template <int HALF> __device__ __forceinline__ uint32_t add_word_of(uint32_t bas
                                                   // build only: cfg3 FAST K2 217 -> 159 ms, but the sums then round differently from the
                                                   // reference's own sequence of adds and sit up to 1.3e-9 from it at cfg3's depth (rms 2.6e-10; a log per term: 4e-11)
 #endif
+#ifndef DMX_SYM_ABLATIONS
+#define DMX_SYM_ABLATIONS 0                       // 1: k_doublet_sym carries its timing-ablation switches (results WRONG) — experiment builds only
+#endif
+#ifndef DMX_SYM_NB
+#define DMX_SYM_NB 3                              // entries per step of k_doublet_sym's software-pipelined phase 2 (0: off)
+#endif
 #ifndef DMX_FAST_LITE_LOG
 #define DMX_FAST_LITE_LOG 1                       // FAST phase-2 terms through dmx_log2_lite (6 FP64 instructions; csrc/dmx_log.hpp) — 0: dmx_log2 (10), as rounds 2-4
 #endif
@@ -2246,13 +2252,19 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
                                                           double* __restrict__ grid, double* __restrict__ l00,
                                                           uint8_t* __restrict__ flagged) {
   const int32_t V = V_and_flags & 0xFFFF;
-  const bool no_dma = (V_and_flags >> 16) & 1;   // kernel experiments (DMX_SYM_NO_DMA)
-  const bool abl_p1 = (V_and_flags >> 17) & 1;   // timing experiment (DMX_SYM_ABLATE_P1; results WRONG): phase 1's global loads all hit the same lines
-  const bool abl_p2 = (V_and_flags >> 18) & 1;   // timing experiment (DMX_SYM_ABLATE_P2; results WRONG): no phase-2 evaluations
-  const bool abl_u = (V_and_flags >> 19) & 1;    // timing experiment (DMX_SYM_ABLATE_U; results WRONG): u is not formed
-  const bool abl_rd = (V_and_flags >> 20) & 1;   // timing experiment (DMX_SYM_ABLATE_RD; results WRONG): phase 1 without its read loop
-  const bool abl_00 = (V_and_flags >> 21) & 1;   // timing experiment (DMX_SYM_ABLATE_00; results WRONG): no llks00 sums
+  const bool no_dma = (V_and_flags >> 16) & 1;   // kernel experiments (DMX_SYM_NO_DMA; bit-identical results)
+#if DMX_SYM_ABLATIONS                             // timing builds only (tools/build_variant.sh ... -DDMX_SYM_ABLATIONS=1): each switch drops one part of the
+                                                  // kernel — results WRONG, time right.  The shipped library does not contain them.
+  const bool abl_p1 = (V_and_flags >> 17) & 1;   // DMX_SYM_ABLATE_P1: phase 1's global loads all hit the same lines
+  const bool abl_p2 = (V_and_flags >> 18) & 1;   // DMX_SYM_ABLATE_P2: no phase-2 evaluations
+  const bool abl_u = (V_and_flags >> 19) & 1;    // DMX_SYM_ABLATE_U: u is not formed
+  const bool abl_rd = (V_and_flags >> 20) & 1;   // DMX_SYM_ABLATE_RD: phase 1 without its read loop
+  const bool abl_00 = (V_and_flags >> 21) & 1;   // DMX_SYM_ABLATE_00: no llks00 sums
+#else
+  constexpr bool abl_p1 = false, abl_p2 = false, abl_u = false, abl_rd = false, abl_00 = false;
+#endif
   const bool no_prod = (V_and_flags >> 22) & 1;  // kernel experiment (DMX_SYM_NO_PRODUCT): a log per term also in full sub-tiles
+  const bool no_pipe = (V_and_flags >> 23) & 1;  // kernel experiment (DMX_SYM_NO_PIPE; bit-identical results): phase 2 without the software pipeline
   // Narrow panels put SEVERAL barcodes in one wavefront (TPC = 32: two, TPC = 16: four): their entries fill the lanes (V = 16: 160
   // entries = 5 per lane of 32; V = 8: 48 = 3 per lane of 16) and the per-tile phases 0-1 are shared instruction-wise.  The tile is
   // what one pass of phase 1 covers: two lanes per pair.
@@ -2556,6 +2568,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
       // the reference's.  That is the problem: the reference's llk carries the rounding of its own 50 000 adds (half an ulp of the running sum each,
       // rms 2e-12 at cfg3's depth), which only the same adds of the same terms reproduce — the per-term form agrees with it to 4e-11, this one to 1.3e-9.
       constexpr bool PROD = !CHK && SUB <= 4 && DMX_FAST_PRODUCT;
+      constexpr int NB = DMX_SYM_NB > 0 ? DMX_SYM_NB : 1;
+      constexpr bool PIPE2 = FIXJ && DMX_SYM_NB > 0 && DMX_FAST_LITE_LOG && !PROD && MINW == 3 && NEP == 0;
       if (PROD && ns == SUB && !abl_p2 && !no_prod) {
         double a[SUB][3];
         if (FIXJ) {
@@ -2581,6 +2595,64 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
             pr = pi ? pr * sj : sj;
           }
           acc[i] += dmx_log2_fastmode(pr, s_log, lk);
+        }
+      } else if (PIPE2 && ns == SUB && !abl_p2 && !no_pipe) {
+        // Round 6: a full sub-tile's SUB x NE evaluations as ONE software-pipelined sequence of steps of NB entries (pair-major, so that every
+        // accumulator still adds its terms in ascending pair order: the same operations on the same operands as the loop below — same bits).
+        // Left to the compiler, a pair's entries were evaluated two at a time with three EXPOSED LDS round trips per two evaluations (u, then each
+        // log's table entry) and only three wavefronts per SIMD to hide them behind: the kernel issued on half of its cycles.  Here step s + 1's
+        // u values are requested, and step s's table entries, BEFORE the polynomial and the add of step s - 1 run: no wait in the steady state.
+        constexpr int NBAT = (NE + NB - 1) / NB, NST = SUB * NBAT;
+        double xu[NB][3];                            // u values of the step whose dot products come next
+        double zq[2][NB]; int32_t kq[2][NB]; double2 tq[2][NB];   // per step: reduced argument, binary exponent << 20, table entry {1/c, log c}
+        double a0, a1, a2;
+        auto load_u = [&](int st) {
+          const int pi = st / NBAT, b0 = (st % NBAT) * NB;
+          const double* up = &s_u[pi * 3 * VUS];
+#pragma unroll
+          for (int q = 0; q < NB; ++q) if (b0 + q < NE) {
+            xu[q][0] = lds_read_f64(&up[ek[b0 + q]]); xu[q][1] = lds_read_f64(&up[VUS + ek[b0 + q]]); xu[q][2] = lds_read_f64(&up[2 * VUS + ek[b0 + q]]);
+          }
+        };
+        auto load_a = [&](int pi) { const float* gr = &s_g[pi * GSS + ej[0] * 3]; a0 = (double)gr[0]; a1 = (double)gr[1]; a2 = (double)gr[2]; };
+        load_a(0);
+        load_u(0);
+#pragma unroll
+        for (int st = 0; st <= NST; ++st) {
+          const int cur = st & 1, prv = cur ^ 1;
+          if (st < NST) {
+            const int b0 = (st % NBAT) * NB;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) if (b0 + q < NE) {         // dot product, argument reduction, table request (dmx_log2_lite, first half)
+              const double sj = __builtin_fma(a2, xu[q][2], __builtin_fma(a1, xu[q][1], a0 * xu[q][0]));
+              if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100);
+              const uint32_t hi = (uint32_t)__double2hiint(sj), lo = (uint32_t)__double2loint(sj);
+              const uint32_t tmp = hi - DMX_LOG2_OFF_HI;
+              const uint32_t k20 = tmp & 0xFFF00000u;
+              zq[cur][q] = __hiloint2double((int)(hi - k20), (int)lo);
+              kq[cur][q] = (int32_t)k20;
+              tq[cur][q] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(s_log) + ((tmp >> 8) & 0xFF0u));
+            }
+            if (st + 1 < NST) {
+              if ((st + 1) % NBAT == 0) load_a((st + 1) / NBAT);
+              load_u(st + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);                       // requests first: nothing of the arithmetic below moves above them
+          }
+          if (st > 0) {
+            const int b0 = ((st - 1) % NBAT) * NB;
+#pragma unroll
+            for (int q = 0; q < NB; ++q) if (b0 + q < NE) {         // dmx_log2_lite, second half, and the ordered add
+              const double r = __builtin_fma(zq[prv][q], tq[prv][q].x, -1.0);
+              const double kd = (double)kq[prv][q];
+              const double w = __builtin_fma(kd, 0x1.62e42fefa39efp-1 * 0x1p-20, tq[prv][q].y);
+              double qq = __builtin_fma(r, lk.m14, lk.c13);
+              qq = __builtin_fma(r, qq, -0.5);
+              qq = __builtin_fma(r, qq, 1.0);
+              acc[b0 + q] += __builtin_fma(r, qq, w);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       } else
 #pragma unroll UPI
@@ -5881,6 +5953,7 @@ int dmx::engine_set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int3
   }
   e->have_sing = e->have_grid = false;
   e->have_pileup = true;
+  e->k1_fn = e->k2_fn = e->k3b_fn = nullptr; e->k1_placement = 0;      // nothing has run on this pileup yet
   return DMX_OK;
 }
 
@@ -6280,7 +6353,8 @@ int launch_doublet(dmx_engine* e) {
   } while (0)
     const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0) |
                               (e->knob("DMX_SYM_ABLATE_P2") ? (1 << 18) : 0) | (e->knob("DMX_SYM_ABLATE_U") ? (1 << 19) : 0) |
-                              (e->knob("DMX_SYM_ABLATE_RD") ? (1 << 20) : 0) | (e->knob("DMX_SYM_ABLATE_00") ? (1 << 21) : 0) | (e->knob("DMX_SYM_NO_PRODUCT") ? (1 << 22) : 0);       // kernel experiments only
+                              (e->knob("DMX_SYM_ABLATE_RD") ? (1 << 20) : 0) | (e->knob("DMX_SYM_ABLATE_00") ? (1 << 21) : 0) | (e->knob("DMX_SYM_NO_PRODUCT") ? (1 << 22) : 0) |
+                              (e->knob("DMX_SYM_NO_PIPE") ? (1 << 23) : 0);       // kernel experiments only (the ABLATE bits do something in -DDMX_SYM_ABLATIONS=1 builds only)
     const bool wide_cells = e->knob("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
     if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
     else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
@@ -6445,6 +6519,7 @@ extern "C" int dmx_engine_run_singlet(dmx_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   if (e->pv.B == 0) { e->have_sing = true; return DMX_OK; }
   hipEvent_t* rs = e->ring_s[e->n_ring_s % dmx_engine::kRing];
+  e->k1_fn = nullptr;                              // dmx_engine_kernel_names: what THIS call launches, never an earlier call's choice
   HIP_TRY(hipEventRecord(e->ev[2], e->stream));
   HIP_TRY(hipEventRecord(rs[0], e->stream));
   if (int rc = launch_singlet(e)) return rc;
@@ -6505,6 +6580,8 @@ int run_doublet_impl(dmx_engine* e, bool with_singlet) {
     HIP_TRY(hipMalloc((void**)&e->d_sing, std::max<size_t>(sizeof(double) * cap * e->V, 16)));
     e->grid_cap = (int32_t)cap;
   }
+  e->k2_fn = e->k3b_fn = nullptr;                  // (dmx_engine_kernel_names reports this call's launches; a run without K3b leaves `certify` empty)
+  if (with_singlet) e->k1_fn = nullptr;
   if (B == 0) { e->have_grid = true; if (with_singlet) e->have_sing = true; return DMX_OK; }
   hipEvent_t* rd = e->ring_d[e->n_ring_d % dmx_engine::kRing];
   if (with_singlet) HIP_TRY(hipEventRecord(e->ev_fork, e->stream));       // (K1 must not start before what precedes this call on the stream)
@@ -6889,8 +6966,12 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   // in waves; while the host arbitrates, formats and appends the rows of wave w, the GPUs already compute wave w + 1 — so a
   // job that is big enough is cut into at least four ranges per engine even when memory does not ask for it.
   const int ngpu = std::max(1, std::min(job->n_gpus > 0 ? job->n_gpus : 1, std::max(B, 1)));
+  // How a job is cut is decided here and nowhere else: the three variables that override it (tests force many ranges, experiments time the
+  // overlap) are read only behind the experiment fence, like the engines' own switches — a stray DMX_* variable cannot change a user's ranges
+  const bool fence_open = [] { const char* x = getenv("DMX_EXPERIMENTS"); return x && x[0] == '1' && !x[1]; }();
+  auto job_knob = [&](const char* name) -> const char* { return fence_open ? getenv(name) : nullptr; };
   size_t budget = (size_t)4 << 30;                                   // bytes of grid per range (host holds two waves of them)
-  if (const char* env = getenv("DMX_RANGE_BYTES")) budget = (size_t)std::max(1ll, atoll(env));   // tests: force many ranges
+  if (const char* env = job_knob("DMX_RANGE_BYTES")) budget = (size_t)std::max(1ll, atoll(env));   // tests: force many ranges
   {
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipSetDevice(job->device % ndev));
@@ -6902,7 +6983,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   const double grid_total = doublet_ok ? (double)B * (double)nAB * 8.0 : 0.0;
   const int by_mem = (int)std::min<double>((double)std::max(B, 1), std::ceil(grid_total / (double)budget));
   int by_overlap = 1;                                                // ranges per engine wanted for host/GPU overlap
-  if (const char* env = getenv("DMX_RANGES_PER_GPU")) by_overlap = std::max(1, atoi(env));
+  if (const char* env = job_knob("DMX_RANGES_PER_GPU")) by_overlap = std::max(1, atoi(env));
   else {
     // worth it when an engine has more than ~0.15 s of kernels ahead of it (at ~6e11 evaluations/s; FAST evaluates the printed
     // entries only): the host then writes range r and stages r + 2 while the GPU computes r + 1
@@ -6959,7 +7040,7 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   // runs beside the compute units) while the host arbitrates and writes wave w.
   const int per_wave = std::min(ngpu, R);
   const int waves = (R + per_wave - 1) / per_wave;
-  const int nset = (waves >= 2 && !getenv("DMX_ONE_ENGINE_PER_GPU")) ? 2 : 1;
+  const int nset = (waves >= 2 && !job_knob("DMX_ONE_ENGINE_PER_GPU")) ? 2 : 1;
   std::vector<dmx_engine*> eng((size_t)per_wave * nset, nullptr);
   tm.n_engines = (int32_t)eng.size();
   struct Guard { std::vector<dmx_engine*>* e; ~Guard() { for (dmx_engine* x : *e) if (x) dmx_engine_destroy(x); } } guard{&eng};

@@ -210,8 +210,9 @@ int dmx_engine_last_kernel_times(dmx_engine*, dmx_kernel_times* out);
  * Synchronises the engine's stream.  reset != 0 forgets the launches seen so far; out may be NULL (reset only). */
 typedef struct { double singlet_ms, doublet_ms, reduce_ms, certify_ms; int32_t n_singlet, n_doublet; } dmx_kernel_time_means;
 int dmx_engine_mean_kernel_times(dmx_engine*, int32_t reset, dmx_kernel_time_means* out);
-/* (ABI 7) Which kernels the engine's last run launched, by the demangled names rocprofv3 prints ("k_doublet_a2<256, 4, 4, true, false, 32>";
- * empty = not run), and where K1 ran: 0 = a launch of its own (run_singlet), 1 = beside K2 on the low-priority stream (dmx_engine_run), 2 = beside
+/* (ABI 7) Which kernels have run on the staged pileup, by the demangled names rocprofv3 prints ("k_doublet_a2<256, 4, 4, true, false, 32>";
+ * empty = not run).  Each entry is what the LAST call that launches that kernel picked: run_singlet replaces `singlet`, run_doublet replaces
+ * `doublet` and `certify` (empty when that run had no K3b), dmx_engine_run all three; staging a pileup clears them.  Where K1 ran: 0 = a launch of its own (run_singlet), 1 = beside K2 on the low-priority stream (dmx_engine_run), 2 = beside
  * K3 + K3b (dmx_engine_run when K2 leaves K1 no room).  A benchmark pairs its committed counter files with these names instead of guessing. */
 typedef struct { char singlet[96], doublet[96], certify[96]; int32_t k1_placement; int32_t reserved[3]; } dmx_kernel_names;
 int dmx_engine_kernel_names(dmx_engine*, dmx_kernel_names* out);

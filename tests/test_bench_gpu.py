@@ -30,7 +30,7 @@ def test_bench_line_singlet():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "none"
     assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -39,26 +39,42 @@ def test_bench_line_singlet():
     assert c["kind"] in ("port", "reference") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
     assert d["value"] > 10 * c["value"] and d["ms_per_step"] > 0
     assert d["config"]["barcodes_per_gpu"] == 1024 and d["config"]["mode"] == "strict"
+    # the timed path's rows against the oracle on the barcodes the CPU leg evaluates
+    p = d["parity_check"]
+    assert p["barcodes"] >= 1 and p["max_abs_delta"] <= 1e-9 and p["calls_identical"] is True and p["ok"] is True
 
 
 def test_bench_line_doublet_configs():
     d = run_bench("--config", "3", "--cells", "64", "--no-cpu-baseline")
-    assert d["pair_evals_per_s"] > 0 and d["roofline"]["kernel"] == "k_doublet" and "cpu_baseline" not in d
+    assert d["pair_evals_per_s"] > 0 and d["roofline"]["kernel"] == "k_doublet" and "cpu_baseline" not in d and "parity_check" not in d
     f = run_bench("--config", "3", "--cells", "64", "--no-cpu-baseline", "--fast")
     assert f["config"]["mode"] == "fast"
 
 
+def test_bench_parity_check_on_the_timed_path_doublet():
+    """cfg3's depth and panel on 8 barcodes, STRICT and FAST: the line carries the comparison of dmx_engine_run's rows (the timed steps' own
+    results) with the oracle — values within 1e-9 (FAST: the printed entries), K3's records making the oracle's calls."""
+    for extra in ((), ("--fast",)):
+        d = run_bench("--config", "3", "--cells", "8", "--only", *extra)
+        p = d["parity_check"]
+        assert 1 <= p["barcodes"] <= 8 and p["max_abs_delta"] <= 1e-9 and p["calls_identical"] is True and p["ok"] is True, p
+        assert d["cpu_baseline"]["value"] > 0
+
+
 def test_bench_default_line_is_cfg3_with_nested_records():
     """The driver's N=1 command (no --config): cfg3 STRICT as the line, cfg3-FAST / cfg2 / cfg5 as nested records."""
-    d = run_bench("--cells", "64", "--no-cpu-baseline")
+    d = run_bench("--cells", "64")
     assert d["config"]["workload"].startswith("cfg3") and d["config"]["mode"] == "strict" and d["pair_evals_per_s"] > 0
-    assert d["roofline"]["kernel"] == "k_doublet" and d["scaling"] == "weak"
+    assert d["roofline"]["kernel"] == "k_doublet" and d["scaling"] == "none"
     names = [a["workload"] for a in d["also"]]
     assert names == ["cfg3/fast", "cfg2/strict", "cfg5/strict", "cfg5/fast", "cfg6/strict", "cfg6/fast", "cfg4/strict", "cfg4/fast", "cfg4-shard/strict"]
     assert set(d["end_to_end"]["cfg6"]) >= {"strict", "fast"} and 0 <= d["end_to_end"]["cfg6"]["fast"]["grid_fetched_frac"] <= 1
     # the counter-derived fractions are quoted only for the kernel the committed counters were collected on (dmx_engine_kernel_names)
     assert d["roofline"]["kernel_launched"].startswith("k_doublet_a2<")
+    assert d["parity_check"]["ok"] is True and d["parity_check"]["max_abs_delta"] <= 1e-9
     for a in d["also"]:
+        if a["workload"] != "cfg4/strict":            # [barcodes, max |delta| vs the oracle, calls identical] of that record's own timed steps
+            assert a["parity"][0] >= 1 and a["parity"][1] <= 1e-9 and a["parity"][2] is True, a
         assert a["value"] > 0 and a["roofline_frac"] > 0 and a["kernel_ms"] > 0 and a["ms_per_step"] >= a["kernel_ms"] * 0.999
     assert d["roofline"]["kernel_ms"] <= d["ms_per_step"] * 1.001 and d["roofline"]["counts"].startswith("profiles/pmc_cfg3_strict")
     assert d["roofline_valu"]["kernel"].startswith("k_doublet")
@@ -76,6 +92,7 @@ def test_bench_sharded_path_with_a_one_rank_group():
     assert d["config"]["workload"].startswith("cfg4") and d["config"]["barcodes_total"] == 96
     # an N > 1 line is judged like the N = 1 line: it carries its own CPU baseline (rank 0, after the timed region) and the ranks' devices
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and len(d["rank_devices"]) == 1
+    assert d["parity_check"]["ok"] is True and d["scaling"] == "strong"
 
 
 def test_bench_gpus_n_without_a_launcher():

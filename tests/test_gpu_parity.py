@@ -1197,3 +1197,35 @@ def test_experiment_switches_are_fenced(eng, monkeypatch):
     monkeypatch.setenv("DMX_EXPERIMENTS", "1")
     monkeypatch.delenv("DMX_NO_CLASSES")
     assert names(after_create=lambda: monkeypatch.setenv("DMX_NO_CLASSES", "1")) == base                              # read at create, not per launch
+    monkeypatch.delenv("DMX_NO_CLASSES")
+
+    # ... and so are the three variables that change how dmx_demuxlet_run cuts a job: DMX_RANGE_BYTES, DMX_RANGES_PER_GPU,
+    # DMX_ONE_ENGINE_PER_GPU.  With the fence shut a stray one cannot change a user's ranges or engines.
+    import tempfile
+    bcs = [f"BC{i:03d}-1" for i in range(B)]
+    sms = [f"S{j}" for j in range(V)]
+
+    def job():
+        with tempfile.TemporaryDirectory() as td:
+            t = eng.demuxlet_run(pl, g, sms, (0.0, 0.5), td + "/o", barcodes=bcs, timing=True)
+        return t["n_ranges"], t["n_engines"]
+
+    for k in ("DMX_RANGE_BYTES", "DMX_RANGES_PER_GPU", "DMX_ONE_ENGINE_PER_GPU"):
+        monkeypatch.delenv(k, raising=False)
+    assert job() == (1, 1)
+    for fence in (None, "0"):
+        if fence is None: monkeypatch.delenv("DMX_EXPERIMENTS", raising=False)
+        else: monkeypatch.setenv("DMX_EXPERIMENTS", fence)
+        monkeypatch.setenv("DMX_RANGE_BYTES", "4096")
+        assert job() == (1, 1)
+        monkeypatch.delenv("DMX_RANGE_BYTES")
+        monkeypatch.setenv("DMX_RANGES_PER_GPU", "4")
+        assert job() == (1, 1)
+        monkeypatch.delenv("DMX_RANGES_PER_GPU")
+    monkeypatch.setenv("DMX_EXPERIMENTS", "1")
+    monkeypatch.setenv("DMX_RANGES_PER_GPU", "4")
+    assert job() == (4, 2)                                                                                           # four ranges, two alternating engines
+    monkeypatch.setenv("DMX_ONE_ENGINE_PER_GPU", "1")
+    assert job() == (4, 1)
+    monkeypatch.setenv("DMX_EXPERIMENTS", "0")
+    assert job() == (1, 1)
