@@ -92,7 +92,7 @@ def test_bench_sharded_path_with_a_one_rank_group():
     assert d["config"]["workload"].startswith("cfg4") and d["config"]["barcodes_total"] == 96
     # an N > 1 line is judged like the N = 1 line: it carries its own CPU baseline (rank 0, after the timed region) and the ranks' devices
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and len(d["rank_devices"]) == 1
-    assert d["parity_check"]["ok"] is True and d["scaling"] == "strong"
+    assert d["parity_check"]["ok"] is True
 
 
 def test_bench_gpus_n_without_a_launcher():
