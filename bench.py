@@ -867,6 +867,7 @@ def main():
     ap.add_argument("--field", default="", help="override the genotype field GT|GP|PL (experiments; not the headline)")
     ap.add_argument("--fast", action="store_true", help="DMX_MODE_FAST for the main record (opt-in, not the headline)")
     ap.add_argument("--alphas", default="", help="override the alpha grid, comma separated (experiments; not the headline)")
+    ap.add_argument("--e2e-write-pair", action="store_true", help="with --config/--cells: add the dmx_demuxlet_run --write-pair leg of this workload to the full record")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
@@ -958,7 +959,8 @@ def main():
         #  right after the timed steps; with a process group the oracle itself runs after the group's last barrier — see the end of main)
         cx.deferred_cpu = None
         out = run_config(cx, cfgno, cfg, "fast" if args.fast else "strict", args.steps, args.warmup,
-                         with_cpu=not args.no_cpu_baseline, with_log=single, with_e2e=single and default_run and not args.only,
+                         with_cpu=not args.no_cpu_baseline, with_log=single,
+                         with_e2e=(single and default_run and not args.only) or (args.e2e_write_pair and "e2e4wp"),
                          defer_cpu=cx.use_dist)
         keys = ("value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "config", "roofline", "roofline_valu", "fp64_valu", "pair_evals_per_s",
                 "ranks_seen", "per_rank_ms_per_step", "gather_ms", "parity_check")

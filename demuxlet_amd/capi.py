@@ -33,7 +33,25 @@ SYMBOLS = [
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
     "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_log2", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_engine_get_cell_grids", "dmx_write_doublet_summary", "dmx_debug_log_dd",
     "dmx_resolve_tie_order", "dmx_engine_mean_kernel_times", "dmx_store_add_batch", "dmx_write_doublet_summary_grids", "dmx_engine_kernel_names", "dmx_debug_device_log2_lite",
+    "dmx_engine_format_pair", "dmx_pair_text_get_info", "dmx_pair_text_read", "dmx_pair_text_free",
 ]
+
+
+class PairOverride(C.Structure):      # dmx_pair_override
+    _fields_ = [("a", C.c_int32), ("b", C.c_int32), ("n", C.c_int32), ("reserved", C.c_int32), ("llk_ab", C.c_double), ("llk_ba", C.c_double)]
+
+
+class PairPatch(C.Structure):         # dmx_pair_patch
+    _fields_ = [("offset", C.c_int64), ("value", C.c_double), ("out_cell", C.c_int32), ("singlet", C.c_int32)]
+
+
+class PairRequest(C.Structure):       # dmx_pair_request
+    _fields_ = [("n_out", C.c_int32), ("cells", C.c_void_p), ("barcodes", C.c_void_p), ("sample_ids", C.c_void_p), ("host_rows", C.c_void_p), ("ovr", C.c_void_p)]
+
+
+class PairTextInfo(C.Structure):      # dmx_pair_text_info
+    _fields_ = [("n_bytes", C.c_int64), ("n_out", C.c_int32), ("n_patches", C.c_int32), ("cell_off", C.POINTER(C.c_int64)), ("cell_flag", C.POINTER(C.c_uint8)),
+                ("patches", C.POINTER(PairPatch)), ("format_ms", C.c_double)]
 
 
 class DmxError(RuntimeError):
@@ -160,6 +178,7 @@ def load() -> C.CDLL:
         "dmx_store_add_batch": [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, i32],
         "dmx_write_doublet_summary_grids": [vp, vp, vp, vp, C.c_char_p],
         "dmx_engine_kernel_names": [vp, vp],
+        "dmx_engine_format_pair": [vp, vp, vp], "dmx_pair_text_get_info": [vp, vp], "dmx_pair_text_read": [vp, C.c_int64, C.c_int64, vp],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -169,6 +188,8 @@ def load() -> C.CDLL:
     L.dmx_store_new.argtypes = []
     L.dmx_store_free.restype = None
     L.dmx_store_barcode.restype = C.c_char_p
+    L.dmx_pair_text_free.restype = None
+    L.dmx_pair_text_free.argtypes = [vp]
     _lib = L
     return L
 

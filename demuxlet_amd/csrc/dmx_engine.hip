@@ -6903,6 +6903,164 @@ extern "C" int dmx_debug_device_log2(const double* x, double* y, int64_t n, int3
 extern "C" int dmx_debug_device_log2_lite(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(3, x, y, n, device); }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// (ABI 8) `.pair` rows formatted on the device (csrc/dmx_format.hpp)
+#include "dmx_format.hpp"
+
+struct dmx_pair_text {
+  int device = 0;
+  char* d_text = nullptr;
+  int64_t n_bytes = 0;
+  std::vector<int64_t> cell_off;
+  std::vector<uint8_t> cell_flag;
+  std::vector<dmx_pair_patch> patches;
+  double format_ms = 0.0;
+};
+
+extern "C" void dmx_pair_text_free(dmx_pair_text* t) {
+  if (!t) return;
+  if (t->d_text) { (void)hipSetDevice(t->device); (void)hipFree(t->d_text); }
+  delete t;
+}
+
+extern "C" int dmx_pair_text_get_info(const dmx_pair_text* t, dmx_pair_text_info* out) {
+  if (!t || !out) return set_error(DMX_ERR_ARG, "dmx_pair_text_get_info: null argument");
+  out->n_bytes = t->n_bytes; out->n_out = (int32_t)t->cell_flag.size(); out->n_patches = (int32_t)t->patches.size();
+  out->cell_off = t->cell_off.data(); out->cell_flag = t->cell_flag.data(); out->patches = t->patches.data(); out->format_ms = t->format_ms;
+  return DMX_OK;
+}
+
+extern "C" int dmx_pair_text_read(dmx_pair_text* t, int64_t offset, int64_t n, void* dst) {
+  if (!t || offset < 0 || n < 0 || offset + n > t->n_bytes || (n && !dst)) return set_error(DMX_ERR_ARG, "dmx_pair_text_read: bad arguments");
+  if (!n) return DMX_OK;
+  HIP_TRY(hipSetDevice(t->device));
+  HIP_TRY(hipMemcpy(dst, t->d_text + offset, (size_t)n, hipMemcpyDeviceToHost));
+  return DMX_OK;
+}
+
+extern "C" int dmx_engine_format_pair(dmx_engine* e, const dmx_pair_request* rq, dmx_pair_text** out) {
+  if (!e || !rq || !out || rq->n_out < 0 || (rq->n_out && (!rq->cells || !rq->barcodes)) || !rq->sample_ids)
+    return set_error(DMX_ERR_ARG, "dmx_engine_format_pair: null argument");
+  if (!e->have_grid) return set_error(DMX_ERR_STATE, "dmx_engine_format_pair: run_doublet has not been called");
+  const int32_t V = e->V, A = e->A, n_out = rq->n_out;
+  if (V > 4095 || A > 255) return set_error(DMX_ERR_ARG, "dmx_engine_format_pair: %d samples x %d alphas exceed the row map's fields", V, A);
+  for (int32_t i = 0; i < n_out; ++i) {
+    if (rq->cells[i] < 0 || rq->cells[i] >= e->pv.B) return set_error(DMX_ERR_ARG, "dmx_engine_format_pair: cell %d out of range (0..%d)", rq->cells[i], e->pv.B - 1);
+    if (!rq->barcodes[i]) return set_error(DMX_ERR_ARG, "dmx_engine_format_pair: barcodes[%d] is null", i);
+  }
+  for (int32_t j = 0; j < V; ++j) if (!rq->sample_ids[j]) return set_error(DMX_ERR_ARG, "dmx_engine_format_pair: sample_ids[%d] is null", j);
+  HIP_TRY(hipSetDevice(e->device));
+  // ---- host-side tables: the rows of one barcode in print order (:772-797), the strings, "\t%.3lf\t" of every alpha, powers of ten
+  std::vector<uint32_t> rowmap;
+  for (int32_t j = 0; j < V; ++j) {
+    rowmap.push_back(((uint32_t)j << 20) | ((uint32_t)j << 8));                                  // :774-781 the singlet row (SM1 = SM2 = j, alpha[0])
+    for (int32_t k = 0; k < V; ++k)
+      for (int32_t a = 1; a < A; ++a) {
+        if (j == k) continue;
+        if (j > k && e->alpha[(size_t)a] == 0.5) continue;                                       // :785
+        rowmap.push_back(((uint32_t)j << 20) | ((uint32_t)k << 8) | (uint32_t)a);
+      }
+  }
+  auto pool_of = [](const char* const* strs, int32_t n, std::string* pool, std::vector<uint32_t>* off, size_t* longest) -> bool {
+    off->assign(1, 0u);
+    for (int32_t i = 0; i < n; ++i) {
+      const size_t len = std::strlen(strs[i]);
+      if (pool->size() + len >= 0xFFFFFFF0ull) return false;
+      pool->append(strs[i], len);
+      off->push_back((uint32_t)pool->size());
+      *longest = std::max(*longest, len);
+    }
+    return true;
+  };
+  std::string bc_pool, sm_pool, al_pool;
+  std::vector<uint32_t> bc_off, sm_off, al_off(1, 0u);
+  size_t bc_max = 0, sm_max = 0, al_max = 0;
+  if (!pool_of(rq->barcodes, n_out, &bc_pool, &bc_off, &bc_max) || !pool_of(rq->sample_ids, V, &sm_pool, &sm_off, &sm_max))
+    return set_error(DMX_ERR_ARG, "dmx_engine_format_pair: more than 4 GB of barcode text");
+  for (int32_t a = 0; a < A; ++a) {
+    char buf[400];
+    const int n = std::snprintf(buf, sizeof buf, "\t%.3lf\t", e->alpha[(size_t)a]);              // the reference's own conversion (:776,:788)
+    if (n < 0 || (size_t)n >= sizeof buf) return set_error(DMX_ERR_ARG, "dmx_engine_format_pair: alpha[%d] does not print", a);
+    al_pool.append(buf, (size_t)n); al_off.push_back((uint32_t)al_pool.size()); al_max = std::max(al_max, (size_t)n);
+  }
+  const size_t max_row = bc_max + 1 + 2 * sm_max + 1 + al_max + 20 + 1 + 12 + 1;
+  const size_t lds = (size_t)dmx_fmt::kFmtThreads * max_row;
+  if (lds > 150 * 1024) return set_error(DMX_ERR_ARG, "dmx_engine_format_pair: rows of up to %zu bytes do not fit the kernel's buffer", max_row);
+  std::vector<double> pow10(310);
+  for (int n = 0; n < 310; ++n) { char b[16]; std::snprintf(b, sizeof b, "1e%d", n); pow10[(size_t)n] = std::strtod(b, nullptr); }   // correctly rounded
+  // ---- device copies (small; per call)
+  struct Dev {
+    std::vector<void*> p;
+    ~Dev() { for (void* x : p) if (x) (void)hipFree(x); }
+  } dev;
+  hipStream_t st = e->stream;
+  auto up = [&](const void* src, size_t bytes, void** d) -> int {
+    HIP_TRY(hipMalloc(d, std::max<size_t>(bytes, 16)));
+    dev.p.push_back(*d);
+    if (bytes && src) HIP_TRY(hipMemcpyAsync(*d, src, bytes, hipMemcpyHostToDevice, st));
+    return DMX_OK;
+  };
+  dmx_fmt::Ctx c{};
+  c.grid = e->d_grid; c.summ = e->d_sum; c.alpha = e->d_alpha; c.prior = e->prior; c.V = V; c.A = A; c.n_out = n_out; c.n_rows = (int32_t)rowmap.size();
+  c.max_row = (int32_t)max_row;
+  void* d = nullptr;
+  if (int rc = up(rq->cells, sizeof(int32_t) * (size_t)n_out, &d)) return rc; c.cells = (const int32_t*)d;
+  if (rq->host_rows) { if (int rc = up(rq->host_rows, (size_t)n_out, &d)) return rc; c.host_rows = (const uint8_t*)d; }
+  if (rq->ovr) { if (int rc = up(rq->ovr, sizeof(dmx_pair_override) * (size_t)n_out, &d)) return rc; c.ovr = (const dmx_pair_override*)d; }
+  if (int rc = up(rowmap.data(), sizeof(uint32_t) * rowmap.size(), &d)) return rc; c.rowmap = (const uint32_t*)d;
+  if (int rc = up(bc_pool.data(), bc_pool.size(), &d)) return rc; c.bc_pool = (const char*)d;
+  if (int rc = up(bc_off.data(), sizeof(uint32_t) * bc_off.size(), &d)) return rc; c.bc_off = (const uint32_t*)d;
+  if (int rc = up(sm_pool.data(), sm_pool.size(), &d)) return rc; c.sm_pool = (const char*)d;
+  if (int rc = up(sm_off.data(), sizeof(uint32_t) * sm_off.size(), &d)) return rc; c.sm_off = (const uint32_t*)d;
+  if (int rc = up(al_pool.data(), al_pool.size(), &d)) return rc; c.al_pool = (const char*)d;
+  if (int rc = up(al_off.data(), sizeof(uint32_t) * al_off.size(), &d)) return rc; c.al_off = (const uint32_t*)d;
+  if (int rc = up(pow10.data(), sizeof(double) * pow10.size(), &d)) return rc; c.pow10 = (const double*)d;
+  int64_t* d_len = nullptr; uint32_t* d_np = nullptr; int64_t* d_off = nullptr; uint32_t* d_poff = nullptr; uint8_t* d_flag = nullptr;
+  if (int rc = up(nullptr, sizeof(int64_t) * (size_t)std::max(n_out, 1), (void**)&d_len)) return rc;
+  if (int rc = up(nullptr, sizeof(uint32_t) * (size_t)std::max(n_out, 1), (void**)&d_np)) return rc;
+  if (int rc = up(nullptr, sizeof(int64_t) * ((size_t)n_out + 1), (void**)&d_off)) return rc;
+  if (int rc = up(nullptr, sizeof(uint32_t) * ((size_t)n_out + 1), (void**)&d_poff)) return rc;
+  if (int rc = up(nullptr, (size_t)std::max(n_out, 1), (void**)&d_flag)) return rc;
+  c.cell_len = d_len; c.cell_npatch = d_np; c.cell_off = d_off; c.cell_poff = d_poff; c.cell_flag = d_flag;
+  std::unique_ptr<dmx_pair_text, void (*)(dmx_pair_text*)> t(new (std::nothrow) dmx_pair_text, dmx_pair_text_free);
+  if (!t) return set_error(DMX_ERR_NOMEM, "dmx_engine_format_pair: out of memory");
+  t->device = e->device;
+  t->cell_off.assign((size_t)n_out + 1, 0);
+  t->cell_flag.assign((size_t)n_out, 0);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  HIP_TRY(hipEventCreate(&ev0)); HIP_TRY(hipEventCreate(&ev1));
+  struct Evs { hipEvent_t a, b; ~Evs() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evs{ev0, ev1};
+  if (n_out > 0) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dmx_fmt::k_pair_write), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_TRY(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL(dmx_fmt::k_pair_lengths, dim3((unsigned)n_out), dim3(dmx_fmt::kFmtThreads), 0, st, c);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(dmx_fmt::k_pair_scan, dim3(1), dim3(1024), 0, st, d_len, d_np, n_out, d_off, d_poff);
+    HIP_TRY(hipGetLastError());
+    uint32_t n_patch = 0;
+    HIP_TRY(hipMemcpyAsync(t->cell_off.data(), d_off, sizeof(int64_t) * ((size_t)n_out + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&n_patch, d_poff + n_out, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(t->cell_flag.data(), d_flag, (size_t)n_out, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    t->n_bytes = t->cell_off[(size_t)n_out];
+    t->patches.resize(n_patch);
+    HIP_TRY(hipMalloc((void**)&t->d_text, (size_t)std::max<int64_t>(t->n_bytes, 16)));
+    dmx_pair_patch* d_patch = nullptr;
+    if (int rc = up(nullptr, sizeof(dmx_pair_patch) * (size_t)std::max<uint32_t>(n_patch, 1), (void**)&d_patch)) return rc;
+    c.text = t->d_text; c.patches = d_patch;
+    hipLaunchKernelGGL(dmx_fmt::k_pair_write, dim3((unsigned)n_out), dim3(dmx_fmt::kFmtThreads), lds, st, c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev1, st));
+    if (n_patch) HIP_TRY(hipMemcpyAsync(t->patches.data(), d_patch, sizeof(dmx_pair_patch) * n_patch, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+    t->format_ms = ms;
+  }
+  *out = t.release();
+  return DMX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // cmd_cram_demuxlet.cpp:390-881 in one call: store (or a frozen pileup) + genotype matrix in, four text files out.
 extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   if (!job || (!job->store && !(job->pileup && job->barcodes)) || !job->g || !job->sample_ids || !job->alpha || !job->out_prefix)
@@ -7031,10 +7189,16 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     std::vector<const double*> cell_grid;
     // device-resident pileups: the host pieces of the barcodes the tie arbiter may have to walk (tie_cell[k] = index here, -1 = not staged)
     std::vector<int32_t> tie_cell, t_snp; std::vector<int64_t> t_po, t_ro; std::vector<uint8_t> t_nrd, t_reads;
+    // write_pair with the rows formatted on the device: the packed text (device memory, owned by the range until it is written) and its output cells
+    dmx_pair_text* ptext = nullptr; std::vector<int32_t> out_cells;
     int32_t lo = 0, hi = 0;
-    void release() { *this = Range(); }
+    void release() { if (ptext) dmx_pair_text_free(ptext); *this = Range(); }
   };
   std::vector<Range> rg((size_t)R);
+  struct RangeGuard { std::vector<Range>* r; ~RangeGuard() { for (Range& x : *r) if (x.ptext) { dmx_pair_text_free(x.ptext); x.ptext = nullptr; } } } range_guard{&rg};
+  // `.pair` rows are formatted on the device (dmx_engine_format_pair) unless the fenced DMX_PAIR_ON_HOST=1 asks for the host formatter (tests compare the two)
+  const bool gpu_pair = job->write_pair && doublet_ok && !job_knob("DMX_PAIR_ON_HOST");
+  double pair_format_ms = 0; int64_t pair_bytes = 0, pair_patches = 0, pair_host_cells = 0;
   // Engines: one per GPU and wave slot.  When the job takes several waves, every GPU gets TWO engines (own stream, own buffers)
   // that alternate between waves, so that the slicing + H2D of wave w + 2 overlaps the kernels of wave w + 1 (the copy engine
   // runs beside the compute units) while the host arbitrates and writes wave w.
@@ -7070,6 +7234,15 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   double stage_s = 0, wait_s = 0, write_s = 0, kernel_ms = 0;
   int32_t n_fetched = 0;
 
+  auto make_fin = [&](Range& x) {
+    dmx_final_input fin{};
+    fin.n_cells = x.hi - x.lo; fin.n_samples = V; fin.n_alpha = A; fin.alpha = job->alpha; fin.doublet_prior = job->doublet_prior;
+    fin.min_total = job->min_total; fin.min_uniq = job->min_uniq; fin.min_snp = job->min_snp; fin.write_pair = job->write_pair;
+    fin.sample_ids = job->sample_ids;
+    if (sliced) { fin.barcodes = x.bc.data(); fin.rd_totl = x.totl.data(); fin.rd_pass = x.pass.data(); fin.rd_uniq = x.uniq.data(); fin.n_snp = x.ns.data(); }
+    else { fin.barcodes = bcs.data(); fin.rd_totl = pl.rd_totl; fin.rd_pass = pl.rd_pass; fin.rd_uniq = pl.rd_uniq; fin.n_snp = nsnp.data(); }
+    return fin;
+  };
   auto eng_of = [&](int r) -> dmx_engine* { return eng[(size_t)(((r / per_wave) % nset) * per_wave + r % per_wave)]; };
   auto launch = [&](int r) -> int {              // stage range r on its engine and start its kernels (asynchronous)
     const clk::time_point t0 = clk::now();
@@ -7104,7 +7277,52 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     int32_t fetched = 0;
     if (doublet_ok) {
       x.l00.resize(nb1 * (size_t)A);
-      if (job->write_pair) {                     // .pair prints the grid: bring all of it
+      if (gpu_pair) {
+        // .pair from the device: the records as below; the barcodes whose printed entries the arbiter may replace (dmx::cell_needs, a BEST-rule comparison
+        // within 1e-7 — decided on the record AFTER resolve_tie_order, as the writers do) keep the host formatter and bring their grids
+        x.sing.resize(nb1 * (size_t)V); x.summ.resize(nb1);
+        if (int rc = dmx_engine_get_doublet(e, nullptr, x.l00.data(), x.summ.data())) return rc;
+        if (int rc = dmx_engine_get_sing(e, x.sing.data())) return rc;
+        x.cell_grid.assign(nb1, nullptr);
+        const dmx_final_input fin = make_fin(x);
+        x.out_cells = dmx::output_cells(&fin, true);
+        const size_t n_out = x.out_cells.size();
+        std::vector<uint8_t> host_rows(std::max<size_t>(n_out, 1), 0);
+        std::vector<dmx_pair_override> ovr(std::max<size_t>(n_out, 1));
+        std::vector<const char*> obc(std::max<size_t>(n_out, 1), nullptr);
+        std::vector<int32_t> hostc;
+        constexpr int32_t kNear = DMX_CELL_NEAR_DOUBLET | DMX_CELL_NEAR_SINGLET;
+        for (size_t i = 0; i < n_out; ++i) {
+          const size_t c = (size_t)x.out_cells[i];
+          dmx_cell_summary sm = x.summ[c];
+          if (sm.flags & DMX_CELL_ORDER_RESOLVABLE) (void)dmx::resolve_tie_order(&sm);
+          const double* sg = x.sing.data() + c * (size_t)V;
+          const bool rule = job->arbiter && sm.n_pairs > 0 &&
+                            dmx::near_rule(sm.llk12, sm.llk1, sm.llk2, sg[std::max(sm.i_sing1, 0)], sg[std::max(sm.i_sing2, 0)], 1e-7);
+          host_rows[i] = (dmx::cell_needs(sm, job->alpha, A, job->arbiter != 0) != 0 || rule) ? 1 : 0;
+          ovr[i] = dmx_pair_override{-1, -1, -1, 0, 0.0, 0.0};
+          if ((sm.flags & DMX_CELL_ORDER_CERTIFIED) && !(sm.flags & kNear) && sm.j_best >= 0 && sm.k_best >= 0)
+            ovr[i] = dmx_pair_override{std::min(sm.j_best, sm.k_best), std::max(sm.j_best, sm.k_best), sm.n_best, 0, sm.llk_ab, sm.llk_ba};
+          obc[i] = fin.barcodes[c];
+          if (host_rows[i]) hostc.push_back((int32_t)c);
+        }
+        dmx_pair_request rq{};
+        rq.n_out = (int32_t)n_out; rq.cells = x.out_cells.data(); rq.barcodes = obc.data(); rq.sample_ids = job->sample_ids;
+        rq.host_rows = host_rows.data(); rq.ovr = ovr.data();
+        if (int rc = dmx_engine_format_pair(e, &rq, &x.ptext)) return rc;
+        dmx_pair_text_info pi{};
+        (void)dmx_pair_text_get_info(x.ptext, &pi);
+        for (size_t i = 0; i < n_out; ++i) if (pi.cell_flag[i] == 2) hostc.push_back(x.out_cells[i]);   // an unprintable entry: the host's printf prints it
+        HIP_TRY(hipSetDevice(e->device));
+        for (int32_t c : hostc) {
+          x.flagged_grid.emplace_back(nAB);
+          HIP_TRY(hipMemcpyAsync(x.flagged_grid.back().data(), e->d_grid + (size_t)c * nAB, sizeof(double) * nAB, hipMemcpyDeviceToHost, e->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (size_t f = 0; f < hostc.size(); ++f) x.cell_grid[(size_t)hostc[f]] = x.flagged_grid[f].data();
+        fetched = (int32_t)hostc.size();
+        { std::lock_guard<std::mutex> lk(tm_mu); pair_format_ms += pi.format_ms; pair_bytes += pi.n_bytes; pair_patches += pi.n_patches; pair_host_cells += (int64_t)hostc.size(); }
+      } else if (job->write_pair) {              // .pair prints the grid: bring all of it (DMX_PAIR_ON_HOST: the host formatter)
         x.grid.resize(nb1 * nAB); x.summ.resize(nb1);
         if (int rc = dmx_engine_get_doublet(e, x.grid.data(), x.l00.data(), x.summ.data())) return rc;
       } else {                                   // otherwise the K3 records say everything, except for cells flagged as near-ties
@@ -7166,15 +7384,70 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
     return DMX_OK;
   };
   const std::string pre(job->out_prefix);
+  // The .pair file of a range whose rows were formatted on the device: the packed text comes over in pieces through one pinned buffer and goes to
+  // write(2) as it is; where the device left a POSTPRB field to the host (dmx_pair_patch: the denormal range, a digit next to a rounding boundary) the
+  // field is computed here with the host libm — the expression of :780 / :792 on the barcode's K3 record — and spliced in; barcodes left to the host
+  // formatter (cell_flag != 0) have their rows (pair_rows, from write_doublet_core) inserted at their place.
+  void* pair_stage = nullptr;
+  constexpr int64_t kPairStage = (int64_t)32 << 20;
+  struct StageGuard { void** p; ~StageGuard() { if (*p) (void)hipHostFree(*p); } } stage_guard{&pair_stage};
+  auto stream_pair = [&](Range& x, const std::vector<std::string>& pair_rows, bool append) -> int {
+    dmx_pair_text_info pi{};
+    if (int rc = dmx_pair_text_get_info(x.ptext, &pi)) return rc;
+    FILE* f = fopen((pre + ".pair").c_str(), append ? "a" : "w");
+    if (!f) return set_error(DMX_ERR_IO, "Cannot create %s.single, %s.pair files", job->out_prefix, job->out_prefix);     // :535-536
+    struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
+    if (!append) fputs("BARCODE\tSM1.ID\tSM2.ID\tLLK12\tPOSTPRB\n", f);                                               // :570
+    if (!pair_stage) HIP_TRY(hipHostMalloc(&pair_stage, (size_t)kPairStage, hipHostMallocDefault));
+    char* buf = (char*)pair_stage;
+    int64_t wbeg = 0, wend = 0;                  // the piece of the text the buffer holds
+    bool ok = true;
+    auto put = [&](int64_t a, int64_t b) -> int {     // text bytes [a, b)
+      while (a < b) {
+        if (a < wbeg || a >= wend) {
+          wbeg = a; wend = std::min(pi.n_bytes, a + kPairStage);
+          if (int rc = dmx_pair_text_read(x.ptext, wbeg, wend - wbeg, buf)) return rc;
+        }
+        const int64_t n = std::min(b, wend) - a;
+        if (fwrite(buf + (a - wbeg), 1, (size_t)n, f) != (size_t)n) ok = false;
+        a += n;
+      }
+      return DMX_OK;
+    };
+    int32_t ip = 0;
+    std::string field;
+    int64_t run_beg = 0;                         // consecutive device-formatted barcodes go out as one run
+    for (int32_t oc = 0; oc < pi.n_out; ++oc) {
+      const int64_t cb = pi.cell_off[oc], ce = pi.cell_off[oc + 1];
+      if (pi.cell_flag[oc] != 0) {
+        if (int rc = put(run_beg, cb)) return rc;
+        const std::string& rows = pair_rows[(size_t)x.out_cells[(size_t)oc]];
+        if (!rows.empty() && fwrite(rows.data(), 1, rows.size(), f) != rows.size()) ok = false;
+        run_beg = ce;
+        continue;
+      }
+      while (ip < pi.n_patches && pi.patches[ip].offset < ce) {
+        const dmx_pair_patch& pp = pi.patches[ip++];
+        if (int rc = put(run_beg, pp.offset)) return rc;
+        run_beg = pp.offset;
+        const dmx_cell_summary& sm = x.summ[(size_t)x.out_cells[(size_t)pp.out_cell]];
+        const double tot = sm.sum_single + sm.sum_double, prior = job->doublet_prior;
+        const double p = pp.singlet ? std::exp(pp.value - sm.max_llk) * (1. - prior) / V / tot
+                                    : std::exp(pp.value - sm.max_llk) * prior / V / (V - 1) / (A - 1) / tot;
+        field.clear();
+        dmx::put_general(field, p, 5);
+        if (fwrite(field.data(), 1, field.size(), f) != field.size()) ok = false;
+      }
+    }
+    if (int rc = put(run_beg, pi.n_bytes)) return rc;
+    closer.f = nullptr;
+    if (fclose(f) != 0 || !ok) return set_error(DMX_ERR_IO, "write failed (%s.pair)", job->out_prefix);
+    return DMX_OK;
+  };
   auto write = [&](int r) -> int {               // append range r's rows (rows of a range are sorted by the writers)
     const clk::time_point t0 = clk::now();
     Range& x = rg[(size_t)r];
-    dmx_final_input fin{};
-    fin.n_cells = x.hi - x.lo; fin.n_samples = V; fin.n_alpha = A; fin.alpha = job->alpha; fin.doublet_prior = job->doublet_prior;
-    fin.min_total = job->min_total; fin.min_uniq = job->min_uniq; fin.min_snp = job->min_snp; fin.write_pair = job->write_pair;
-    fin.sample_ids = job->sample_ids;
-    if (sliced) { fin.barcodes = x.bc.data(); fin.rd_totl = x.totl.data(); fin.rd_pass = x.pass.data(); fin.rd_uniq = x.uniq.data(); fin.n_snp = x.ns.data(); }
-    else { fin.barcodes = bcs.data(); fin.rd_totl = pl.rd_totl; fin.rd_pass = pl.rd_pass; fin.rd_uniq = pl.rd_uniq; fin.n_snp = nsnp.data(); }
+    dmx_final_input fin = make_fin(x);
     fin.llks = x.llks.data(); fin.llk0s = x.llk0s.data();
     if (int rc = dmx::write_single_impl(&fin, (pre + ".single").c_str(), r > 0)) return rc;
     if (doublet_ok) {
@@ -7189,9 +7462,12 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
       dmx::DoubletSource src{};
       if (dev_pl) { if (job->arbiter) src.tie_cell = x.tie_cell.data(); }
       else if (sliced) src.tie_cell = order.data() + x.lo;
-      if (job->write_pair) { fin.llksAB = x.grid.data(); src.grid_all = x.grid.data(); src.summary = x.summ.data(); }
+      std::vector<std::string> pair_rows;                     // device-formatted .pair: the rows of the barcodes left to the host formatter
+      if (x.ptext) { pair_rows.resize((size_t)std::max(fin.n_cells, 1)); src.pair_rows = &pair_rows; }
+      if (job->write_pair && !x.ptext) { fin.llksAB = x.grid.data(); src.grid_all = x.grid.data(); src.summary = x.summ.data(); }
       else { src.sing = x.sing.data(); src.summary = x.summ.data(); src.cell_grid = x.cell_grid.data(); }
       if (int rc = dmx::write_doublet_core(&fin, src, job->out_prefix, r > 0, "dmx_demuxlet_run")) return rc;
+      if (x.ptext) if (int rc = stream_pair(x, pair_rows, r > 0)) return rc;
     }
     x.release();
     { std::lock_guard<std::mutex> lk(tm_mu); write_s += secs(t0, clk::now()); }
@@ -7250,8 +7526,10 @@ extern "C" int dmx_demuxlet_run(const dmx_job* job) {
   if (job->timing) *job->timing = tm;
   if (getenv("DMX_E2E_TIMING"))
     fprintf(stderr, "{\"dmx_demuxlet_run\": {\"freeze_s\": %.4f, \"setup_s\": %.4f, \"stage_s\": %.4f, \"wait_s\": %.4f, \"write_s\": %.4f, \"total_s\": %.4f, "
-                    "\"kernel_ms\": %.3f, \"ranges\": %d, \"engines\": %d, \"cells_grid_fetched\": %d}}\n",
-            tm.freeze_s, tm.setup_s, tm.stage_s, tm.wait_s, tm.write_s, tm.total_s, tm.kernel_ms, tm.n_ranges, tm.n_engines, tm.n_cells_grid_fetched);
+                    "\"kernel_ms\": %.3f, \"ranges\": %d, \"engines\": %d, \"cells_grid_fetched\": %d, \"pair_on_device\": %d, \"pair_format_ms\": %.3f, "
+                    "\"pair_bytes\": %lld, \"pair_patches\": %lld, \"pair_host_cells\": %lld}}\n",
+            tm.freeze_s, tm.setup_s, tm.stage_s, tm.wait_s, tm.write_s, tm.total_s, tm.kernel_ms, tm.n_ranges, tm.n_engines, tm.n_cells_grid_fetched,
+            gpu_pair ? 1 : 0, pair_format_ms, (long long)pair_bytes, (long long)pair_patches, (long long)pair_host_cells);
   if (!doublet_ok) return set_error(DMX_ERR_ARG, "dmx_demuxlet_run: the doublet stage needs >= 2 samples and >= 2 alphas (got %d, %d)", V, A);
   return DMX_OK;
 }

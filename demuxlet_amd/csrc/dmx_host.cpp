@@ -881,6 +881,7 @@ void put_general(std::string& out, double v, int prec) {
   if (v == 0.0 && !std::signbit(v)) { out.push_back('0'); return; }
   appendf(out, "%.*lg", prec, v);
 }
+void put_general_impl(std::string& out, double v, int prec) { put_general(out, v, prec); }
 
 // Host threads for the formatters: DMX_THREADS, else the smaller of the visible CPUs and the container's CPU quota.
 int host_threads() {
@@ -957,7 +958,12 @@ std::vector<int32_t> output_cells(const dmx_final_input* in, bool need_snps) {
   return out;
 }
 
+std::vector<int32_t> output_cells_impl(const dmx_final_input* in, bool need_snps) { return output_cells(in, need_snps); }
+
 }  // namespace
+
+std::vector<int32_t> dmx::output_cells(const dmx_final_input* in, bool need_snps) { return output_cells_impl(in, need_snps); }
+void dmx::put_general(std::string& out, double v, int prec) { put_general_impl(out, v, prec); }
 
 extern "C" int dmx_write_single(const dmx_final_input* in, const char* path) { return dmx::write_single_impl(in, path, false); }
 
@@ -1032,7 +1038,8 @@ extern "C" int dmx_write_doublet_summary_grids(const dmx_final_input* in, const 
 int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src, const char* out_prefix, bool append, const char* who) {
   const int32_t V = in->n_samples, A = in->n_alpha;
   if (V < 2 || A < 2) return set_error(DMX_ERR_ARG, "%s: needs >= 2 samples and >= 2 alphas (got %d, %d)", who, V, A);
-  if (in->write_pair && !src.grid_all) return set_error(DMX_ERR_ARG, "%s: .pair rows need the full grid", who);
+  if (in->write_pair && !src.grid_all && !src.pair_rows) return set_error(DMX_ERR_ARG, "%s: .pair rows need the full grid", who);
+  const bool pair_here = in->write_pair && !src.pair_rows;       // this function writes the .pair file (else: rows formatted on the device, DoubletSource)
   const double tol = in->tie_tol > 0 ? in->tie_tol : 1e-7;
   const bool arbiter = in->tie_pileup && in->tie_g;
   if (arbiter && in->tie_pileup->memory != DMX_MEM_HOST) return set_error(DMX_ERR_ARG, "%s: the tie arbiter needs a HOST pileup", who);
@@ -1059,7 +1066,7 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
   }
   const std::string pre(out_prefix);
   File sing2, pairf, best;
-  if (!sing2.open(pre + ".sing2", append) || !best.open(pre + ".best", append) || (in->write_pair && !pairf.open(pre + ".pair", append)))
+  if (!sing2.open(pre + ".sing2", append) || !best.open(pre + ".best", append) || (pair_here && !pairf.open(pre + ".pair", append)))
     return set_error(DMX_ERR_IO, "Cannot create %s.single, %s.pair files", out_prefix, out_prefix);     // :535-536
   if (!append) fputs("BARCODE\tSM_ID\tRD.TOTL\tRD.PASS\tRD.UNIQ\tN.SNP\tLLK1\tLLK0\tPOSTPRB\n", sing2.f);             // :533
   if (pairf.f && !append) fputs("BARCODE\tSM1.ID\tSM2.ID\tLLK12\tPOSTPRB\n", pairf.f);                              // :570 (5 names for 6 fields: reference quirk)
@@ -1244,9 +1251,10 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
       put_fixed(o, v, 4); o.push_back('\t'); o.append(l0s); o.push_back('\t');
       put_general(o, std::exp(v - max_llk) * (1. - prior) / V / sum_single, 3); o.push_back('\n');
     }
-    if (pairf.f) {                                                         // :772-797 (.pair) "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n"
+    std::string* const pair_out = pairf.f ? &ck.out[1] : ((src.pair_rows && grid) ? &(*src.pair_rows)[(size_t)c] : nullptr);
+    if (pair_out) {                                                        // :772-797 (.pair) "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n"
       const double tot = sum_single + sum_double;
-      std::string& o = ck.out[1];
+      std::string& o = *pair_out;
       for (int32_t j = 0; j < V; ++j) {
         const double vs = grid[(size_t)j * V * A];
         std::string hj;

@@ -64,7 +64,13 @@ struct DoubletSource {
   const double* sing = nullptr;                  // [n_cells][V]
   const dmx_cell_summary* summary = nullptr;     // [n_cells]
   const int32_t* tie_cell = nullptr;             // [n_cells] -> the cell's index in in->tie_pileup (NULL: the same index; -1: not staged there)
+  // (round 6) write_pair with the `.pair` rows formatted on the device (dmx_engine_format_pair): the writer does not touch the .pair file.  The
+  // barcodes that come with a grid here (cell_grid[c] != NULL: the ones left to the host formatter) have their rows stored in (*pair_rows)[c];
+  // the caller splices them into the device's text.
+  std::vector<std::string>* pair_rows = nullptr; // [n_cells]
 };
+std::vector<int32_t> output_cells(const dmx_final_input* in, bool need_snps);   // the cells that get rows, in output order (barcode order; :480,:581,:592)
+void put_general(std::string& out, double v, int prec);                        // printf("%.<prec>lg")
 // What the doublet-stage writers need of a barcode BEYOND its K3 record — ONE predicate for the code that stages (dmx_demuxlet_run's fetch, a
 // multi-GPU rank choosing what rides along in the gather) and the code that writes (write_doublet_core); ADVICE r4: the two used to be maintained
 // apart.  `sm` = the record after resolve_tie_order (a DMX_CELL_ORDER_RESOLVABLE record that this host's libm settles counts as certified).

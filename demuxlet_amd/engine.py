@@ -235,6 +235,37 @@ class Engine:
         check(self._L.dmx_engine_get_cell_grids(self._h, cells.ctypes.data, len(cells), out.ctypes.data))
         return out
 
+    def format_pair(self, cells, barcodes: Sequence[str], sample_ids: Sequence[str], host_rows=None, ovr=None):
+        """dmx_engine_format_pair: the `.pair` rows (cmd_cram_demuxlet.cpp:772-797) of the barcodes `cells` (ids of the staged pileup, output order) formatted on
+        the device.  Returns (text bytes, cell_off[n+1], cell_flag[n], patches as a list of (offset, value, out_cell, singlet), format_ms): the POSTPRB fields the
+        device leaves to the host's libm are EMPTY in the text and listed in `patches`."""
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        n = len(cells)
+        bc, k1 = _cstrs(barcodes)
+        sm, k2 = _cstrs(sample_ids)
+        hr = np.ascontiguousarray(host_rows, dtype=np.uint8) if host_rows is not None else None
+        ov = None
+        if ovr is not None:
+            ov = (capi.PairOverride * max(n, 1))()
+            for i, o in enumerate(ovr):
+                ov[i] = capi.PairOverride(*o) if o is not None else capi.PairOverride(-1, -1, -1, 0, 0.0, 0.0)
+        rq = capi.PairRequest(n, cells.ctypes.data if n else None, C.cast(bc, C.c_void_p), C.cast(sm, C.c_void_p),
+                              hr.ctypes.data if hr is not None else None, C.cast(ov, C.c_void_p) if ov is not None else None)
+        h = C.c_void_p()
+        check(self._L.dmx_engine_format_pair(self._h, C.byref(rq), C.byref(h)))
+        try:
+            info = capi.PairTextInfo()
+            check(self._L.dmx_pair_text_get_info(h, C.byref(info)))
+            buf = C.create_string_buffer(max(int(info.n_bytes), 1))
+            check(self._L.dmx_pair_text_read(h, 0, info.n_bytes, buf))
+            off = np.array([info.cell_off[i] for i in range(n + 1)], dtype=np.int64)
+            flag = np.array([info.cell_flag[i] for i in range(n)], dtype=np.uint8)
+            patches = [(int(info.patches[i].offset), float(info.patches[i].value), int(info.patches[i].out_cell), int(info.patches[i].singlet))
+                       for i in range(info.n_patches)]
+            return buf.raw[:info.n_bytes], off, flag, patches, float(info.format_ms)
+        finally:
+            self._L.dmx_pair_text_free(h)
+
     def device_view(self) -> capi.DeviceView:
         v = capi.DeviceView()
         check(self._L.dmx_engine_device_view(self._h, C.byref(v)))

@@ -22,11 +22,12 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 7   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up, dmx_engine_run; 6: dmx_engine_get_cell_grids;
+#define DMX_ABI_VERSION 8   /* 4: dmx_store_add_batch, dmx_engine_mean_kernel_times; 5: dmx_device_warm_up, dmx_engine_run; 6: dmx_engine_get_cell_grids;
                                7: DMX_CELL_NEAR_RULE, dmx_write_doublet_summary_grids, dmx_engine_kernel_names, dmx_debug_device_log2_lite.  ABI 6 had grown dmx_final_input in place by a
                                trailing `cell_grid` member; a by-pointer input struct without a size member cannot grow (a caller compiled against ABI 5
                                passes a shorter object), so ABI 7 WITHDRAWS that member — the struct has its ABI 5 layout again and the grids travel as an
-                               argument of the new entry point.  Additions only otherwise: callers of ABI <= 5 run unchanged. */
+                               argument of the new entry point.  Additions only otherwise: callers of ABI <= 5 run unchanged.
+                               8: dmx_engine_format_pair / dmx_pair_text_* (`.pair` rows formatted on the device).  Additions only. */
 
 typedef enum {
   DMX_OK = 0,
@@ -194,6 +195,42 @@ int dmx_engine_get_sing(dmx_engine*, double* sing);
 /* llksAB[V][V][A] of the n cells cells[0..n) (ids of the staged pileup) -> out[n][V][V][A]: the grids of the barcodes whose K3 record
  * carries a near-tie flag are all that a records-only consumer (dmx_write_doublet_summary, a multi-GPU gather) needs besides the records. */
 int dmx_engine_get_cell_grids(dmx_engine*, const int32_t* cells, int32_t n, double* out);
+
+/* (ABI 8) The `.pair` rows of `--write-pair` (cmd_cram_demuxlet.cpp:772-797, "%s\t%s\t%s\t%.3lf\t%.5lf\t%.5lg\n") formatted ON THE DEVICE from the grid that
+ * already lies in HBM, packed in output order, ready for write(2) — instead of V + V(V-1)(A-1) rows per barcode through host threads.
+ *   request   n_out barcodes in output order: `cells` = their ids in the staged pileup, `barcodes` / `sample_ids` the strings to print;
+ *             host_rows[i] != 0: the caller prints this barcode's rows itself (the barcodes whose grid entries the tie arbiter may replace —
+ *             dmx::cell_needs, a BEST-rule comparison within 1e-7 — dmx_demuxlet_run decides); ovr[i].n >= 0: the two certified entries of an
+ *             alpha = 0.5 best doublet, llksAB[a][b][n] = llk_ab and llksAB[b][a][n] = llk_ba, to print instead of the device's own.
+ *   text      LLK (`%.5lf`) is exact 128-bit integer arithmetic (printf's digits); POSTPRB (`%.5lg`) is printed only where its five digits cannot depend on the
+ *             last bits of exp() — elsewhere (the denormal range, a value within 4e-13 of a rounding boundary) the field is left EMPTY and listed in
+ *             `patches`: the caller inserts, at byte `offset` of the text, "%.5lg" of exp(value - maxLLK) * c / (sumSingle + sumDouble) computed with ITS
+ *             libm (c = (1 - prior) / V for a singlet row, prior / V / (V-1) / (A-1) else; the record of barcode cells[out_cell] has the three scalars).
+ *             cell_flag[i]: 0 = rows in the text at [cell_off[i], cell_off[i+1]); 1 = left to the caller as requested; 2 = left to the caller because
+ *             an entry is not printable here (nan, inf, |v| >= 2^43) — both with an empty range: the caller's rows go in at cell_off[i].
+ * dmx_demuxlet_run uses this for `write_pair` jobs; the result is byte-identical to the host formatter's (tests/test_gpu_pair_text.py). */
+typedef struct { int32_t a, b, n, reserved; double llk_ab, llk_ba; } dmx_pair_override;   /* n < 0: none */
+typedef struct { int64_t offset; double value; int32_t out_cell, singlet; } dmx_pair_patch;
+typedef struct {
+  int32_t n_out;
+  const int32_t* cells;             /* [n_out] */
+  const char* const* barcodes;      /* [n_out] */
+  const char* const* sample_ids;    /* [n_samples] */
+  const uint8_t* host_rows;         /* [n_out] or NULL */
+  const dmx_pair_override* ovr;     /* [n_out] or NULL */
+} dmx_pair_request;
+typedef struct dmx_pair_text dmx_pair_text;   /* owns the device text; host copies of the small arrays */
+typedef struct {
+  int64_t n_bytes; int32_t n_out, n_patches;
+  const int64_t* cell_off;          /* [n_out + 1] */
+  const uint8_t* cell_flag;         /* [n_out] */
+  const dmx_pair_patch* patches;    /* [n_patches], ascending offset */
+  double format_ms;                 /* HIP-event time of the three kernels */
+} dmx_pair_text_info;
+int  dmx_engine_format_pair(dmx_engine*, const dmx_pair_request*, dmx_pair_text** out);   /* needs run_doublet's results; synchronises */
+int  dmx_pair_text_get_info(const dmx_pair_text*, dmx_pair_text_info* out);
+int  dmx_pair_text_read(dmx_pair_text*, int64_t offset, int64_t n_bytes, void* dst);     /* device -> host copy of a piece of the text */
+void dmx_pair_text_free(dmx_pair_text*);
 
 /* Device views for zero-copy hand-off (torch tensors over them, RCCL gather of the per-cell records). */
 typedef struct {

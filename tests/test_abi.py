@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 
 
 def test_abi_version(lib):
-    assert lib.dmx_abi_version() == 7
+    assert lib.dmx_abi_version() == 8
 
 
 def test_by_pointer_input_structs_do_not_grow():
