@@ -2265,6 +2265,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #endif
   const bool no_prod = (V_and_flags >> 22) & 1;  // kernel experiment (DMX_SYM_NO_PRODUCT): a log per term also in full sub-tiles
   const bool no_pipe = (V_and_flags >> 23) & 1;  // kernel experiment (DMX_SYM_NO_PIPE; bit-identical results): phase 2 without the software pipeline
+  const bool wait_all = (V_and_flags >> 24) & 1; // test switch (DMX_SYM_WAIT_ALL; bit-identical results): vmcnt(0) instead of the three-buffer form's counted wait
   // Narrow panels put SEVERAL barcodes in one wavefront (TPC = 32: two, TPC = 16: four): their entries fill the lanes (V = 16: 160
   // entries = 5 per lane of 32; V = 8: 48 = 3 per lane of 16) and the per-tile phases 0-1 are shared instruction-wise.  The tile is
   // what one pass of phase 1 covers: two lanes per pair.
@@ -2516,7 +2517,10 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
           // rows x pieces per row, per request and barcode (request_rows).  The wavefront's other barcode issues its own requests in between (or
           // none: its tile may be shorter), which can only make this wait longer, never too short.
           static_assert((GSS + TPC - 1) / TPC <= 2 && 2 * SUB <= 15, "vmcnt field / pieces per row");
-          if (sub + SUB >= tp) __builtin_amdgcn_s_waitcnt(0x0F70);                            // nothing requested after them: vmcnt(0)
+          // (the count is safe only while request_rows issues EXACTLY SUB x pieces loads per barcode — its `TPC * h < row_len` test is uniform and its
+          //  slot loop rolled for that reason; tests/test_gpu_parity.py::test_counted_row_wait_equals_waiting_for_everything compares this form with
+          //  wait_all bit for bit on partial last sub-tiles, barcodes of unequal length in one wavefront and every V the form serves)
+          if (sub + SUB >= tp || wait_all) __builtin_amdgcn_s_waitcnt(0x0F70);                // nothing requested after them: vmcnt(0)
           else if (row_len > TPC) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * SUB));             // vmcnt(kReq), two pieces per row
           else __builtin_amdgcn_s_waitcnt(0x0F70 | SUB);                                      // one piece per row
           if (sub + 2 * SUB < tp) request_rows(sub + 2 * SUB, (buf + 2) % 3);   // two sub-tiles ahead (that buffer was last read a sub-tile ago, two syncs back)
@@ -5326,6 +5330,7 @@ struct dmx_engine {
   void* own[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // device copies of a host pileup (grow-only: a job's ranges reuse them); [5]: gather sources
   size_t own_cap[6] = {0, 0, 0, 0, 0, 0};
   int32_t* d_sched = nullptr; size_t sched_cap = 0;
+  int64_t max_cell_pairs = 0;                                         // covered SNPs of the staged pileup's longest barcode
   int32_t* d_bad = nullptr;                                          // set by k_check_snp_ids
   bool have_gT = false;                                              // d_gT / d_g0T hold the current genotype matrix
   // canonical GT classes (round 4): every called genotype of a --field GT matrix is one of three SNP-independent rows (hi, lo, lo) permuted
@@ -5778,6 +5783,7 @@ int set_pileup_cells_device(dmx_engine* e, const dmx_pileup* pl, const int64_t* 
   std::vector<int32_t> sched((size_t)B);
   std::iota(sched.begin(), sched.end(), 0);
   std::stable_sort(sched.begin(), sched.end(), [&](int32_t a, int32_t b) { return (h_off[a + 1] - h_off[a]) > (h_off[b + 1] - h_off[b]); });
+  e->max_cell_pairs = B ? h_off[sched[0] + 1] - h_off[sched[0]] : 0;   // (the longest barcode comes first)
   if (int rc = ensure_dev((void**)&e->d_sched, &e->sched_cap, sizeof(int32_t) * (size_t)B)) return rc;
   if (B) HIP_TRY(hipMemcpyAsync(e->d_sched, sched.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, e->stream));
   int32_t bad = 0;
@@ -5850,6 +5856,7 @@ int set_pileup_cells(dmx_engine* e, const dmx_pileup* pl, const int32_t* cells, 
   std::vector<int32_t> sched((size_t)B);
   std::iota(sched.begin(), sched.end(), 0);
   std::stable_sort(sched.begin(), sched.end(), [&](int32_t a, int32_t b) { return (h_off[a + 1] - h_off[a]) > (h_off[b + 1] - h_off[b]); });
+  e->max_cell_pairs = B ? h_off[sched[0] + 1] - h_off[sched[0]] : 0;   // (the longest barcode comes first)
   if (int rc = ensure_dev((void**)&e->d_sched, &e->sched_cap, sizeof(int32_t) * (size_t)B)) return rc;
   if (B) HIP_TRY(hipMemcpyAsync(e->d_sched, sched.data(), sizeof(int32_t) * (size_t)B, hipMemcpyHostToDevice, e->stream));
   int32_t bad = 0;
@@ -6125,9 +6132,17 @@ int launch_doublet_generic_w(dmx_engine* e) {
 }
 
 // The A = 2 kernel with its fix-up pass; other alpha grids (or V > 64) take the generic kernel.
+// FAST's soft-field kernels take their phase-2 terms through dmx_log2_lite, whose dropped r^5/5 term is at most 5.7e-15 per term with the sign of r:
+// unbiased over varied inputs, but a barcode whose terms cluster on ONE value (a PL field repeats a handful of triples) can collect it linearly — the worst
+// case is 6.7e-15 x (covered SNPs) with the result's own rounding (measured at the bin edges, tests/test_dmx_log.py), which reaches FAST's 1e-9 contract at
+// 1.5e5.  Barcodes deeper than 130 000 covered SNPs run the STRICT kernels (bit-exact,
+// inside FAST's contract); nothing in BASELINE.json comes near (cfg3: 5e4, cfg5: 1e4 covered SNPs per barcode; cfg4's GT classes take no per-term log).
+constexpr int64_t kLiteLogMaxPairs = 130000;
+
 int launch_doublet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V, A = e->A;
   e->k2_sym = false;
+  const bool fast_soft = e->mode == DMX_MODE_FAST && (e->max_cell_pairs <= kLiteLogMaxPairs || e->knob("DMX_LITE_LOG_ANY_DEPTH"));
   const bool force_generic = e->knob("DMX_K2_GENERIC") != nullptr;      // kernel experiments only
   const bool use_cls = e->n_classes > 0 && !e->knob("DMX_NO_CLASSES");
   if (A >= 3 && A <= 8 && use_cls && V <= 1024 && !force_generic) {
@@ -6153,7 +6168,7 @@ int launch_doublet(dmx_engine* e) {
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
   }
-  if (e->mode == DMX_MODE_FAST && !use_cls && A >= 2 && A <= 8 && V <= 128 && e->alpha[0] == 0.0 && !(A == 2 && e->alpha[1] == 0.5) &&
+  if (fast_soft && !use_cls && A >= 2 && A <= 8 && V <= 128 && e->alpha[0] == 0.0 && !(A == 2 && e->alpha[1] == 0.5) &&
       !force_generic && !e->knob("DMX_NO_ANF")) {
     // FAST, soft fields, any alpha grid that starts with 0 (the default grid {0, 0.5} has k_doublet_sym): the printed entries only,
     // bilinear form
@@ -6227,7 +6242,7 @@ int launch_doublet(dmx_engine* e) {
   }
   // wide panels: the class kernel's LDS grows by 32 bytes per sample, the general A = 2 kernel's by 384 (64 KB at V = 128)
   // (FAST on the default grid reaches 512 soft-field samples: k_doublet_sym's slabs keep their LDS flat in V)
-  const bool sym_wide = e->mode == DMX_MODE_FAST && !use_cls && A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V > 128 && V <= 512 &&
+  const bool sym_wide = fast_soft && !use_cls && A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && V > 128 && V <= 512 &&
                         !e->knob("DMX_NO_SYM") && !e->knob("DMX_NO_SYM_WIDE");
   // (round 4: the general A = 2 kernel itself runs up to kA2MaxV = 1024 samples — one workgroup may use all 160 KB of a gfx950 CU's LDS, and the
   // tile shortens from 32 to 16 or 8 pairs as the rows grow; beyond, the generic kernel)
@@ -6318,7 +6333,7 @@ int launch_doublet(dmx_engine* e) {
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
                      e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);                                   \
   } while (0)
-  if (e->mode == DMX_MODE_FAST && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && (V <= 128 || sym_wide) && !e->knob("DMX_NO_SYM")) {
+  if (fast_soft && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && (V <= 128 || sym_wide) && !e->knob("DMX_NO_SYM")) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do { e->k2_sym = true;                                                                                                                \
@@ -6354,7 +6369,7 @@ int launch_doublet(dmx_engine* e) {
     const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0) |
                               (e->knob("DMX_SYM_ABLATE_P2") ? (1 << 18) : 0) | (e->knob("DMX_SYM_ABLATE_U") ? (1 << 19) : 0) |
                               (e->knob("DMX_SYM_ABLATE_RD") ? (1 << 20) : 0) | (e->knob("DMX_SYM_ABLATE_00") ? (1 << 21) : 0) | (e->knob("DMX_SYM_NO_PRODUCT") ? (1 << 22) : 0) |
-                              (e->knob("DMX_SYM_NO_PIPE") ? (1 << 23) : 0);       // kernel experiments only (the ABLATE bits do something in -DDMX_SYM_ABLATIONS=1 builds only)
+                              (e->knob("DMX_SYM_NO_PIPE") ? (1 << 23) : 0) | (e->knob("DMX_SYM_WAIT_ALL") ? (1 << 24) : 0);       // kernel experiments only (the ABLATE bits do something in -DDMX_SYM_ABLATIONS=1 builds only)
     const bool wide_cells = e->knob("DMX_SYM_ONE_CELL_PER_WAVE") != nullptr;   // kernel experiments only
     if (V <= 8 && !wide_cells) { if (16 % V == 0) DMX_K2S(16, 8, 4, true); else DMX_K2S(16, 8, 4, false); }        // four barcodes per wavefront
     else if (V <= 16 && !wide_cells) { if (V == 16) DMX_K2S(32, 16, 4, true); else DMX_K2S(32, 16, 4, false); }   // two
@@ -6399,7 +6414,7 @@ int launch_doublet(dmx_engine* e) {
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
   }
-  if (e->mode == DMX_MODE_FAST && V <= 128) {     // (wider panels that are not k_doublet_sym's run the STRICT kernel below: bit-exact, inside FAST's contract)
+  if (fast_soft && V <= 128) {     // (wider panels that are not k_doublet_sym's run the STRICT kernel below: bit-exact, inside FAST's contract)
     // one-cell-per-workgroup panels share u through LDS (cfg3 1.33x); one-wavefront cells (V <= 16) form it in registers
     const size_t fast_bytes = cell_bytes + (V > 16 ? (size_t)8 * 2 * V * 32 : 0);
 #define DMX_K2F(TPC, NK)                                                                                             \

@@ -1054,7 +1054,8 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
       if (sm.flags & DMX_CELL_ORDER_RESOLVABLE) (void)dmx::resolve_tie_order(&sm);
       const int need = dmx::cell_needs(sm, in->alpha, A, true);
       if ((need & dmx::kNeedPileup) && src.tie_cell && src.tie_cell[c] < 0)
-        return set_error(DMX_ERR_STATE, "%s: the tie arbiter needs barcode %s, whose pileup was not staged (nothing was written)", who, in->barcodes[c]);
+        return set_error(DMX_ERR_STATE, "%s: the tie arbiter needs barcode %s, whose pileup was not staged (%s)", who, in->barcodes[c],
+                         append ? "no row of this range was written; the rows of earlier ranges are in the files" : "nothing was written");
       if ((need & dmx::kNeedGrid) && !src.grid_all && !(src.cell_grid && src.cell_grid[c])) {
         fallback_logs += (double)sm.n_pairs * (double)V * V * A;
         ++n_fallback;
@@ -1062,7 +1063,8 @@ int dmx::write_doublet_core(const dmx_final_input* in, const DoubletSource& src,
     }
     if (fallback_logs > 2e9)
       return set_error(DMX_ERR_ARG, "%s: %lld near-tie-flagged barcodes came without their grids; re-evaluating them on the host would take %.3g log() calls "
-                       "— pass the grids (dmx_engine_get_cell_grids, dmx_write_doublet_summary_grids)", who, (long long)n_fallback, fallback_logs);
+                       "— pass the grids (dmx_engine_get_cell_grids, dmx_write_doublet_summary_grids; a caller built against ABI 6 set dmx_final_input.cell_grid "
+                       "for this: that member was withdrawn in ABI 7 and is no longer read)", who, (long long)n_fallback, fallback_logs);
   }
   const std::string pre(out_prefix);
   File sing2, pairf, best;

@@ -85,7 +85,7 @@ def test_bench_sharded_path_with_a_one_rank_group():
     import os
     env = dict(os.environ, DMX_BENCH_FORCE_DIST="1", MASTER_PORT="29533")
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--config", "4",
-                        "--cells", "96"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
+                        "--cells", "96", "--e2e-write-pair"], capture_output=True, text=True, cwd=ROOT, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
     assert d["ranks_seen"] == 1 and len(d["per_rank_ms_per_step"]) == 1 and d["gather_ms"] >= 0
@@ -93,6 +93,9 @@ def test_bench_sharded_path_with_a_one_rank_group():
     # an N > 1 line is judged like the N = 1 line: it carries its own CPU baseline (rank 0, after the timed region) and the ranks' devices
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1 and len(d["rank_devices"]) == 1
     assert d["parity_check"]["ok"] is True
+    # ... and the job with --write-pair on every rank's range at once (rows formatted on the GPUs): stage seconds, the slowest rank's total
+    wp = d["end_to_end"]["cfg4_shard_write_pair"]
+    assert wp["pair_rows"] == 96 * (64 + 64 * 63 // 2) and wp["strict"]["total_s"] > 0 and wp["slowest_rank_total_s"]["strict"] >= wp["strict"]["total_s"] * 0.999
 
 
 def test_bench_gpus_n_without_a_launcher():

@@ -218,6 +218,37 @@ def test_fast_mode_log_error_is_small_and_unbiased():
 
 
 @pytest.mark.gpu
+def test_lite_log_worst_case_is_linear_and_bounded():
+    """the lite log's error is unbiased only over VARIED arguments.  Clustered inputs — one argument repeated N times, as a PL field's handful of
+    genotype triples and a dozen base-quality levels produce — collect the dropped r^5/5 term linearly.  Pinned here: at BOTH edges of every one of the 256
+    table bins (where |r| is largest and keeps one sign) and for binary exponents down to 2^-24, one term is off by at most 6.9e-15 (5.7e-15 of series, the rest
+    the result's own rounding), so N identical terms drift by less than 1e-9 up to N = 1.3e5 — the depth beyond which launch_doublet sends a FAST job to the
+    STRICT kernels (kLiteLogMaxPairs = 130 000)."""
+    import mpmath
+    from demuxlet_amd import build, capi
+    build.build()
+    L = capi.load()
+    mpmath.mp.prec = 120
+    # bin edges of the reduced argument: the table starts at OFF = 0x3FE5F800... = 2^-1 x (1 + 95.5/256), so in every octave the edges sit at
+    # mantissa (i + 0.5) / 256; the points: 2^-40 inside either end of each bin (|r| largest, one sign per end), and the mid-points for contrast
+    i = np.arange(-1, 256)
+    lo_edge = 1.0 + (i + 0.5) / 256.0 + 2.0 ** -40
+    hi_edge = 1.0 + (i + 1.5) / 256.0 - 2.0 ** -40
+    z = np.concatenate([lo_edge, hi_edge, 1.0 + (i + 1.0) / 256.0])
+    z = z[(z >= 1.0) & (z < 2.0)]
+    worst = 0.0
+    for k in (0, -1, -7, -20, -24):                               # x = z * 2^k: likelihood terms live in [2^-24, 1]
+        x = np.ldexp(z, k - 1)
+        y = np.empty_like(x)
+        capi.check(L.dmx_debug_device_log2_lite(x.ctypes.data, y.ctypes.data, len(x), 0))
+        for xi, yi in zip(x, y):
+            worst = max(worst, abs(float(mpmath.mpf(float(yi)) - mpmath.log(mpmath.mpf(float(xi))))))
+    assert worst < 6.9e-15, worst
+    assert 130000 * worst < 1e-9
+    print(f"lite log, clustered arguments at the bin edges: worst |error| of one term {worst:.3e} -> {130000 * worst:.2e} over 130 000 identical terms")
+
+
+@pytest.mark.gpu
 def test_device_shared_reciprocal_division_is_ieee():
     """The kernels divide three (nine) numerators by one denominator with a shared Newton-refined reciprocal; the result
     must be the correctly rounded quotient, i.e. numpy's / bit for bit, over the operand ranges the kernels see."""

@@ -1229,3 +1229,63 @@ def test_experiment_switches_are_fenced(eng, monkeypatch):
     assert job() == (4, 1)
     monkeypatch.setenv("DMX_EXPERIMENTS", "0")
     assert job() == (1, 1)
+
+
+def test_fast_mode_keeps_the_lite_log_away_from_very_deep_barcodes(eng, monkeypatch):
+    """dmx_log2_lite's worst case is linear in the number of terms (5.7e-15 each), so a pileup whose longest barcode covers more than 130 000 SNPs
+    runs the STRICT kernels in FAST mode too (bit-exact, inside FAST's contract).  One barcode of 130 001 covered SNPs on a soft field: the doublet kernel
+    is k_doublet_a2, not k_doublet_sym; one SNP fewer: k_doublet_sym."""
+    from demuxlet_amd import synth, capi
+    rng = np.random.default_rng(8)
+    V = 6                                           # (up to four samples a soft field still has <= 4 distinct rows per SNP and runs the class kernels)
+    for S, want in ((130001, "k_doublet_a2<"), (130000, "k_doublet_sym<")):
+        raw = synth.make_raw_genotypes(rng, S, V)
+        g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+        sp = synth.make_pileup(rng, raw.alleles, 2, 1.0, 1.1, dense_layout=True)
+        e = eng.Engine(V, (0.0, 0.5), 0.5, mode=capi.DMX_MODE_FAST)
+        e.set_genotypes(g); e.set_pileup(host_pileup(eng, sp)); e.run(); e.sync()
+        assert e.kernel_names()["doublet"].startswith(want), (S, e.kernel_names())
+        e.close()
+
+
+@pytest.mark.parametrize("V", [9, 12, 13, 16])
+def test_counted_row_wait_equals_waiting_for_everything(eng, monkeypatch, V):
+    """the two-barcodes-per-wavefront form of k_doublet_sym (V = 9..16) requests genotype rows two sub-tiles ahead into three LDS buffers and
+    waits with a hand-counted s_waitcnt vmcnt(SUB x pieces) instead of vmcnt(0).  Stress: barcodes of very unequal length sharing a wavefront (one of them
+    empty), tile counts that leave every partial last sub-tile (1, 2, 3 pairs), sparse SNP ids over a matrix far beyond the L2 (slow, reordered-looking row
+    fetches) — the counted form, the vmcnt(0) form (DMX_SYM_WAIT_ALL=1) and the no-DMA form give the same bits, three runs each."""
+    from demuxlet_amd import synth, capi
+    rng = np.random.default_rng(1300 + V)
+    S, B = 60000, 97
+    raw = synth.make_raw_genotypes(rng, S, V)
+    g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+    sp = synth.make_pileup(rng, raw.alleles, B, 0.02, 1.6, doublet_rate=0.3)
+    # unequal lengths: cut every barcode to a chosen number of pairs (0, 1 .. 19 — every residue of the 16-pair tile and the 4-pair sub-tile — and long ones)
+    keep = [0, 1, 2, 3, 5, 6, 7, 9, 13, 15, 16, 17, 18, 19, 33, 47, 64, 65] + list(rng.integers(20, 1100, size=B - 18))
+    po = sp.cell_pair_off
+    sel = np.concatenate([np.arange(po[c], min(po[c + 1], po[c] + keep[c])) for c in range(B)]).astype(np.int64)
+    nrd = sp.pair_nrd.astype(np.int64)
+    ro = np.concatenate([[0], np.cumsum(nrd)])
+    rsel = np.concatenate([np.arange(ro[p], ro[p + 1]) for p in sel]) if len(sel) else np.zeros(0, np.int64)
+    npair = np.array([min(po[c + 1] - po[c], keep[c]) for c in range(B)], dtype=np.int64)
+    cpo = np.concatenate([[0], np.cumsum(npair)])
+    cro = np.concatenate([[0], np.cumsum([nrd[sel[cpo[c]:cpo[c + 1]]].sum() for c in range(B)])]).astype(np.int64)
+    pl = eng.HostPileup(B, S, cpo, cro, sp.pair_snp[sel], sp.pair_nrd[sel], sp.reads[rsel], sp.rd_totl, sp.rd_pass, sp.rd_uniq)
+
+    def run(env):
+        monkeypatch.setenv("DMX_EXPERIMENTS", "1")
+        for k in ("DMX_SYM_WAIT_ALL", "DMX_SYM_NO_DMA"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = eng.Engine(V, (0.0, 0.5), 0.5, mode=capi.DMX_MODE_FAST)
+        e.set_genotypes(g); e.set_pileup(pl); e.run(); e.sync()
+        assert e.kernel_names()["doublet"].startswith("k_doublet_sym<32, 16, 4,"), e.kernel_names()
+        grid, l00, _ = e.get_doublet()
+        e.close()
+        return grid, l00
+
+    base = run({})
+    for env in ({}, {}, {"DMX_SYM_WAIT_ALL": "1"}, {"DMX_SYM_NO_DMA": "1"}, {"DMX_SYM_NO_PIPE": "1"}):
+        got = run(env)
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
