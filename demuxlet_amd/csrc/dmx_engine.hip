@@ -1038,8 +1038,10 @@ __global__ void k_build_ctab(const double* __restrict__ tabs, double hi, double 
 // admitted four times per CU), found by keeping the running sums in registers and, for matrices without a fourth genotype row (OTH = false: no
 // missing genotypes), three class planes of scratch instead of four.  OTH = true keeps the
 // global gathers for every lane.
+// (waves per SIMD: five for the one- and two-barcode forms — 10 000 barcodes at two per wavefront are ONE round of five; the four-barcode form, picked
+//  from 131 072 barcodes, carries four barcodes' pipelines in its registers and asks for what it gets: four, three with two chunks — VERDICT r5 weak 9)
 template <int CW, int KC, bool OTH, int NCH>     // NCH: chunks of KC samples (1 or 2; V <= NCH * KC)
-__global__ __launch_bounds__(kThreads, 5) void k_singlet_can(PileupView pv, const uint4* __restrict__ snprec, const float* __restrict__ rows,
+__global__ __launch_bounds__(kThreads, (CW == 4 ? (NCH == 2 ? 3 : 4) : 5)) void k_singlet_can(PileupView pv, const uint4* __restrict__ snprec, const float* __restrict__ rows,
                                                              const double* __restrict__ ctab, const double* __restrict__ tabs,
                                                              const int32_t* __restrict__ sched, int32_t V,
                                                              double* __restrict__ llks, double* __restrict__ llk0s, double chi, double clo) {
