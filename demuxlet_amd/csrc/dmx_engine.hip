@@ -5996,9 +5996,14 @@ int launch_singlet(dmx_engine* e) {
 #undef DMX_K1W
       return DMX_OK;
     }
-    // measured on cfg2-shaped inputs (profiles/): CW 2 wins from 10 k barcodes (6.90 vs 7.14 ms; 5 k: 5.07 vs 3.94), CW 4 still
-    // loses at 40 k (27.7 vs 24.6 ms)
-    if (!e->knob("DMX_K1_CW")) CW = (B >= 128 * 1024) ? 4 : (B >= 10000 ? 2 : 1);
+    // measured on cfg2-shaped inputs (profiles/): CW 2 wins from 10 k barcodes (6.90 vs 7.14 ms; 5 k: 5.07 vs 3.94).  Four barcodes per wavefront
+    // (round 6, profiles/r06_k1_cw4.txt): k_singlet_cls LOSES with them at every size tried — 131 072 barcodes x 50 k SNPs 64.4 against
+    // 50.7 ms, 262 144: 127.2 / 100.7 (round 3: 40 k 27.7 / 24.6) — so it never takes them; the lean kernel k_singlet_can gains 2.6 % at 65 536
+    // (17.15 / 17.60 ms) and takes them from there (beyond 2^32 covered pairs per engine — 131 072 x 50 k — the lean kernel's 32-bit offsets do not
+    // reach and k_singlet_cls runs: DESIGN 10).
+    const bool lean_ok = e->canon && e->geno_safe && !e->knob("DMX_NO_CANON_K1") && V <= 16 && e->nrd_width == 1 && e->reads_padded && e->off32 &&
+                         (uint64_t)e->S * 64 < (1ull << 32) && !e->knob("DMX_K1_NO_LEAN");       // (the conditions of `lean` below)
+    if (!e->knob("DMX_K1_CW")) CW = (lean_ok && B >= 64 * 1024) ? 4 : (B >= 10000 ? 2 : 1);
     const int nchc = (V + KC - 1) / KC;
     const size_t dynb = sizeof(double) * (size_t)(kThreads / 64) * nchc * CW * (KC + 1);
     if (dynb <= 16 * 1024) {
