@@ -32,7 +32,7 @@ SYMBOLS = [
     "dmx_engine_sync", "dmx_engine_get_singlet", "dmx_engine_get_doublet", "dmx_engine_device_view",
     "dmx_engine_last_kernel_times", "dmx_engine_algorithmic_bytes", "dmx_write_single", "dmx_write_doublet",
     "dmx_demuxlet_run", "dmx_debug_device_log", "dmx_debug_device_log2", "dmx_debug_device_div", "dmx_debug_log_rate", "dmx_engine_get_sing", "dmx_engine_get_cell_grids", "dmx_write_doublet_summary", "dmx_debug_log_dd",
-    "dmx_resolve_tie_order", "dmx_engine_mean_kernel_times", "dmx_store_add_batch", "dmx_write_doublet_summary_grids", "dmx_engine_kernel_names", "dmx_debug_device_log2_lite",
+    "dmx_resolve_tie_order", "dmx_engine_mean_kernel_times", "dmx_store_add_batch", "dmx_write_doublet_summary_grids", "dmx_engine_kernel_names", "dmx_debug_device_log2_lite", "dmx_debug_device_log2_lite32",
     "dmx_engine_format_pair", "dmx_pair_text_get_info", "dmx_pair_text_read", "dmx_pair_text_free",
 ]
 
@@ -167,7 +167,7 @@ def load() -> C.CDLL:
         "dmx_engine_get_doublet": [vp, vp, vp, vp], "dmx_engine_device_view": [vp, vp],
         "dmx_engine_last_kernel_times": [vp, vp], "dmx_engine_algorithmic_bytes": [vp, vp],
         "dmx_write_single": [vp, C.c_char_p], "dmx_write_doublet": [vp, C.c_char_p], "dmx_demuxlet_run": [vp],
-        "dmx_debug_device_log": [vp, vp, C.c_int64, i32], "dmx_debug_device_log2": [vp, vp, C.c_int64, i32], "dmx_debug_device_log2_lite": [vp, vp, C.c_int64, i32],
+        "dmx_debug_device_log": [vp, vp, C.c_int64, i32], "dmx_debug_device_log2": [vp, vp, C.c_int64, i32], "dmx_debug_device_log2_lite": [vp, vp, C.c_int64, i32], "dmx_debug_device_log2_lite32": [vp, vp, C.c_int64, i32],
         "dmx_engine_get_sing": [vp, vp], "dmx_write_doublet_summary": [vp, vp, vp, C.c_char_p],
         "dmx_debug_device_div": [vp, vp, vp, C.c_int64, i32],
         "dmx_debug_log_rate": [i32, i32, i32, vp],

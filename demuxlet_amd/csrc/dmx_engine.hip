@@ -80,7 +80,8 @@ constexpr int kTriple = dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCode
 constexpr int kTabAll = kTabK1 + 2 * kPair + 2 * kTriple;
 constexpr int kTabLogLo = kTabAll;                      // then dmx_log_dd's second-order table (128 doubles)
 constexpr int kTabLog2 = kTabAll + 128;                 // then dmx_log2's 256-bin {invc, logc} table (the doublet kernels' log, round 4)
-constexpr int kTabTotal = kTabLog2 + DMX_LOG2_TABLE_DOUBLES;
+constexpr int kTabLog32 = kTabLog2 + DMX_LOG2_TABLE_DOUBLES;   // then dmx_log2_lite32's split 32-bin table rc[32] | logc[32] (FAST k_doublet_sym, round 6)
+constexpr int kTabTotal = kTabLog32 + DMX_LOG32_TABLE_DOUBLES;
 // canonical-class log table (k_build_canon_logs): entries in the order of the final GL tables — one read (257, the last = no read) | two | three
 constexpr int64_t kCanL2 = 257, kCanL3 = 257 + 128 * 128, kCanN = kCanL3 + (int64_t)dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes;
 constexpr int kLut2 = 2 * 128;                           // the doublet kernels read mat | err/3 only (the third LUT part is the singlet kernels')
@@ -302,6 +303,12 @@ template <int HALF> __device__ __forceinline__ uint32_t add_word_of(uint32_t bas
 #ifndef DMX_SYM_NB
 #define DMX_SYM_NB 3                              // entries per step of k_doublet_sym's software-pipelined phase 2 (0: off)
 #endif
+#ifndef DMX_SYM_TIMING
+#define DMX_SYM_TIMING 0                          // timing builds only (results WRONG): 1 = phase-2 polynomial one FMA shorter, 2 = k ln 2 from an LDS look-up and one add
+#endif                                            //   instead of cvt + fma, 3 = both — what a 2 048-bin table / a k-indexed table would buy
+#ifndef DMX_SYM_HYB
+#define DMX_SYM_HYB 0                             // k_doublet_sym's mix of the two FAST logs: 0 none, 1 every third entry of a lane through dmx_log2_lite32, 2 two of three, 3 all, 4 every second
+#endif
 #ifndef DMX_FAST_LITE_LOG
 #define DMX_FAST_LITE_LOG 1                       // FAST phase-2 terms through dmx_log2_lite (6 FP64 instructions; csrc/dmx_log.hpp) — 0: dmx_log2 (10), as rounds 2-4
 #endif
@@ -324,6 +331,83 @@ __device__ __forceinline__ uint32_t load_nrd(const void* __restrict__ base, int6
 constexpr int kFlagHead = 16;
 __device__ __forceinline__ void flag_cell(uint8_t* __restrict__ flagged, int32_t cell) { flagged[cell] = 1; *(flagged - kFlagHead) = 1; }
 __device__ __forceinline__ bool flags_any(const uint8_t* __restrict__ flagged) { return *(const volatile uint8_t*)(flagged - kFlagHead) != 0; }
+
+// Round 6: FINAL phase-1 values of the default grid {0, 0.5} — the five distinct alpha = 0.5 values q[l + m] and the three of alpha = 0 after the read loop AND
+// the +1e-6 renormalisation of :649-663 (k_doublet_sym's phase 1, certify_pair_values<5>) —
+// for every pair whose reads index a table: no read, one read, two reads of base quality < 64, three of base quality < 48 (K1's TripleTables codes).  One
+// thread per entry runs the loop of :597-639 and the finish for BOTH alpha lanes (the maxima run across them): the operations of k_certify's two lanes on
+// the same operands, hence the same bits.  A tile none of whose pairs is deeper takes its values from here and skips the seeds, the loop, the finish and
+// the hand-over between the lanes (at 1.25 reads per pair: 93 % of the tiles; 43 % with the one- and two-read entries alone).
+constexpr int kCFinStride = 8;                   // doubles per entry: alpha 0.5's five values, alpha 0's three (one 64-byte line)
+constexpr int64_t kCFin1 = 1, kCFin2 = 1 + 256, kCFin3 = kCFin2 + 128 * 128,
+                  kCFinN = kCFin3 + (int64_t)dmx::kTripleCodes * dmx::kTripleCodes * dmx::kTripleCodes;
+__device__ __forceinline__ int32_t certify_final_index(uint32_t cnt, uint32_t rd4) {     // -1: the pair's reads are not in the table
+  const uint32_t b0 = rd4 & 0xFFu, b1 = (rd4 >> 8) & 0xFFu, b2 = (rd4 >> 16) & 0xFFu;
+  const uint32_t q0 = b0 & 127u, q1 = b1 & 127u, q2 = b2 & 127u;
+  const uint32_t i2 = ((((b0 & 0x80u) >> 1) | (b0 & 0x3Fu)) << 7) | (((b1 & 0x80u) >> 1) | (b1 & 0x3Fu));
+  const uint32_t c0 = ((b0 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q0, c1 = ((b1 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q1,
+                 c2 = ((b2 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q2;
+  const uint32_t i3 = __umul24(__umul24(c0, (uint32_t)dmx::kTripleCodes) + c1, (uint32_t)dmx::kTripleCodes) + c2;
+  int32_t idx = -1;
+  idx = (cnt == 3 && max(max(q0, q1), q2) < (uint32_t)dmx::kTripleBq) ? (int32_t)kCFin3 + (int32_t)i3 : idx;
+  idx = (cnt == 2 && ((b0 | b1) & 0x40u) == 0) ? (int32_t)kCFin2 + (int32_t)i2 : idx;
+  idx = cnt == 1 ? (int32_t)kCFin1 + (int32_t)b0 : idx;
+  idx = cnt == 0 ? 0 : idx;
+  return idx;
+}
+__global__ void k_build_certify_finals(const double* __restrict__ tabs, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kCFinN) return;
+  uint32_t bytes[3] = {0u, 0u, 0u}; int nb;
+  if (e < kCFin1) nb = 0;
+  else if (e < kCFin2) { bytes[0] = (uint32_t)(e - kCFin1); nb = 1; }
+  else if (e < kCFin3) {
+    const uint32_t i2 = (uint32_t)(e - kCFin2), c0 = i2 >> 7, c1 = i2 & 127u;
+    bytes[0] = ((c0 & 0x40u) << 1) | (c0 & 0x3Fu); bytes[1] = ((c1 & 0x40u) << 1) | (c1 & 0x3Fu); nb = 2;
+  } else {
+    uint32_t c = (uint32_t)(e - kCFin3);
+    const uint32_t c2 = c % (uint32_t)dmx::kTripleCodes; c /= (uint32_t)dmx::kTripleCodes;
+    const uint32_t c1 = c % (uint32_t)dmx::kTripleCodes, c0 = c / (uint32_t)dmx::kTripleCodes;
+    const uint32_t cs[3] = {c0, c1, c2};
+    for (int r = 0; r < 3; ++r) bytes[r] = cs[r] >= (uint32_t)dmx::kTripleBq ? (0x80u | (cs[r] - (uint32_t)dmx::kTripleBq)) : cs[r];
+    nb = 3;
+  }
+  double wA[2][5], wR[2][5], pG[2][5];
+  for (int n1 = 0; n1 < 2; ++n1)
+    for (int q = 0; q < 5; ++q) {                  // the weights of k_certify's FIVE form
+      const int l = n1 ? (q > 2 ? 2 : q) : min(q, 2), m = n1 ? q - l : 0;
+      const double p = 0.5 * l + (m - l) * 0.5 * (n1 ? 0.5 : 0.0);
+      wA[n1][q] = p; wR[n1][q] = 1.0 - p; pG[n1][q] = 1.0;
+    }
+  for (int r = 0; r < nb; ++r) {
+    const uint32_t byte = bytes[r], bq = byte & 127u;
+    const bool alt = (byte >> 7) != 0;
+    const double pR = alt ? tabs[128 + bq] : tabs[bq];
+    const double pA = alt ? tabs[bq] : tabs[128 + bq];
+    double mx[2] = {0.0, 0.0};
+    for (int n1 = 0; n1 < 2; ++n1)
+      for (int i = 0; i < 5; ++i) {
+        pG[n1][i] *= (pR * wR[n1][i] + pA * wA[n1][i]);
+        mx[n1] = fmax(mx[n1], pG[n1][i]);
+      }
+    const double m = fmax(mx[0], mx[1]);
+    const double y = rcp_refined(m);
+    for (int n1 = 0; n1 < 2; ++n1)
+      for (int i = 0; i < 5; ++i) pG[n1][i] = div_by(pG[n1][i], m, y);
+  }
+  double mx[2] = {0.0, 0.0};
+  for (int n1 = 0; n1 < 2; ++n1)
+    for (int i = 0; i < 5; ++i) {
+      pG[n1][i] += 1e-6;                                                     // :649
+      mx[n1] = fmax(mx[n1], pG[n1][i]);
+    }
+  const double m = fmax(mx[0], mx[1]);
+  const double y = rcp_refined(m);
+  double* o = out + (size_t)e * kCFinStride;
+  for (int i = 0; i < 5; ++i) o[i] = div_by(pG[1][i], m, y);                 // :656-663, the alpha = 0.5 lane's values (what both lanes of a k_certify pair use)
+  for (int i = 0; i < 3; ++i) o[5 + i] = div_by(pG[0][i], m, y);             // ... and the alpha = 0 lane's three distinct ones (k_doublet_sym's phase 1)
+}
+
 
 // K1.  Wavefronts are independent (no workgroup barrier in the loop).  A wavefront owns CW cells for their whole SNP
 // range and walks them tile by tile, T = 64/CW SNP-pairs per cell per tile:
@@ -1744,13 +1828,16 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 // found finite, non-negative and not vanishing (k_check_geno) — then every phase-2 sum is >= max_l g_j[l] * (1e-6 / (1 + 1e-6)) *
 // max_m g_k[m] > 2^-830, a normal positive number, and the test cannot fire.
 // TP: covered pairs per tile (32; 16 or 8 on panels of more than ~180 samples, whose 32 staged genotype rows would leave one workgroup per CU)
+// (the 64-thread-cell forms run three workgroups of four cells per CU = three wavefronts per SIMD: bounded to their 168 registers — left unbounded the
+//  compiler's count moved from 158 to 246 with an unrelated edit of phase 1 and cfg5 STRICT lost a wavefront per SIMD, 144 -> 168 ms)
 template <int TPC, int NK, int MINW = 1, bool GD = false, bool CHK = true, int TP = 32>
-__global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
+__global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                          const double* __restrict__ alpha,
                                                          const int32_t* __restrict__ sched, int32_t V, int32_t GS,
                                                          double* __restrict__ grid, double* __restrict__ l00,
-                                                         uint8_t* __restrict__ flagged) {
+                                                         uint8_t* __restrict__ flagged, const double* __restrict__ pfin) {
+  // pfin (round 6; NULL unless the grid is {0, 0.5} and the pileup shallow): k_build_certify_finals' table of finished phase-1 values
   constexpr int A = 2;
   static_assert(TP == 32 || TP == 16 || TP == 8, "phase 1 runs on the first 2 * TP lanes of the cell's first wavefront");
   constexpr int CPW = kThreads / TPC;            // cells per workgroup
@@ -1837,6 +1924,21 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
       const uint32_t cnt = on ? s_cnt[ti1] : 0u;
       const int64_t off = on ? s_off[ti1] : 0;
       const uint32_t rd4 = load_rd4(pv, off, cnt);       // the first four read bytes in one load (one dependent latency instead of four)
+      // Round 6 (default grid {0, 0.5}): pairs of up to three tabled reads take their finished values from the table — alpha 0.5's five distinct ones
+      // q[l + m], alpha 0's three q[l]: entries of equal mixing weight go through identical operations, so the nine of the loop below repeat them bit for
+      // bit — and the loop and the +1e-6 renormalisation run only in tiles with a deeper pair (wave-uniform branch); see k_doublet_sym.
+      // (a tile with a deeper pair runs the loop for ALL its lanes, as before: no merge of the two sources, no register held across the loop)
+      double vf[9];
+      const int32_t fi = pfin ? certify_final_index(cnt, rd4) : -1;
+      if (!__any(fi < 0)) {
+        const double* fp = pfin + (size_t)fi * kCFinStride + (n1 ? 0 : 5);
+        const double f0 = fp[0], f1 = fp[1], f2 = fp[2], f3 = n1 ? fp[3] : 0.0, f4 = n1 ? fp[4] : 0.0;
+        const double f5[5] = {f0, f1, f2, f3, f4};
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) vf[l * 3 + m] = n1 ? f5[l + m] : f5[l];
+      } else {
       double pG[9], wA[9], wR[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) { pG[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][9 + i]; }   // :597
@@ -1880,8 +1982,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
         const double o = shfl_xor1(mx);
         mx = fmax(mx, o);
       }
-      if (on) {
+      {
         const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
+#pragma unroll
+        for (int i = 0; i < 9; ++i) vf[i] = div_by(pG[i], mx, y);            // :656-663
+      }
+      }
+      if (on) {
         const double* g0 = gp0 + (size_t)s_snp[ti1] * 3;
         const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
         const double qq[3] = {q0, q1, q2};
@@ -1890,7 +1997,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2(PileupView pv, in
         for (int l = 0; l < 3; ++l)
 #pragma unroll
           for (int m = 0; m < 3; ++m) {
-            const double v = div_by(pG[l * 3 + m], mx, y);                   // :656-663
+            const double v = vf[l * 3 + m];
             s_pG[(ti1 * 2 + n1) * 9 + l * 3 + m] = v;
             sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
           }
@@ -2252,7 +2359,8 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
                                                           const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                           const int32_t* __restrict__ sched, int32_t V_and_flags,
                                                           double* __restrict__ grid, double* __restrict__ l00,
-                                                          uint8_t* __restrict__ flagged) {
+                                                          uint8_t* __restrict__ flagged, const double* __restrict__ pfin) {
+  // pfin (round 6; NULL: none): k_build_certify_finals' table — the finished phase-1 values of pairs of up to three tabled reads
   const int32_t V = V_and_flags & 0xFFFF;
   const bool no_dma = (V_and_flags >> 16) & 1;   // kernel experiments (DMX_SYM_NO_DMA; bit-identical results)
 #if DMX_SYM_ABLATIONS                             // timing builds only (tools/build_variant.sh ... -DDMX_SYM_ABLATIONS=1): each switch drops one part of the
@@ -2284,9 +2392,17 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][10];                  // mixing weights of :613 per alpha and distinct value: [n][0..4] = p (ALT), [n][5..9] = 1 - p
+  __shared__ __attribute__((aligned(256))) double s_log32[DMX_LOG32_TABLE_DOUBLES];   // dmx_log2_lite32's rc[32] | logc[32]
   const double* s_log = s_tab + kLut2;
   const int t = threadIdx.x;
   stage_k2_tables(s_tab, tabs, t, kThreads);
+  if (t < DMX_LOG32_TABLE_DOUBLES) s_log32[t] = tabs[kTabLog32 + t];
+  // Round 6: WHICH of the two FAST logs an entry takes is a compile-time function of its slot i in the lane's entry list (so every accumulator sees one log
+  // for the whole run, in every code path of this instantiation): dmx_log2_lite (256 bins, 16-byte gather with bank conflicts, 6 FP64 instructions) loads the
+  // LDS, dmx_log2_lite32 (split 32-bin table, conflict-free, 8) loads the VALU — mixing them balances the two units that bind this kernel.
+  constexpr int HYB = (FIXJ && MINW == 3 && NEP == 0 && DMX_FAST_LITE_LOG) ? DMX_SYM_HYB : 0;
+  auto kind32 = [](int i) constexpr { return HYB == 3 || (HYB == 1 && i % 3 == 2) || (HYB == 2 && i % 3 != 0) || (HYB == 4 && (i & 1)); };
+  const DmxLog32Pins lk32 = dmx_log32_pins();
   if (t < 10) {
     // alpha 0: p = 0.5 l does not depend on m -> slots 0..2 hold l = 0..2 (slots 3, 4 repeat l = 2); alpha 0.5: p = 0.25 (l + m)
     // -> slot = l + m.  Same operands, same operations as the nine entries of the reference: the values are bit-identical.
@@ -2420,7 +2536,20 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
       const int32_t snp1 = on ? (abl_p1 ? (s_snp[ti1] & 15) : s_snp[ti1]) : 0;
       const float* g0r = g + (size_t)snp1 * row_len;             // sample 0's row (alpha-0 lanes use it)
       const float gf0 = g0r[0], gf1 = g0r[1], gf2 = g0r[2];
-      double q[5], wA[5], wR[5];                                           // the weights live in registers during phase 1 only
+      double q[5];
+      // Round 6: a pair of up to three tabled reads takes its FINISHED values from the table (one 64-byte entry per read code: the alpha = 0.5 lane its
+      // five, the alpha = 0 lane its three); the read loop and the +1e-6 renormalisation below run only in tiles with a deeper pair (wave-uniform branch).
+      // Timing builds: the loop is 22 of cfg3 FAST's 201 ms (a dependent chain — products, maximum, the neighbour's, reciprocal, quotients — per read,
+      // with LDS look-ups in it), at 1.25 reads per pair 93 % of the tiles skip it.  Same operations on the same operands (k_build_certify_finals): same bits.
+      // (a tile with a deeper pair runs the loop for ALL its lanes, as before: no merge of the two sources, no register held across the loop)
+      const int32_t fi = pfin ? certify_final_index(cnt, rd4) : -1;
+      if (!__any(fi < 0)) {
+        const double* fp = pfin + (size_t)fi * kCFinStride + (n1 ? 0 : 5);
+        q[0] = fp[0]; q[1] = fp[1]; q[2] = fp[2];
+        q[3] = n1 ? fp[3] : 0.0; q[4] = n1 ? fp[4] : 0.0;
+      } else {
+      double wA[5], wR[5];                                                 // the weights live in registers during phase 1 only
+      {
 #pragma unroll
       for (int i = 0; i < 5; ++i) { q[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }   // :597
       for (uint32_t r = 0; __any(r < (abl_rd ? 0u : cnt)); ++r) {
@@ -2463,10 +2592,14 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
         const double o = shfl_xor1(mx);
         mx = fmax(mx, o);
       }
-      if (on) {
+      {
         const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
 #pragma unroll
         for (int i = 0; i < 5; ++i) q[i] = div_by(q[i], mx, y);              // :656-663
+      }
+      }
+      }
+      if (on) {
         const double* g0 = gp0 + (size_t)snp1 * 3;
         const double q0 = g0[0], q1 = g0[1], q2 = g0[2];
         const double qq[3] = {q0, q1, q2};
@@ -2633,10 +2766,15 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
               const double sj = __builtin_fma(a2, xu[q][2], __builtin_fma(a1, xu[q][1], a0 * xu[q][0]));
               if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100);
               const uint32_t hi = (uint32_t)__double2hiint(sj), lo = (uint32_t)__double2loint(sj);
-              const uint32_t tmp = hi - DMX_LOG2_OFF_HI;
+              const uint32_t tmp = hi - (kind32(b0 + q) ? DMX_LOG32_OFF_HI : DMX_LOG2_OFF_HI);
               const uint32_t k20 = tmp & 0xFFF00000u;
               zq[cur][q] = __hiloint2double((int)(hi - k20), (int)lo);
               kq[cur][q] = (int32_t)k20;
+              if (kind32(b0 + q)) {
+                const char* e32 = reinterpret_cast<const char*>(s_log32) + ((tmp >> 12) & 0xF8u);
+                tq[cur][q].x = lds_read_f64(reinterpret_cast<const double*>(e32));
+                tq[cur][q].y = lds_read_f64(reinterpret_cast<const double*>(e32 + 256));
+              } else
               tq[cur][q] = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(s_log) + ((tmp >> 8) & 0xFF0u));
             }
             if (st + 1 < NST) {
@@ -2650,10 +2788,22 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 #pragma unroll
             for (int q = 0; q < NB; ++q) if (b0 + q < NE) {         // dmx_log2_lite, second half, and the ordered add
               const double r = __builtin_fma(zq[prv][q], tq[prv][q].x, -1.0);
+#if DMX_SYM_TIMING & 2
+              const double w = tq[prv][q].y + lds_read_f64(reinterpret_cast<const double*>(reinterpret_cast<const char*>(s_log) + 1024 + (kq[prv][q] >> 17)));
+#else
               const double kd = (double)kq[prv][q];
               const double w = __builtin_fma(kd, 0x1.62e42fefa39efp-1 * 0x1p-20, tq[prv][q].y);
-              double qq = __builtin_fma(r, lk.m14, lk.c13);
+#endif
+              double qq;
+              if (kind32(b0 + q)) {
+                qq = __builtin_fma(r, lk32.a5, lk32.a4);
+                qq = __builtin_fma(r, qq, lk32.a3);
+                qq = __builtin_fma(r, qq, lk32.a2);
+              } else
+              qq = __builtin_fma(r, lk.m14, lk.c13);
+#if !(DMX_SYM_TIMING & 1)
               qq = __builtin_fma(r, qq, -0.5);
+#endif
               qq = __builtin_fma(r, qq, 1.0);
               acc[b0 + q] += __builtin_fma(r, qq, w);
             }
@@ -2675,7 +2825,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
                          x2 = DMX_LDS_NOMERGE ? lds_read_f64(&up[2 * VUS + ek[i]]) : up[2 * VUS + ek[i]];
             const double sj = __builtin_fma(a2, x2, __builtin_fma(a1, x1, a0 * x0));
             if (CHK) ok &= __builtin_amdgcn_class(sj, 0x100);
-            acc[i] += dmx_log2_fastmode(sj, s_log, lk);
+            acc[i] += kind32(i) ? dmx_log2_lite32(sj, s_log32, lk32) : dmx_log2_fastmode(sj, s_log, lk);
           }
         }
       }
@@ -5116,7 +5266,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
                                                       const double* __restrict__ tabs, const double* __restrict__ alpha,
                                                       int32_t V, dmx_cell_summary* __restrict__ summ,
                                                       const int64_t* __restrict__ blk, int32_t blk_i, int32_t nblk, double* __restrict__ park,
-                                                      const double* __restrict__ cseed) {
+                                                      const double* __restrict__ cseed, const double* __restrict__ cfin) {
   // blk != nullptr (round 4): this launch covers SNP block blk_i of nblk only — sparse pileups whose genotype matrix does not fit an XCD's L2
   // gather two pieces of a V*12-byte row per pair, and walking the SNP axis block by block (launch_certify; the table is k_snp_blocks',
   // shared with sparse K1) keeps the rows a launch touches L2-resident.  Between launches a barcode's state — the four chains, the open
@@ -5212,7 +5362,16 @@ __global__ __launch_bounds__(kThreads, MINW) void k_certify(PileupView pv, int n
       double v[9];                                 // pG[1][l][m] of the pair (five: v[l + m])
       if constexpr (five) {
         double v5[5];
-        certify_pair_values<5>(pv, cnt, off, rd4, s_tab, wA5, wR5, n1, v5, cseed);
+        // round 6: pairs of up to three tabled reads take their FINAL values from k_build_certify_finals' table (both lanes of a pair the same entry);
+        // the walk below runs only in tiles with a deeper pair (wave-uniform branch)
+        const int32_t fi = cfin ? certify_final_index(cnt, rd4) : -1;
+        if (!__any(fi < 0)) {
+          const double* fp = cfin + (size_t)fi * kCFinStride;
+          const double2 a = *reinterpret_cast<const double2*>(fp), b = *reinterpret_cast<const double2*>(fp + 2);
+          v5[0] = a.x; v5[1] = a.y; v5[2] = b.x; v5[3] = b.y; v5[4] = fp[4];
+        } else {                                   // (a tile with a deeper pair: the walk for ALL its lanes, as before)
+          certify_pair_values<5>(pv, cnt, off, rd4, s_tab, wA5, wR5, n1, v5, cseed);
+        }
 #pragma unroll
         for (int l = 0; l < 3; ++l)
 #pragma unroll
@@ -5344,6 +5503,7 @@ struct dmx_engine {
   bool off32 = false;                                     // every absolute pair index and read offset of the staged pileup fits 32 bits
   bool reads_padded = false;                              // four bytes past the staged pileup's last read byte are readable (k_singlet_can's unconditional 4-byte loads)
   double* d_cseed = nullptr; bool cseed_valid = false;   // certify_pair_values' seeds (k_build_certify_seeds; a function of the phred tables)
+  double* d_cfin = nullptr; bool cfin_valid = false;     // ... and its final values for pairs of up to three tabled reads (k_build_certify_finals, round 6)
   double* d_park = nullptr; size_t park_cap = 0;   // k_certify's per-barcode state between the launches of its SNP-blocked walk
   int64_t* d_blk = nullptr; size_t blk_cap = 0; int32_t blk_shift = 0, blk_n = 0;   // k_snp_blocks table of the staged (sparse) pileup; blk_n = 0: none
   bool geno_safe = false;                                            // every genotype row finite, non-negative, max >= 2^-400 (k_check_geno)
@@ -5472,6 +5632,7 @@ extern "C" int dmx_engine_create(const dmx_engine_config* cfg, dmx_engine** out)
   HIP_TRY(hipMemcpy(e->d_lut + kLut, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabLogLo, dmx_log_table_lo_host, sizeof(double) * 128, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabLog2, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(e->d_lut + kTabLog32, dmx_log32_table_host, sizeof(double) * DMX_LOG32_TABLE_DOUBLES, hipMemcpyHostToDevice));
   e->certify = !(cfg->flags & DMX_ENGINE_NO_CERTIFY) && !e->knob("DMX_NO_CERTIFY") && dmx::libm_log_within_brackets();
   HIP_TRY(hipMalloc((void**)&e->d_alpha, sizeof(double) * 64));
   HIP_TRY(hipMemcpy(e->d_alpha, e->alpha.data(), sizeof(double) * e->A, hipMemcpyHostToDevice));
@@ -5500,6 +5661,7 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_blk) (void)hipFree(e->d_blk);
   if (e->d_park) (void)hipFree(e->d_park);
   if (e->d_cseed) (void)hipFree(e->d_cseed);
+  if (e->d_cfin) (void)hipFree(e->d_cfin);
   if (e->d_ltab) (void)hipFree(e->d_ltab);
   if (e->d_oth) (void)hipFree(e->d_oth);
   if (e->d_snprec) (void)hipFree(e->d_snprec);
@@ -5539,7 +5701,7 @@ extern "C" int dmx_engine_set_phred_tables(dmx_engine* e, const double mat[256],
   const dmx::TripleTables& tt = dmx::build_triple_tables(lut, *pt);
   HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair, tt.third.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(e->d_lut + kTabK1 + 2 * kPair + kTriple, tt.final3.data(), sizeof(double) * kTriple, hipMemcpyHostToDevice));
-  e->ltab_valid = false; e->cseed_valid = false; e->ctab_valid = false;   // (the canonical-class log tables and k_certify's seeds are functions of these tables)
+  e->ltab_valid = false; e->cseed_valid = false; e->cfin_valid = false; e->ctab_valid = false;   // (the canonical-class log tables and k_certify's seeds are functions of these tables)
   return DMX_OK;
 }
 
@@ -5973,6 +6135,23 @@ namespace {
 #define DMX_LAUNCH(SLOT, K, ...) do { e->SLOT = reinterpret_cast<const void*>(&K); hipLaunchKernelGGL(K, __VA_ARGS__); } while (0)
 #define DMX_LAUNCH_IF(COND, SLOT, K, ...) do { if (COND) e->SLOT = reinterpret_cast<const void*>(&K); hipLaunchKernelGGL(K, __VA_ARGS__); } while (0)
 
+// k_build_certify_finals' table (round 6), for the kernels that run phase 1 of the default grid {0, 0.5}: k_doublet_sym and k_certify<FIVE>.  Only shallow
+// pileups take it — at most 1.6 stored reads per covered pair on average: a tile skips its read loop only when NONE of its 16 / 32 pairs is deeper than
+// three reads (1.25 reads per pair: 93 % of the tiles; 2 reads per pair, cfg5: 7 %, and there the look-ups into a table beyond the L2 cost more than
+// they save — measured, k_certify 7.57 -> 8.23 ms).  *out stays NULL when the pileup is deeper.
+int ensure_finals(dmx_engine* e, const double** out) {
+  *out = nullptr;
+  if ((double)e->R > 1.6 * (double)std::max<int64_t>(e->P, 1) && !e->knob("DMX_FINALS_ANY_DEPTH")) return DMX_OK;
+  if (!e->cfin_valid) {
+    if (!e->d_cfin) HIP_TRY(hipMalloc((void**)&e->d_cfin, sizeof(double) * kCFinStride * (size_t)kCFinN));
+    hipLaunchKernelGGL(k_build_certify_finals, dim3((unsigned)((kCFinN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, e->d_cfin);
+    HIP_TRY(hipGetLastError());
+    e->cfin_valid = true;
+  }
+  *out = e->d_cfin;
+  return DMX_OK;
+}
+
 int launch_singlet(dmx_engine* e) {
   const int32_t B = e->pv.B, V = e->V;
   // cells per wavefront: more cells amortise the ordered sums, fewer keep >= ~4 wavefronts per SIMD in flight (1024 SIMDs)
@@ -6329,19 +6508,25 @@ int launch_doublet(dmx_engine* e) {
   const size_t cell_bytes = (size_t)32 * 18 * 8 + (size_t)32 * GS * 4 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
   HIP_TRY(hipMemsetAsync(e->d_flag - kFlagHead, 0, (size_t)B + kFlagHead, e->stream));
   const dim3 block(kThreads);
+  // k_doublet_a2's phase 1 on the default grid {0, 0.5}: finished values of pairs of up to three tabled reads from the table (round 6; shallow pileups only,
+  // ensure_finals; DMX_A2_NO_FINALS=1: the read loop everywhere) — other grids have other mixing weights and keep the loop
+  const double* pfin_a2 = nullptr;
+  if (A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && !e->knob("DMX_A2_NO_FINALS")) if (int rc = ensure_finals(e, &pfin_a2)) return rc;
 #define DMX_K2A(TPC, NK)                                                                                             \
   do {                                                                                                                \
     if (e->geno_safe)                                                                                                 \
       DMX_LAUNCH(k2_fn, (k_doublet_a2<TPC, NK, 1, false, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                          cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,    \
-                         e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);                               \
+                         e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);                               \
     else                                                                                                              \
   DMX_LAUNCH(k2_fn, (k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
-                     e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);                                   \
+                     e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);                                   \
   } while (0)
   if (fast_soft && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && (V <= 128 || sym_wide) && !e->knob("DMX_NO_SYM")) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
+    const double* pfin = nullptr;                 // phase 1's finished values of pairs of up to three tabled reads (DMX_SYM_NO_FINALS=1: the read loop everywhere)
+    if (!e->knob("DMX_SYM_NO_FINALS")) if (int rc = ensure_finals(e, &pfin)) return rc;
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do { e->k2_sym = true;                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
@@ -6356,11 +6541,11 @@ int launch_doublet(dmx_engine* e) {
     if (e->geno_safe)                                                                                                  \
       DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX, 3, 0, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                          block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,         \
-                         e->d_grid, e->d_l00, e->d_flag);                                                              \
+                         e->d_grid, e->d_l00, e->d_flag, pfin);                                                              \
     else                                                                                                               \
     DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
-                       e->d_grid, e->d_l00, e->d_flag);                                                                \
+                       e->d_grid, e->d_l00, e->d_flag, pfin);                                                                \
   } while (0)
 #define DMX_K2SV(TPC, VMAX, SUB, FIX, MINW)                                                                            \
   do { e->k2_sym = true;                                                                                                                \
@@ -6371,7 +6556,7 @@ int launch_doublet(dmx_engine* e) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
     DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
-                       e->d_grid, e->d_l00, e->d_flag);                                                                \
+                       e->d_grid, e->d_l00, e->d_flag, pfin);                                                                \
   } while (0)
     const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0) |
                               (e->knob("DMX_SYM_ABLATE_P2") ? (1 << 18) : 0) | (e->knob("DMX_SYM_ABLATE_U") ? (1 << 19) : 0) |
@@ -6406,10 +6591,10 @@ int launch_doublet(dmx_engine* e) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
     if (e->geno_safe)                                                                                                  \
       DMX_LAUNCH(k2_fn, (k_doublet_sym<256, VMAX, SUB, FIX, 3, 9, false>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
-                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);      \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag, pfin);      \
     else                                                                                                               \
     DMX_LAUNCH(k2_fn, (k_doublet_sym<256, VMAX, SUB, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
-                       e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag);        \
+                       e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag, pfin);        \
   } while (0)
       if (V <= 96) DMX_K2SS(96, 8, false); else if (V == 128) DMX_K2SS(128, 8, true); else if (V < 128) DMX_K2SS(128, 8, false);
       else if (V <= 192) DMX_K2SS(192, 4, false); else if (V <= 256) DMX_K2SS(256, 4, false);        // (sub-tiles of 4 pairs: 40 / 53 KB of LDS per workgroup)
@@ -6449,13 +6634,13 @@ int launch_doublet(dmx_engine* e) {
       const size_t cbd = (size_t)32 * 18 * 8 + (size_t)32 * GS * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
       if (e->geno_safe)
         DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4, true, false>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
-                           e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
+                           e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);
       else
       DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4, true>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
-                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
+                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);
     } else if (!e->knob("DMX_A2_MINW1"))
       DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4>), dim3((unsigned)B, slabs_of(256, 4)), block, cell_bytes, e->stream, e->pv, e->nrd_width, e->d_g,
-                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);
+                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);
     else DMX_K2A(256, 4);
   }
   else if (V <= 128) DMX_K2A(256, 16);            // <= 55 KB of LDS
@@ -6477,12 +6662,12 @@ int launch_doublet(dmx_engine* e) {
       if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2<256, 16, 1, false, false, TPP>),  \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
       DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 16, 1, false, false, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,  \
-                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);  \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);  \
     } else {                                                                                                          \
       if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2<256, 16, 1, false, true, TPP>),   \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
       DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 16, 1, false, true, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,   \
-                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag);  \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);  \
     }                                                                                                                 \
   } while (0)
     if (tp == 32) DMX_K2AW(32); else if (tp == 16) DMX_K2AW(16); else DMX_K2AW(8);
@@ -6514,7 +6699,7 @@ int launch_certify(dmx_engine* e) {
 #define DMX_K3B(MINW_, FIVE_, DENSE_)                                                                                  \
   for (int bi = 0; bi < n_launch; ++bi)                                                                                 \
     DMX_LAUNCH(k3b_fn, (k_certify<MINW_, FIVE_, DENSE_>), dim3((unsigned)((B + 3) / 4)), dim3(kThreads), 0, e->stream, e->pv, e->nrd_width, e->d_g, gT, \
-                       e->d_lut, e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park, cseed)
+                       e->d_lut, e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park, cseed, cfin)
   const bool five = e->alpha[0] == 0.0;
   const double* cseed = nullptr;                  // the first one or two reads of a pair from a table (DMX_CERTIFY_NO_SEEDS=1: the whole loop)
   if (five && !e->knob("DMX_CERTIFY_NO_SEEDS")) {
@@ -6526,6 +6711,8 @@ int launch_certify(dmx_engine* e) {
     }
     cseed = e->d_cseed;
   }
+  const double* cfin = nullptr;                   // final values of pairs of up to three tabled reads (DMX_CERTIFY_NO_FINALS=1 / DMX_CERTIFY_NO_SEEDS=1: none)
+  if (cseed && !e->knob("DMX_CERTIFY_NO_FINALS")) if (int rc = ensure_finals(e, &cfin)) return rc;
   if (e->knob("DMX_CERTIFY_MINW3")) { if (gT) DMX_K3B(3, false, true); else DMX_K3B(3, false, false); }      // kernel experiments only
   else if (gT) { if (five) DMX_K3B(4, true, true); else DMX_K3B(4, false, true); }
   else { if (five) DMX_K3B(4, true, false); else DMX_K3B(4, false, false); }
@@ -6806,13 +6993,14 @@ extern "C" int dmx_engine_kernel_names(dmx_engine* e, dmx_kernel_names* out) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-template <int WHICH>   // 0: dmx_log (128 bins; the singlet kernels), 2: dmx_log2 (256 bins; the doublet kernels)
+template <int WHICH>   // 0: dmx_log (128 bins; the singlet kernels), 2: dmx_log2 (256 bins; the doublet kernels), 3: dmx_log2_lite, 4: dmx_log2_lite32 (FAST)
 __global__ void k_debug_log(const double* __restrict__ x, double* __restrict__ y, int64_t n, const double* __restrict__ tab) {
   __shared__ double s_log[DMX_LOG2_TABLE_DOUBLES];
-  for (int i = threadIdx.x; i < (WHICH >= 2 ? DMX_LOG2_TABLE_DOUBLES : DMX_LOG_TABLE_DOUBLES); i += blockDim.x) s_log[i] = tab[i];
+  for (int i = threadIdx.x; i < (WHICH == 4 ? DMX_LOG32_TABLE_DOUBLES : WHICH >= 2 ? DMX_LOG2_TABLE_DOUBLES : DMX_LOG_TABLE_DOUBLES); i += blockDim.x) s_log[i] = tab[i];
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double v = WHICH == 3 ? dmx_log2_lite(x[i], s_log, dmx_log_pins()) : (WHICH == 2 ? dmx_log2_fast(x[i], s_log) : dmx_log_fast(x[i], s_log));
+    const double v = WHICH == 4 ? dmx_log2_lite32(x[i], s_log, dmx_log32_pins())
+                   : WHICH == 3 ? dmx_log2_lite(x[i], s_log, dmx_log_pins()) : (WHICH == 2 ? dmx_log2_fast(x[i], s_log) : dmx_log_fast(x[i], s_log));
     y[i] = dmx_log_is_special(x[i]) ? log(x[i]) : v;
   }
 }
@@ -6909,9 +7097,11 @@ int debug_device_log(int which, const double* x, double* y, int64_t n, int32_t d
   HIP_TRY(hipMalloc((void**)&dy, std::max<size_t>(sizeof(double) * (size_t)n, 16)));
   HIP_TRY(hipMalloc((void**)&dt, sizeof(double) * DMX_LOG2_TABLE_DOUBLES));
   HIP_TRY(hipMemcpy(dx, x, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
-  if (which >= 2) HIP_TRY(hipMemcpy(dt, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  if (which == 4) HIP_TRY(hipMemcpy(dt, dmx_log32_table_host, sizeof(double) * DMX_LOG32_TABLE_DOUBLES, hipMemcpyHostToDevice));
+  else if (which >= 2) HIP_TRY(hipMemcpy(dt, dmx_log2_table_host, sizeof(double) * DMX_LOG2_TABLE_DOUBLES, hipMemcpyHostToDevice));
   else HIP_TRY(hipMemcpy(dt, dmx_log_table_host, sizeof(double) * DMX_LOG_TABLE_DOUBLES, hipMemcpyHostToDevice));
-  if (which == 3) hipLaunchKernelGGL((k_debug_log<3>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
+  if (which == 4) hipLaunchKernelGGL((k_debug_log<4>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
+  else if (which == 3) hipLaunchKernelGGL((k_debug_log<3>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
   else if (which == 2) hipLaunchKernelGGL((k_debug_log<2>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
   else hipLaunchKernelGGL((k_debug_log<0>), dim3(1024), dim3(256), 0, 0, dx, dy, n, dt);
   HIP_TRY(hipGetLastError());
@@ -6923,6 +7113,7 @@ int debug_device_log(int which, const double* x, double* y, int64_t n, int32_t d
 extern "C" int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(0, x, y, n, device); }
 extern "C" int dmx_debug_device_log2(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(2, x, y, n, device); }
 extern "C" int dmx_debug_device_log2_lite(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(3, x, y, n, device); }
+extern "C" int dmx_debug_device_log2_lite32(const double* x, double* y, int64_t n, int32_t device) { return debug_device_log(4, x, y, n, device); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // (ABI 8) `.pair` rows formatted on the device (csrc/dmx_format.hpp)

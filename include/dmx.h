@@ -310,6 +310,7 @@ int dmx_resolve_tie_order(dmx_cell_summary* summary, int64_t n);
  * to show the device function performs exactly the IEEE operation sequence whose accuracy is measured on the host. */
 int dmx_debug_device_log(const double* x, double* y, int64_t n, int32_t device);
 int dmx_debug_device_log2(const double* x, double* y, int64_t n, int32_t device);   /* dmx_log2: the doublet kernels' log (256 bins, ABI 6) */
+int dmx_debug_device_log2_lite32(const double* x, double* y, int64_t n, int32_t device); /* (ABI 8, appended in round 6) FAST's second phase-2 log: split 32-bin table (conflict-free LDS reads), degree-5 near-minimax tail — 8 FP64 instructions, |error| <= 1.2e-15 absolute (csrc/dmx_log.hpp) */
 int dmx_debug_device_log2_lite(const double* x, double* y, int64_t n, int32_t device);   /* (ABI 7) DMX_MODE_FAST's phase-2 log: dmx_log2's table, series cut after r^4/4 — 6 FP64 instructions, |error| <= 6e-15 absolute, unbiased (csrc/dmx_log.hpp) */
 /* Diagnostics: the device's log() ceiling, measured by a register-resident microkernel (no memory traffic): which = 0 the
  * kernels' dmx_log, which = 1 ocml's log().  bench.py reports both next to the kernels' achieved log rate. */

@@ -19,11 +19,12 @@ def emul(tmp_path_factory):
     L.dmx_log_emul_n.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
     L.dmx_log_lite_emul_n.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
     L.dmx_log2_emul_n.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
+    L.dmx_log2_lite32_emul_n.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
 
-    def f(x, lite=False, k2=False):
+    def f(x, lite=False, k2=False, lite32=False):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.empty_like(x)
-        (L.dmx_log2_emul_n if k2 else (L.dmx_log_lite_emul_n if lite else L.dmx_log_emul_n))(x.ctypes.data, y.ctypes.data, len(x))
+        (L.dmx_log2_lite32_emul_n if lite32 else L.dmx_log2_emul_n if k2 else (L.dmx_log_lite_emul_n if lite else L.dmx_log_emul_n))(x.ctypes.data, y.ctypes.data, len(x))
         return y
     return f
 
@@ -154,6 +155,53 @@ def test_special_values(emul):
         y = emul(np.array([0.0, -1.0, np.inf, np.nan, 5e-324, 2.2250738585072014e-308]))
     assert y[0] == -np.inf and np.isnan(y[1]) and y[2] == np.inf and np.isnan(y[3])
     assert y[4] == np.log(5e-324) and abs(y[5] - np.log(2.2250738585072014e-308)) <= np.spacing(708.0)
+
+
+def lite32_edge_points():
+    """Both ends of every bin of dmx_log2_lite32's reduction (z = OFF32 + i 2^47 mantissa units, OFF32 = 0x3FE64000...), 2^-40 inside, and the mid-points,
+    at binary exponents 0, -1, -7, -20, -24: where |r| is largest and keeps one sign — the clustered-argument worst case of ADVICE r5."""
+    off32 = 0x3FE6400000000000
+    pts = []
+    for i in range(32):
+        lo, hi = off32 + (i << 47), off32 + ((i + 1) << 47)
+        pts += [lo + (1 << 12), hi - (1 << 12), (lo + hi) // 2, lo, hi - 1]
+    z = np.array(pts, dtype=np.uint64).view(np.float64)
+    return np.concatenate([np.ldexp(z, k) for k in (0, -1, -7, -20, -24)])
+
+
+def test_lite32_log_accuracy_bound(emul):
+    """dmx_log2_lite32 (FAST k_doublet_sym's second log, round 6): the host emulation of the device's operation sequence against mpmath.  Budget stated in
+    csrc/dmx_log.hpp: the polynomial is within 8.0e-16 of log1p over the table's r range; with the roundings of r, w and the final fma every value stays
+    within 1.2e-15 + 1 ulp of the result ABSOLUTE — tighter than dmx_log2_lite's 6.9e-15, so kLiteLogMaxPairs covers a mix of the two."""
+    import mpmath
+    mpmath.mp.prec = 120
+    rng = np.random.default_rng(41)
+    x = np.concatenate([lite32_edge_points(), rng.uniform(1e-6, 1.0, 20000), np.exp(rng.uniform(np.log(1e-30), 0.0, 10000)), rng.uniform(0.9, 1.1, 10000)])
+    y = emul(x, lite32=True)
+    worst = 0.0
+    for xi, yi in zip(x, y):
+        t = mpmath.log(mpmath.mpf(float(xi)))
+        worst = max(worst, float(abs(mpmath.mpf(float(yi)) - t)) - float(np.spacing(abs(float(t)))))
+    assert worst < 1.2e-15, worst
+    # next to no bias over the range likelihood terms live in
+    lik = rng.uniform(1e-6, 1.0, 400000)
+    err = emul(lik, lite32=True) - np.log(lik)
+    assert abs(err.mean()) < 2e-16, err.mean()
+
+
+@pytest.mark.gpu
+def test_device_lite32_log_is_the_emulated_arithmetic(emul):
+    """The device's dmx_log2_lite32 executes the emulated operation sequence: same bits on 3e5 points incl. every bin edge."""
+    from demuxlet_amd import build, capi
+    build.build()
+    L = capi.load()
+    rng = np.random.default_rng(299)
+    x = np.concatenate([sample_points_k2(rng, 300000), lite32_edge_points()])
+    x = x[np.isfinite(x) & (x >= 2.2250738585072014e-308)]
+    y = np.empty_like(x)
+    capi.check(L.dmx_debug_device_log2_lite32(x.ctypes.data, y.ctypes.data, len(x), 0))
+    h = emul(x, lite32=True)
+    assert np.array_equal(y, h), f"{np.sum(y != h)} of {len(x)} differ"
 
 
 @pytest.mark.gpu

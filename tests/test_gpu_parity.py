@@ -504,15 +504,22 @@ def test_certify_seed_tables_leave_every_record_unchanged(eng, V, field, dense):
     z = np.zeros(B, dtype=np.int32)
     pl = eng.HostPileup(B, S, cpo, cro, pair_snp, nrd, reads, z, z, z)
     os.environ.pop("DMX_CERTIFY_NO_SEEDS", None)
-    a = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+    os.environ.pop("DMX_CERTIFY_NO_FINALS", None)
+    a = run_engine(eng, pl, g, (0.0, 0.5), 0.5)       # round 6: final values of 0..3-read pairs from k_build_certify_finals' table, seeds for the deeper ones
     os.environ["DMX_CERTIFY_NO_SEEDS"] = "1"
     try:
-        b = run_engine(eng, pl, g, (0.0, 0.5), 0.5)
+        b = run_engine(eng, pl, g, (0.0, 0.5), 0.5)   # no table at all
     finally:
         os.environ.pop("DMX_CERTIFY_NO_SEEDS", None)
+    os.environ["DMX_CERTIFY_NO_FINALS"] = "1"
+    try:
+        c = run_engine(eng, pl, g, (0.0, 0.5), 0.5)   # seeds only (rounds 4-5)
+    finally:
+        os.environ.pop("DMX_CERTIFY_NO_FINALS", None)
     from demuxlet_amd import capi
     assert ((a["summ"]["flags"] & (capi.DMX_CELL_ORDER_CERTIFIED | capi.DMX_CELL_ORDER_RESOLVABLE)) != 0).sum() > B // 4
     assert a["summ"].tobytes() == b["summ"].tobytes()
+    assert c["summ"].tobytes() == b["summ"].tobytes()
 
 
 def test_all_base_qualities_and_depths(eng, oracle):
@@ -1289,3 +1296,78 @@ def test_counted_row_wait_equals_waiting_for_everything(eng, monkeypatch, V):
     for env in ({}, {}, {"DMX_SYM_WAIT_ALL": "1"}, {"DMX_SYM_NO_DMA": "1"}, {"DMX_SYM_NO_PIPE": "1"}):
         got = run(env)
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
+
+
+def _mixed_depth_problem(eng, V, dense):
+    """Soft-field genotypes and a pileup with pairs of 0..6 reads (and a few beyond kSafeReads), base qualities over the whole range, and alternating 64-pair
+    blocks without a pair deeper than three reads (tiles that skip the phase-1 read loop) — the inputs of the final-value-table tests."""
+    from demuxlet_amd import synth
+    rng = np.random.default_rng(9100 + V + (1 if dense else 0))
+    S, B = 700, 37
+    raw = synth.make_raw_genotypes(rng, S, V)
+    g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+    if dense:
+        npair = np.full(B, S); pair_snp = None
+    else:
+        cov = rng.random((B, S)) < 0.3
+        npair = cov.sum(axis=1)
+        pair_snp = np.concatenate([np.nonzero(cov[c])[0] for c in range(B)]).astype(np.int32)
+    P = int(npair.sum())
+    nrd = rng.choice(np.arange(7), size=P, p=[0.05, 0.55, 0.25, 0.1, 0.02, 0.02, 0.01]).astype(np.uint8)
+    blocks = (np.arange(P) // 64) % 2 == 0
+    nrd[blocks & (nrd > 3)] = 1
+    nrd[rng.random(P) < 0.001] = 20                                       # beyond kSafeReads
+    nr = int(nrd.sum())
+    bq = np.where(rng.random(nr) < 0.85, rng.integers(2, 45, size=nr), rng.integers(0, 128, size=nr)).astype(np.uint8)
+    reads = bq | (rng.integers(0, 2, size=nr).astype(np.uint8) << 7)
+    cpo = np.concatenate([[0], np.cumsum(npair)]).astype(np.int64)
+    cro = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(B), npair), weights=nrd, minlength=B))]).astype(np.int64)
+    z = np.zeros(B, dtype=np.int32)
+    return g, eng.HostPileup(B, S, cpo, cro, pair_snp, nrd, reads, z, z, z)
+
+
+def _grid_with_env(eng, monkeypatch, g, pl, V, mode, env, kernel_prefix, alphas=(0.0, 0.5)):
+    monkeypatch.setenv("DMX_EXPERIMENTS", "1")
+    for k in ("DMX_SYM_NO_FINALS", "DMX_A2_NO_FINALS", "DMX_FINALS_ANY_DEPTH"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = eng.Engine(V, alphas, 0.5, mode=mode)
+    e.set_genotypes(g); e.set_pileup(pl); e.run(); e.sync()
+    assert e.kernel_names()["doublet"].startswith(kernel_prefix), e.kernel_names()
+    grid, l00, _ = e.get_doublet()
+    e.close()
+    return grid, l00
+
+
+@pytest.mark.parametrize("V,dense", [(8, True), (12, False), (16, False), (16, True), (20, True), (32, True), (32, False), (40, False), (64, True), (70, False)])
+def test_phase1_final_tables_leave_the_fast_grid_unchanged(eng, monkeypatch, V, dense):
+    """Round 6: k_doublet_sym's phase 1 takes the FINISHED values of pairs of up to three tabled reads (no read, one read, two of base quality < 64, three of
+    base quality < 48) from k_build_certify_finals' table and runs its read loop only in tiles with a deeper pair.  Same operations on the same operands:
+    the grid and llks00 must equal the table-free kernel's (DMX_SYM_NO_FINALS=1) bit for bit — pairs of 0..6 reads and beyond kSafeReads (the plain division),
+    base qualities over the whole range, tiles with and without a deep pair, every panel form of the kernel (4 / 2 / 1 barcodes per wavefront, 256-thread
+    workgroups, entry slabs).  DMX_FINALS_ANY_DEPTH=1 lifts the launch rule (<= 1.6 reads per pair) so that deeper pileups exercise the table too."""
+    from demuxlet_amd import capi
+    g, pl = _mixed_depth_problem(eng, V, dense)
+    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_FAST, {"DMX_SYM_NO_FINALS": "1"}, "k_doublet_sym<")
+    for env in ({"DMX_FINALS_ANY_DEPTH": "1"}, {}):
+        got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_FAST, env, "k_doublet_sym<")
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
+    assert np.isfinite(base[0]).all()
+
+
+@pytest.mark.parametrize("V,dense", [(5, True), (8, False), (16, True), (24, False), (32, True), (40, False), (130, True)])
+def test_phase1_final_tables_leave_the_strict_grid_unchanged(eng, monkeypatch, V, dense):
+    """The same table in STRICT's k_doublet_a2 (default grid {0, 0.5} only: the table holds that grid's mixing weights): alpha 0.5's five distinct values and
+    alpha 0's three expand to the nine per alpha the read loop computes — entries of equal weight go through identical operations.  Bit for bit against
+    DMX_A2_NO_FINALS=1 on every form of the kernel (64-thread cells, 256-thread cells with binary64 rows, j-slabs, the wide-panel tiles); another grid keeps the loop."""
+    from demuxlet_amd import capi
+    g, pl = _mixed_depth_problem(eng, V, dense)
+    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_FINALS": "1"}, "k_doublet_a2<")
+    for env in ({"DMX_FINALS_ANY_DEPTH": "1"}, {}):
+        got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, env, "k_doublet_a2<")
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
+    if V == 16:                                  # a grid the table does not describe: the loop runs, the switch changes nothing
+        a = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_FINALS_ANY_DEPTH": "1"}, "k_doublet_a2<", alphas=(0.1, 0.5))
+        b = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_FINALS": "1"}, "k_doublet_a2<", alphas=(0.1, 0.5))
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

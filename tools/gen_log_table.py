@@ -70,6 +70,48 @@ def build_rows(off, n_bins, shift):
     return rows, worst, rmax, centre_bin
 
 
+def build_rows32():
+    """dmx_log2_lite32 (round 6, FAST's k_doublet_sym only): 32 bins of 2^47 mantissa units over [OFF32, 2 OFF32), OFF32 = 0x3FE64000_00000000;
+    bin 19 = [1-2^-7, 1+2^-6) has c = 1.  The table is SPLIT — rc[32] then logc[32], 256 bytes each: a wavefront's ds_read_b64 of either array touches every LDS
+    bank at most once (32 x 8 B = the 64 banks), whatever bins its lanes ask for: no bank conflicts, where the 256-bin table's 16-byte gathers cost ~6 extra
+    LDS cycles per wavefront and evaluation (profiles/pmc_cfg3_fast.json).  FAST rounds k ln 2 + log c once, so logc is plain RN(-log rc), rc = RN(1 / centre).
+    The polynomial is a weighted least-squares (Lawson) near-minimax fit of log1p(r) = r (1 - r/2 + a2 r^2 + ... + a5 r^5) over the table's r range."""
+    off, nb, sh = 0x3FE6400000000000, 32, 47
+    rc, lc, rmin, rmax, cb = [], [], mp.mpf(0), mp.mpf(0), None
+    for i in range(nb):
+        zlo, zhi = mp.mpf(bits2d(off + (i << sh))), mp.mpf(bits2d(off + ((i + 1) << sh)))
+        if zlo < 1 < zhi:
+            inv, cb = 1.0, i
+        else:
+            inv = float(1 / ((zlo + zhi) / 2))
+        rc.append(inv)
+        lc.append(float(-mp.log(mp.mpf(inv))) if inv != 1.0 else 0.0)
+        rmin, rmax = min(rmin, zlo * mp.mpf(inv) - 1), max(rmax, zhi * mp.mpf(inv) - 1)
+    M, n = 400, 5
+    xs = [(rmin + rmax) / 2 + (rmax - rmin) / 2 * mp.cos(mp.pi * (2 * k + 1) / (2 * M)) for k in range(M)]
+    w = [mp.mpf(1)] * M
+    for _ in range(60):
+        A, b = mp.matrix(M, n - 1), mp.matrix(M, 1)
+        for k, x in enumerate(xs):
+            for c in range(2, n + 1):
+                A[k, c - 2] = w[k] * x ** (c + 1)
+            b[k] = w[k] * (mp.log1p(x) - x + x * x / 2)
+        sol = mp.lu_solve(A.T * A, A.T * b)
+        errs = [abs(x - x * x / 2 + sum(sol[c - 2] * x ** (c + 1) for c in range(2, n + 1)) - mp.log1p(x)) for x in xs]
+        mx = max(errs)
+        w = [w[k] * (errs[k] / mx + mp.mpf("0.05")) for k in range(M)]
+        tot = sum(w)
+        w = [v * M / tot for v in w]
+    coef = [float(v) for v in sol]
+    # the error of the ROUNDED coefficients on a dense grid (exact arithmetic; the evaluation's own roundings come on top: tests/test_dmx_log.py)
+    worst = mp.mpf(0)
+    for k in range(4001):
+        x = rmin + (rmax - rmin) * k / 4000
+        v = x - x * x / 2 + sum(mp.mpf(coef[c - 2]) * x ** (c + 1) for c in range(2, n + 1))
+        worst = max(worst, abs(v - mp.log1p(x)))
+    return rc, lc, coef, float(rmin), float(rmax), cb, float(worst)
+
+
 def main():
     out = Path(__file__).resolve().parents[1] / "demuxlet_amd" / "csrc" / "dmx_log_table.inc"
     two43 = mp.mpf(2) ** 43
@@ -103,6 +145,18 @@ def main():
         f.write("static const double dmx_log2_table_host[512] = {\n")
         for inv, logc in rows2:
             f.write(f"  {inv.hex()}, {logc.hex()},\n")
+        f.write("};\n")
+        rc32, lc32, coef32, rmin32, rmax32, cb32, worst32 = build_rows32()
+        assert cb32 == 19
+        f.write("// dmx_log2_lite32(): 32 bins of 2^47 mantissa units over [OFF32, 2 OFF32), OFF32 = 0x3FE64000_00000000; bin 19 = [1-2^-7, 1+2^-6) has c = 1;\n")
+        f.write("// rc[32] then logc[32] (split: conflict-free 8-byte LDS reads); log1p(r) ~ r (1 - r/2 + A2 r^2 + A3 r^3 + A4 r^4 + A5 r^5)\n")
+        f.write(f"// r in [{rmin32:.6e}, {rmax32:.6e}]; worst |polynomial - log1p| (exact arithmetic) = {worst32:.3e}\n")
+        f.write("#define DMX_LOG32_OFF_HI 0x3FE64000u\n")
+        for c, v in enumerate(coef32):
+            f.write(f"#define DMX_LOG32_A{c + 2} {v.hex()}\n")
+        f.write("static const double dmx_log32_table_host[64] = {\n")
+        for v in rc32 + lc32:
+            f.write(f"  {v.hex()},\n")
         f.write("};\n")
     print(f"wrote {out}: worst logc error {worst:.3e} / {worst2:.3e}, max|r| {rmax:.6e} / {rmax2:.6e}")
 
