@@ -1352,6 +1352,225 @@ __global__ __launch_bounds__(kThreads, (CW == 4 ? (NCH == 2 ? 3 : 4) : 5)) void 
   }
 }
 
+// K1, canonical GT classes, DENSE pileups, up to 8 samples (cfg2): producers / consumer (round 6).  k_singlet_can's lanes are pairs
+// for the table look-up and the llk0 term and then 18 of 64 lanes are chains: per 64-pair tile it spends 32 ordered adds on 18 lanes and 17 LDS
+// instructions on handing the terms from the pair lanes to the chain lanes (9 stores, 8 class look-ups), and the LDS (0.67 busy) binds it with the VALU
+// close behind.  Here a workgroup is SEVEN producer wavefronts — one barcode each, lane = pair: headers, table entry, llk0 term, then ONE 32-byte record
+// {log(GL . row_0), log(GL . row_1), log(GL . row_2), llk0 term} per pair into an LDS ring — and ONE consumer wavefront whose 63 lanes own the 7 x 9
+// chains: chain (barcode b, sample k) adds record[b][pair][class of sample k at the pair's SNP] in ascending SNP order — the doubles k_singlet_can adds,
+// in its order: the same bits.  On a dense pileup the pair's SNP is its index, so a sample's classes are one byte stream shared by all barcodes
+// (clsb[k][snp] = 8 x class: the byte offset inside a record; row 8 = 24: the llk0 chain): the consumer takes 64 of them in four 16-byte loads a tile
+// ahead and a chain step is one v_add_u32_sdwa (record address), one ds_read_b64 and one v_add_f64 — 64 steps per 448 pairs instead of 32 per 64.
+// One workgroup barrier per tile: tile t is consumed from ring half t & 1 while the producers fill the other half with tile t + 1.
+constexpr int kCpB = 7;                          // barcodes (producer wavefronts) per workgroup
+constexpr int kCpThreads = (kCpB + 1) * 64;
+__global__ void k_build_clsb(const uint8_t* __restrict__ ids, int32_t S, int32_t V, uint32_t stride, uint8_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)9 * stride) return;
+  const int k = (int)(i / stride); const int64_t sidx = i % stride;
+  out[i] = k == 8 ? (uint8_t)24 : ((k < V && sidx < S) ? (uint8_t)((ids[sidx * V + k] & 3u) * 8u) : (uint8_t)0);
+}
+#define DMX_CP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")   // LDS traffic done, then the workgroup's barrier (NOT vmcnt: the prefetches stay in flight)
+template <int MINW>
+__global__ __launch_bounds__(kCpThreads, MINW) void k_singlet_canp(PileupView pv, const uint4* __restrict__ snprec, const uint8_t* __restrict__ clsb, uint32_t cls_stride,
+                                                              const double* __restrict__ ctab, const double* __restrict__ tabs,
+                                                              const int32_t* __restrict__ sched, int32_t V,
+                                                              double* __restrict__ llks, double* __restrict__ llk0s, double chi, double clo) {
+  constexpr int T = 64;
+  __shared__ double s_log_tab[DMX_LOG_TABLE_DOUBLES];
+  __shared__ __attribute__((aligned(16))) double s_ct[kCtLds * 6];
+  __shared__ __attribute__((aligned(16))) double s_ring[2][kCpB][T][4];
+  __shared__ uint32_t s_np[kCpB];
+  const double* s_log = s_log_tab;
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  for (int i = t; i < DMX_LOG_TABLE_DOUBLES; i += kCpThreads) s_log_tab[i] = tabs[kLut + i];
+  for (int i = t; i < kCtLds * 6; i += kCpThreads) {
+    const int e = i / 6, f = i % 6;
+    const int b = e == 2 * kCtBq ? 256 : (e >= kCtBq ? (0x80 | (e - kCtBq)) : e);   // the read byte (allele << 7) | bq of code e
+    s_ct[i] = ctab[8 * b + f];
+  }
+  const int slot0 = blockIdx.x * kCpB;
+  if (t < kCpB) s_np[t] = slot0 + t < pv.B ? (uint32_t)(pv.cell_pair_off[sched[slot0 + t] + 1] - pv.cell_pair_off[sched[slot0 + t]]) : 0u;
+  __syncthreads();
+  uint32_t max_np = 0u, min_np = 0xFFFFFFFFu;    // over the workgroup's barcodes (uniform)
+#pragma unroll
+  for (int b = 0; b < kCpB; ++b) { const uint32_t v = s_np[b]; max_np = max(max_np, v); if (slot0 + b < pv.B) min_np = min(min_np, v); }
+  const uint32_t ntiles = (max_np + T - 1) / T;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(3))) v2d_t* LdsD2;
+  typedef const __attribute__((address_space(3))) double* LdsD;
+
+  if (w == kCpB) {
+    // ------------------------------------------------------------------------------------------------ the consumer
+    const int b = lane / 9, kk = lane % 9;
+    const bool valid = lane < kCpB * 9 && slot0 + b < pv.B;
+    const int32_t cell = valid ? sched[slot0 + b] : 0;
+    const uint32_t np_b = valid ? s_np[b] : 0u;
+    const uint8_t* __restrict__ row = clsb + (size_t)kk * cls_stride;
+    const uint32_t ring_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)&s_ring[0][lane < kCpB * 9 ? b : 0][0][0];
+    constexpr uint32_t kHalf = (uint32_t)(sizeof(double) * kCpB * T * 4);
+    double acc = 0.0;
+    uint4 cw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cw[i] = reinterpret_cast<const uint4*>(row)[i];
+    for (uint32_t tile = 0; tile < ntiles; ++tile) {
+      uint4 nw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nw[i] = reinterpret_cast<const uint4*>(row + (size_t)(tile + 1) * T)[i];   // (the table carries one tile of padding)
+      DMX_CP_BARRIER();                            // the producers' tile is in the ring
+      const uint32_t base = ring_a + (tile & 1u) * kHalf;
+      if ((tile + 1) * T <= min_np) {              // whole for every barcode of the workgroup (uniform)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {              // 16 steps at a time: addresses, reads, then the ordered adds
+          const uint32_t w0 = cw[q].x, w1 = cw[q].y, w2 = cw[q].z, w3 = cw[q].w;
+          double v[16];
+          v[0] = *(LdsD)(uintptr_t)(add_byte_of<0>(base, w0) + (q * 16 + 0) * 32);
+          v[1] = *(LdsD)(uintptr_t)(add_byte_of<1>(base, w0) + (q * 16 + 1) * 32);
+          v[2] = *(LdsD)(uintptr_t)(add_byte_of<2>(base, w0) + (q * 16 + 2) * 32);
+          v[3] = *(LdsD)(uintptr_t)(add_byte_of<3>(base, w0) + (q * 16 + 3) * 32);
+          v[4] = *(LdsD)(uintptr_t)(add_byte_of<0>(base, w1) + (q * 16 + 4) * 32);
+          v[5] = *(LdsD)(uintptr_t)(add_byte_of<1>(base, w1) + (q * 16 + 5) * 32);
+          v[6] = *(LdsD)(uintptr_t)(add_byte_of<2>(base, w1) + (q * 16 + 6) * 32);
+          v[7] = *(LdsD)(uintptr_t)(add_byte_of<3>(base, w1) + (q * 16 + 7) * 32);
+          v[8] = *(LdsD)(uintptr_t)(add_byte_of<0>(base, w2) + (q * 16 + 8) * 32);
+          v[9] = *(LdsD)(uintptr_t)(add_byte_of<1>(base, w2) + (q * 16 + 9) * 32);
+          v[10] = *(LdsD)(uintptr_t)(add_byte_of<2>(base, w2) + (q * 16 + 10) * 32);
+          v[11] = *(LdsD)(uintptr_t)(add_byte_of<3>(base, w2) + (q * 16 + 11) * 32);
+          v[12] = *(LdsD)(uintptr_t)(add_byte_of<0>(base, w3) + (q * 16 + 12) * 32);
+          v[13] = *(LdsD)(uintptr_t)(add_byte_of<1>(base, w3) + (q * 16 + 13) * 32);
+          v[14] = *(LdsD)(uintptr_t)(add_byte_of<2>(base, w3) + (q * 16 + 14) * 32);
+          v[15] = *(LdsD)(uintptr_t)(add_byte_of<3>(base, w3) + (q * 16 + 15) * 32);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc += v[i];                          // ascending SNP order: the reference's order (:457-460)
+        }
+      } else {                                     // a barcode ends inside this tile: each chain counts its own pairs
+        const uint32_t done = tile * T;
+        const int cnt = np_b >= done + T ? T : (np_b > done ? (int)(np_b - done) : 0);
+        const uint8_t* rp = row + (size_t)done;
+        for (int i = 0; i < cnt; ++i) acc += *(LdsD)(uintptr_t)(base + (uint32_t)rp[i] + (uint32_t)i * 32u);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cw[i] = nw[i];
+    }
+    if (valid) {
+      if (kk < 8) { if (kk < V) llks[(size_t)cell * V + kk] = acc; }
+      else llk0s[cell] = acc;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- a producer: barcode slot0 + w
+  const bool cell_ok = slot0 + w < pv.B;
+  if (!cell_ok) { for (uint32_t tile = 0; tile < ntiles; ++tile) DMX_CP_BARRIER(); return; }
+  const int32_t cell = sched[slot0 + w];
+  const uint32_t p_beg = (uint32_t)pv.cell_pair_off[cell];                  // (the launcher checked: every offset fits 32 bits)
+  const uint32_t np = s_np[w];
+  uint32_t rd_base = (uint32_t)pv.cell_read_off[cell];
+  const uint8_t* __restrict__ nrd8 = (const uint8_t*)pv.pair_nrd;
+  const uint8_t* __restrict__ reads = pv.reads;
+  const uint4* __restrict__ recA = snprec;
+  const uint4* __restrict__ recB = snprec + pv.S;
+  const uint32_t ct_a = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) double*)s_ct;
+  // stages A - C: k_singlet_can's three-deep pipeline with one barcode per wavefront (T = 64) — tile t + 3's read counts, tile t + 2's scan and leading
+  // read bytes, tile t + 1's table entry and SNP record are in flight while tile t computes
+  struct Raw { uint32_t n; uint32_t snp; };
+  auto stage_a = [&](uint32_t tile) {
+    Raw r;
+    const uint32_t pi = tile * T + lane;
+    const bool v = pi < np;
+    r.n = v ? (uint32_t)nrd8[p_beg + pi] : 0u;
+    r.snp = v ? pi : 0u;                           // dense: the pair's SNP is its index
+    return r;
+  };
+  struct Hdr { uint32_t n, snp, rd4, off; };
+  auto stage_b = [&](const Raw& r) {
+    Hdr h;
+    h.n = r.n; h.snp = r.snp;
+    const uint32_t incl = seg_scan_incl<T>(r.n);
+    h.off = rd_base + (incl - r.n);
+    rd_base += seg_last<T>(incl, lane);
+    uint32_t v;
+    __builtin_memcpy(&v, reads + (r.n ? h.off : 0u), 4);        // (the launcher checked: four bytes past the last read are readable)
+    h.rd4 = v;
+    return h;
+  };
+  struct Seed { double2 a, b, cc; double q0, q1, q2; uint32_t lds; bool fast; };   // lds: byte offset of the entry in the LDS copy, or ~0u
+  auto stage_c = [&](const Hdr& h) {
+    Seed sd;
+    const uint32_t n = h.n, rd4 = h.rd4;
+    sd.fast = true;
+    sd.lds = (n == 0 ? (uint32_t)(2 * kCtBq) : (((rd4 & 0x80u) ? (uint32_t)kCtBq : 0u) + (rd4 & 0x7Fu))) * 48u;
+    if (!(n == 0 || (n == 1 && (rd4 & 0x7Fu) < (uint32_t)kCtBq))) {
+      sd.lds = ~0u;
+      uint32_t idx = rd4 & 0xFFu;
+      idx = n == 2 ? kCt2 + (rd4 & 0xFFFFu) : idx;
+      bool fast = n <= 2;
+      if (n == 3) {
+        const uint32_t q0 = rd4 & 127u, q1 = (rd4 >> 8) & 127u, q2 = (rd4 >> 16) & 127u;
+        if (max(max(q0, q1), q2) < (uint32_t)dmx::kTripleBq) {
+          const uint32_t c0 = ((rd4 & 0x80u) ? (uint32_t)dmx::kTripleBq : 0u) + q0, c1 = ((rd4 & 0x8000u) ? (uint32_t)dmx::kTripleBq : 0u) + q1,
+                         c2 = ((rd4 & 0x800000u) ? (uint32_t)dmx::kTripleBq : 0u) + q2;
+          idx = kCt3 + __umul24(__umul24(c0, (uint32_t)dmx::kTripleCodes) + c1, (uint32_t)dmx::kTripleCodes) + c2;
+          fast = true;
+        }
+      }
+      sd.fast = fast;
+      const double2* e = reinterpret_cast<const double2*>(ctab + 8u * idx);
+      sd.a = e[0]; sd.b = e[1]; sd.cc = e[2];
+    }
+    const uint4 r0 = recA[h.snp], r1 = recB[h.snp];
+    sd.q0 = __hiloint2double((int)r0.y, (int)r0.x); sd.q1 = __hiloint2double((int)r0.w, (int)r0.z);
+    sd.q2 = __hiloint2double((int)r1.y, (int)r1.x);
+    return sd;
+  };
+  // stage D: one tile -> the ring.  Lanes beyond the barcode's last pair carry n = 0, SNP 0 (stage A): they compute like any other lane, into records
+  // the chains never reach.
+  auto compute = [&](const Hdr& cur, Seed& cs, uint32_t tile) {
+    if (cs.lds != ~0u) {                           // the LDS copy's entry
+      LdsD2 p = (LdsD2)(uintptr_t)(ct_a + cs.lds);
+      const v2d_t va = p[0], vb = p[1], vc = p[2];
+      cs.a.x = va.x; cs.a.y = va.y; cs.b.x = vb.x; cs.b.y = vb.y; cs.cc.x = vc.x; cs.cc.y = vc.y;
+    }
+    double G0 = cs.a.x, G1 = cs.a.y, G2 = cs.b.x, t0 = cs.b.y, t1 = cs.cc.x, t2 = cs.cc.y;
+    if (!cs.fast) {                                // deeper pairs, qualities beyond the tables: the read loop and the three logs, as k_singlet_can
+      const GlSeed sd = gl_seed(tabs, cur.n, cur.rd4);
+      gl_finish(sd, cur.n, cur.rd4, reads, (int64_t)cur.off, tabs, G0, G1, G2);
+      t0 = dmx_log_fast(G0 * chi + G1 * clo + G2 * clo, s_log);
+      t1 = dmx_log_fast(G0 * clo + G1 * chi + G2 * clo, s_log);
+      t2 = dmx_log_fast(G0 * clo + G1 * clo + G2 * chi, s_log);
+    }
+    const double l0 = dmx_log_fast(G0 * cs.q0 + G1 * cs.q1 + G2 * cs.q2, s_log);                                  // llk0 (:459)
+    v2d_t* o = reinterpret_cast<v2d_t*>(&s_ring[tile & 1u][w][lane][0]);
+    v2d_t r01, r23;
+    r01.x = t0; r01.y = t1; r23.x = t2; r23.y = l0;
+    o[0] = r01; o[1] = r23;
+    DMX_CP_BARRIER();
+  };
+  Hdr h1 = stage_b(stage_a(0));
+  Hdr h2 = stage_b(stage_a(1));
+  Raw pre = stage_a(2);
+  Seed sA = stage_c(h1), sB = sA;
+  for (uint32_t tile = 0; tile < ntiles; tile += 2) {
+    {
+      const Hdr cur = h1;
+      h1 = h2;
+      sB = stage_c(h1);                            // tile + 1
+      h2 = stage_b(pre);                           // tile + 2
+      pre = stage_a(tile + 3);                     // tile + 3
+      compute(cur, sA, tile);
+    }
+    if (tile + 1 >= ntiles) break;
+    {
+      const Hdr cur = h1;
+      h1 = h2;
+      sA = stage_c(h1);
+      h2 = stage_b(pre);
+      pre = stage_a(tile + 4);
+      compute(cur, sB, tile + 1);
+    }
+  }
+}
+
 // K1 over genotype classes, wide-panel form (V >= 20, measured crossover): all V+1 accumulators of a cell are summed in one pass per tile.
 // Same walk and ownership as k_singlet; per pair the lane evaluates log(GL . row_d) once per class d plus the llk0 term,
 // and stores those five terms and the SNP's packed class ids; chain lane (cell, k) then adds term[id[snp][k]] for the
@@ -5499,6 +5718,7 @@ struct dmx_engine {
   // genotype's HWE row, :381-388), and K1 takes log(GL . row) of the three canonical rows from a table indexed like the GL tables (d_ltab)
   bool canon = false, ltab_valid = false; float can_hi = 0.f, can_lo = 0.f; double* d_ltab = nullptr; uint8_t* d_oth = nullptr;
   uint4* d_snprec = nullptr; bool snprec_valid = false; double* d_ctab = nullptr; bool ctab_valid = false;   // k_singlet_can's per-SNP records and merged GL / class-log table
+  uint8_t* d_clsb = nullptr; bool clsb_valid = false; uint32_t clsb_stride = 0;                             // k_singlet_canp's per-sample class byte streams (k_build_clsb)
   bool any_oth = false;                                   // some SNP of the canonical-class matrix has a fourth row (k_canon_apply's oth)
   bool off32 = false;                                     // every absolute pair index and read offset of the staged pileup fits 32 bits
   bool reads_padded = false;                              // four bytes past the staged pileup's last read byte are readable (k_singlet_can's unconditional 4-byte loads)
@@ -5662,6 +5882,7 @@ extern "C" int dmx_engine_destroy(dmx_engine* e) {
   if (e->d_park) (void)hipFree(e->d_park);
   if (e->d_cseed) (void)hipFree(e->d_cseed);
   if (e->d_cfin) (void)hipFree(e->d_cfin);
+  if (e->d_clsb) (void)hipFree(e->d_clsb);
   if (e->d_ltab) (void)hipFree(e->d_ltab);
   if (e->d_oth) (void)hipFree(e->d_oth);
   if (e->d_snprec) (void)hipFree(e->d_snprec);
@@ -5763,7 +5984,7 @@ extern "C" int dmx_engine_set_genotypes(dmx_engine* e, const float* g, int32_t n
     e->n_classes = (h_max >= 1 && h_max <= kMaxCls) ? h_max : 0;
     if (!e->n_classes) { (void)hipFree(e->d_rows); (void)hipFree(e->d_ids); (void)hipFree(e->d_idw); (void)hipFree(e->d_idd); e->d_rows = nullptr; e->d_ids = nullptr; e->d_idw = nullptr; e->d_idd = nullptr; }
     // canonical GT classes (see k_canon_apply): relabel when the matrix has that shape
-    e->canon = false; e->ltab_valid = false; e->ctab_valid = false; e->snprec_valid = false;
+    e->canon = false; e->ltab_valid = false; e->ctab_valid = false; e->snprec_valid = false; e->clsb_valid = false;
     if (e->d_oth) { (void)hipFree(e->d_oth); e->d_oth = nullptr; }
     if (e->n_classes && !e->knob("DMX_NO_CANON")) {
       int32_t* d_w = nullptr;
@@ -6209,6 +6430,29 @@ int launch_singlet(dmx_engine* e) {
         // (a matrix with a fourth genotype row somewhere — missing genotypes — keeps four class planes of scratch and gathers every entry from the
         //  global table; without one the commonest entries come from an LDS copy: see the kernel)
         const bool oth = e->any_oth;
+        // dense pileups of up to 8 samples without a fourth genotype row (cfg2): producers / consumer (k_singlet_canp) — an EXPERIMENT (DMX_K1_CANP=1), bit-identical
+        // and not faster: cfg2 3.34 ms at three workgroups per CU against k_singlet_can's 3.15 (4.11 at two, 7.8 at four with spills).  Its consumer does what
+        // it was built for (64 ordered steps of sdwa-add / ds_read / add for 448 pairs), but a producer's own per-tile work — scan, table index, look-up, llk0 log:
+        // ~120 VALU instructions — is what both kernels are made of, and both wait for the same two HBM streams (timing builds without the read-count and
+        // read-byte loads: 2.31 and 2.71 ms; touching those lines 4 / 8 / 16 tiles ahead from the consumer's spare lanes: 3.44-3.50 ms, no help) — DESIGN 11.
+        if (!oth && V <= 8 && e->pv.pair_snp == nullptr && e->knob("DMX_K1_CANP") && !e->knob("DMX_K1_NO_CANP") && !e->knob("DMX_K1_CW")) {
+          if (!e->clsb_valid) {
+            if (e->d_clsb) { (void)hipFree(e->d_clsb); e->d_clsb = nullptr; }
+            e->clsb_stride = (uint32_t)(((int64_t)e->S + 63) / 64 * 64 + 64);
+            HIP_TRY(hipMalloc((void**)&e->d_clsb, (size_t)9 * e->clsb_stride));
+            hipLaunchKernelGGL(k_build_clsb, dim3((unsigned)(((size_t)9 * e->clsb_stride + 255) / 256)), dim3(256), 0, e->stream, e->d_ids, e->S, V, e->clsb_stride, e->d_clsb);
+            HIP_TRY(hipGetLastError());
+            e->clsb_valid = true;
+          }
+          const dim3 grdp((unsigned)((B + kCpB - 1) / kCpB));
+          if (e->knob("DMX_K1_CANP_MINW4"))        // kernel experiments only (two workgroups per CU)
+            DMX_LAUNCH(k1_fn, (k_singlet_canp<4>), grdp, dim3(kCpThreads), 0, e->stream, e->pv, e->d_snprec, e->d_clsb, e->clsb_stride, e->d_ctab, e->d_lut, e->d_sched, V,
+                               e->d_llks, e->d_llk0s, (double)e->can_hi, (double)e->can_lo);
+          else
+            DMX_LAUNCH(k1_fn, (k_singlet_canp<6>), grdp, dim3(kCpThreads), 0, e->stream, e->pv, e->d_snprec, e->d_clsb, e->clsb_stride, e->d_ctab, e->d_lut, e->d_sched, V,
+                               e->d_llks, e->d_llk0s, (double)e->can_hi, (double)e->can_lo);
+          return DMX_OK;
+        }
 #define DMX_K1L_(CC, KK, OO, NN) DMX_LAUNCH(k1_fn, (k_singlet_can<CC, KK, OO, NN>), grd, blk, 0, e->stream, e->pv, e->d_snprec, e->d_rows, e->d_ctab, e->d_lut, e->d_sched, V, \
                                             e->d_llks, e->d_llk0s, (double)e->can_hi, (double)e->can_lo)
 #define DMX_K1L(CC, KK, NN) do { if (oth) DMX_K1L_(CC, KK, true, NN); else DMX_K1L_(CC, KK, false, NN); } while (0)

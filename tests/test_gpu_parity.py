@@ -1371,3 +1371,52 @@ def test_phase1_final_tables_leave_the_strict_grid_unchanged(eng, monkeypatch, V
         a = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_FINALS_ANY_DEPTH": "1"}, "k_doublet_a2<", alphas=(0.1, 0.5))
         b = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_FINALS": "1"}, "k_doublet_a2<", alphas=(0.1, 0.5))
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("V,B,S", [(8, 37, 700), (8, 7, 64), (8, 8, 129), (5, 100, 333), (4, 6, 50), (3, 15, 1000), (1, 9, 200), (8, 1, 65), (7, 64, 4096)])
+def test_producer_consumer_k1_gives_k_singlet_cans_bits(eng, oracle, monkeypatch, V, B, S):
+    """Round 6 (an experiment kernel, DMX_K1_CANP=1; not faster than k_singlet_can): k_singlet_canp (dense pileups, canonical GT classes, <= 8
+    samples, no fourth genotype row) — seven producer wavefronts put one 32-byte
+    record per pair into an LDS ring, one consumer wavefront's 63 lanes own the 7 x 9 chains.  The chains add the doubles k_singlet_can adds, in its order:
+    llks and llk0s must be bit-identical (DMX_K1_NO_CANP=1), on barcode counts that are not multiples of 7, SNP counts that are not multiples of 64 (a partial
+    last tile), pairs of 0..6 reads and beyond kSafeReads, base qualities beyond
+    the tables; and both agree with the oracle."""
+    from demuxlet_amd import synth, capi
+    rng = np.random.default_rng(7700 + 13 * V + B)
+    raw = synth.make_raw_genotypes(rng, S, V, missing_rate=0.0)
+    g = np.stack([eng.geno_from_gt(raw.alleles[s], 0.01) for s in range(S)])
+    npair = np.full(B, S)                                                 # the dense layout: every barcode covers every SNP (pair index = SNP index)
+    P = int(npair.sum())
+    nrd = rng.choice(np.arange(7), size=P, p=[0.05, 0.55, 0.25, 0.1, 0.02, 0.02, 0.01]).astype(np.uint8)
+    nrd[rng.random(P) < 0.002] = 20
+    nr = int(nrd.sum())
+    bq = np.where(rng.random(nr) < 0.85, rng.integers(2, 45, size=nr), rng.integers(0, 128, size=nr)).astype(np.uint8)
+    reads = bq | (rng.integers(0, 2, size=nr).astype(np.uint8) << 7)
+    cpo = np.concatenate([[0], np.cumsum(npair)]).astype(np.int64)
+    cro = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(B), npair), weights=nrd, minlength=B))]).astype(np.int64)
+    z = np.zeros(B, dtype=np.int32)
+    pl = eng.HostPileup(B, S, cpo, cro, None, nrd, reads, z, z, z)
+
+    def run(env, want):
+        monkeypatch.setenv("DMX_EXPERIMENTS", "1")
+        for k in ("DMX_K1_CANP", "DMX_K1_NO_CANP", "DMX_K1_CANP_MINW4"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = eng.Engine(V, (0.0, 0.5), 0.5)
+        e.set_genotypes(g); e.set_pileup(pl); e.run_singlet(); e.sync()
+        assert e.kernel_names()["singlet"].startswith(want), e.kernel_names()
+        llks, llk0s = e.get_singlet()
+        e.close()
+        return llks, llk0s
+
+    base = run({"DMX_K1_NO_CANP": "1"}, "k_singlet_can<")
+    for env in ({"DMX_K1_CANP": "1"}, {"DMX_K1_CANP": "1", "DMX_K1_CANP_MINW4": "1"}, {"DMX_K1_CANP": "1"}):
+        got = run(env, "k_singlet_canp<")
+        assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
+    # the oracle on the same pileup (K1 only)
+    words = ((reads >> 7).astype(np.uint32) << 24) | ((reads & 0x7F).astype(np.uint32) << 16) | 1
+    pair_snp = np.concatenate([np.arange(n, dtype=np.int32) for n in npair]) if P else np.zeros(0, np.int32)
+    csr = oracle.Csr([f"c{i:06d}" for i in range(B)], cpo, pair_snp, np.concatenate([[0], np.cumsum(nrd.astype(np.int64))]), words.astype(np.uint32), z, z, z)
+    ref = oracle.run_csr(csr, [f"s{j}" for j in range(V)], g, oracle.Params((0.0, 0.5), 0.5), None, True)
+    assert np.abs(base[0] - ref.llks).max() < TOL and np.abs(base[1] - ref.llk0s).max() < TOL
