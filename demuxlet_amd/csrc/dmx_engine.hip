@@ -3074,6 +3074,286 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// K2 STRICT, default grid {0, 0.5}, 32 soft-field samples (cfg3 — the headline): k_doublet_a2's arithmetic with SYMMETRIC ownership (round 6).
+// At alpha = 0.5 the mixture is symmetric, pG[1][l][m] == pG[1][m][l] bit for bit (equal mixing weights go through identical operations), so the nine
+// terms (g_k[l] g_j[m]) pG[1][l][m] of entry [k][j] are the nine terms T[l][m] = (g_j[l] g_k[m]) pG[1][l][m] of entry [j][k], transposed: the reference adds
+// them row-major for [j][k] and column-major for [k][j] — two different roundings of one set of products.  A lane that owns BOTH entries forms the exact
+// products E[l][m] = g_j[l] g_k[m] once (they serve both entries at both alphas) and T once: 36 multiplies per unordered pair instead of 54, the 32 adds,
+// four logs and four accumulator adds unchanged — 112 FP64 instructions where k_doublet_a2 spends 130, every operation the reference's on its operands
+// in its order: the same bits (tests/test_gpu_parity.py::test_symmetric_strict_kernel_gives_k_doublet_a2s_bits).
+// Ownership: lane (j = lane & 31, h = lane >> 5) of slab s (blockIdx.y, two per barcode) owns the unordered pairs {j, (j + d) & 31}, d = 1 + 2 (4 s + i) + h,
+// i = 0..3 — d = 1..16, d = 16 from j < 16 only — with four accumulators each ([j][k][0], [j][k][1], [k][j][0], [k][j][1]), and slab 0 owns the diagonal:
+// lane (j, h) the entry [j][j][h].  496 pairs x 112 + 64 x 37 instructions per covered pair against 1 024 x 65.  One wavefront per (barcode, slab), no
+// workgroup barrier: each slab runs the cheap per-tile phases for itself (k_doublet_sym's: headers, rows straight into the LDS one sub-tile ahead, phase 1
+// with the final-value table), then its pairs.
+template <int SUB, int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2s(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                          const int32_t* __restrict__ sched,
+                                                          double* __restrict__ grid, double* __restrict__ l00, const double* __restrict__ pfin) {
+  constexpr int V = 32, A = 2, TP = 32, TPC = 64, CPW = kThreads / TPC, T00 = TP + 2, NU = 4, GSS = 3 * V, row_len = 3 * V;
+  __shared__ double s_tab[kTab2];
+  __shared__ double s_w[2][10];
+  __shared__ __attribute__((aligned(16))) double s_pq_all[CPW][TP][8];       // per pair: alpha 0.5's five distinct values q[l + m] | alpha 0's three q[l]
+  __shared__ double s_t00_all[CPW][2][T00];
+  __shared__ int64_t s_off_all[CPW][TP];
+  __shared__ int32_t s_snp_all[CPW][TP];
+  __shared__ uint32_t s_cnt_all[CPW][TP];
+  __shared__ __attribute__((aligned(16))) float s_g_all[CPW][2][SUB][GSS];
+  const double* s_log = s_tab + kLut2;
+  const int t = threadIdx.x;
+  stage_k2_tables(s_tab, tabs, t, kThreads);
+  if (t < 10) {                                  // the FIVE-form weights (k_doublet_sym): alpha 0: p = 0.5 l (slots 3, 4 repeat l = 2); alpha 0.5: p = 0.25 (l + m), slot l + m
+    const int n = t / 5, q = t % 5;
+    const int l = n ? (q > 2 ? 2 : q) : min(q, 2), m = n ? q - l : 0;
+    const double p = 0.5 * l + (m - l) * 0.5 * (n ? 0.5 : 0.0);
+    s_w[n][q] = p;
+    s_w[n][5 + q] = 1.0 - p;
+  }
+  __syncthreads();
+  const int cw = t / TPC, tid = t % TPC;
+  double* s_pq = &s_pq_all[cw][0][0]; double* s_t00 = &s_t00_all[cw][0][0];
+  int64_t* s_off = s_off_all[cw]; int32_t* s_snp = s_snp_all[cw]; uint32_t* s_cnt = s_cnt_all[cw];
+  float* s_g0 = &s_g_all[cw][0][0][0];
+  const int slot = blockIdx.x * CPW + cw;
+  if (slot >= pv.B) return;                      // (no workgroup barrier below)
+  const int slab = (int)blockIdx.y;
+  const int32_t cell = sched[slot];
+  const int64_t p_beg = pv.cell_pair_off[cell];
+  const int64_t np = pv.cell_pair_off[cell + 1] - p_beg;
+  int64_t rd_base = pv.cell_read_off[cell];
+  const int j = tid & 31, h = tid >> 5;
+  int kk[NU];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) kk[i] = (j + 1 + 2 * (NU * slab + i) + h) & 31;
+  double acc[NU][4];
+#pragma unroll
+  for (int i = 0; i < NU; ++i) { acc[i][0] = 0.0; acc[i][1] = 0.0; acc[i][2] = 0.0; acc[i][3] = 0.0; }
+  double accd = 0.0, acc00 = 0.0;
+  const DmxLogPins lk = dmx_log_pins();
+  const int ti1 = tid >> 1, n1 = tid & 1;
+  // the diagonal lane's value of (l, m): alpha 0.5 (h = 1) q[l + m] = s_pq[l + m], alpha 0 (h = 0) q[l] = s_pq[5 + l]: index (5 + l) + h (m - 5)
+  const int dg[3] = {h * -5, h * -4, h * -3};
+  auto request_rows = [&](int sub, int buf) {    // rows of the pairs sub .. sub+SUB-1 of the current tile -> s_g0[buf], asynchronously (k_doublet_sym)
+    using gptr = const __attribute__((address_space(1))) void*;
+    using lptr = __attribute__((address_space(3))) void*;
+#pragma unroll
+    for (int pi = 0; pi < SUB; ++pi) {
+      const float* src = g + (size_t)__builtin_amdgcn_readfirstlane(s_snp[sub + pi]) * row_len;
+#pragma unroll
+      for (int hh = 0; hh < (GSS + TPC - 1) / TPC; ++hh) {
+        const int r = tid + TPC * hh;
+        if (r < row_len) __builtin_amdgcn_global_load_lds((gptr)(src + r), (lptr)(s_g0 + (buf * SUB + pi) * GSS + TPC * hh), 4, 0, 0);
+      }
+    }
+  };
+  for (int64_t tbase = 0; tbase < np; tbase += TP) {
+    const int tp = (int)min((int64_t)TP, np - tbase);
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const int32_t sn = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+      const uint32_t incl = seg_scan_incl<TP>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = sn;
+    }
+    DMX_WAVE_LDS_ORDER();
+    rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    request_rows(0, 0);                            // sub-tile 0's rows travel while phase 1 runs
+    // ---- phase 1 (:597-663), k_doublet_sym's: lane (pair ti1, alpha n1), five distinct values
+    {
+      const bool on = ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);
+      const int32_t snp1 = on ? s_snp[ti1] : 0;
+      double q[5];
+      const int32_t fi = pfin ? certify_final_index(cnt, rd4) : -1;
+      if (!__any(fi < 0)) {
+        const double* fp = pfin + (size_t)fi * kCFinStride + (n1 ? 0 : 5);
+        q[0] = fp[0]; q[1] = fp[1]; q[2] = fp[2];
+        q[3] = n1 ? fp[3] : 0.0; q[4] = n1 ? fp[4] : 0.0;
+      } else {
+        double wA[5], wR[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { q[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }   // :597
+        for (uint32_t r = 0; __any(r < cnt); ++r) {
+          const bool live = r < cnt;
+          const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
+          const uint32_t bq = byte & 127u;
+          const bool alt = (byte >> 7) != 0;
+          const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+          const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+          double mx = 0.0;
+          if (live) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+              q[i] *= (pR * wR[i] + pA * wA[i]);                              // :625
+              mx = fmax(mx, q[i]);                                            // :626-627
+            }
+          }
+          {
+            const double o = shfl_xor1(mx);                                   // one max across both alphas of the pair
+            mx = fmax(mx, o);
+          }
+          if (live) {
+            if (cnt <= kSafeReads) {
+              const double y = rcp_refined(mx);
+#pragma unroll
+              for (int i = 0; i < 5; ++i) q[i] = div_by(q[i], mx, y);         // :632-639
+            } else {
+#pragma unroll
+              for (int i = 0; i < 5; ++i) q[i] = div_slow(q[i], mx);
+            }
+          }
+        }
+        double mx = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          q[i] += 1e-6;                                                        // :649
+          mx = fmax(mx, q[i]);
+        }
+        {
+          const double o = shfl_xor1(mx);
+          mx = fmax(mx, o);
+        }
+        const double y = rcp_refined(mx);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) q[i] = div_by(q[i], mx, y);                // :656-663
+      }
+      if (on) {
+        const double* g0 = gp0 + (size_t)snp1 * 3;
+        const double qq[3] = {g0[0], g0[1], g0[2]};
+        double sum = 0.0;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const double v = n1 ? q[l + m] : q[l];                           // pG[n][l][m]
+            sum += ((qq[l] * qq[m]) * v);                                    // gp00 (:555) then :702-705
+          }
+        s_t00[n1 * T00 + ti1] = dmx_log2_fast(sum, s_log);                    // :708-709 term
+        if (n1) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) s_pq[ti1 * 8 + i] = q[i];
+        } else {
+#pragma unroll
+          for (int l = 0; l < 3; ++l) s_pq[ti1 * 8 + 5 + l] = q[l];
+        }
+      }
+    }
+    DMX_WAVE_LDS_ORDER();
+    if (tid < 2 && slab == 0) {                    // llks00: lane n adds its alpha's terms in pair order
+      const double* row = &s_t00[tid * T00];
+      for (int i = 0; i < tp; ++i) acc00 += row[i];
+    }
+    // ---- phase 2 in sub-tiles of SUB pairs
+#pragma unroll 1
+    for (int sub = 0; sub < tp; sub += SUB) {
+      const int ns = min(SUB, tp - sub);
+      const int buf = (sub / SUB) & 1;
+      const float* s_g = s_g0 + buf * SUB * GSS;
+      __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): this sub-tile's rows have landed ...
+      if (sub + SUB < tp) request_rows(sub + SUB, buf ^ 1);   // ... the next one's take off (its buffer was last read two syncs ago)
+      DMX_WAVE_LDS_ORDER();
+#pragma unroll 1
+      for (int pi = 0; pi < ns; ++pi) {                    // (two pairs per trip: 1 227.8 against 1 206.2 ms)
+        const float* gr = &s_g[pi * GSS];
+        const double* pq = &s_pq[(sub + pi) * 8];
+        const double a[3] = {(double)gr[j * 3], (double)gr[j * 3 + 1], (double)gr[j * 3 + 2]};
+        constexpr bool ROOMY = MINW <= 3;          // 168 registers: the pair's q values stay in registers, the next unit's row is read a unit ahead, the four logs interleave
+        double Pr[5], Qr[3];
+        if (ROOMY) {
+#pragma unroll
+          for (int c = 0; c < 5; ++c) Pr[c] = pq[c];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Qr[c] = pq[5 + c];
+        }
+        float bn[3] = {gr[kk[0] * 3], gr[kk[0] * 3 + 1], gr[kk[0] * 3 + 2]};
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+          const double b[3] = {(double)bn[0], (double)bn[1], (double)bn[2]};
+          if (ROOMY && i + 1 < NU) { const int kn = kk[i + 1]; bn[0] = gr[kn * 3]; bn[1] = gr[kn * 3 + 1]; bn[2] = gr[kn * 3 + 2]; }
+          else if (!ROOMY && i + 1 < NU) { const int kn = kk[i + 1]; bn[0] = gr[kn * 3]; bn[1] = gr[kn * 3 + 1]; bn[2] = gr[kn * 3 + 2]; }
+          // two halves so that no more than the nine products, two sums and two logs are live at once (128 registers = four wavefronts per SIMD): first
+          // the exact products E and the two alpha-0 entries, then E becomes T = E q[l + m] in place and serves the two alpha-0.5 entries
+          double E[3][3];
+#pragma unroll
+          for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) E[l][m] = a[l] * b[m];                  // :553 (exact) — shared by [j][k] and [k][j] at both alphas
+          {
+            // [j][k][0]: l-major over (l, m) of (g_j[l] g_k[m]) q0[l]; [k][j][0]: of (g_k[l] g_j[m]) q0[l] = E[m][l] q0[l].  The first product initialises
+            // the sum (0 + x == x for these non-negative products: the reference's bits, one add fewer).  (The pair's q values are re-read per half —
+            // uniform LDS reads — instead of held across the pair's units: 16 registers the kernel does not have at four wavefronts per SIMD.)
+            const double Q[3] = {ROOMY ? Qr[0] : lds_read_f64(&pq[5]), ROOMY ? Qr[1] : lds_read_f64(&pq[6]), ROOMY ? Qr[2] : lds_read_f64(&pq[7])};
+            double s_jk0 = E[0][0] * Q[0], s_kj0 = E[0][0] * Q[0];
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+              for (int m = 0; m < 3; ++m) {
+                if (l == 0 && m == 0) continue;
+                s_jk0 += (E[l][m] * Q[l]);
+                s_kj0 += (E[m][l] * Q[l]);
+              }
+            acc[i][0] += dmx_log2_fast_pinned(s_jk0, s_log, lk);               // :683
+            acc[i][2] += dmx_log2_fast_pinned(s_kj0, s_log, lk);
+          }
+          if (!ROOMY) __builtin_amdgcn_sched_barrier(0);
+          {
+            const double P[5] = {ROOMY ? Pr[0] : lds_read_f64(&pq[0]), ROOMY ? Pr[1] : lds_read_f64(&pq[1]), ROOMY ? Pr[2] : lds_read_f64(&pq[2]),
+                                 ROOMY ? Pr[3] : lds_read_f64(&pq[3]), ROOMY ? Pr[4] : lds_read_f64(&pq[4])};
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+              for (int m = 0; m < 3; ++m) E[l][m] = E[l][m] * P[l + m];         // T: :677-679 at alpha 0.5 — [k][j]'s nine terms are these, transposed
+            double s_jk1 = E[0][0], s_kj1 = E[0][0];
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+              for (int m = 0; m < 3; ++m) {
+                if (l == 0 && m == 0) continue;
+                s_jk1 += E[l][m];
+                s_kj1 += E[m][l];
+              }
+            acc[i][1] += dmx_log2_fast_pinned(s_jk1, s_log, lk);
+            acc[i][3] += dmx_log2_fast_pinned(s_kj1, s_log, lk);
+          }
+          __builtin_amdgcn_sched_barrier(0);       // one pair of entries at a time
+        }
+        if (slab == 0) {                           // the diagonal entry [j][j][h]
+          double sd = 0.0;
+#pragma unroll
+          for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              const double v = pq[5 + l + dg[m]];
+              const double term = (a[l] * a[m]) * v;
+              sd = (l == 0 && m == 0) ? term : sd + term;
+            }
+          accd += dmx_log2_fast_pinned(sd, s_log, lk);
+        }
+      }
+      DMX_WAVE_LDS_ORDER();
+    }
+  }
+  double* G = grid + (size_t)cell * V * V * A;
+#pragma unroll
+  for (int i = 0; i < NU; ++i) {
+    const int d = 1 + 2 * (NU * slab + i) + h, k = kk[i];
+    if (d < 16 || j < 16) {                        // d = 16 is reached from both sides: the j < 16 lane stores
+      G[((size_t)j * V + k) * A] = acc[i][0]; G[((size_t)j * V + k) * A + 1] = acc[i][1];
+      G[((size_t)k * V + j) * A] = acc[i][2]; G[((size_t)k * V + j) * A + 1] = acc[i][3];
+    }
+  }
+  if (slab == 0) {
+    G[((size_t)j * V + j) * A + h] = accd;
+    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K2 for alpha grids of 3..8 entries: k_doublet_a2's ownership, order and arithmetic with AP (= A rounded up to 2, 4 or 8)
 // alphas per pair.  Phase 1 spreads the TP * AP (pair, alpha) lanes over all the cell's threads, in passes when the cell has
 // fewer than that; the one-max-across-ALL-alphas renormalisation (:626-639) is a butterfly over the AP lanes of a pair.
@@ -6755,7 +7035,8 @@ int launch_doublet(dmx_engine* e) {
   // k_doublet_a2's phase 1 on the default grid {0, 0.5}: finished values of pairs of up to three tabled reads from the table (round 6; shallow pileups only,
   // ensure_finals; DMX_A2_NO_FINALS=1: the read loop everywhere) — other grids have other mixing weights and keep the loop
   const double* pfin_a2 = nullptr;
-  if (A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && !e->knob("DMX_A2_NO_FINALS")) if (int rc = ensure_finals(e, &pfin_a2)) return rc;
+  const bool pfin_a2_grid = A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5;
+  if (pfin_a2_grid && !e->knob("DMX_A2_NO_FINALS")) if (int rc = ensure_finals(e, &pfin_a2)) return rc;
 #define DMX_K2A(TPC, NK)                                                                                             \
   do {                                                                                                                \
     if (e->geno_safe)                                                                                                 \
@@ -6870,7 +7151,21 @@ int launch_doublet(dmx_engine* e) {
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
   }
-  if (V <= 8) DMX_K2A(64, 1);
+  if (V == 32 && pfin_a2_grid && e->geno_safe && e->knob("DMX_A2_SYM")) {
+    // 32 soft-field samples on the default grid (cfg3, the headline): symmetric ownership — one lane owns [j][k] and [k][j], their shared products once.
+    // An EXPERIMENT (DMX_A2_SYM=1), bit-identical, 9 % fewer instructions (967 FP64 + 212 others against 1 040 + 260 per covered pair and barcode) and
+    // about as fast: the 17 accumulators per lane do not fit four wavefronts per SIMD (128 registers: 18 spill accesses per pair in the loop, 3 139 ms),
+    // and at three it runs alone 1 206 ms (sub-tiles of 8 pairs, DMX_A2S_SUB8=1: 1 177-1 191) against k_doublet_a2's 1 214-1 223 on the same boxes, the STEP
+    // 1 229-1 235 against 1 237-1 250 — K1 beside it costs it more than it costs k_doublet_a2.  Not worth a second headline kernel.
+    const dim3 grds((unsigned)((B + 3) / 4), 2);
+    if (e->knob("DMX_A2S_SUB8"))                 // kernel experiments only
+      DMX_LAUNCH(k2_fn, (k_doublet_a2s<8, 3>), grds, block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, e->d_grid, e->d_l00, pfin_a2);
+    else if (!e->knob("DMX_A2S_MINW4"))          // (three wavefronts per SIMD unless the spilling four-wavefront form is asked for)
+      DMX_LAUNCH(k2_fn, (k_doublet_a2s<4, 3>), grds, block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, e->d_grid, e->d_l00, pfin_a2);
+    else
+      DMX_LAUNCH(k2_fn, (k_doublet_a2s<4, 4>), grds, block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, e->d_grid, e->d_l00, pfin_a2);
+  }
+  else if (V <= 8) DMX_K2A(64, 1);
   else if (V <= 16) DMX_K2A(64, 4);
   else if (V <= 32) {
     // 4 wavefronts per SIMD (128 VGPRs, a few spills outside the hot loop) measured 2.8 % faster than 3 (158 VGPRs) on cfg3

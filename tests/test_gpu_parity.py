@@ -1328,7 +1328,7 @@ def _mixed_depth_problem(eng, V, dense):
 
 def _grid_with_env(eng, monkeypatch, g, pl, V, mode, env, kernel_prefix, alphas=(0.0, 0.5)):
     monkeypatch.setenv("DMX_EXPERIMENTS", "1")
-    for k in ("DMX_SYM_NO_FINALS", "DMX_A2_NO_FINALS", "DMX_FINALS_ANY_DEPTH"):
+    for k in ("DMX_SYM_NO_FINALS", "DMX_A2_NO_FINALS", "DMX_FINALS_ANY_DEPTH", "DMX_A2_SYM", "DMX_A2S_MINW4"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -1420,3 +1420,35 @@ def test_producer_consumer_k1_gives_k_singlet_cans_bits(eng, oracle, monkeypatch
     csr = oracle.Csr([f"c{i:06d}" for i in range(B)], cpo, pair_snp, np.concatenate([[0], np.cumsum(nrd.astype(np.int64))]), words.astype(np.uint32), z, z, z)
     ref = oracle.run_csr(csr, [f"s{j}" for j in range(V)], g, oracle.Params((0.0, 0.5), 0.5), None, True)
     assert np.abs(base[0] - ref.llks).max() < TOL and np.abs(base[1] - ref.llk0s).max() < TOL
+
+
+@pytest.mark.parametrize("dense,field", [(True, "GP"), (False, "GP"), (False, "PL")])
+def test_symmetric_strict_kernel_gives_k_doublet_a2s_bits(eng, oracle, monkeypatch, dense, field):
+    """Round 6 (an experiment kernel, DMX_A2_SYM=1; not faster than k_doublet_a2): k_doublet_a2s (STRICT, default grid, 32 soft-field samples —
+    cfg3's shape): one lane owns the entries [j][k] and [k][j] and forms the products
+    they share once — the exact g_j[l] g_k[m], and at alpha 0.5 (symmetric mixture) the nine terms themselves, which the reference adds row-major for one
+    entry and column-major for the other.  Every operation is the reference's on its operands in its order: the grid, llks00 and the K3 records must equal
+    k_doublet_a2's bit for bit — pairs of 0..6 reads and beyond kSafeReads, whole-range base qualities, tiles with and without a
+    deep pair (the final-value table on and off), ragged last sub-tiles — and agree with the oracle."""
+    from demuxlet_amd import synth, capi
+    V = 32
+    g, pl = _mixed_depth_problem(eng, V, dense)
+    if field == "PL":
+        rng = np.random.default_rng(4242)
+        raw = synth.make_raw_genotypes(rng, g.shape[0], V)
+        g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, raw.alleles)])
+    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {}, "k_doublet_a2<")
+    for env in ({"DMX_A2_SYM": "1"}, {"DMX_A2_SYM": "1", "DMX_A2_NO_FINALS": "1"}, {"DMX_A2_SYM": "1", "DMX_FINALS_ANY_DEPTH": "1"}, {"DMX_A2_SYM": "1", "DMX_A2S_MINW4": "1"}):
+        got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, env, "k_doublet_a2s<")
+        assert np.array_equal(got[0], base[0]), (env, np.argwhere(got[0] != base[0])[:5])
+        assert np.array_equal(got[1], base[1]), env
+    # the oracle on the same pileup
+    B, S = pl.n_cells, pl.n_snps
+    words = ((pl.reads >> 7).astype(np.uint32) << 24) | ((pl.reads & 0x7F).astype(np.uint32) << 16) | 1
+    pair_snp = pl.pair_snp if pl.pair_snp is not None else np.tile(np.arange(S, dtype=np.int32), B)
+    z = np.zeros(B, dtype=np.int32)
+    csr = oracle.Csr([f"c{i:06d}" for i in range(B)], pl.cell_pair_off, pair_snp, np.concatenate([[0], np.cumsum(pl.pair_nrd.astype(np.int64))]),
+                     words.astype(np.uint32), z, z, z)
+    ref = oracle.run_csr(csr, [f"s{j}" for j in range(V)], g, oracle.Params((0.0, 0.5), 0.5), None, False)
+    proc = ref.processed.astype(bool)
+    assert np.abs(base[0][proc] - ref.llksAB[proc]).max() < TOL
