@@ -1373,8 +1373,9 @@ def test_phase1_final_tables_leave_the_strict_grid_unchanged(eng, monkeypatch, V
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
-@pytest.mark.parametrize("V,B,S", [(8, 37, 700), (8, 7, 64), (8, 8, 129), (5, 100, 333), (4, 6, 50), (3, 15, 1000), (1, 9, 200), (8, 1, 65), (7, 64, 4096)])
-def test_producer_consumer_k1_gives_k_singlet_cans_bits(eng, oracle, monkeypatch, V, B, S):
+@pytest.mark.parametrize("V,B,S,deep", [(8, 37, 700, False), (8, 7, 64, False), (8, 8, 129, False), (5, 100, 333, False), (4, 6, 50, False), (3, 15, 1000, False),
+                                        (1, 9, 200, False), (8, 1, 65, False), (7, 64, 4096, False), (8, 30, 1500, True), (6, 10, 257, True)])
+def test_producer_consumer_k1_gives_k_singlet_cans_bits(eng, oracle, monkeypatch, V, B, S, deep):
     """Round 6 (an experiment kernel, DMX_K1_CANP=1; not faster than k_singlet_can): k_singlet_canp (dense pileups, canonical GT classes, <= 8
     samples, no fourth genotype row) — seven producer wavefronts put one 32-byte
     record per pair into an LDS ring, one consumer wavefront's 63 lanes own the 7 x 9 chains.  The chains add the doubles k_singlet_can adds, in its order:
@@ -1389,6 +1390,9 @@ def test_producer_consumer_k1_gives_k_singlet_cans_bits(eng, oracle, monkeypatch
     P = int(npair.sum())
     nrd = rng.choice(np.arange(7), size=P, p=[0.05, 0.55, 0.25, 0.1, 0.02, 0.02, 0.01]).astype(np.uint8)
     nrd[rng.random(P) < 0.002] = 20
+    if deep:                                     # stretches of 3..6 reads per pair: whole tiles on the slow path (reads beyond the tables)
+        run_ = (np.arange(P) // 300) % 3 == 1
+        nrd[run_] = rng.integers(3, 7, size=int(run_.sum())).astype(np.uint8)
     nr = int(nrd.sum())
     bq = np.where(rng.random(nr) < 0.85, rng.integers(2, 45, size=nr), rng.integers(0, 128, size=nr)).astype(np.uint8)
     reads = bq | (rng.integers(0, 2, size=nr).astype(np.uint8) << 7)
