@@ -408,6 +408,132 @@ __global__ void k_build_certify_finals(const double* __restrict__ tabs, double* 
   for (int i = 0; i < 3; ++i) o[5 + i] = div_by(pG[0][i], m, y);             // ... and the alpha = 0 lane's three distinct ones (k_doublet_sym's phase 1)
 }
 
+// Phase 1 of k_certify for one (pair, alpha) lane: the pG values of :597-663 with the one-max-across-both-alphas renormalisation
+// after every read, finished (:656-663) and handed from the alpha = 0.5 lane to its alpha = 0 neighbour.  NV = 9: the nine
+// values pG[l][m]; NV = 5 (alpha[0] == 0): the five distinct values of alpha 0.5 (weight p = (l + m) / 4, index l + m) beside the
+// three of alpha 0 (p = l / 2) — entries with equal weights go through identical operations, so the values are bit-identical.
+// seeds (NV = 5, the default grid; round 4): the lane's five values after the pair's first read — or first two, both of base quality < 64 — come from a
+// table built on the device with this very loop (k_build_certify_seeds: [256 + 16 384 read codes][alpha lane][6]), and the loop starts at read 1 or 2:
+// at 1.25 reads per pair it used to run max(cnt) ~ 2.6 times per tile of 32 pairs with most lanes idle, now 0.6 times.
+constexpr int kCSeedStride = 6;                  // doubles per (entry, alpha lane): five values + pad (16-byte aligned loads)
+constexpr int64_t kCSeedN = 256 + 128 * 128;
+template <int NV, bool HAND = true>            // HAND: k_certify's hand-over at the end (both lanes of a pair leave with the alpha = 0.5 lane's values); false: each lane keeps its own
+__device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32_t cnt, int64_t off, uint32_t rd4, const double* s_tab,
+                                                    const double (&wA)[NV], const double (&wR)[NV], int n1, double (&v)[NV],
+                                                    const double* __restrict__ cseed = nullptr) {
+  double pG[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) pG[i] = 1.0;                               // :597
+  uint32_t r_start = 0;
+  if (NV == 5 && cseed) {
+    if (cnt >= 1 && cnt <= kSafeReads) {
+      const uint32_t b0 = rd4 & 0xFFu, b1 = (rd4 >> 8) & 0xFFu;
+      const bool two = cnt >= 2 && ((b0 | b1) & 0x40u) == 0;
+      const uint32_t i2 = ((((b0 & 0x80u) >> 1) | (b0 & 0x3Fu)) << 7) | (((b1 & 0x80u) >> 1) | (b1 & 0x3Fu));
+      const double* sp = cseed + ((size_t)(two ? 256u + i2 : b0) * 2 + (size_t)n1) * kCSeedStride;
+      const double2 a = *reinterpret_cast<const double2*>(sp), b = *reinterpret_cast<const double2*>(sp + 2);
+      pG[0] = a.x; pG[1] = a.y; pG[2] = b.x; pG[3] = b.y; pG[NV - 1] = sp[4];
+      r_start = two ? 2u : 1u;
+    }
+  }
+  // first read any lane still has to apply (wave-uniform)
+  uint32_t r = 0;
+  if (NV == 5 && cseed) r = __any(r_start == 0 && cnt > 0) ? 0u : (__any(r_start <= 1 && cnt > 1) ? 1u : 2u);
+  for (; __any(r < cnt); ++r) {
+    const bool live = r >= r_start && r < cnt;
+    const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
+    const uint32_t bq = byte & 127u;
+    const bool alt = (byte >> 7) != 0;
+    const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
+    const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
+    double mx = 0.0;
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
+        mx = fmax(mx, pG[i]);                                 // :626-627
+      }
+    }
+    {
+      const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
+      mx = fmax(mx, o);
+    }
+    if (live) {
+      if (cnt <= kSafeReads) {
+        const double y = rcp_refined(mx);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) pG[i] = div_by(pG[i], mx, y);      // :632-639
+      } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) pG[i] = div_slow(pG[i], mx);
+      }
+    }
+  }
+  double mx = 0.0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    pG[i] += 1e-6;                                                       // :649
+    mx = fmax(mx, pG[i]);
+  }
+  {
+    const double o = shfl_xor1(mx);
+    mx = fmax(mx, o);
+  }
+  // the alpha = 0.5 lane finishes its values (:656-663) and hands a copy to its alpha = 0 neighbour (which only had to contribute
+  // to the shared maxima): the two lanes of a pair then take one accumulator each
+  const double y = rcp_refined(mx);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = div_by(pG[i], mx, y);
+  if (HAND) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = shfl_odd(v[i]);   // (the alpha = 0.5 lane is the odd one: n1 == lane & 1)
+  }
+  (void)n1;
+}
+
+// The seeds of certify_pair_values<5>: one thread per read code (256 one-read codes, then 128 x 128 two-read codes of base quality < 64) runs the
+// loop of :597-639 for BOTH alpha lanes (0 and 0.5: the maximum of :626-627 runs across them) — the same operations on the same operands as the
+// two lanes of k_certify, hence the same bits.
+__global__ void k_build_certify_seeds(const double* __restrict__ tabs, double* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= kCSeedN) return;
+  uint32_t bytes[2]; int nb;
+  if (e < 256) { bytes[0] = (uint32_t)e; bytes[1] = 0; nb = 1; }
+  else {
+    const uint32_t i2 = (uint32_t)(e - 256), c0 = i2 >> 7, c1 = i2 & 127u;
+    bytes[0] = ((c0 & 0x40u) << 1) | (c0 & 0x3Fu); bytes[1] = ((c1 & 0x40u) << 1) | (c1 & 0x3Fu); nb = 2;
+  }
+  double wA[2][5], wR[2][5], pG[2][5];
+  for (int n1 = 0; n1 < 2; ++n1)
+    for (int q = 0; q < 5; ++q) {                  // the weights of k_certify's FIVE form
+      const int l = n1 ? (q > 2 ? 2 : q) : min(q, 2), m = n1 ? q - l : 0;
+      const double p = 0.5 * l + (m - l) * 0.5 * (n1 ? 0.5 : 0.0);
+      wA[n1][q] = p; wR[n1][q] = 1.0 - p; pG[n1][q] = 1.0;
+    }
+  for (int r = 0; r < nb; ++r) {
+    const uint32_t byte = bytes[r], bq = byte & 127u;
+    const bool alt = (byte >> 7) != 0;
+    const double pR = alt ? tabs[128 + bq] : tabs[bq];
+    const double pA = alt ? tabs[bq] : tabs[128 + bq];
+    double mx[2] = {0.0, 0.0};
+    for (int n1 = 0; n1 < 2; ++n1)
+      for (int i = 0; i < 5; ++i) {
+        pG[n1][i] *= (pR * wR[n1][i] + pA * wA[n1][i]);
+        mx[n1] = fmax(mx[n1], pG[n1][i]);
+      }
+    const double m = fmax(mx[0], mx[1]);
+    const double y = rcp_refined(m);
+    for (int n1 = 0; n1 < 2; ++n1)
+      for (int i = 0; i < 5; ++i) pG[n1][i] = div_by(pG[n1][i], m, y);
+  }
+  for (int n1 = 0; n1 < 2; ++n1) {
+    double* o = out + ((size_t)e * 2 + n1) * kCSeedStride;
+    for (int i = 0; i < 5; ++i) o[i] = pG[n1][i];
+    o[5] = 0.0;
+  }
+}
+
+
 
 // K1.  Wavefronts are independent (no workgroup barrier in the loop).  A wavefront owns CW cells for their whole SNP
 // range and walks them tile by tile, T = 64/CW SNP-pairs per cell per tile:
@@ -2055,8 +2181,11 @@ __global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void
                                                          const double* __restrict__ alpha,
                                                          const int32_t* __restrict__ sched, int32_t V, int32_t GS,
                                                          double* __restrict__ grid, double* __restrict__ l00,
-                                                         uint8_t* __restrict__ flagged, const double* __restrict__ pfin) {
-  // pfin (round 6; NULL unless the grid is {0, 0.5} and the pileup shallow): k_build_certify_finals' table of finished phase-1 values
+                                                         uint8_t* __restrict__ flagged, const double* __restrict__ pfin, const double* __restrict__ pseed) {
+  // pfin (round 6; NULL unless the grid is {0, 0.5} and the pileup shallow): k_build_certify_finals' table of finished phase-1 values;
+  // pseed (NULL unless the grid is {0, 0.5}): k_build_certify_seeds' table — on that grid the tiles that walk the read loop walk it in the five-value form
+  // (alpha 0.5's five distinct mixing weights, alpha 0's three: entries of equal weight go through identical operations, so the nine values are these,
+  // repeated) from the state after a pair's first one or two reads
   constexpr int A = 2;
   static_assert(TP == 32 || TP == 16 || TP == 8, "phase 1 runs on the first 2 * TP lanes of the cell's first wavefront");
   constexpr int CPW = kThreads / TPC;            // cells per workgroup
@@ -2157,6 +2286,20 @@ __global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void
         for (int l = 0; l < 3; ++l)
 #pragma unroll
           for (int m = 0; m < 3; ++m) vf[l * 3 + m] = n1 ? f5[l + m] : f5[l];
+      } else if (pseed) {
+        double q5[5], wA5[5], wR5[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {                // the five-value form's weights: alpha 0.5: p = 0.25 (l + m), slot l + m; alpha 0: p = 0.5 l, slots 0..2 (3, 4 repeat 2)
+          const int l = n1 ? (q > 2 ? 2 : q) : min(q, 2), m = n1 ? q - l : 0;
+          const double p = 0.5 * l + (m - l) * 0.5 * (n1 ? 0.5 : 0.0);
+          wA5[q] = p;
+          wR5[q] = 1.0 - p;
+        }
+        certify_pair_values<5, false>(pv, cnt, off, rd4, s_tab, wA5, wR5, n1, q5, pseed);
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+          for (int m = 0; m < 3; ++m) vf[l * 3 + m] = n1 ? q5[l + m] : q5[l];
       } else {
       double pG[9], wA[9], wR[9];
 #pragma unroll
@@ -2578,8 +2721,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
                                                           const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                           const int32_t* __restrict__ sched, int32_t V_and_flags,
                                                           double* __restrict__ grid, double* __restrict__ l00,
-                                                          uint8_t* __restrict__ flagged, const double* __restrict__ pfin) {
-  // pfin (round 6; NULL: none): k_build_certify_finals' table — the finished phase-1 values of pairs of up to three tabled reads
+                                                          uint8_t* __restrict__ flagged, const double* __restrict__ pfin, const double* __restrict__ pseed) {
+  // pfin (round 6; NULL: none): k_build_certify_finals' table — the finished phase-1 values of pairs of up to three tabled reads; pseed (NULL: none):
+  // k_build_certify_seeds' table — the state after a pair's first one or two reads, for the pairs that walk the loop
   const int32_t V = V_and_flags & 0xFFFF;
   const bool no_dma = (V_and_flags >> 16) & 1;   // kernel experiments (DMX_SYM_NO_DMA; bit-identical results)
 #if DMX_SYM_ABLATIONS                             // timing builds only (tools/build_variant.sh ... -DDMX_SYM_ABLATIONS=1): each switch drops one part of the
@@ -2587,10 +2731,9 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
   const bool abl_p1 = (V_and_flags >> 17) & 1;   // DMX_SYM_ABLATE_P1: phase 1's global loads all hit the same lines
   const bool abl_p2 = (V_and_flags >> 18) & 1;   // DMX_SYM_ABLATE_P2: no phase-2 evaluations
   const bool abl_u = (V_and_flags >> 19) & 1;    // DMX_SYM_ABLATE_U: u is not formed
-  const bool abl_rd = (V_and_flags >> 20) & 1;   // DMX_SYM_ABLATE_RD: phase 1 without its read loop
   const bool abl_00 = (V_and_flags >> 21) & 1;   // DMX_SYM_ABLATE_00: no llks00 sums
 #else
-  constexpr bool abl_p1 = false, abl_p2 = false, abl_u = false, abl_rd = false, abl_00 = false;
+  constexpr bool abl_p1 = false, abl_p2 = false, abl_u = false, abl_00 = false;
 #endif
   const bool no_prod = (V_and_flags >> 22) & 1;  // kernel experiment (DMX_SYM_NO_PRODUCT): a log per term also in full sub-tiles
   const bool no_pipe = (V_and_flags >> 23) & 1;  // kernel experiment (DMX_SYM_NO_PIPE; bit-identical results): phase 2 without the software pipeline
@@ -2767,56 +2910,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
         q[0] = fp[0]; q[1] = fp[1]; q[2] = fp[2];
         q[3] = n1 ? fp[3] : 0.0; q[4] = n1 ? fp[4] : 0.0;
       } else {
-      double wA[5], wR[5];                                                 // the weights live in registers during phase 1 only
-      {
+        // the loop of :597-639 and the +1e-6 renormalisation (:649-663) — k_certify's function (each lane keeps its own alpha's values): on the default
+        // grid a pair's first one or two reads come from the seed table (round 6 for this kernel: the loop starts at read 1 or 2 — what matters for pileups
+        // too deep for the final-value table, cfg5's 2 reads per pair)
+        double wA[5], wR[5];                                               // the weights live in registers during phase 1 only
 #pragma unroll
-      for (int i = 0; i < 5; ++i) { q[i] = 1.0; wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }   // :597
-      for (uint32_t r = 0; __any(r < (abl_rd ? 0u : cnt)); ++r) {
-        const bool live = r < cnt;
-        const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
-        const uint32_t bq = byte & 127u;
-        const bool alt = (byte >> 7) != 0;
-        const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
-        const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
-        double mx = 0.0;
-        if (live) {
-#pragma unroll
-          for (int i = 0; i < 5; ++i) {
-            q[i] *= (pR * wR[i] + pA * wA[i]);                              // :625
-            mx = fmax(mx, q[i]);                                   // :626-627
-          }
-        }
-        {
-          const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
-          mx = fmax(mx, o);
-        }
-        if (live) {
-          if (cnt <= kSafeReads) {
-            const double y = rcp_refined(mx);
-#pragma unroll
-            for (int i = 0; i < 5; ++i) q[i] = div_by(q[i], mx, y);         // :632-639
-          } else {
-#pragma unroll
-            for (int i = 0; i < 5; ++i) q[i] = div_slow(q[i], mx);
-          }
-        }
-      }
-      double mx = 0.0;
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        q[i] += 1e-6;                                                        // :649
-        mx = fmax(mx, q[i]);
-      }
-      {
-        const double o = shfl_xor1(mx);
-        mx = fmax(mx, o);
-      }
-      {
-        const double y = rcp_refined(mx);                                    // numerators >= 1e-6, mx in [1e-6, 1+1e-6]
-#pragma unroll
-        for (int i = 0; i < 5; ++i) q[i] = div_by(q[i], mx, y);              // :656-663
-      }
-      }
+        for (int i = 0; i < 5; ++i) { wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }
+        certify_pair_values<5, false>(pv, cnt, off, rd4, s_tab, wA, wR, n1, q, pseed);
       }
       if (on) {
         const double* g0 = gp0 + (size_t)snp1 * 3;
@@ -5625,129 +5725,6 @@ __global__ __launch_bounds__(kThreads) void k_reduce(const double* __restrict__ 
   }
 }
 
-// Phase 1 of k_certify for one (pair, alpha) lane: the pG values of :597-663 with the one-max-across-both-alphas renormalisation
-// after every read, finished (:656-663) and handed from the alpha = 0.5 lane to its alpha = 0 neighbour.  NV = 9: the nine
-// values pG[l][m]; NV = 5 (alpha[0] == 0): the five distinct values of alpha 0.5 (weight p = (l + m) / 4, index l + m) beside the
-// three of alpha 0 (p = l / 2) — entries with equal weights go through identical operations, so the values are bit-identical.
-// seeds (NV = 5, the default grid; round 4): the lane's five values after the pair's first read — or first two, both of base quality < 64 — come from a
-// table built on the device with this very loop (k_build_certify_seeds: [256 + 16 384 read codes][alpha lane][6]), and the loop starts at read 1 or 2:
-// at 1.25 reads per pair it used to run max(cnt) ~ 2.6 times per tile of 32 pairs with most lanes idle, now 0.6 times.
-constexpr int kCSeedStride = 6;                  // doubles per (entry, alpha lane): five values + pad (16-byte aligned loads)
-constexpr int64_t kCSeedN = 256 + 128 * 128;
-template <int NV>
-__device__ __forceinline__ void certify_pair_values(const PileupView& pv, uint32_t cnt, int64_t off, uint32_t rd4, const double* s_tab,
-                                                    const double (&wA)[NV], const double (&wR)[NV], int n1, double (&v)[NV],
-                                                    const double* __restrict__ cseed = nullptr) {
-  double pG[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) pG[i] = 1.0;                               // :597
-  uint32_t r_start = 0;
-  if (NV == 5 && cseed) {
-    if (cnt >= 1 && cnt <= kSafeReads) {
-      const uint32_t b0 = rd4 & 0xFFu, b1 = (rd4 >> 8) & 0xFFu;
-      const bool two = cnt >= 2 && ((b0 | b1) & 0x40u) == 0;
-      const uint32_t i2 = ((((b0 & 0x80u) >> 1) | (b0 & 0x3Fu)) << 7) | (((b1 & 0x80u) >> 1) | (b1 & 0x3Fu));
-      const double* sp = cseed + ((size_t)(two ? 256u + i2 : b0) * 2 + (size_t)n1) * kCSeedStride;
-      const double2 a = *reinterpret_cast<const double2*>(sp), b = *reinterpret_cast<const double2*>(sp + 2);
-      pG[0] = a.x; pG[1] = a.y; pG[2] = b.x; pG[3] = b.y; pG[NV - 1] = sp[4];
-      r_start = two ? 2u : 1u;
-    }
-  }
-  // first read any lane still has to apply (wave-uniform)
-  uint32_t r = 0;
-  if (NV == 5 && cseed) r = __any(r_start == 0 && cnt > 0) ? 0u : (__any(r_start <= 1 && cnt > 1) ? 1u : 2u);
-  for (; __any(r < cnt); ++r) {
-    const bool live = r >= r_start && r < cnt;
-    const uint32_t byte = live ? (r < 4 ? (rd4 >> (8 * r)) & 0xFFu : (uint32_t)pv.reads[off + r]) : 0u;
-    const uint32_t bq = byte & 127u;
-    const bool alt = (byte >> 7) != 0;
-    const double pR = alt ? s_tab[128 + bq] : s_tab[bq];                // :606
-    const double pA = alt ? s_tab[bq] : s_tab[128 + bq];                // :607
-    double mx = 0.0;
-    if (live) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        pG[i] *= (pR * wR[i] + pA * wA[i]);                             // :625
-        mx = fmax(mx, pG[i]);                                 // :626-627
-      }
-    }
-    {
-      const double o = shfl_xor1(mx);                               // one max across both alphas of the pair
-      mx = fmax(mx, o);
-    }
-    if (live) {
-      if (cnt <= kSafeReads) {
-        const double y = rcp_refined(mx);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) pG[i] = div_by(pG[i], mx, y);      // :632-639
-      } else {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) pG[i] = div_slow(pG[i], mx);
-      }
-    }
-  }
-  double mx = 0.0;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    pG[i] += 1e-6;                                                       // :649
-    mx = fmax(mx, pG[i]);
-  }
-  {
-    const double o = shfl_xor1(mx);
-    mx = fmax(mx, o);
-  }
-  // the alpha = 0.5 lane finishes its values (:656-663) and hands a copy to its alpha = 0 neighbour (which only had to contribute
-  // to the shared maxima): the two lanes of a pair then take one accumulator each
-  const double y = rcp_refined(mx);
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = div_by(pG[i], mx, y);
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = shfl_odd(v[i]);     // (the alpha = 0.5 lane is the odd one: n1 == lane & 1)
-  (void)n1;
-}
-
-// The seeds of certify_pair_values<5>: one thread per read code (256 one-read codes, then 128 x 128 two-read codes of base quality < 64) runs the
-// loop of :597-639 for BOTH alpha lanes (0 and 0.5: the maximum of :626-627 runs across them) — the same operations on the same operands as the
-// two lanes of k_certify, hence the same bits.
-__global__ void k_build_certify_seeds(const double* __restrict__ tabs, double* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= kCSeedN) return;
-  uint32_t bytes[2]; int nb;
-  if (e < 256) { bytes[0] = (uint32_t)e; bytes[1] = 0; nb = 1; }
-  else {
-    const uint32_t i2 = (uint32_t)(e - 256), c0 = i2 >> 7, c1 = i2 & 127u;
-    bytes[0] = ((c0 & 0x40u) << 1) | (c0 & 0x3Fu); bytes[1] = ((c1 & 0x40u) << 1) | (c1 & 0x3Fu); nb = 2;
-  }
-  double wA[2][5], wR[2][5], pG[2][5];
-  for (int n1 = 0; n1 < 2; ++n1)
-    for (int q = 0; q < 5; ++q) {                  // the weights of k_certify's FIVE form
-      const int l = n1 ? (q > 2 ? 2 : q) : min(q, 2), m = n1 ? q - l : 0;
-      const double p = 0.5 * l + (m - l) * 0.5 * (n1 ? 0.5 : 0.0);
-      wA[n1][q] = p; wR[n1][q] = 1.0 - p; pG[n1][q] = 1.0;
-    }
-  for (int r = 0; r < nb; ++r) {
-    const uint32_t byte = bytes[r], bq = byte & 127u;
-    const bool alt = (byte >> 7) != 0;
-    const double pR = alt ? tabs[128 + bq] : tabs[bq];
-    const double pA = alt ? tabs[bq] : tabs[128 + bq];
-    double mx[2] = {0.0, 0.0};
-    for (int n1 = 0; n1 < 2; ++n1)
-      for (int i = 0; i < 5; ++i) {
-        pG[n1][i] *= (pR * wR[n1][i] + pA * wA[n1][i]);
-        mx[n1] = fmax(mx[n1], pG[n1][i]);
-      }
-    const double m = fmax(mx[0], mx[1]);
-    const double y = rcp_refined(m);
-    for (int n1 = 0; n1 < 2; ++n1)
-      for (int i = 0; i < 5; ++i) pG[n1][i] = div_by(pG[n1][i], m, y);
-  }
-  for (int n1 = 0; n1 < 2; ++n1) {
-    double* o = out + ((size_t)e * 2 + n1) * kCSeedStride;
-    for (int i = 0; i < 5; ++i) o[i] = pG[n1][i];
-    o[5] = 0.0;
-  }
-}
-
 // K3b — the tie-order certificate (DESIGN.md "Ties").  At alpha = 0.5 the reference's llksAB[j][k] and llksAB[k][j] are one number
 // mathematically and differ by the rounding noise of its own evaluation order; its strict-< scan then names the doublet
 // "a-b" or "b-a" by that noise.  To print the same order one has to know BOTH accumulators as the reference computes them, bit for
@@ -6640,6 +6617,16 @@ namespace {
 // pileups take it — at most 1.6 stored reads per covered pair on average: a tile skips its read loop only when NONE of its 16 / 32 pairs is deeper than
 // three reads (1.25 reads per pair: 93 % of the tiles; 2 reads per pair, cfg5: 7 %, and there the look-ups into a table beyond the L2 cost more than
 // they save — measured, k_certify 7.57 -> 8.23 ms).  *out stays NULL when the pileup is deeper.
+int ensure_seeds(dmx_engine* e, const double** out) {      // k_build_certify_seeds' table (default grid {0, 0.5}: k_certify<FIVE>, k_doublet_sym)
+  if (!e->cseed_valid) {
+    if (!e->d_cseed) HIP_TRY(hipMalloc((void**)&e->d_cseed, sizeof(double) * 2 * kCSeedStride * (size_t)kCSeedN));
+    hipLaunchKernelGGL(k_build_certify_seeds, dim3((unsigned)((kCSeedN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, e->d_cseed);
+    HIP_TRY(hipGetLastError());
+    e->cseed_valid = true;
+  }
+  *out = e->d_cseed;
+  return DMX_OK;
+}
 int ensure_finals(dmx_engine* e, const double** out) {
   *out = nullptr;
   if ((double)e->R > 1.6 * (double)std::max<int64_t>(e->P, 1) && !e->knob("DMX_FINALS_ANY_DEPTH")) return DMX_OK;
@@ -7037,21 +7024,25 @@ int launch_doublet(dmx_engine* e) {
   const double* pfin_a2 = nullptr;
   const bool pfin_a2_grid = A == 2 && e->alpha[0] == 0.0 && e->alpha[1] == 0.5;
   if (pfin_a2_grid && !e->knob("DMX_A2_NO_FINALS")) if (int rc = ensure_finals(e, &pfin_a2)) return rc;
+  const double* pseed_a2 = nullptr;              // ... and the tiles that walk the loop walk it in the five-value form from the seed table (DMX_A2_NO_SEEDS=1: the nine-value loop)
+  if (pfin_a2_grid && !e->knob("DMX_A2_NO_SEEDS")) if (int rc = ensure_seeds(e, &pseed_a2)) return rc;
 #define DMX_K2A(TPC, NK)                                                                                             \
   do {                                                                                                                \
     if (e->geno_safe)                                                                                                 \
       DMX_LAUNCH(k2_fn, (k_doublet_a2<TPC, NK, 1, false, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                          cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,    \
-                         e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);                               \
+                         e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);                               \
     else                                                                                                              \
   DMX_LAUNCH(k2_fn, (k_doublet_a2<TPC, NK>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC)), slabs_of(TPC, NK)), block,  \
                      cell_bytes * (kThreads / TPC), e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut,        \
-                     e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);                                   \
+                     e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);                                   \
   } while (0)
   if (fast_soft && e->alpha[0] == 0.0 && e->alpha[1] == 0.5 && (V <= 128 || sym_wide) && !e->knob("DMX_NO_SYM")) {
     // demuxlet's default grid {0, 0.5}: only the printed entries (singlet column + one evaluation per unordered pair)
     const double* pfin = nullptr;                 // phase 1's finished values of pairs of up to three tabled reads (DMX_SYM_NO_FINALS=1: the read loop everywhere)
     if (!e->knob("DMX_SYM_NO_FINALS")) if (int rc = ensure_finals(e, &pfin)) return rc;
+    const double* pseed = nullptr;                // the state after a pair's first one or two reads (DMX_SYM_NO_SEEDS=1: the loop from its start)
+    if (!e->knob("DMX_SYM_NO_SEEDS")) if (int rc = ensure_seeds(e, &pseed)) return rc;
 #define DMX_K2S(TPC, VMAX, SUB, FIX)                                                                                  \
   do { e->k2_sym = true;                                                                                                                \
     constexpr int GSS_ = (3 * VMAX + 3) & ~3, VUS_ = (VMAX + 2) & ~1, TP_ = TPC >= 64 ? 32 : TPC / 2;                   \
@@ -7066,11 +7057,11 @@ int launch_doublet(dmx_engine* e) {
     if (e->geno_safe)                                                                                                  \
       DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX, 3, 0, false>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                          block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,         \
-                         e->d_grid, e->d_l00, e->d_flag, pfin);                                                              \
+                         e->d_grid, e->d_l00, e->d_flag, pfin, pseed);                                                              \
     else                                                                                                               \
     DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
-                       e->d_grid, e->d_l00, e->d_flag, pfin);                                                                \
+                       e->d_grid, e->d_l00, e->d_flag, pfin, pseed);                                                                \
   } while (0)
 #define DMX_K2SV(TPC, VMAX, SUB, FIX, MINW)                                                                            \
   do { e->k2_sym = true;                                                                                                                \
@@ -7081,7 +7072,7 @@ int launch_doublet(dmx_engine* e) {
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));          \
     DMX_LAUNCH(k2_fn, (k_doublet_sym<TPC, VMAX, SUB, FIX, MINW>), dim3((unsigned)((B + (kThreads / TPC) - 1) / (kThreads / TPC))), \
                        block, lds, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags,           \
-                       e->d_grid, e->d_l00, e->d_flag, pfin);                                                                \
+                       e->d_grid, e->d_l00, e->d_flag, pfin, pseed);                                                                \
   } while (0)
     const int32_t sym_flags = (e->knob("DMX_SYM_NO_DMA") ? (1 << 16) : 0) | (e->knob("DMX_SYM_ABLATE_P1") ? (1 << 17) : 0) |
                               (e->knob("DMX_SYM_ABLATE_P2") ? (1 << 18) : 0) | (e->knob("DMX_SYM_ABLATE_U") ? (1 << 19) : 0) |
@@ -7116,10 +7107,10 @@ int launch_doublet(dmx_engine* e) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)cb_));                               \
     if (e->geno_safe)                                                                                                  \
       DMX_LAUNCH(k2_fn, (k_doublet_sym<256, VMAX, SUB, FIX, 3, 9, false>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
-                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag, pfin);      \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag, pfin, pseed);      \
     else                                                                                                               \
     DMX_LAUNCH(k2_fn, (k_doublet_sym<256, VMAX, SUB, FIX, 3, 9>), dim3((unsigned)B, ns), block, cb_, e->stream, e->pv, \
-                       e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag, pfin);        \
+                       e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, V | sym_flags, e->d_grid, e->d_l00, e->d_flag, pfin, pseed);        \
   } while (0)
       if (V <= 96) DMX_K2SS(96, 8, false); else if (V == 128) DMX_K2SS(128, 8, true); else if (V < 128) DMX_K2SS(128, 8, false);
       else if (V <= 192) DMX_K2SS(192, 4, false); else if (V <= 256) DMX_K2SS(256, 4, false);        // (sub-tiles of 4 pairs: 40 / 53 KB of LDS per workgroup)
@@ -7173,13 +7164,13 @@ int launch_doublet(dmx_engine* e) {
       const size_t cbd = (size_t)32 * 18 * 8 + (size_t)32 * GS * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
       if (e->geno_safe)
         DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4, true, false>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
-                           e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);
+                           e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);
       else
       DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4, true>), dim3((unsigned)B, slabs_of(256, 4)), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
-                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);
+                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);
     } else if (!e->knob("DMX_A2_MINW1"))
       DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 4, 4>), dim3((unsigned)B, slabs_of(256, 4)), block, cell_bytes, e->stream, e->pv, e->nrd_width, e->d_g,
-                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);
+                         e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);
     else DMX_K2A(256, 4);
   }
   else if (V <= 128) DMX_K2A(256, 16);            // <= 55 KB of LDS
@@ -7201,12 +7192,12 @@ int launch_doublet(dmx_engine* e) {
       if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2<256, 16, 1, false, false, TPP>),  \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
       DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 16, 1, false, false, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,  \
-                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);  \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);  \
     } else {                                                                                                          \
       if (lds > 60 * 1024) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_doublet_a2<256, 16, 1, false, true, TPP>),   \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));        \
       DMX_LAUNCH(k2_fn, (k_doublet_a2<256, 16, 1, false, true, TPP>), dim3((unsigned)B, slabs_of(256, 16)), block, lds, e->stream, e->pv,   \
-                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2);  \
+                         e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);  \
     }                                                                                                                 \
   } while (0)
     if (tp == 32) DMX_K2AW(32); else if (tp == 16) DMX_K2AW(16); else DMX_K2AW(8);
@@ -7241,15 +7232,7 @@ int launch_certify(dmx_engine* e) {
                        e->d_lut, e->d_alpha, e->V, e->d_sum, blk, (bi * bstride) | (bstride << 16), e->blk_n, park, cseed, cfin)
   const bool five = e->alpha[0] == 0.0;
   const double* cseed = nullptr;                  // the first one or two reads of a pair from a table (DMX_CERTIFY_NO_SEEDS=1: the whole loop)
-  if (five && !e->knob("DMX_CERTIFY_NO_SEEDS")) {
-    if (!e->cseed_valid) {
-      if (!e->d_cseed) HIP_TRY(hipMalloc((void**)&e->d_cseed, sizeof(double) * 2 * kCSeedStride * (size_t)kCSeedN));
-      hipLaunchKernelGGL(k_build_certify_seeds, dim3((unsigned)((kCSeedN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, e->d_cseed);
-      HIP_TRY(hipGetLastError());
-      e->cseed_valid = true;
-    }
-    cseed = e->d_cseed;
-  }
+  if (five && !e->knob("DMX_CERTIFY_NO_SEEDS")) if (int rc = ensure_seeds(e, &cseed)) return rc;
   const double* cfin = nullptr;                   // final values of pairs of up to three tabled reads (DMX_CERTIFY_NO_FINALS=1 / DMX_CERTIFY_NO_SEEDS=1: none)
   if (cseed && !e->knob("DMX_CERTIFY_NO_FINALS")) if (int rc = ensure_finals(e, &cfin)) return rc;
   if (e->knob("DMX_CERTIFY_MINW3")) { if (gT) DMX_K3B(3, false, true); else DMX_K3B(3, false, false); }      // kernel experiments only

@@ -1328,7 +1328,7 @@ def _mixed_depth_problem(eng, V, dense):
 
 def _grid_with_env(eng, monkeypatch, g, pl, V, mode, env, kernel_prefix, alphas=(0.0, 0.5)):
     monkeypatch.setenv("DMX_EXPERIMENTS", "1")
-    for k in ("DMX_SYM_NO_FINALS", "DMX_A2_NO_FINALS", "DMX_FINALS_ANY_DEPTH", "DMX_A2_SYM", "DMX_A2S_MINW4"):
+    for k in ("DMX_SYM_NO_FINALS", "DMX_A2_NO_FINALS", "DMX_FINALS_ANY_DEPTH", "DMX_A2_SYM", "DMX_A2S_MINW4", "DMX_SYM_NO_SEEDS", "DMX_A2_NO_SEEDS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -1349,8 +1349,9 @@ def test_phase1_final_tables_leave_the_fast_grid_unchanged(eng, monkeypatch, V, 
     workgroups, entry slabs).  DMX_FINALS_ANY_DEPTH=1 lifts the launch rule (<= 1.6 reads per pair) so that deeper pileups exercise the table too."""
     from demuxlet_amd import capi
     g, pl = _mixed_depth_problem(eng, V, dense)
-    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_FAST, {"DMX_SYM_NO_FINALS": "1"}, "k_doublet_sym<")
-    for env in ({"DMX_FINALS_ANY_DEPTH": "1"}, {}):
+    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_FAST, {"DMX_SYM_NO_FINALS": "1", "DMX_SYM_NO_SEEDS": "1"}, "k_doublet_sym<")
+    # ... and the pairs that do walk the loop start it from the seed table (the state after their first one or two reads): DMX_SYM_NO_SEEDS=1 is the loop from read 0
+    for env in ({"DMX_SYM_NO_FINALS": "1"}, {"DMX_FINALS_ANY_DEPTH": "1"}, {"DMX_FINALS_ANY_DEPTH": "1", "DMX_SYM_NO_SEEDS": "1"}, {}):
         got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_FAST, env, "k_doublet_sym<")
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
     assert np.isfinite(base[0]).all()
@@ -1363,8 +1364,9 @@ def test_phase1_final_tables_leave_the_strict_grid_unchanged(eng, monkeypatch, V
     DMX_A2_NO_FINALS=1 on every form of the kernel (64-thread cells, 256-thread cells with binary64 rows, j-slabs, the wide-panel tiles); another grid keeps the loop."""
     from demuxlet_amd import capi
     g, pl = _mixed_depth_problem(eng, V, dense)
-    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_FINALS": "1"}, "k_doublet_a2<")
-    for env in ({"DMX_FINALS_ANY_DEPTH": "1"}, {}):
+    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_FINALS": "1", "DMX_A2_NO_SEEDS": "1"}, "k_doublet_a2<")
+    # ... and on that grid the tiles that walk the loop walk it in the five-value form from the seed table (DMX_A2_NO_SEEDS=1: the nine-value loop from read 0)
+    for env in ({"DMX_A2_NO_FINALS": "1"}, {"DMX_FINALS_ANY_DEPTH": "1"}, {"DMX_FINALS_ANY_DEPTH": "1", "DMX_A2_NO_SEEDS": "1"}, {}):
         got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, env, "k_doublet_a2<")
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
     if V == 16:                                  # a grid the table does not describe: the loop runs, the switch changes nothing
