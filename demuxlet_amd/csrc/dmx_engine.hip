@@ -6616,7 +6616,7 @@ namespace {
 // k_build_certify_finals' table (round 6), for the kernels that run phase 1 of the default grid {0, 0.5}: k_doublet_sym and k_certify<FIVE>.  Only shallow
 // pileups take it — at most 1.6 stored reads per covered pair on average: a tile skips its read loop only when NONE of its 16 / 32 pairs is deeper than
 // three reads (1.25 reads per pair: 93 % of the tiles; 2 reads per pair, cfg5: 7 %, and there the look-ups into a table beyond the L2 cost more than
-// they save — measured, k_certify 7.57 -> 8.23 ms).  *out stays NULL when the pileup is deeper.
+// they save — measured, k_certify 7.57 -> 8.23 ms).  *out stays NULL when the pileup is deeper, or too small to pay for the table.
 int ensure_seeds(dmx_engine* e, const double** out) {      // k_build_certify_seeds' table (default grid {0, 0.5}: k_certify<FIVE>, k_doublet_sym)
   if (!e->cseed_valid) {
     if (!e->d_cseed) HIP_TRY(hipMalloc((void**)&e->d_cseed, sizeof(double) * 2 * kCSeedStride * (size_t)kCSeedN));
@@ -6630,6 +6630,9 @@ int ensure_seeds(dmx_engine* e, const double** out) {      // k_build_certify_se
 int ensure_finals(dmx_engine* e, const double** out) {
   *out = nullptr;
   if ((double)e->R > 1.6 * (double)std::max<int64_t>(e->P, 1) && !e->knob("DMX_FINALS_ANY_DEPTH")) return DMX_OK;
+  // ... and only jobs big enough to pay for it: allocating and filling the 58 MB table costs an engine ~1.5 ms (cfg6's 0.035 s job: +4 %, measured),
+  // what it saves is ~2 ms per 1e8 covered pairs (cfg3, 5e8 pairs: 13 ms STRICT, 7 ms FAST)
+  if (e->P < 100000000 && !e->cfin_valid && !e->knob("DMX_FINALS_ANY_DEPTH")) return DMX_OK;
   if (!e->cfin_valid) {
     if (!e->d_cfin) HIP_TRY(hipMalloc((void**)&e->d_cfin, sizeof(double) * kCFinStride * (size_t)kCFinN));
     hipLaunchKernelGGL(k_build_certify_finals, dim3((unsigned)((kCFinN + 255) / 256)), dim3(256), 0, e->stream, e->d_lut, e->d_cfin);

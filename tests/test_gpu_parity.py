@@ -505,7 +505,9 @@ def test_certify_seed_tables_leave_every_record_unchanged(eng, V, field, dense):
     pl = eng.HostPileup(B, S, cpo, cro, pair_snp, nrd, reads, z, z, z)
     os.environ.pop("DMX_CERTIFY_NO_SEEDS", None)
     os.environ.pop("DMX_CERTIFY_NO_FINALS", None)
+    os.environ["DMX_FINALS_ANY_DEPTH"] = "1"          # (the launch rule keeps the table from pileups this small or this deep: lifted here)
     a = run_engine(eng, pl, g, (0.0, 0.5), 0.5)       # round 6: final values of 0..3-read pairs from k_build_certify_finals' table, seeds for the deeper ones
+    os.environ.pop("DMX_FINALS_ANY_DEPTH", None)
     os.environ["DMX_CERTIFY_NO_SEEDS"] = "1"
     try:
         b = run_engine(eng, pl, g, (0.0, 0.5), 0.5)   # no table at all
@@ -1346,7 +1348,7 @@ def test_phase1_final_tables_leave_the_fast_grid_unchanged(eng, monkeypatch, V, 
     base quality < 48) from k_build_certify_finals' table and runs its read loop only in tiles with a deeper pair.  Same operations on the same operands:
     the grid and llks00 must equal the table-free kernel's (DMX_SYM_NO_FINALS=1) bit for bit — pairs of 0..6 reads and beyond kSafeReads (the plain division),
     base qualities over the whole range, tiles with and without a deep pair, every panel form of the kernel (4 / 2 / 1 barcodes per wavefront, 256-thread
-    workgroups, entry slabs).  DMX_FINALS_ANY_DEPTH=1 lifts the launch rule (<= 1.6 reads per pair) so that deeper pileups exercise the table too."""
+    workgroups, entry slabs).  DMX_FINALS_ANY_DEPTH=1 lifts the launch rule (<= 1.6 reads per pair, >= 1e8 covered pairs) so that these small, deeper pileups exercise the table."""
     from demuxlet_amd import capi
     g, pl = _mixed_depth_problem(eng, V, dense)
     base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_FAST, {"DMX_SYM_NO_FINALS": "1", "DMX_SYM_NO_SEEDS": "1"}, "k_doublet_sym<")
