@@ -2175,13 +2175,16 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 // TP: covered pairs per tile (32; 16 or 8 on panels of more than ~180 samples, whose 32 staged genotype rows would leave one workgroup per CU)
 // (the 64-thread-cell forms run three workgroups of four cells per CU = three wavefronts per SIMD: bounded to their 168 registers — left unbounded the
 //  compiler's count moved from 158 to 246 with an unrelated edit of phase 1 and cfg5 STRICT lost a wavefront per SIMD, 144 -> 168 ms)
-template <int TPC, int NK, int MINW = 1, bool GD = false, bool CHK = true, int TP = 32>
-__global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
+// SYMU (round 6, k_doublet_a2u below; V == 32, default grid): phase 2 over UNORDERED pairs — thread t owns the pairs {j, (j + d) & 31} of units u = t and t + 256
+// (u < 496: d = 1 + u / 32, j = u % 32; d = 16 from j < 16 only) with the four accumulators [j][k][0..1], [k][j][0..1] each: eight per thread, as before.
+template <int TPC, int NK, int MINW, bool GD, bool CHK, int TP, bool SYMU>
+__device__ __forceinline__ void a2_body(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                          const double* __restrict__ alpha,
                                                          const int32_t* __restrict__ sched, int32_t V, int32_t GS,
                                                          double* __restrict__ grid, double* __restrict__ l00,
                                                          uint8_t* __restrict__ flagged, const double* __restrict__ pfin, const double* __restrict__ pseed) {
+  static_assert(!SYMU || (TPC == 256 && NK == 4 && !CHK), "symmetric ownership: 256 threads per barcode, eight accumulators per thread, provably safe rows");
   // pfin (round 6; NULL unless the grid is {0, 0.5} and the pileup shallow): k_build_certify_finals' table of finished phase-1 values;
   // pseed (NULL unless the grid is {0, 0.5}): k_build_certify_seeds' table — on that grid the tiles that walk the read loop walk it in the five-value form
   // (alpha 0.5's five distinct mixing weights, alpha 0's three: entries of equal weight go through identical operations, so the nine values are these,
@@ -2238,6 +2241,11 @@ __global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void
   for (int kk = 0; kk < NK; ++kk) { acc[kk][0] = 0.0; acc[kk][1] = 0.0; }
   bool ok = true;
   const DmxLogPins lk = dmx_log_pins();
+  int uj[2] = {0, 0}, uk[2] = {0, 0};            // SYMU: the thread's two unordered pairs; acc[2 su] = [j][k][0..1], acc[2 su + 1] = [k][j][0..1]
+  if constexpr (SYMU) {
+#pragma unroll
+    for (int su = 0; su < 2; ++su) { const int u = tid + 256 * su; uj[su] = u & 31; uk[su] = (uj[su] + 1 + (u >> 5)) & 31; }
+  }
   // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1; mixing weights of :613
   const int ti1 = tid >> 1, n1 = tid & 1;
   double acc00 = 0.0;                            // lane n1 == tid < 2 owns llks00[n]
@@ -2382,6 +2390,60 @@ __global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void
       }
     }
     // ---- phase 2
+    if constexpr (SYMU) {
+      // At alpha 0.5 the mixture is symmetric — pG[1][l][m] == pG[1][m][l] bit for bit (equal mixing weights go through identical operations) — so the
+      // nine terms (g_k[l] g_j[m]) pG[1][l][m] of entry [k][j] are entry [j][k]'s T[l][m] = (g_j[l] g_k[m]) pG[1][l][m], transposed: the reference adds them
+      // l-major for [j][k] and, seen from [j][k]'s indices, m-major for [k][j].  The owner of both forms the exact products E and the terms T once: 36
+      // multiplies per unordered pair instead of 54; the 32 adds, the four logs and the four accumulator adds are the reference's, on its operands, in its order.
+      for (int ti = 0; ti < tp; ++ti) {
+        const double* P = &s_pG[ti * 18];
+        const double Q[3] = {P[0], P[3], P[6]};                              // pG[0][l][m] = q0[l]
+        const double P1[5] = {P[9], P[10], P[11], P[14], P[17]};             // pG[1][l][m] = q1[l + m]
+        const g_t* gr = &s_g[ti * GS];
+#pragma unroll
+        for (int su = 0; su < 2; ++su) {
+          const int js = uj[su], ks = uk[su];
+          const double a[3] = {(double)gr[js * 3], (double)gr[js * 3 + 1], (double)gr[js * 3 + 2]};
+          const double b[3] = {(double)gr[ks * 3], (double)gr[ks * 3 + 1], (double)gr[ks * 3 + 2]};
+          double E[3][3];
+#pragma unroll
+          for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) E[l][m] = a[l] * b[m];                  // :553 (exact) — shared by [j][k] and [k][j] at both alphas
+          {
+            // [j][k][0]: l-major over (l, m) of (g_j[l] g_k[m]) q0[l]; [k][j][0]: of (g_k[l] g_j[m]) q0[l] = E[m][l] q0[l] (the first product initialises the sum)
+            double s_jk0 = E[0][0] * Q[0], s_kj0 = E[0][0] * Q[0];
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+              for (int m = 0; m < 3; ++m) {
+                if (l == 0 && m == 0) continue;
+                s_jk0 += (E[l][m] * Q[l]);
+                s_kj0 += (E[m][l] * Q[l]);
+              }
+            acc[2 * su][0] += dmx_log2_fast_pinned(s_jk0, s_log, lk);          // :683
+            acc[2 * su + 1][0] += dmx_log2_fast_pinned(s_kj0, s_log, lk);
+          }
+          {
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+              for (int m = 0; m < 3; ++m) E[l][m] = E[l][m] * P1[l + m];        // T: :677-679 at alpha 0.5 — [k][j]'s nine terms are these, transposed
+            double s_jk1 = E[0][0], s_kj1 = E[0][0];
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+#pragma unroll
+              for (int m = 0; m < 3; ++m) {
+                if (l == 0 && m == 0) continue;
+                s_jk1 += E[l][m];
+                s_kj1 += E[m][l];
+              }
+            acc[2 * su][1] += dmx_log2_fast_pinned(s_jk1, s_log, lk);
+            acc[2 * su + 1][1] += dmx_log2_fast_pinned(s_kj1, s_log, lk);
+          }
+        }
+      }
+    } else
     if (owner) {
       for (int ti = 0; ti < tp; ++ti) {
         const double* P = &s_pG[ti * 18];
@@ -2417,6 +2479,18 @@ __global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void
     DMX_K2_SYNC();
   }
   if (cell_ok) {
+    if constexpr (SYMU) {
+#pragma unroll
+      for (int su = 0; su < 2; ++su) {
+        const int u = tid + 256 * su, d = 1 + (u >> 5);
+        if (d < 16 || (d == 16 && uj[su] < 16)) {  // d = 16 is reached from both sides: the j < 16 thread stores; units beyond 495 do not exist
+          double* o = grid + (((size_t)cell * V + uj[su]) * V + uk[su]) * A;
+          o[0] = acc[2 * su][0]; o[1] = acc[2 * su][1];
+          double* o2 = grid + (((size_t)cell * V + uk[su]) * V + uj[su]) * A;
+          o2[0] = acc[2 * su + 1][0]; o2[1] = acc[2 * su + 1][1];
+        }
+      }
+    } else
     if (owner) {
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
@@ -2431,6 +2505,26 @@ __global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void
     if (!ok) flag_cell(flagged, cell);
   }
 #undef DMX_K2_SYNC
+}
+template <int TPC, int NK, int MINW = 1, bool GD = false, bool CHK = true, int TP = 32>
+__global__ __launch_bounds__(kThreads, (MINW == 1 && TPC == 64) ? 3 : MINW) void k_doublet_a2(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                         const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                         const double* __restrict__ alpha,
+                                                         const int32_t* __restrict__ sched, int32_t V, int32_t GS,
+                                                         double* __restrict__ grid, double* __restrict__ l00,
+                                                         uint8_t* __restrict__ flagged, const double* __restrict__ pfin, const double* __restrict__ pseed) {
+  a2_body<TPC, NK, MINW, GD, CHK, TP, false>(pv, nrd_width, g, gp0, tabs, alpha, sched, V, GS, grid, l00, flagged, pfin, pseed);
+}
+// k_doublet_a2 over unordered pairs (STRICT, default grid, 32 soft-field samples: cfg3 — the headline): everything of k_doublet_a2<256,4,4,GD,noCHK> but phase 2's
+// ownership (SYMU above).  The 32 diagonal entries [j][j][n] are not its: k_doublet_a2s<.., 0> (one wavefront per barcode) adds them behind it.
+template <int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2u(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                          const double* __restrict__ alpha,
+                                                          const int32_t* __restrict__ sched, int32_t V, int32_t GS,
+                                                          double* __restrict__ grid, double* __restrict__ l00,
+                                                          uint8_t* __restrict__ flagged, const double* __restrict__ pfin, const double* __restrict__ pseed) {
+  a2_body<256, 4, MINW, true, false, 32, true>(pv, nrd_width, g, gp0, tabs, alpha, sched, V, GS, grid, l00, flagged, pfin, pseed);
 }
 
 // K2, A = 2, FAST mode (dmx_engine_config.mode = DMX_MODE_FAST): k_doublet_a2 with the bilinear factoring of SURVEY H3.  Not the
@@ -3186,12 +3280,13 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_sym(PileupView pv, i
 // lane (j, h) the entry [j][j][h].  496 pairs x 112 + 64 x 37 instructions per covered pair against 1 024 x 65.  One wavefront per (barcode, slab), no
 // workgroup barrier: each slab runs the cheap per-tile phases for itself (k_doublet_sym's: headers, rows straight into the LDS one sub-tile ahead, phase 1
 // with the final-value table), then its pairs.
-template <int SUB, int MINW>
+template <int SUB, int MINW, int NUP = 4>     // NUP = 0: the diagonal entries only (behind k_doublet_a2u, which owns everything else and llks00)
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2s(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                           const double* __restrict__ gp0, const double* __restrict__ tabs,
                                                           const int32_t* __restrict__ sched,
                                                           double* __restrict__ grid, double* __restrict__ l00, const double* __restrict__ pfin) {
-  constexpr int V = 32, A = 2, TP = 32, TPC = 64, CPW = kThreads / TPC, T00 = TP + 2, NU = 4, GSS = 3 * V, row_len = 3 * V;
+  constexpr int V = 32, A = 2, TP = 32, TPC = 64, CPW = kThreads / TPC, T00 = TP + 2, NU = NUP ? NUP : 1, GSS = 3 * V, row_len = 3 * V;
+  constexpr bool DIAG_ONLY = NUP == 0;
   __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][10];
   __shared__ __attribute__((aligned(16))) double s_pq_all[CPW][TP][8];       // per pair: alpha 0.5's five distinct values q[l + m] | alpha 0's three q[l]
@@ -3344,7 +3439,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2s(PileupView pv, i
       }
     }
     DMX_WAVE_LDS_ORDER();
-    if (tid < 2 && slab == 0) {                    // llks00: lane n adds its alpha's terms in pair order
+    if (!DIAG_ONLY && tid < 2 && slab == 0) {      // llks00: lane n adds its alpha's terms in pair order
       const double* row = &s_t00[tid * T00];
       for (int i = 0; i < tp; ++i) acc00 += row[i];
     }
@@ -3372,7 +3467,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2s(PileupView pv, i
         }
         float bn[3] = {gr[kk[0] * 3], gr[kk[0] * 3 + 1], gr[kk[0] * 3 + 2]};
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
+        for (int i = 0; i < (DIAG_ONLY ? 0 : NU); ++i) {
           const double b[3] = {(double)bn[0], (double)bn[1], (double)bn[2]};
           if (ROOMY && i + 1 < NU) { const int kn = kk[i + 1]; bn[0] = gr[kn * 3]; bn[1] = gr[kn * 3 + 1]; bn[2] = gr[kn * 3 + 2]; }
           else if (!ROOMY && i + 1 < NU) { const int kn = kk[i + 1]; bn[0] = gr[kn * 3]; bn[1] = gr[kn * 3 + 1]; bn[2] = gr[kn * 3 + 2]; }
@@ -3440,7 +3535,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2s(PileupView pv, i
   }
   double* G = grid + (size_t)cell * V * V * A;
 #pragma unroll
-  for (int i = 0; i < NU; ++i) {
+  for (int i = 0; i < (DIAG_ONLY ? 0 : NU); ++i) {
     const int d = 1 + 2 * (NU * slab + i) + h, k = kk[i];
     if (d < 16 || j < 16) {                        // d = 16 is reached from both sides: the j < 16 lane stores
       G[((size_t)j * V + k) * A] = acc[i][0]; G[((size_t)j * V + k) * A + 1] = acc[i][1];
@@ -3449,7 +3544,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2s(PileupView pv, i
   }
   if (slab == 0) {
     G[((size_t)j * V + j) * A + h] = accd;
-    if (tid < 2) l00[(size_t)cell * A + tid] = acc00;
+    if (!DIAG_ONLY && tid < 2) l00[(size_t)cell * A + tid] = acc00;
   }
 }
 
@@ -7145,7 +7240,16 @@ int launch_doublet(dmx_engine* e) {
     HIP_TRY(hipGetLastError());
     return launch_doublet_generic_w<true>(e);
   }
-  if (V == 32 && pfin_a2_grid && e->geno_safe && e->knob("DMX_A2_SYM")) {
+  if (V == 32 && pfin_a2_grid && e->geno_safe && !e->knob("DMX_A2_SYM") && !e->knob("DMX_A2_NO_SYMU") && !e->knob("DMX_A2_NO_GD") && !e->knob("DMX_A2_MINW1")) {
+    // 32 soft-field samples on the default grid (cfg3, the headline): k_doublet_a2's kernel over UNORDERED pairs — a thread owns [j][k] and [k][j] and forms
+    // the products they share once — and the 64 diagonal accumulators of a barcode on one wavefront behind it (DMX_A2_NO_SYMU=1: k_doublet_a2)
+    const size_t cbd = (size_t)32 * 18 * 8 + (size_t)32 * GS * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
+    DMX_LAUNCH(k2_fn, (k_doublet_a2u<4>), dim3((unsigned)B, 1), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
+                       e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);
+    hipLaunchKernelGGL((k_doublet_a2s<4, 4, 0>), dim3((unsigned)((B + 3) / 4), 1), block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched,
+                       e->d_grid, e->d_l00, pfin_a2);
+  }
+  else if (V == 32 && pfin_a2_grid && e->geno_safe && e->knob("DMX_A2_SYM")) {
     // 32 soft-field samples on the default grid (cfg3, the headline): symmetric ownership — one lane owns [j][k] and [k][j], their shared products once.
     // An EXPERIMENT (DMX_A2_SYM=1), bit-identical, 9 % fewer instructions (967 FP64 + 212 others against 1 040 + 260 per covered pair and barcode) and
     // about as fast: the 17 accumulators per lane do not fit four wavefronts per SIMD (128 registers: 18 spill accesses per pair in the loop, 3 139 ms),

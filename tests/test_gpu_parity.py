@@ -1330,7 +1330,7 @@ def _mixed_depth_problem(eng, V, dense):
 
 def _grid_with_env(eng, monkeypatch, g, pl, V, mode, env, kernel_prefix, alphas=(0.0, 0.5)):
     monkeypatch.setenv("DMX_EXPERIMENTS", "1")
-    for k in ("DMX_SYM_NO_FINALS", "DMX_A2_NO_FINALS", "DMX_FINALS_ANY_DEPTH", "DMX_A2_SYM", "DMX_A2S_MINW4", "DMX_SYM_NO_SEEDS", "DMX_A2_NO_SEEDS"):
+    for k in ("DMX_SYM_NO_FINALS", "DMX_A2_NO_FINALS", "DMX_FINALS_ANY_DEPTH", "DMX_A2_SYM", "DMX_A2S_MINW4", "DMX_SYM_NO_SEEDS", "DMX_A2_NO_SEEDS", "DMX_A2_NO_SYMU"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -1366,10 +1366,10 @@ def test_phase1_final_tables_leave_the_strict_grid_unchanged(eng, monkeypatch, V
     DMX_A2_NO_FINALS=1 on every form of the kernel (64-thread cells, 256-thread cells with binary64 rows, j-slabs, the wide-panel tiles); another grid keeps the loop."""
     from demuxlet_amd import capi
     g, pl = _mixed_depth_problem(eng, V, dense)
-    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_FINALS": "1", "DMX_A2_NO_SEEDS": "1"}, "k_doublet_a2<")
+    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_FINALS": "1", "DMX_A2_NO_SEEDS": "1"}, "k_doublet_a2")
     # ... and on that grid the tiles that walk the loop walk it in the five-value form from the seed table (DMX_A2_NO_SEEDS=1: the nine-value loop from read 0)
     for env in ({"DMX_A2_NO_FINALS": "1"}, {"DMX_FINALS_ANY_DEPTH": "1"}, {"DMX_FINALS_ANY_DEPTH": "1", "DMX_A2_NO_SEEDS": "1"}, {}):
-        got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, env, "k_doublet_a2<")
+        got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, env, "k_doublet_a2")
         assert np.array_equal(got[0], base[0]) and np.array_equal(got[1], base[1]), env
     if V == 16:                                  # a grid the table does not describe: the loop runs, the switch changes nothing
         a = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_FINALS_ANY_DEPTH": "1"}, "k_doublet_a2<", alphas=(0.1, 0.5))
@@ -1445,7 +1445,13 @@ def test_symmetric_strict_kernel_gives_k_doublet_a2s_bits(eng, oracle, monkeypat
         rng = np.random.default_rng(4242)
         raw = synth.make_raw_genotypes(rng, g.shape[0], V)
         g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, raw.alleles)])
-    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {}, "k_doublet_a2<")
+    base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_SYMU": "1"}, "k_doublet_a2<")
+    # the shipped form: k_doublet_a2's kernel over unordered pairs (k_doublet_a2u) + the diagonal entries on one wavefront per barcode behind it
+    for env in ({}, {"DMX_A2_NO_FINALS": "1"}, {"DMX_FINALS_ANY_DEPTH": "1"}, {"DMX_A2_NO_SEEDS": "1", "DMX_A2_NO_FINALS": "1"}):
+        got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, env, "k_doublet_a2u<")
+        assert np.array_equal(got[0], base[0]), (env, np.argwhere(got[0] != base[0])[:5])
+        assert np.array_equal(got[1], base[1]), env
+    # the one-wavefront-per-(barcode, slab) experiment kernel
     for env in ({"DMX_A2_SYM": "1"}, {"DMX_A2_SYM": "1", "DMX_A2_NO_FINALS": "1"}, {"DMX_A2_SYM": "1", "DMX_FINALS_ANY_DEPTH": "1"}, {"DMX_A2_SYM": "1", "DMX_A2S_MINW4": "1"}):
         got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, env, "k_doublet_a2s<")
         assert np.array_equal(got[0], base[0]), (env, np.argwhere(got[0] != base[0])[:5])
