@@ -1466,3 +1466,51 @@ def test_symmetric_strict_kernel_gives_k_doublet_a2s_bits(eng, oracle, monkeypat
     ref = oracle.run_csr(csr, [f"s{j}" for j in range(V)], g, oracle.Params((0.0, 0.5), 0.5), None, False)
     proc = ref.processed.astype(bool)
     assert np.abs(base[0][proc] - ref.llksAB[proc]).max() < TOL
+
+
+@pytest.mark.parametrize("B,S,cover", [(5, 45, 0.5), (1, 31, 1.0), (9, 333, 0.08), (130, 64, 0.3)])
+def test_unordered_pair_kernel_on_ragged_small_problems(eng, monkeypatch, B, S, cover):
+    """k_doublet_a2u + its diagonal kernel on the shapes the big tests do not reach: barcode counts that are not multiples of 4 (the diagonal kernel's
+    workgroups hold four barcodes), barcodes without any covered SNP, fewer pairs than a tile or a sub-tile, a single barcode — bit for bit k_doublet_a2's grid,
+    llks00 and K3 records."""
+    from demuxlet_amd import synth, capi
+    V = 32
+    rng = np.random.default_rng(6100 + B + S)
+    raw = synth.make_raw_genotypes(rng, S, V)
+    g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
+    cov = rng.random((B, S)) < cover
+    if B > 2:
+        cov[1, :] = False                                                 # a barcode without a pair
+    if cover >= 1.0:
+        cov[:] = True
+    npair = cov.sum(axis=1)
+    dense = bool(cov.all())
+    pair_snp = None if dense else np.concatenate([np.nonzero(cov[c])[0] for c in range(B)]).astype(np.int32)
+    P = int(npair.sum())
+    nrd = rng.choice(np.arange(5), size=P, p=[0.1, 0.6, 0.2, 0.07, 0.03]).astype(np.uint8)
+    nr = int(nrd.sum())
+    reads = (rng.integers(2, 60, size=nr).astype(np.uint8)) | (rng.integers(0, 2, size=nr).astype(np.uint8) << 7)
+    cpo = np.concatenate([[0], np.cumsum(npair)]).astype(np.int64)
+    cro = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(B), npair), weights=nrd, minlength=B))]).astype(np.int64)
+    z = np.zeros(B, dtype=np.int32)
+    pl = eng.HostPileup(B, S, cpo, cro, pair_snp, nrd, reads, z, z, z)
+
+    def run(env, want):
+        monkeypatch.setenv("DMX_EXPERIMENTS", "1")
+        for k in ("DMX_A2_NO_SYMU", "DMX_FINALS_ANY_DEPTH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = eng.Engine(V, (0.0, 0.5), 0.5)
+        e.set_genotypes(g); e.set_pileup(pl); e.run(); e.sync()
+        assert e.kernel_names()["doublet"].startswith(want), e.kernel_names()
+        out = e.get_doublet()
+        e.close()
+        return out
+
+    a = run({"DMX_A2_NO_SYMU": "1"}, "k_doublet_a2<")
+    for env in ({}, {"DMX_FINALS_ANY_DEPTH": "1"}):
+        b = run(env, "k_doublet_a2u<")
+        covered = npair > 0
+        assert np.array_equal(a[0][covered], b[0][covered]) and np.array_equal(a[1][covered], b[1][covered]), env
+        assert a[2].tobytes() == b[2].tobytes(), env
