@@ -3549,6 +3549,131 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2s(PileupView pv, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The diagonal of k_doublet_a2u's grid: entries [j][j][0..1] of 32 samples (STRICT, default grid).  Lane j of a barcode's 32 lanes owns BOTH alphas of its
+// sample — the six distinct exact products g_j[l] g_j[m] once, two nine-term l-major sums, two logs, two accumulators — and a wavefront carries two barcodes
+// (k_doublet_a2s<.., 0>, the first form, spent a 64-lane wavefront per barcode: lane (j, alpha), 62 instructions per pair; this one 83 per pair for two
+// barcodes).  Per tile of 16 pairs and barcode: headers (16 lanes), phase 1 (32 lanes = pair x alpha; k_doublet_sym's, from the final-value table where
+// every pair of the wavefront's two tiles is on it), then the lane's own three floats per pair straight from the matrix.  No workgroup barrier.
+template <int MINW>
+__global__ __launch_bounds__(kThreads, MINW) void k_doublet_diag(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                           const double* __restrict__ tabs, const int32_t* __restrict__ sched,
+                                                           double* __restrict__ grid, const double* __restrict__ pfin) {
+  constexpr int V = 32, A = 2, TPC = 32, TP = 16, CPW = kThreads / TPC, row_len = 3 * V, PB = 8;
+  __shared__ double s_tab[kTab2];
+  __shared__ double s_w[2][10];
+  __shared__ __attribute__((aligned(16))) double s_pq_all[CPW][TP][8];
+  __shared__ int64_t s_off_all[CPW][TP];
+  __shared__ int32_t s_snp_all[CPW][TP];
+  __shared__ uint32_t s_cnt_all[CPW][TP];
+  const double* s_log = s_tab + kLut2;
+  const int t = threadIdx.x;
+  stage_k2_tables(s_tab, tabs, t, kThreads);
+  if (t < 10) {
+    const int n = t / 5, q = t % 5;
+    const int l = n ? (q > 2 ? 2 : q) : min(q, 2), m = n ? q - l : 0;
+    const double p = 0.5 * l + (m - l) * 0.5 * (n ? 0.5 : 0.0);
+    s_w[n][q] = p;
+    s_w[n][5 + q] = 1.0 - p;
+  }
+  __syncthreads();
+  const int cw = t / TPC, tid = t % TPC;
+  double* s_pq = &s_pq_all[cw][0][0];
+  int64_t* s_off = s_off_all[cw]; int32_t* s_snp = s_snp_all[cw]; uint32_t* s_cnt = s_cnt_all[cw];
+  const int slot = blockIdx.x * CPW + cw;
+  if ((blockIdx.x * CPW + (cw & ~1)) >= pv.B) return;       // both barcodes of the wavefront past the end (no workgroup barrier below)
+  const bool cell_ok = slot < pv.B;
+  const int32_t cell = cell_ok ? sched[slot] : 0;
+  const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
+  const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
+  int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
+  int64_t np_w = np;                               // the longer of the wavefront's two barcodes: the tile loop is wave-uniform
+  { const int64_t o = __shfl_xor(np, 32); np_w = np_w > o ? np_w : o; }
+  const int j = tid;
+  double acc0 = 0.0, acc1 = 0.0;
+  const DmxLogPins lk = dmx_log_pins();
+  const int ti1 = tid >> 1, n1 = tid & 1;
+  for (int64_t tbase = 0; tbase < np_w; tbase += TP) {
+    const int tp = (int)max((int64_t)0, min((int64_t)TP, np - tbase));
+    if (tid < TP) {
+      const bool v = tid < tp;
+      const uint32_t n = v ? load_nrd(pv.pair_nrd, p_beg + tbase + tid, nrd_width) : 0u;
+      const int32_t sn = v ? (pv.pair_snp ? pv.pair_snp[p_beg + tbase + tid] : (int32_t)(tbase + tid)) : 0;
+      const uint32_t incl = seg_scan_incl<TP>(n);
+      s_cnt[tid] = n;
+      s_off[tid] = rd_base + (int64_t)(incl - n);
+      s_snp[tid] = sn;
+    }
+    DMX_WAVE_LDS_ORDER();
+    if (tp > 0) rd_base = s_off[tp - 1] + (int64_t)s_cnt[tp - 1];
+    // ---- phase 1 (:597-663), k_doublet_sym's: lane (pair ti1, alpha n1), five distinct values
+    {
+      const bool on = ti1 < tp;
+      const uint32_t cnt = on ? s_cnt[ti1] : 0u;
+      const int64_t off = on ? s_off[ti1] : 0;
+      const uint32_t rd4 = load_rd4(pv, off, cnt);
+      double q[5];
+      const int32_t fi = pfin ? certify_final_index(cnt, rd4) : -1;
+      if (!__any(fi < 0)) {
+        const double* fp = pfin + (size_t)fi * kCFinStride + (n1 ? 0 : 5);
+        q[0] = fp[0]; q[1] = fp[1]; q[2] = fp[2];
+        q[3] = n1 ? fp[3] : 0.0; q[4] = n1 ? fp[4] : 0.0;
+      } else {
+        double wA[5], wR[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }
+        certify_pair_values<5, false>(pv, cnt, off, rd4, s_tab, wA, wR, n1, q, nullptr);
+      }
+      if (on) {
+        if (n1) {
+#pragma unroll
+          for (int i = 0; i < 5; ++i) s_pq[ti1 * 8 + i] = q[i];
+        } else {
+#pragma unroll
+          for (int l = 0; l < 3; ++l) s_pq[ti1 * 8 + 5 + l] = q[l];
+        }
+      }
+    }
+    DMX_WAVE_LDS_ORDER();
+    // ---- phase 2: the lane's sample against itself, PB pairs' rows requested at once
+#pragma unroll 1
+    for (int sub = 0; sub < TP; sub += PB) {
+      if (!__any(sub < tp)) break;
+      float ar[PB][3];
+#pragma unroll
+      for (int pi = 0; pi < PB; ++pi) {
+        const float* src = g + (size_t)s_snp[sub + pi] * row_len + j * 3;     // (entries past the tile's last pair hold SNP 0)
+        ar[pi][0] = src[0]; ar[pi][1] = src[1]; ar[pi][2] = src[2];
+      }
+#pragma unroll
+      for (int pi = 0; pi < PB; ++pi) {
+        if (sub + pi < tp) {
+          const double* pq = &s_pq[(sub + pi) * 8];
+          const double a[3] = {(double)ar[pi][0], (double)ar[pi][1], (double)ar[pi][2]};
+          const double P[5] = {pq[0], pq[1], pq[2], pq[3], pq[4]}, Q[3] = {pq[5], pq[6], pq[7]};
+          double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+          for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              const double e = a[l] * a[m];                                   // :553 (exact; a[l] a[m] == a[m] a[l]: six distinct)
+              const double t0 = e * Q[l], t1 = e * P[l + m];                  // :677-679 at alpha 0 (pG = q0[l]) and alpha 0.5 (pG = q1[l + m])
+              s0 = (l == 0 && m == 0) ? t0 : s0 + t0;                         // l-major; the first product initialises the sum (0 + x == x)
+              s1 = (l == 0 && m == 0) ? t1 : s1 + t1;
+            }
+          acc0 += dmx_log2_fast_pinned(s0, s_log, lk);                        // :683
+          acc1 += dmx_log2_fast_pinned(s1, s_log, lk);
+        }
+      }
+    }
+    DMX_WAVE_LDS_ORDER();
+  }
+  if (cell_ok) {
+    double* o = grid + (((size_t)cell * V + j) * V + j) * A;
+    o[0] = acc0; o[1] = acc1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K2 for alpha grids of 3..8 entries: k_doublet_a2's ownership, order and arithmetic with AP (= A rounded up to 2, 4 or 8)
 // alphas per pair.  Phase 1 spreads the TP * AP (pair, alpha) lanes over all the cell's threads, in passes when the cell has
 // fewer than that; the one-max-across-ALL-alphas renormalisation (:626-639) is a butterfly over the AP lanes of a pair.
@@ -7246,8 +7371,11 @@ int launch_doublet(dmx_engine* e) {
     const size_t cbd = (size_t)32 * 18 * 8 + (size_t)32 * GS * 8 + 2 * 34 * 8 + 32 * (4 + 4 + 8);
     DMX_LAUNCH(k2_fn, (k_doublet_a2u<4>), dim3((unsigned)B, 1), block, cbd, e->stream, e->pv, e->nrd_width, e->d_g,
                        e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);
-    hipLaunchKernelGGL((k_doublet_a2s<4, 4, 0>), dim3((unsigned)((B + 3) / 4), 1), block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched,
-                       e->d_grid, e->d_l00, pfin_a2);
+    if (e->knob("DMX_A2U_DIAG_WAVE"))             // kernel experiments only: the diagonal on one wavefront per barcode (the first form)
+      hipLaunchKernelGGL((k_doublet_a2s<4, 4, 0>), dim3((unsigned)((B + 3) / 4), 1), block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched,
+                         e->d_grid, e->d_l00, pfin_a2);
+    else
+      hipLaunchKernelGGL((k_doublet_diag<5>), dim3((unsigned)((B + 7) / 8)), block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_lut, e->d_sched, e->d_grid, pfin_a2);
   }
   else if (V == 32 && pfin_a2_grid && e->geno_safe && e->knob("DMX_A2_SYM")) {
     // 32 soft-field samples on the default grid (cfg3, the headline): symmetric ownership — one lane owns [j][k] and [k][j], their shared products once.
