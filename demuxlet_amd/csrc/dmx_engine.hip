@@ -2175,8 +2175,9 @@ __global__ __launch_bounds__(kThreads) void k_doublet_generic(PileupView pv, con
 // TP: covered pairs per tile (32; 16 or 8 on panels of more than ~180 samples, whose 32 staged genotype rows would leave one workgroup per CU)
 // (the 64-thread-cell forms run three workgroups of four cells per CU = three wavefronts per SIMD: bounded to their 168 registers — left unbounded the
 //  compiler's count moved from 158 to 246 with an unrelated edit of phase 1 and cfg5 STRICT lost a wavefront per SIMD, 144 -> 168 ms)
-// SYMU (round 6, k_doublet_a2u below; V == 32, default grid): phase 2 over UNORDERED pairs — thread t owns the pairs {j, (j + d) & 31} of units u = t and t + 256
-// (u < 496: d = 1 + u / 32, j = u % 32; d = 16 from j < 16 only) with the four accumulators [j][k][0..1], [k][j][0..1] each: eight per thread, as before.
+// SYMU (round 6, k_doublet_a2u below; V = 32 on 256 threads or 16 on 64, default grid): phase 2 over UNORDERED pairs — thread t owns the pairs {j, (j + d) % V} of units u = t
+// and t + TPC (d = 1 + u / V, j = u % V; d = V/2 from j < V/2 only: 496 of 512 slots at V = 32, 120 of 128 at 16) with the four accumulators [j][k][0..1],
+// [k][j][0..1] each: eight per thread, as before.
 template <int TPC, int NK, int MINW, bool GD, bool CHK, int TP, bool SYMU>
 __device__ __forceinline__ void a2_body(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
@@ -2184,7 +2185,8 @@ __device__ __forceinline__ void a2_body(PileupView pv, int nrd_width, const floa
                                                          const int32_t* __restrict__ sched, int32_t V, int32_t GS,
                                                          double* __restrict__ grid, double* __restrict__ l00,
                                                          uint8_t* __restrict__ flagged, const double* __restrict__ pfin, const double* __restrict__ pseed) {
-  static_assert(!SYMU || (TPC == 256 && NK == 4 && !CHK), "symmetric ownership: 256 threads per barcode, eight accumulators per thread, provably safe rows");
+  static_assert(!SYMU || ((TPC == 256 || TPC == 64) && NK == 4 && !CHK), "symmetric ownership: 32 samples on 256 threads or 16 on 64, eight accumulators per thread, provably safe rows");
+  constexpr int kUV = TPC == 256 ? 32 : 16, kUSh = kUV == 32 ? 5 : 4;       // SYMU: the panel (V (V - 1) / 2 unordered pairs on 2 TPC slots) and log2 of it
   // pfin (round 6; NULL unless the grid is {0, 0.5} and the pileup shallow): k_build_certify_finals' table of finished phase-1 values;
   // pseed (NULL unless the grid is {0, 0.5}): k_build_certify_seeds' table — on that grid the tiles that walk the read loop walk it in the five-value form
   // (alpha 0.5's five distinct mixing weights, alpha 0's three: entries of equal weight go through identical operations, so the nine values are these,
@@ -2244,7 +2246,7 @@ __device__ __forceinline__ void a2_body(PileupView pv, int nrd_width, const floa
   int uj[2] = {0, 0}, uk[2] = {0, 0};            // SYMU: the thread's two unordered pairs; acc[2 su] = [j][k][0..1], acc[2 su + 1] = [k][j][0..1]
   if constexpr (SYMU) {
 #pragma unroll
-    for (int su = 0; su < 2; ++su) { const int u = tid + 256 * su; uj[su] = u & 31; uk[su] = (uj[su] + 1 + (u >> 5)) & 31; }
+    for (int su = 0; su < 2; ++su) { const int u = tid + TPC * su; uj[su] = u & (kUV - 1); uk[su] = (uj[su] + 1 + (u >> kUSh)) & (kUV - 1); }
   }
   // phase-1 identity (first wavefront of the cell): pair ti1, alpha n1; mixing weights of :613
   const int ti1 = tid >> 1, n1 = tid & 1;
@@ -2482,8 +2484,8 @@ __device__ __forceinline__ void a2_body(PileupView pv, int nrd_width, const floa
     if constexpr (SYMU) {
 #pragma unroll
       for (int su = 0; su < 2; ++su) {
-        const int u = tid + 256 * su, d = 1 + (u >> 5);
-        if (d < 16 || (d == 16 && uj[su] < 16)) {  // d = 16 is reached from both sides: the j < 16 thread stores; units beyond 495 do not exist
+        const int u = tid + TPC * su, d = 1 + (u >> kUSh);
+        if (d < kUV / 2 || (d == kUV / 2 && uj[su] < kUV / 2)) {   // d = V/2 is reached from both sides: the j < V/2 thread stores; units beyond the last pair do not exist
           double* o = grid + (((size_t)cell * V + uj[su]) * V + uk[su]) * A;
           o[0] = acc[2 * su][0]; o[1] = acc[2 * su][1];
           double* o2 = grid + (((size_t)cell * V + uk[su]) * V + uj[su]) * A;
@@ -2525,6 +2527,15 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2u(PileupView pv, i
                                                           double* __restrict__ grid, double* __restrict__ l00,
                                                           uint8_t* __restrict__ flagged, const double* __restrict__ pfin, const double* __restrict__ pseed) {
   a2_body<256, 4, MINW, true, false, 32, true>(pv, nrd_width, g, gp0, tabs, alpha, sched, V, GS, grid, l00, flagged, pfin, pseed);
+}
+// ... and for 16 samples (cfg5): k_doublet_a2<64,4,1,noCHK>'s kernel — 64 threads per barcode, four barcodes per workgroup, three wavefronts per SIMD
+__global__ __launch_bounds__(kThreads, 3) void k_doublet_a2u16(PileupView pv, int nrd_width, const float* __restrict__ g,
+                                                          const double* __restrict__ gp0, const double* __restrict__ tabs,
+                                                          const double* __restrict__ alpha,
+                                                          const int32_t* __restrict__ sched, int32_t V, int32_t GS,
+                                                          double* __restrict__ grid, double* __restrict__ l00,
+                                                          uint8_t* __restrict__ flagged, const double* __restrict__ pfin, const double* __restrict__ pseed) {
+  a2_body<64, 4, 1, false, false, 32, true>(pv, nrd_width, g, gp0, tabs, alpha, sched, V, GS, grid, l00, flagged, pfin, pseed);
 }
 
 // K2, A = 2, FAST mode (dmx_engine_config.mode = DMX_MODE_FAST): k_doublet_a2 with the bilinear factoring of SURVEY H3.  Not the
@@ -3554,11 +3565,12 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_a2s(PileupView pv, i
 // (k_doublet_a2s<.., 0>, the first form, spent a 64-lane wavefront per barcode: lane (j, alpha), 62 instructions per pair; this one 83 per pair for two
 // barcodes).  Per tile of 16 pairs and barcode: headers (16 lanes), phase 1 (32 lanes = pair x alpha; k_doublet_sym's, from the final-value table where
 // every pair of the wavefront's two tiles is on it), then the lane's own three floats per pair straight from the matrix.  No workgroup barrier.
-template <int MINW>
+template <int MINW, int VP = 32>                // VP: the panel — 32 samples (two barcodes per wavefront) or 16 (four)
 __global__ __launch_bounds__(kThreads, MINW) void k_doublet_diag(PileupView pv, int nrd_width, const float* __restrict__ g,
                                                            const double* __restrict__ tabs, const int32_t* __restrict__ sched,
-                                                           double* __restrict__ grid, const double* __restrict__ pfin) {
-  constexpr int V = 32, A = 2, TPC = 32, TP = 16, CPW = kThreads / TPC, row_len = 3 * V, PB = 8;
+                                                           double* __restrict__ grid, const double* __restrict__ pfin, const double* __restrict__ pseed) {
+  static_assert(VP == 32 || VP == 16, "panel");
+  constexpr int V = VP, A = 2, TPC = VP, TP = VP / 2, CPW = kThreads / TPC, row_len = 3 * V, PB = 8, WPC = 64 / TPC;
   __shared__ double s_tab[kTab2];
   __shared__ double s_w[2][10];
   __shared__ __attribute__((aligned(16))) double s_pq_all[CPW][TP][8];
@@ -3580,14 +3592,15 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_diag(PileupView pv, 
   double* s_pq = &s_pq_all[cw][0][0];
   int64_t* s_off = s_off_all[cw]; int32_t* s_snp = s_snp_all[cw]; uint32_t* s_cnt = s_cnt_all[cw];
   const int slot = blockIdx.x * CPW + cw;
-  if ((blockIdx.x * CPW + (cw & ~1)) >= pv.B) return;       // both barcodes of the wavefront past the end (no workgroup barrier below)
+  if ((blockIdx.x * CPW + (cw & ~(WPC - 1))) >= pv.B) return;   // every barcode of the wavefront past the end (no workgroup barrier below)
   const bool cell_ok = slot < pv.B;
   const int32_t cell = cell_ok ? sched[slot] : 0;
   const int64_t p_beg = cell_ok ? pv.cell_pair_off[cell] : 0;
   const int64_t np = cell_ok ? pv.cell_pair_off[cell + 1] - p_beg : 0;
   int64_t rd_base = cell_ok ? pv.cell_read_off[cell] : 0;
   int64_t np_w = np;                               // the longer of the wavefront's two barcodes: the tile loop is wave-uniform
-  { const int64_t o = __shfl_xor(np, 32); np_w = np_w > o ? np_w : o; }
+#pragma unroll
+  for (int d = TPC; d < 64; d <<= 1) { const int64_t o = __shfl_xor(np_w, d); np_w = np_w > o ? np_w : o; }
   const int j = tid;
   double acc0 = 0.0, acc1 = 0.0;
   const DmxLogPins lk = dmx_log_pins();
@@ -3621,7 +3634,7 @@ __global__ __launch_bounds__(kThreads, MINW) void k_doublet_diag(PileupView pv, 
         double wA[5], wR[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) { wA[i] = s_w[n1][i]; wR[i] = s_w[n1][5 + i]; }
-        certify_pair_values<5, false>(pv, cnt, off, rd4, s_tab, wA, wR, n1, q, nullptr);
+        certify_pair_values<5, false>(pv, cnt, off, rd4, s_tab, wA, wR, n1, q, pseed);
       }
       if (on) {
         if (n1) {
@@ -7375,7 +7388,7 @@ int launch_doublet(dmx_engine* e) {
       hipLaunchKernelGGL((k_doublet_a2s<4, 4, 0>), dim3((unsigned)((B + 3) / 4), 1), block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched,
                          e->d_grid, e->d_l00, pfin_a2);
     else
-      hipLaunchKernelGGL((k_doublet_diag<5>), dim3((unsigned)((B + 7) / 8)), block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_lut, e->d_sched, e->d_grid, pfin_a2);
+      hipLaunchKernelGGL((k_doublet_diag<5>), dim3((unsigned)((B + 7) / 8)), block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_lut, e->d_sched, e->d_grid, pfin_a2, pseed_a2);
   }
   else if (V == 32 && pfin_a2_grid && e->geno_safe && e->knob("DMX_A2_SYM")) {
     // 32 soft-field samples on the default grid (cfg3, the headline): symmetric ownership — one lane owns [j][k] and [k][j], their shared products once.
@@ -7390,6 +7403,12 @@ int launch_doublet(dmx_engine* e) {
       DMX_LAUNCH(k2_fn, (k_doublet_a2s<4, 3>), grds, block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, e->d_grid, e->d_l00, pfin_a2);
     else
       DMX_LAUNCH(k2_fn, (k_doublet_a2s<4, 4>), grds, block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_gp0, e->d_lut, e->d_sched, e->d_grid, e->d_l00, pfin_a2);
+  }
+  else if (V == 16 && pfin_a2_grid && e->geno_safe && !e->knob("DMX_A2_NO_SYMU")) {
+    // 16 soft-field samples on the default grid (cfg5): the same — unordered pairs on k_doublet_a2<64,4>'s kernel, the diagonal on 16 lanes per barcode behind it
+    DMX_LAUNCH(k2_fn, (k_doublet_a2u16), dim3((unsigned)((B + 3) / 4), 1), block, cell_bytes * 4, e->stream, e->pv, e->nrd_width, e->d_g,
+                       e->d_gp0, e->d_lut, e->d_alpha, e->d_sched, V, GS, e->d_grid, e->d_l00, e->d_flag, pfin_a2, pseed_a2);
+    hipLaunchKernelGGL((k_doublet_diag<5, 16>), dim3((unsigned)((B + 15) / 16)), block, 0, e->stream, e->pv, e->nrd_width, e->d_g, e->d_lut, e->d_sched, e->d_grid, pfin_a2, pseed_a2);
   }
   else if (V <= 8) DMX_K2A(64, 1);
   else if (V <= 16) DMX_K2A(64, 4);

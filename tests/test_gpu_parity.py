@@ -1445,8 +1445,10 @@ def test_symmetric_strict_kernel_gives_k_doublet_a2s_bits(eng, oracle, monkeypat
         rng = np.random.default_rng(4242)
         raw = synth.make_raw_genotypes(rng, g.shape[0], V)
         g = np.stack([eng.geno_from_pl(x) for x in synth.raw_pl_from_alleles(rng, raw.alleles)])
+    first = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {}, "k_doublet_a2u<")   # (before k_doublet_a2 has left its results in any buffer)
     base = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, {"DMX_A2_NO_SYMU": "1"}, "k_doublet_a2<")
-    # the shipped form: k_doublet_a2's kernel over unordered pairs (k_doublet_a2u) + the diagonal entries on one wavefront per barcode behind it
+    assert np.array_equal(first[0], base[0]) and np.array_equal(first[1], base[1])
+    # the shipped form: k_doublet_a2's kernel over unordered pairs (k_doublet_a2u) + the diagonal entries (k_doublet_diag) behind it
     for env in ({}, {"DMX_A2_NO_FINALS": "1"}, {"DMX_FINALS_ANY_DEPTH": "1"}, {"DMX_A2_NO_SEEDS": "1", "DMX_A2_NO_FINALS": "1"}):
         got = _grid_with_env(eng, monkeypatch, g, pl, V, capi.DMX_MODE_STRICT, env, "k_doublet_a2u<")
         assert np.array_equal(got[0], base[0]), (env, np.argwhere(got[0] != base[0])[:5])
@@ -1468,14 +1470,14 @@ def test_symmetric_strict_kernel_gives_k_doublet_a2s_bits(eng, oracle, monkeypat
     assert np.abs(base[0][proc] - ref.llksAB[proc]).max() < TOL
 
 
-@pytest.mark.parametrize("B,S,cover", [(5, 45, 0.5), (1, 31, 1.0), (9, 333, 0.08), (130, 64, 0.3)])
-def test_unordered_pair_kernel_on_ragged_small_problems(eng, monkeypatch, B, S, cover):
-    """k_doublet_a2u + its diagonal kernel on the shapes the big tests do not reach: barcode counts that are not multiples of 4 (the diagonal kernel's
+@pytest.mark.parametrize("V", [32, 16])
+@pytest.mark.parametrize("B,S,cover", [(5, 45, 0.5), (1, 31, 1.0), (9, 333, 0.08), (130, 64, 0.3), (37, 700, 1.0), (41, 900, 0.35)])
+def test_unordered_pair_kernel_on_ragged_small_problems(eng, monkeypatch, B, S, cover, V):
+    """k_doublet_a2u (32 samples) / k_doublet_a2u16 (16) + their diagonal kernel on the shapes the big tests do not reach: barcode counts that are not multiples of 4 (the diagonal kernel's
     workgroups hold four barcodes), barcodes without any covered SNP, fewer pairs than a tile or a sub-tile, a single barcode — bit for bit k_doublet_a2's grid,
     llks00 and K3 records."""
     from demuxlet_amd import synth, capi
-    V = 32
-    rng = np.random.default_rng(6100 + B + S)
+    rng = np.random.default_rng(6100 + B + S + V)
     raw = synth.make_raw_genotypes(rng, S, V)
     g = np.stack([eng.geno_from_gp(x, 0.01) for x in synth.raw_gp_from_alleles(rng, raw.alleles)])
     cov = rng.random((B, S)) < cover
@@ -1487,9 +1489,11 @@ def test_unordered_pair_kernel_on_ragged_small_problems(eng, monkeypatch, B, S, 
     dense = bool(cov.all())
     pair_snp = None if dense else np.concatenate([np.nonzero(cov[c])[0] for c in range(B)]).astype(np.int32)
     P = int(npair.sum())
-    nrd = rng.choice(np.arange(5), size=P, p=[0.1, 0.6, 0.2, 0.07, 0.03]).astype(np.uint8)
+    nrd = rng.choice(np.arange(7), size=P, p=[0.1, 0.55, 0.2, 0.07, 0.04, 0.02, 0.02]).astype(np.uint8)
+    if P > 100:
+        nrd[rng.random(P) < 0.003] = 20                                   # beyond kSafeReads
     nr = int(nrd.sum())
-    reads = (rng.integers(2, 60, size=nr).astype(np.uint8)) | (rng.integers(0, 2, size=nr).astype(np.uint8) << 7)
+    reads = (rng.integers(2, 70, size=nr).astype(np.uint8)) | (rng.integers(0, 2, size=nr).astype(np.uint8) << 7)
     cpo = np.concatenate([[0], np.cumsum(npair)]).astype(np.int64)
     cro = np.concatenate([[0], np.cumsum(np.bincount(np.repeat(np.arange(B), npair), weights=nrd, minlength=B))]).astype(np.int64)
     z = np.zeros(B, dtype=np.int32)
@@ -1508,9 +1512,10 @@ def test_unordered_pair_kernel_on_ragged_small_problems(eng, monkeypatch, B, S, 
         e.close()
         return out
 
+    # (the unordered-pair kernel FIRST: its buffers must not hold a previous run's identical results where it fails to write)
+    bs = [run(env, "k_doublet_a2u") for env in ({}, {"DMX_FINALS_ANY_DEPTH": "1"})]
     a = run({"DMX_A2_NO_SYMU": "1"}, "k_doublet_a2<")
-    for env in ({}, {"DMX_FINALS_ANY_DEPTH": "1"}):
-        b = run(env, "k_doublet_a2u<")
+    for env, b in zip(({}, {"DMX_FINALS_ANY_DEPTH": "1"}), bs):
         covered = npair > 0
         assert np.array_equal(a[0][covered], b[0][covered]) and np.array_equal(a[1][covered], b[1][covered]), env
         assert a[2].tobytes() == b[2].tobytes(), env

@@ -72,7 +72,7 @@ dom = max(dom, key=lambda k: res[k].get("SQ_WAVE_CYCLES", 0))
 d = dict(res[dom])
 # k_doublet_a2u (round 6) leaves a barcode's 64 diagonal accumulators to k_doublet_diag (k_doublet_a2s<.., 0> in its first form), launched right behind it inside the same K2 event pair: the
 # counts of one K2 launch are the two kernels' together (named in "kernel_group"; "kernel" stays the one dmx_engine_kernel_names reports)
-group = [dom] + ([k for k in res if k.startswith("k_doublet_diag<") or (k.startswith("k_doublet_a2s<") and k.rstrip(">").endswith(", 0"))] if dom.startswith("k_doublet_a2u<") else [])
+group = [dom] + ([k for k in res if k.startswith("k_doublet_diag<") or (k.startswith("k_doublet_a2s<") and k.rstrip(">").endswith(", 0"))] if dom.startswith("k_doublet_a2u") else [])
 for k in group[1:]:
     for c, v in res[k].items():
         if isinstance(v, (int, float)) and c != "cycles_per_other_valu_inst" and isinstance(d.get(c), (int, float)):
